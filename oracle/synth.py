@@ -1,0 +1,130 @@
+"""Deterministic synthetic weights and inputs for parity tests.   *** TEST INFRASTRUCTURE ***
+
+No pretrained PARSeq weights are reachable (no network), and the reference initialiser zeroes every bias and
+sets every LayerNorm to (1, 0) (strhub/models/utils.py:107-125, timm ViT init) — a kernel that dropped a bias or
+an LN affine term would still pass parity on such weights.  So tests use a synthetic `state_dict` with
+non-trivial values everywhere, generated per key from a seed so that the oracle (CPU) and the HIP path load
+bit-identical tensors on any box without shipping 95 MB files.
+
+The key set / shapes are those of the reference inner model (`strhub/models/parseq/model.py:56-67`,
+`modules.py:33-43`, timm ViT), listed in SURVEY.md section 8(b); `oracle/make_golden.py` verifies them by
+`load_state_dict(strict=True)` into the reference's own module.
+"""
+from __future__ import annotations
+
+import hashlib
+from collections import OrderedDict
+
+import torch
+
+from .parseq_oracle import OracleConfig
+
+
+def state_dict_spec(cfg: OracleConfig) -> 'OrderedDict[str, tuple]':
+    E = cfg.embed_dim
+    N = cfg.num_patches
+    ph, pw = cfg.patch_size
+    spec = OrderedDict()
+    spec['pos_queries'] = (1, cfg.max_label_length + 1, E)
+    spec['encoder.pos_embed'] = (1, N, E)
+    spec['encoder.patch_embed.proj.weight'] = (E, 3, ph, pw)
+    spec['encoder.patch_embed.proj.bias'] = (E,)
+    for i in range(cfg.enc_depth):
+        p = f'encoder.blocks.{i}.'
+        spec[p + 'norm1.weight'] = (E,)
+        spec[p + 'norm1.bias'] = (E,)
+        spec[p + 'attn.qkv.weight'] = (3 * E, E)
+        spec[p + 'attn.qkv.bias'] = (3 * E,)
+        spec[p + 'attn.proj.weight'] = (E, E)
+        spec[p + 'attn.proj.bias'] = (E,)
+        spec[p + 'norm2.weight'] = (E,)
+        spec[p + 'norm2.bias'] = (E,)
+        spec[p + 'mlp.fc1.weight'] = (E * cfg.enc_mlp_ratio, E)
+        spec[p + 'mlp.fc1.bias'] = (E * cfg.enc_mlp_ratio,)
+        spec[p + 'mlp.fc2.weight'] = (E, E * cfg.enc_mlp_ratio)
+        spec[p + 'mlp.fc2.bias'] = (E,)
+    spec['encoder.norm.weight'] = (E,)
+    spec['encoder.norm.bias'] = (E,)
+    for i in range(cfg.dec_depth):
+        p = f'decoder.layers.{i}.'
+        for attn in ('self_attn', 'cross_attn'):
+            spec[p + attn + '.in_proj_weight'] = (3 * E, E)
+            spec[p + attn + '.in_proj_bias'] = (3 * E,)
+            spec[p + attn + '.out_proj.weight'] = (E, E)
+            spec[p + attn + '.out_proj.bias'] = (E,)
+        F_ = E * cfg.dec_mlp_ratio
+        spec[p + 'linear1.weight'] = (F_, E)
+        spec[p + 'linear1.bias'] = (F_,)
+        spec[p + 'linear2.weight'] = (E, F_)
+        spec[p + 'linear2.bias'] = (E,)
+        for n in ('norm1', 'norm2', 'norm_q', 'norm_c'):
+            spec[p + n + '.weight'] = (E,)
+            spec[p + n + '.bias'] = (E,)
+    spec['decoder.norm.weight'] = (E,)
+    spec['decoder.norm.bias'] = (E,)
+    spec['head.weight'] = (cfg.num_tokens - 2, E)
+    spec['head.bias'] = (cfg.num_tokens - 2,)
+    spec['text_embed.embedding.weight'] = (cfg.num_tokens, E)
+    return spec
+
+
+def _key_seed(seed: int, key: str) -> int:
+    h = hashlib.sha256(f'{seed}:{key}'.encode()).digest()
+    return int.from_bytes(h[:7], 'little')
+
+
+def synth_state_dict(cfg: OracleConfig, seed: int = 0, eos_bias: float = 2.5, gain: float = 1.0) -> 'OrderedDict[str, torch.Tensor]':
+    """Per-key seeded weights in a 'trained-like' regime: Linear/Conv weights ~ N(0, gain/sqrt(fan_in)) so that
+    activations stay O(1) and attention is far from uniform; biases ~ N(0, 0.1); LayerNorm weight ~ 1 + N(0, 0.1),
+    bias ~ N(0, 0.1); embeddings / positional tables ~ N(0, 0.5 or 0.05).  `eos_bias` lifts the [E] logit so that
+    end-of-sequence actually occurs at mixed positions (exercises early exit and the refinement padding mask).
+    CPU generator => identical bits on every x86 box with the same torch build."""
+    sd = OrderedDict()
+    for key, shape in state_dict_spec(cfg).items():
+        g = torch.Generator(device='cpu').manual_seed(_key_seed(seed, key))
+        n = torch.randn(shape, generator=g, dtype=torch.float32)
+        leaf = key.rsplit('.', 1)[-1]
+        is_norm = any(t in key for t in ('norm1', 'norm2', 'norm_q', 'norm_c', '.norm.', 'encoder.norm', 'decoder.norm'))
+        if key == 'pos_queries':
+            t = 0.5 * n
+        elif key == 'encoder.pos_embed':
+            t = 0.3 * n
+        elif key == 'text_embed.embedding.weight':
+            t = 0.05 * n          # multiplied by sqrt(E) ~ 19.6 in TokenEmbedding
+        elif is_norm:
+            t = 1.0 + 0.1 * n if leaf == 'weight' else 0.1 * n
+        elif leaf in ('weight', 'in_proj_weight'):
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = (gain / fan_in ** 0.5) * n
+            if 'attn.qkv' in key or 'in_proj' in key:
+                t = 1.6 * t       # sharper attention logits
+        else:                     # biases
+            t = 0.1 * n
+        sd[key] = t.contiguous()
+    sd['head.bias'][cfg.eos_id] += eos_bias
+    return sd
+
+
+def synth_images(batch: int, cfg: OracleConfig, seed: int = 1234) -> torch.Tensor:
+    """Crops as the reference's transform produces them: float32 in [-1, 1] (strhub/data/module.py:78-80,
+    Normalize(0.5, 0.5) after ToTensor).  SURVEY.md section 8(d)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.rand(batch, 3, cfg.img_size[0], cfg.img_size[1], generator=g, dtype=torch.float32) * 2 - 1
+
+
+def state_dict_fingerprint(sd) -> float:
+    """Cheap order-dependent checksum used by goldens to detect RNG drift between boxes."""
+    acc = 0.0
+    for i, (k, v) in enumerate(sd.items()):
+        acc += (i + 1) * float(v.double().abs().sum())
+    return acc
+
+
+CONFIGS = {
+    # configs/model/parseq.yaml:5-14 + configs/main.yaml:9-10 + configs/charset/94_full.yaml (94 chars -> 97 tokens)
+    'parseq': OracleConfig(),
+    # configs/experiment/parseq-tiny.yaml:5-9
+    'parseq-tiny': OracleConfig(embed_dim=192, enc_num_heads=3, dec_num_heads=6),
+}
