@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Throughput of the PARSeq inference hot path on MI355X (BASELINE.json metric: images/sec of 32x128 crops, PARSeq-S,
+AR decode + 1 refinement iteration), with the roofline fraction of the dominant kernel and the CPU oracle timed on the
+same box.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 512] [--precision bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one forward of one batch of synthetic crops that already sit in HBM (config 2 of BASELINE.json: batch 512 per
+GPU).  With N > 1 every rank runs its own 512-crop shard (weak scaling) and the step ends with the one RCCL all-gather of
+logits the north star names.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic FLOPs (2 x MAC) per image, minimal algorithm (memory K/V once, content K/V cached)
+GFLOP_PER_IMG = {('parseq', 0): 5.938, ('parseq', 1): 6.053, ('parseq', 2): 6.168,
+                 ('parseq-tiny', 0): 1.564, ('parseq-tiny', 1): 1.595, ('parseq-tiny', 2): 1.626}
+PEAK = {'bf16': 2500.0, 'fp32': 157.3}    # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md:41-42
+
+
+def gemm_flops(family, B, cfg):
+    """Algorithmic FLOPs of one launch of an encoder GEMM family (M = B * 128 rows)."""
+    E, M = cfg['embed_dim'], B * 128
+    F = E * cfg['enc_mlp_ratio']
+    return {'enc.qkv_gemm': 2.0 * M * 3 * E * E, 'enc.proj_gemm': 2.0 * M * E * E, 'enc.fc1_gelu_gemm': 2.0 * M * F * E,
+            'enc.fc2_gemm': 2.0 * M * E * F, 'dec.memory_kv_gemm': 2.0 * M * 2 * E * E,
+            'enc.attention': 4.0 * B * cfg['enc_num_heads'] * 128 * 128 * 64}.get(family)
+
+
+def cpu_baseline(name, sd_cpu, refine_iters, seconds=12.0, batch=64):
+    """The CPU oracle (a port of the reference algorithm, oracle/parseq_oracle.py) on this box's host cores: fp32,
+    torch.inference_mode, all cores, PARSeq-S AR + refine at batch 64 (the CPU's best operating point in SURVEY 8d),
+    repeated for ~`seconds` of wall time."""
+    from oracle import parseq_oracle as O
+    from oracle.synth import CONFIGS, synth_images
+    cfg = CONFIGS[name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = synth_images(batch, cfg, seed=1234)
+    with torch.inference_mode():
+        O.forward(sd_cpu, cfg, x[:8], 25, decode_ar=True, refine_iters=refine_iters)      # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            O.forward(sd_cpu, cfg, x, 25, decode_ar=True, refine_iters=refine_iters)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or n >= 20:
+                break
+    return {'value': round(n * batch / dt, 2), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} x batch {batch} PARSeq-S fp32 AR(26 steps)+{refine_iters} refine, oracle/parseq_oracle.py, {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=512, help='crops per GPU per step')
+    ap.add_argument('--model', default='parseq')
+    ap.add_argument('--refine-iters', type=int, default=1)
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--natural-exit', action='store_true', help='max_length=None (early exit); default forces 26 AR steps')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)       # 'nccl' is RCCL on ROCm
+
+    from parseq_amd import create_model
+    from parseq_amd.parallel import all_gather_logits
+    torch.manual_seed(0)
+    model = create_model(args.model, decode_ar=True, refine_iters=args.refine_iters, precision=args.precision)
+    sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+    model = model.eval().to(dev)
+    B = args.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = (torch.rand(B, 3, 32, 128, generator=g) * 2 - 1).to(dev)      # already resident in HBM when timing starts
+    if args.precision == 'bf16':
+        images = images.bfloat16()
+    max_length = None if args.natural_exit else 25
+
+    def step():
+        with torch.inference_mode():
+            logits = model(images, max_length)
+            if dist is not None:
+                logits = all_gather_logits(logits)
+        return logits
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    result = {
+        'metric': 'images/sec (32x128 crops) PARSeq-S AR+refine', 'value': round(value, 1), 'unit': 'images/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.precision, 'data': 'synthetic',
+        'config': {'workload': f'{args.model} {args.precision}, 32x128 crops, batch={B}/GPU, AR decode '
+                               f'({"natural exit" if args.natural_exit else "26 steps forced"}) + {args.refine_iters} refine iter '
+                               f'(BASELINE.json configs[1]); random-init weights (reference init, seed 0); '
+                               f'inputs resident in HBM as {"bf16" if args.precision == "bf16" else "fp32"}',
+                   'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-gather of logits' if world > 1 else ''),
+                   'output_shape': list(out.shape)},
+    }
+    gf = GFLOP_PER_IMG.get((args.model, args.refine_iters))
+    if gf:
+        result['end_to_end_tflops'] = round(value * gf / 1e3, 2)
+        result['end_to_end_frac_of_mfma_peak'] = round(value * gf / 1e3 / (PEAK[args.precision] * world), 4)
+
+    if rank == 0 and not args.no_profile:
+        # per-kernel-family durations measured live with HIP events on the launch stream (separate pass: the events
+        # perturb throughput), roofline of the family with the largest share of the step
+        model.model.set_profiling(True, B)
+        nprof = 3
+        with torch.inference_mode():
+            for _ in range(nprof):
+                model(images, max_length)
+        torch.cuda.synchronize()
+        prof = model.model.get_profile(B)
+        model.model.set_profiling(False, B)
+        total = sum(ms for ms, _ in prof.values()) or 1.0
+        fam = {k: {'ms_per_step': round(ms / nprof, 4), 'launches_per_step': n // nprof, 'avg_us': round(1e3 * ms / max(n, 1), 2),
+                   'share': round(ms / total, 4)} for k, (ms, n) in prof.items() if n}
+        result['kernel_families'] = fam
+        cfg = dict(model.hparams)
+        dom = max((k for k in fam if gemm_flops(k, B, cfg)), key=lambda k: fam[k]['share'])
+        fl = gemm_flops(dom, B, cfg)
+        ach = fl / (fam[dom]['avg_us'] * 1e-6) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # HBM bytes/launch from rocprofv3 --pmc passes, if collected
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom)
+        result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK[args.precision], 'unit': 'TFLOP/s',
+                              'frac': round(ach / PEAK[args.precision], 4), 'traffic': traffic,
+                              'flops_per_launch': fl, 'avg_launch_us': fam[dom]['avg_us']}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args.model, sd_cpu, args.refine_iters)
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

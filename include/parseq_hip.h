@@ -1,0 +1,146 @@
+/*
+ * parseq_hip.h — C ABI of libparseq_hip.so, the MI355X (gfx950) implementation of the PARSeq inference hot path.
+ *
+ * The reference (baudm/parseq @ /root/reference, strhub 1.2.0) is pure Python and has NO plugin / operator / FFI
+ * interface for this path: the boundary it exposes is `PARSeq.forward(tokenizer, images, max_length)`
+ * (strhub/models/parseq/model.py:105-169, called through strhub/models/parseq/system.py:87-88).  This header is the
+ * interface a native backend sits behind; each entry point names the reference code it replaces.  The Python
+ * binding a maintainer would add is shown in INTEGRATION.md; this repo's own binding is parseq_amd/_native.py
+ * (ctypes).
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes.  No torch / ATen types.
+ *   - every `const void*` / `float*` below that is documented "device" must be a pointer into HIP device memory
+ *     of the device that was current when the model was created.  The caller owns all such buffers.
+ *   - every call enqueues on the `hipStream_t` passed as `void* stream` (NULL = the default stream) and returns
+ *     without synchronising, EXCEPT where stated (parseq_forward with PARSEQ_FLAG_TESTING and refine_iters == 0,
+ *     which has to read one int back — the reference has a device->host sync per AR step at model.py:144).
+ *   - return value: 0 on success, a negative PARSEQ_E_* code otherwise; parseq_last_error() gives the message
+ *     (thread-local).  No exceptions cross the boundary.
+ *   - a model and its plans are not internally locked: use one plan per host thread / stream.
+ */
+#ifndef PARSEQ_HIP_H_
+#define PARSEQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARSEQ_ABI_VERSION 1
+
+typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
+typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
+
+/* Constructor arguments of the reference model that shape the arithmetic
+ * (strhub/models/parseq/model.py:33-49; values from configs/model/parseq.yaml, configs/main.yaml:9-10). */
+typedef struct parseq_config {
+    int32_t img_h, img_w;          /* 32, 128 */
+    int32_t patch_h, patch_w;      /* 4, 8 */
+    int32_t embed_dim;             /* 384 (PARSeq-S), 192 (PARSeq-Ti) */
+    int32_t enc_depth, enc_heads, enc_mlp_ratio;   /* 12, 6 | 3, 4 */
+    int32_t dec_depth, dec_heads, dec_mlp_ratio;   /* 1 (only value supported), 12 | 6, 4 */
+    int32_t num_tokens;            /* len(tokenizer) = 97 for the 94-char set; the head predicts num_tokens - 2 classes */
+    int32_t max_label_length;      /* 25 */
+    int32_t bos_id, eos_id, pad_id;/* 95, 0, 96  (strhub/data/utils.py:107-111) */
+    float enc_ln_eps, dec_ln_eps;  /* 1e-6 (timm ViT), 1e-5 (nn.LayerNorm default) */
+} parseq_config;
+
+enum {
+    PARSEQ_F32 = 0,    /* exact mode: f32 storage, v_mfma_f32_16x16x4_f32; parity target |dlogit| <= 1e-3 vs CPU fp32 */
+    PARSEQ_BF16 = 1    /* throughput mode: bf16 GEMM/attention operands, fp32 accumulate / residual / LayerNorm / softmax */
+};
+
+enum {
+    PARSEQ_FLAG_DECODE_AR = 1,   /* model.decode_ar (model.py:53,119): autoregressive vs one-shot NAR decoding */
+    PARSEQ_FLAG_TESTING = 2      /* max_length was None (model.py:106): batch-level early exit applies (model.py:144-145) */
+};
+
+enum {
+    PARSEQ_E_INVALID = -1,       /* bad argument / unsupported configuration */
+    PARSEQ_E_HIP = -2,           /* a HIP runtime call failed */
+    PARSEQ_E_STATE = -3,         /* weights missing / not finalised */
+    PARSEQ_E_ARCH = -4           /* device is not gfx950 */
+};
+
+int parseq_abi_version(void);
+const char* parseq_last_error(void);
+
+/* ---- model: replaces the nn.Module parameter storage of strhub/models/parseq/model.py:56-67 ---------------------- */
+
+/* Validates the configuration (dec_depth == 1, head dims 64 / 32, embed_dim in {192, 384, 768}, 128 tokens) and the
+ * device architecture.  Allocates device storage for the fp32 master weights. */
+int parseq_model_create(const parseq_config* cfg, parseq_model** out);
+void parseq_model_destroy(parseq_model* m);
+
+/* Copies one parameter (fp32, contiguous, `numel` elements) from device memory.  `key` is the reference
+ * state_dict key (e.g. "encoder.blocks.3.attn.qkv.weight", "decoder.layers.0.cross_attn.in_proj_weight",
+ * "pos_queries"; full list: SURVEY.md section 8b), so a released checkpoint can be streamed in key by key.
+ * Unknown key or wrong numel -> PARSEQ_E_INVALID. */
+int parseq_model_set_param(parseq_model* m, const char* key, const float* device_ptr, int64_t numel, void* stream);
+
+/* Number of parameters / i-th key and element count, for binding-side validation. */
+int parseq_model_num_params(const parseq_model* m);
+int parseq_model_param_info(const parseq_model* m, int index, const char** key, int64_t* numel);
+
+/* ---- plan: per-(max_batch, precision) workspace, packed weights and batch-independent decoder tables ------------ */
+
+/* All device memory the hot path needs is allocated here, never inside parseq_forward / parseq_encode.
+ * Requires every parameter to have been set.  (Re)packs weights for `precision`; call parseq_plan_refresh after
+ * parameters change. */
+int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out);
+int parseq_plan_refresh(parseq_plan* p, void* stream);
+void parseq_plan_destroy(parseq_plan* p);
+size_t parseq_plan_workspace_bytes(const parseq_plan* p);
+
+/* Optional per-kernel-family timing: while enabled, every launch is bracketed by HIP events on the caller's stream
+ * (this perturbs throughput: use a separate pass).  parseq_plan_get_profile(index) returns 0 and fills the family name,
+ * accumulated milliseconds and launch count since profiling was (re-)enabled, or returns 1 when index is past the last
+ * family; it synchronises on the recorded events. */
+int parseq_plan_set_profiling(parseq_plan* p, int enable);
+int parseq_plan_get_profile(parseq_plan* p, int index, const char** name, double* total_ms, int64_t* launches);
+
+/* ---- hot path ---------------------------------------------------------------------------------------------------- */
+
+/* model.PARSeq.encode (model.py:83-84 -> modules.py:163-165 -> timm ViT.forward_features).
+ * images: device, [batch, 3, img_h, img_w], contiguous, fp32 (images_dtype = PARSEQ_F32) or bf16 (PARSEQ_BF16).
+ * memory_out: device fp32 [batch, tokens, embed_dim], or NULL to keep the result only inside the plan. */
+int parseq_encode(parseq_plan* p, const void* images, int images_dtype, int batch, float* memory_out, void* stream);
+
+/* model.PARSeq.forward (model.py:105-169): encode, AR loop or NAR pass, `refine_iters` cloze refinements.
+ * num_steps = min(max_length, max_label_length) + 1 (model.py:107-110), i.e. 26 by default.
+ * logits_out: device fp32 [batch, num_steps, num_tokens - 2], contiguous.  Rows [*, 0:L, *] are valid, where L is
+ * written to *out_len (host int): L = num_steps, except AR + PARSEQ_FLAG_TESTING + refine_iters == 0, where L is the
+ * early-exit length of model.py:144-145 and the call synchronises the stream to read it. */
+int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int batch, int flags, int refine_iters,
+                   int num_steps, float* logits_out, int* out_len, void* stream);
+
+/* model.PARSeq.decode + head for the contexts the reference's forward() builds (model.py:86-103, 138, 152, 167),
+ * exposed for per-stage parity tests: `memory` must have been produced by parseq_encode on this plan (its K/V
+ * projection is cached in the plan).  tokens: device int32 [batch, ctx_len] (tgt_in).  Queries are
+ * pos_queries[q_start : q_start + q_len].  query_mask: device uint8 [num_steps? no: (max_label_length + 1)] x ctx_len
+ * rows indexed by absolute query position, or NULL; key_padding_mask: device uint8 [batch, ctx_len] or NULL
+ * (non-zero = masked, torch semantics).  logits_out: device fp32 [batch, q_len, num_tokens - 2]. */
+int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
+                         const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream);
+
+/* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
+
+/* y = LayerNorm(x) over the last dim `E` (192 | 384 | 768); x fp32 [rows, E]; y in out_dtype. */
+int parseq_op_layernorm(const float* x, const float* w, const float* b, void* y, int out_dtype, int rows, int E,
+                        float eps, void* stream);
+/* C = A W^T + bias.  A [M, K] and W [N, K] in `dtype`, bias fp32 [N] or NULL, C fp32 [M, N] (act = 0) or
+ * C in `dtype` with exact-erf GELU applied (act = 1).  K must be a multiple of 8. */
+int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
+                     void* stream);
+/* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;
+ * out [bh / heads * 128, heads * 64] in `dtype`. */
+int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads,
+                                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARSEQ_HIP_H_ */

@@ -1,0 +1,108 @@
+"""ctypes binding of libparseq_hip.so (C ABI: include/parseq_hip.h).
+
+This is the only way compute reaches the GPU in this package.  If the library is missing or fails to load the import
+of this module's `lib()` raises — there is deliberately no fallback (a silent eager/CPU path would void every parity
+and performance claim).  Device memory, streams and the caching allocator are torch's: tensors are passed as raw
+device pointers + the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+PARSEQ_F32, PARSEQ_BF16 = 0, 1
+FLAG_DECODE_AR, FLAG_TESTING = 1, 2
+ABI_VERSION = 1
+
+
+class ParseqConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'img_h', 'img_w', 'patch_h', 'patch_w', 'embed_dim', 'enc_depth', 'enc_heads', 'enc_mlp_ratio',
+        'dec_depth', 'dec_heads', 'dec_mlp_ratio', 'num_tokens', 'max_label_length', 'bos_id', 'eos_id', 'pad_id')]
+    _fields_ += [('enc_ln_eps', C.c_float), ('dec_ln_eps', C.c_float)]
+
+
+class NativeError(RuntimeError):
+    """A libparseq_hip entry point returned a non-zero status."""
+
+
+_LIB: Optional[C.CDLL] = None
+
+# name: (restype, argtypes) — must list every symbol include/parseq_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    'parseq_abi_version': (C.c_int, []),
+    'parseq_last_error': (C.c_char_p, []),
+    'parseq_model_create': (C.c_int, [C.POINTER(ParseqConfig), C.POINTER(C.c_void_p)]),
+    'parseq_model_destroy': (None, [C.c_void_p]),
+    'parseq_model_set_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'parseq_model_num_params': (C.c_int, [C.c_void_p]),
+    'parseq_model_param_info': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
+    'parseq_plan_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    'parseq_plan_refresh': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'parseq_plan_destroy': (None, [C.c_void_p]),
+    'parseq_plan_workspace_bytes': (C.c_size_t, [C.c_void_p]),
+    'parseq_plan_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
+    'parseq_plan_get_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'parseq_encode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'parseq_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                 C.POINTER(C.c_int), C.c_void_p]),
+    'parseq_decode_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    'parseq_op_layernorm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, C.c_void_p]),
+    'parseq_op_linear': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_void_p]),
+    'parseq_op_encoder_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p]),
+}
+
+
+def lib_path() -> str:
+    return os.environ.get('PARSEQ_HIP_LIB', _build.LIB_PATH)
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library.  Raises if it is not there: build it with
+    `python -m parseq_amd.build` / `__graft_entry__.build()`."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f'libparseq_hip.so not found at {path}. The PARSeq HIP backend has no CPU/eager fallback; '
+                f'build it first: python -m parseq_amd.build')
+        handle = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError here = header/library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        if handle.parseq_abi_version() != ABI_VERSION:
+            raise RuntimeError(f'libparseq_hip ABI {handle.parseq_abi_version()} != binding ABI {ABI_VERSION}')
+        _LIB = handle
+    return _LIB
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = lib().parseq_last_error()
+        raise NativeError(f'libparseq_hip error {status}: {msg.decode() if msg else "?"}')
+
+
+def stream_ptr() -> C.c_void_p:
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t) -> int:
+    import torch
+    if t == torch.float32:
+        return PARSEQ_F32
+    if t == torch.bfloat16:
+        return PARSEQ_BF16
+    raise TypeError(f'unsupported dtype {t}: libparseq_hip takes float32 or bfloat16')
+
+
+def ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

@@ -1,0 +1,49 @@
+"""Builds parseq_amd/lib/libparseq_hip.so from parseq_amd/csrc with hipcc for gfx950 (cross-compiles without a GPU).
+
+The shared library is the product: there is no pure-Python or CPU execution path.  It is built in-tree so that it
+travels with the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libparseq_hip.so')
+SOURCES = ['parseq_hip.hip']
+HEADERS = ['common.h', 'gemm.h', 'encoder_attn.h', 'decoder_attn.h', 'rowops.h', os.path.join('..', '..', 'include', 'parseq_hip.h')]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)')
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-pass-failed',
+           '-o', LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print('[parseq_amd.build]', ' '.join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,84 @@
+// Common device helpers for the PARSeq gfx950 kernels: storage types, 16-byte fragments, MFMA wrappers.
+// Written for CDNA4 only (wave64, v_mfma_f32_16x16x32_bf16 / v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x4_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pq {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // a 16-byte chunk in registers (HIP's uint4 is a struct:
+                                                                   // selects on it go through scratch memory)
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return static_cast<float>(v); }
+
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return static_cast<bf16_t>(v); }  // RNE
+
+// A 16-byte operand fragment: 8 bf16 or 4 f32, exactly what one lane feeds to one k-group of a 16x16 (or 32x32)
+// MFMA.  In BYTES the two storage types look the same (64 bytes of K per 16x16 k-group), which lets the tiled
+// kernels share all their address arithmetic.
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { bf16x8 v; };
+template <> struct Frag<float> { f32x4 v; };
+
+template <typename T> constexpr int frag_elems() { return 16 / (int)sizeof(T); }
+
+// acc(16x16 tile, 4 f32 per lane) += A(16 x K-group) * B(K-group x 16).
+// Operand convention (cdna_hip_programming.md section 3): the first operand's lane l supplies row (l & 15),
+// k-slots of group (l >> 4); the second operand's lane l supplies column (l & 15), same k-slots.
+// Result: lane l holds D[row = 4 * (l >> 4) + r][col = l & 15], r = 0..3.
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& acc, const Frag<float>& a, const Frag<float>& b) {
+    // exact-f32 MFMA: 4 instructions of K=4, lane group g = l >> 4 supplies k = g for each; element j of the
+    // 16-byte fragment is k-slot (4 g + j) of the 16-wide k-group.  Bitwise an fmaf chain.
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[0], b.v[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[1], b.v[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[2], b.v[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[3], b.v[3], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// reductions over an aligned group of 32 lanes (one half-wave)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    // exact-erf GELU (torch.nn.GELU() default / F.gelu): 0.5 x (1 + erf(x / sqrt(2)))
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* p, const float v[4]);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float v[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const float v[4]) {
+    bf16x4 o;
+    o[0] = static_cast<bf16_t>(v[0]); o[1] = static_cast<bf16_t>(v[1]);
+    o[2] = static_cast<bf16_t>(v[2]); o[3] = static_cast<bf16_t>(v[3]);
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+}  // namespace pq

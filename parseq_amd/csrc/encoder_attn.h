@@ -1,0 +1,185 @@
+// Encoder self-attention for one (image, head): softmax(q k^T * hd^-0.5) v over N = 128 visual tokens, hd = 64.
+// (timm Attention with fused_attn -> F.scaled_dot_product_attention, no mask)
+//
+// Inputs come from the qkv GEMM epilogue (gemm.h EpiQKV): q, k as [B][H][N][hd], v transposed as vt [B][H][hd][N].
+// Output: ao[(b * N + t)][h * hd + d]  (row-major [B*N, E], the A operand of the proj GEMM).
+//
+// bf16 path (attn_mfma_kernel): one workgroup of 4 waves per (b, h); wave w owns queries 32w .. 32w+31.
+//   S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q straight from global): every lane then holds
+//   64 of the 128 scores of ONE query (its partner lane l ^ 32 holds the other 64), so the row max / row sum are
+//   register-local plus one cross-half shuffle.  The un-normalised probabilities are packed to bf16 in registers and
+//   are, as they sit, the B operand of O^T = V^T P^T (A = V^T rows from LDS) — no LDS round trip, no permutes: the
+//   k-slot -> key assignment of the second MFMA is chosen to be whatever the first MFMA's C layout produced, and the
+//   V^T fragment is gathered with the same assignment (two 8-byte runs per lane).
+//   O^T leaves each lane with 4 consecutive d for its query -> 8-byte stores.
+// f32 path (attn_f32_kernel): exact-mode reference structure, one thread per query, K / V^T broadcast from LDS.
+#pragma once
+#include "common.h"
+
+namespace pq {
+
+constexpr int ATT_N = 128;     // tokens
+constexpr int ATT_HD = 64;     // head dim
+constexpr int ATT_KROWB = ATT_HD * 2 + 16;    // K row pitch in LDS (bytes): 144 -> conflict-free ds_read_b128
+constexpr int ATT_VROWB = ATT_N * 2 + 8;      // V^T row pitch in LDS (bytes): 264 -> conflict-free ds_read_b64
+
+__global__ __launch_bounds__(256)
+void attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
+                      bf16_t* __restrict__ ao, int heads, float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_N * ATT_KROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[ATT_HD * ATT_VROWB];
+
+    const int bh = blockIdx.x;                 // b * heads + h
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t base = (size_t)bh * ATT_N * ATT_HD;     // same element count for q, k and vt blocks
+    const int E = heads * ATT_HD;
+
+    // ---- stage K [128][64] and V^T [64][128] into LDS (contiguous 16 KB each in global) ----
+    {
+        const uint4* kg = reinterpret_cast<const uint4*>(k + base);
+        const uint4* vg = reinterpret_cast<const uint4*>(vt + base);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int c = it * 256 + tid;
+            const uint4 kv = kg[c];
+            *reinterpret_cast<uint4*>(Ks + (c >> 3) * ATT_KROWB + (c & 7) * 16) = kv;
+            const uint4 vv = vg[c];
+            unsigned char* dst = Vs + (c >> 4) * ATT_VROWB + (c & 15) * 16;     // 8-byte aligned only
+            *reinterpret_cast<uint2*>(dst) = make_uint2(vv.x, vv.y);
+            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(vv.z, vv.w);
+        }
+    }
+
+    // ---- Q fragments for this wave's 32 queries: B operand, lane (query = l & 31, hi = l >> 5), d = 16 ks + 8 hi + j ----
+    const int qi = lane & 31, hi = lane >> 5;
+    const int q0 = wid * 32;
+    bf16x8 qf[4];
+    {
+        const bf16_t* qrow = q + base + (size_t)(q0 + qi) * ATT_HD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: st[t][r] = score(key = 32 t + (r & 3) + 8 (r >> 2) + 4 hi, query = qi) ----
+    f32x16 st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        st[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned char* kb = Ks + (t * 32 + qi) * ATT_KROWB + hi * 16;      // A operand: row = key 32 t + (l & 31)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + ks * 32);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[t], 0, 0, 0);
+        }
+    }
+
+    // ---- softmax over the 128 keys of query qi (64 here, 64 in lane ^ 32) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c = scale * 1.44269504088896340736f;       // exp(scale (s - m)) = exp2(c s - c m)
+    const float mc = mx * c;
+    float sum = 0.f;
+    bf16x8 pf[4][2];                                        // B operand of the PV MFMA, k-step (t, m2)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = exp2f(st[t][m2 * 8 + j] * c - mc);
+                sum += p;
+                pf[t][m2][j] = static_cast<bf16_t>(p);
+            }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    // ---- O^T = V^T P^T : A operand lane (d = 32 nt + (l & 31), hi): V^T[d][32 t + 16 m2 + 4 hi + {0..3, 8..11}] ----
+    f32x16 ot[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        ot[nt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned char* vb = Vs + (nt * 32 + qi) * ATT_VROWB + hi * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const unsigned char* p0 = vb + (t * 32 + m2 * 16) * 2;
+                union { bf16x8 v; uint2 u[2]; } vf;
+                vf.u[0] = *reinterpret_cast<const uint2*>(p0);
+                vf.u[1] = *reinterpret_cast<const uint2*>(p0 + 16);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf[t][m2], ot[nt], 0, 0, 0);
+            }
+    }
+
+    // ---- store: lane holds, for query qi, d = 32 nt + 8 rg + 4 hi + {0..3} ----
+    bf16_t* orow = ao + ((size_t)b * ATT_N + q0 + qi) * E + h * ATT_HD + 4 * hi;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float o[4] = {ot[nt][rg * 4 + 0] * inv, ot[nt][rg * 4 + 1] * inv, ot[nt][rg * 4 + 2] * inv, ot[nt][rg * 4 + 3] * inv};
+            store4<bf16_t>(orow + nt * 32 + rg * 8, o);
+        }
+}
+
+// Exact-f32 attention: 128 threads, thread = query; K [128][64] and V^T [64][128] broadcast-read from LDS.
+__global__ __launch_bounds__(128)
+void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vt,
+                     float* __restrict__ ao, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];
+    float* Ks = reinterpret_cast<float*>(smem_att);                 // [128][64]
+    float* Vs = Ks + ATT_N * ATT_HD;                                // [64][128]
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x;
+    const size_t base = (size_t)bh * ATT_N * ATT_HD;
+    const int E = heads * ATT_HD;
+    {
+        const float4* kg = reinterpret_cast<const float4*>(k + base);
+        const float4* vg = reinterpret_cast<const float4*>(vt + base);
+        float4* kd = reinterpret_cast<float4*>(Ks);
+        float4* vd = reinterpret_cast<float4*>(Vs);
+        for (int c = tid; c < ATT_N * ATT_HD / 4; c += 128) { kd[c] = kg[c]; vd[c] = vg[c]; }
+    }
+    float qr[ATT_HD];
+    {
+        const float4* qg = reinterpret_cast<const float4*>(q + base + (size_t)tid * ATT_HD);
+#pragma unroll
+        for (int i = 0; i < ATT_HD / 4; ++i) { const float4 v = qg[i]; qr[4 * i] = v.x; qr[4 * i + 1] = v.y; qr[4 * i + 2] = v.z; qr[4 * i + 3] = v.w; }
+    }
+    __syncthreads();
+    // pass 1: scores' max; pass 2: exp / sum / weighted V.  (Scores recomputed instead of stored: 128 regs saved.)
+    float mx = -INFINITY;
+    for (int key = 0; key < ATT_N; ++key) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < ATT_HD; ++d) s = fmaf(qr[d], Ks[key * ATT_HD + d], s);
+        mx = fmaxf(mx, s * scale);
+    }
+    float acc[ATT_HD];
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) acc[d] = 0.f;
+    float sum = 0.f;
+    for (int key = 0; key < ATT_N; ++key) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < ATT_HD; ++d) s = fmaf(qr[d], Ks[key * ATT_HD + d], s);
+        const float p = expf(s * scale - mx);
+        sum += p;
+#pragma unroll
+        for (int d = 0; d < ATT_HD; ++d) acc[d] = fmaf(p, Vs[d * ATT_N + key], acc[d]);
+    }
+    const float inv = 1.0f / sum;
+    float4* og = reinterpret_cast<float4*>(ao + ((size_t)b * ATT_N + tid) * E + h * ATT_HD);
+#pragma unroll
+    for (int i = 0; i < ATT_HD / 4; ++i)
+        og[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
+}
+
+}  // namespace pq

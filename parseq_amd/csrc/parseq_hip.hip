@@ -1,0 +1,673 @@
+// libparseq_hip.so — C ABI (include/parseq_hip.h) and launch orchestration of the PARSeq inference path on gfx950.
+// Host side only decides WHICH kernels run in WHAT order on the caller's stream; all arithmetic is in the kernels of
+// gemm.h / encoder_attn.h / decoder_attn.h / rowops.h.  No CPU fallback exists: without a gfx950 device every entry
+// point fails with PARSEQ_E_ARCH / PARSEQ_E_HIP.
+#include "../../include/parseq_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+#include "decoder_attn.h"
+#include "encoder_attn.h"
+#include "gemm.h"
+#include "rowops.h"
+
+using namespace pq;
+
+// -------------------------------------------------------------------------------------------------------------------
+// errors
+// -------------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(PARSEQ_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(expr)                   \
+    do {                            \
+        int r_ = (expr);            \
+        if (r_ != 0) return r_;     \
+    } while (0)
+
+// -------------------------------------------------------------------------------------------------------------------
+// optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
+// -------------------------------------------------------------------------------------------------------------------
+enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_COUNT };
+static const char* const kProfNames[T_COUNT] = {"enc.patch_embed_gemm", "enc.layernorm", "enc.qkv_gemm", "enc.attention", "enc.proj_gemm",
+                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
+                                                "dec.cross_attention", "dec.layernorm", "dec.misc"};
+struct Profiler {
+    bool enabled = false;
+    std::vector<hipEvent_t> pool;          // events, used pairwise
+    std::vector<int> tags;                 // tag of pair i
+    size_t used = 0;                       // pairs in flight
+    double total_ms[T_COUNT] = {0};
+    long long launches[T_COUNT] = {0};
+    int begin(int tag, hipStream_t s) {
+        if (!enabled) return -1;
+        if ((used + 1) * 2 > pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+            pool.push_back(a); pool.push_back(b);
+        }
+        if (tags.size() <= used) tags.resize(used + 1);
+        tags[used] = tag;
+        (void)hipEventRecord(pool[2 * used], s);
+        return (int)used++;
+    }
+    void end(int id, hipStream_t s) { if (id >= 0) (void)hipEventRecord(pool[2 * id + 1], s); }
+    void collect() {
+        for (size_t i = 0; i < used; ++i) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pool[2 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms, pool[2 * i], pool[2 * i + 1]) == hipSuccess) {
+                total_ms[tags[i]] += ms; launches[tags[i]]++;
+            }
+        }
+        used = 0;
+    }
+    void reset() { collect(); for (int t = 0; t < T_COUNT; ++t) { total_ms[t] = 0; launches[t] = 0; } }
+    ~Profiler() { for (auto e : pool) (void)hipEventDestroy(e); }
+};
+struct ProfScope {
+    Profiler* p; int id; hipStream_t s;
+    ProfScope(Profiler* p_, int tag, hipStream_t s_) : p(p_), id(p_ ? p_->begin(tag, s_) : -1), s(s_) {}
+    ~ProfScope() { if (p) p->end(id, s); }
+};
+
+extern "C" int parseq_abi_version(void) { return PARSEQ_ABI_VERSION; }
+extern "C" const char* parseq_last_error(void) { return g_err; }
+
+// -------------------------------------------------------------------------------------------------------------------
+// model
+// -------------------------------------------------------------------------------------------------------------------
+struct ParamSpec { std::string key; int64_t numel; size_t offset; bool set; };
+
+struct parseq_model {
+    parseq_config cfg;
+    int device = 0;
+    int tokens = 0;           // visual tokens per image
+    int patch_k = 0;          // 3 * patch_h * patch_w
+    int classes = 0;          // num_tokens - 2
+    std::vector<ParamSpec> params;
+    std::unordered_map<std::string, int> index;
+    float* master = nullptr;  // device, all parameters fp32 back to back (each 16-byte aligned)
+    size_t master_elems = 0;
+    uint64_t version = 0;
+
+    const float* p(const std::string& key) const { return master + params[index.at(key)].offset; }
+};
+
+static void add_param(parseq_model* m, const std::string& key, int64_t numel) {
+    ParamSpec s{key, numel, m->master_elems, false};
+    m->index[key] = (int)m->params.size();
+    m->params.push_back(s);
+    m->master_elems += (size_t)((numel + 7) / 8 * 8);   // keeps every tensor 16-byte aligned in bf16 too
+}
+
+static int check_arch() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(PARSEQ_E_HIP, "hipGetDevice failed: %s (no ROCm device visible?)", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(PARSEQ_E_ARCH, "libparseq_hip is built for gfx950 (MI355X) only; device %d is %s", dev, prop.gcnArchName);
+    return 0;
+}
+
+extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {
+    if (!c || !out) return fail(PARSEQ_E_INVALID, "null argument");
+    CHK(check_arch());
+    const int E = c->embed_dim;
+    if (c->dec_depth != 1) return fail(PARSEQ_E_INVALID, "dec_depth=%d: only the reference's dec_depth == 1 is supported", c->dec_depth);
+    if (E != 192 && E != 384 && E != 768) return fail(PARSEQ_E_INVALID, "embed_dim=%d not in {192, 384, 768}", E);
+    if (c->enc_heads <= 0 || E / c->enc_heads != ATT_HD || E % c->enc_heads) return fail(PARSEQ_E_INVALID, "encoder head_dim must be 64 (embed_dim %d / heads %d)", E, c->enc_heads);
+    if (c->dec_heads <= 0 || E / c->dec_heads != 32 || E % c->dec_heads) return fail(PARSEQ_E_INVALID, "decoder head_dim must be 32 (embed_dim %d / heads %d)", E, c->dec_heads);
+    if (c->patch_h <= 0 || c->patch_w <= 0 || c->img_h % c->patch_h || c->img_w % c->patch_w || c->patch_w % 8)
+        return fail(PARSEQ_E_INVALID, "unsupported image/patch geometry %dx%d / %dx%d", c->img_h, c->img_w, c->patch_h, c->patch_w);
+    const int tokens = (c->img_h / c->patch_h) * (c->img_w / c->patch_w);
+    if (tokens != ATT_N) return fail(PARSEQ_E_INVALID, "%d visual tokens: this build of the encoder attention kernel handles exactly %d (32x128 crops, 4x8 patches)", tokens, ATT_N);
+    if (c->max_label_length < 1 || c->max_label_length + 1 > DEC_MAXL) return fail(PARSEQ_E_INVALID, "max_label_length=%d outside [1, %d]", c->max_label_length, DEC_MAXL - 1);
+    if (c->num_tokens < 3) return fail(PARSEQ_E_INVALID, "num_tokens=%d", c->num_tokens);
+
+    auto* m = new parseq_model();
+    m->cfg = *c;
+    HIPCHK(hipGetDevice(&m->device));
+    m->tokens = tokens;
+    m->patch_k = 3 * c->patch_h * c->patch_w;
+    m->classes = c->num_tokens - 2;
+    const int64_t F = (int64_t)E * c->enc_mlp_ratio, Fd = (int64_t)E * c->dec_mlp_ratio;
+    add_param(m, "pos_queries", (int64_t)(c->max_label_length + 1) * E);
+    add_param(m, "encoder.pos_embed", (int64_t)tokens * E);
+    add_param(m, "encoder.patch_embed.proj.weight", (int64_t)E * m->patch_k);
+    add_param(m, "encoder.patch_embed.proj.bias", E);
+    for (int i = 0; i < c->enc_depth; ++i) {
+        const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+        add_param(m, p + "norm1.weight", E); add_param(m, p + "norm1.bias", E);
+        add_param(m, p + "attn.qkv.weight", (int64_t)3 * E * E); add_param(m, p + "attn.qkv.bias", 3 * E);
+        add_param(m, p + "attn.proj.weight", (int64_t)E * E); add_param(m, p + "attn.proj.bias", E);
+        add_param(m, p + "norm2.weight", E); add_param(m, p + "norm2.bias", E);
+        add_param(m, p + "mlp.fc1.weight", F * E); add_param(m, p + "mlp.fc1.bias", F);
+        add_param(m, p + "mlp.fc2.weight", E * F); add_param(m, p + "mlp.fc2.bias", E);
+    }
+    add_param(m, "encoder.norm.weight", E); add_param(m, "encoder.norm.bias", E);
+    {
+        const std::string p = "decoder.layers.0.";
+        for (const char* a : {"self_attn.", "cross_attn."}) {
+            add_param(m, p + a + "in_proj_weight", (int64_t)3 * E * E); add_param(m, p + a + "in_proj_bias", 3 * E);
+            add_param(m, p + a + "out_proj.weight", (int64_t)E * E); add_param(m, p + a + "out_proj.bias", E);
+        }
+        add_param(m, p + "linear1.weight", Fd * E); add_param(m, p + "linear1.bias", Fd);
+        add_param(m, p + "linear2.weight", E * Fd); add_param(m, p + "linear2.bias", E);
+        for (const char* n : {"norm1.", "norm2.", "norm_q.", "norm_c."}) { add_param(m, p + n + "weight", E); add_param(m, p + n + "bias", E); }
+    }
+    add_param(m, "decoder.norm.weight", E); add_param(m, "decoder.norm.bias", E);
+    add_param(m, "head.weight", (int64_t)m->classes * E); add_param(m, "head.bias", m->classes);
+    add_param(m, "text_embed.embedding.weight", (int64_t)c->num_tokens * E);
+    hipError_t e = hipMalloc(&m->master, m->master_elems * sizeof(float));
+    if (e != hipSuccess) { delete m; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) failed: %s", m->master_elems * sizeof(float), hipGetErrorString(e)); }
+    *out = m;
+    return 0;
+}
+
+extern "C" void parseq_model_destroy(parseq_model* m) {
+    if (!m) return;
+    if (m->master) (void)hipFree(m->master);
+    delete m;
+}
+
+extern "C" int parseq_model_set_param(parseq_model* m, const char* key, const float* device_ptr, int64_t numel, void* stream) {
+    if (!m || !key || !device_ptr) return fail(PARSEQ_E_INVALID, "null argument");
+    auto it = m->index.find(key);
+    if (it == m->index.end()) return fail(PARSEQ_E_INVALID, "unknown parameter key '%s'", key);
+    ParamSpec& s = m->params[it->second];
+    if (s.numel != numel) return fail(PARSEQ_E_INVALID, "parameter '%s': expected %lld elements, got %lld", key, (long long)s.numel, (long long)numel);
+    HIPCHK(hipMemcpyAsync(m->master + s.offset, device_ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    s.set = true;
+    m->version++;
+    return 0;
+}
+
+extern "C" int parseq_model_num_params(const parseq_model* m) { return m ? (int)m->params.size() : 0; }
+extern "C" int parseq_model_param_info(const parseq_model* m, int index, const char** key, int64_t* numel) {
+    if (!m || index < 0 || index >= (int)m->params.size()) return fail(PARSEQ_E_INVALID, "bad parameter index");
+    if (key) *key = m->params[index].key.c_str();
+    if (numel) *numel = m->params[index].numel;
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// plan
+// -------------------------------------------------------------------------------------------------------------------
+__global__ void cvt_f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        const float o[4] = {v.x, v.y, v.z, v.w};
+        store4<bf16_t>(dst + i, o);
+    } else {
+        for (size_t j = i; j < n; ++j) dst[j] = static_cast<bf16_t>(src[j]);
+    }
+}
+
+__global__ void cloze_mask_kernel(unsigned char* __restrict__ mask, int n, int ld) {
+    // model.py:117,157: causal triu(1) with triu(2) cleared -> query i may not see key i + 1 only
+    const int i = blockIdx.x, j = threadIdx.x;
+    if (i < n && j < ld) mask[i * ld + j] = (j == i + 1) ? 1 : 0;
+}
+
+struct parseq_plan {
+    parseq_model* m = nullptr;
+    int max_batch = 0;
+    int precision = PARSEQ_BF16;
+    uint64_t packed_version = ~0ull;
+    unsigned char* arena = nullptr;
+    size_t arena_bytes = 0;
+    // carved pointers (typed at use)
+    void* wpack = nullptr;         // all parameters in storage type T (bf16 mode only; f32 mode aliases the master)
+    void* kvtab = nullptr;         // T [npos][num_tokens][2E]
+    float* qself = nullptr;        // [npos][E], pre-scaled
+    void* ctab_ln = nullptr;       // T [npos * num_tokens][E] scratch for table build
+    float* x = nullptr;            // fp32 [B*N][E]
+    void *xn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ao = nullptr, *h = nullptr, *kvmem = nullptr;
+    void *sa = nullptr, *tn = nullptr, *ca = nullptr, *hdn = nullptr;
+    float *t = nullptr, *qc = nullptr;
+    int* tok = nullptr;            // [B][LDT]
+    unsigned char* kpm = nullptr;  // [B][LDT]
+    unsigned char* eos_seen = nullptr;
+    unsigned char* cloze = nullptr;  // [npos][LDT]
+    unsigned char* qmask_user = nullptr;  // [npos][LDT] staging for parseq_decode_logits
+    int* counters = nullptr;       // [0] eos_rows, [1] ar_len
+    int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
+    Profiler prof;
+};
+constexpr int LDT = 32;            // row pitch of token / mask arrays
+
+static size_t carve(size_t& off, size_t bytes) {
+    const size_t o = off;
+    off += (bytes + 255) / 256 * 256;
+    return o;
+}
+
+template <typename T> struct Weights {
+    const parseq_model* m; const T* base;
+    const T* w(const std::string& key) const { return base + m->params[m->index.at(key)].offset; }
+};
+
+template <typename T>
+static Weights<T> weights_of(const parseq_plan* p) {
+    if constexpr (sizeof(T) == 4) return Weights<T>{p->m, reinterpret_cast<const T*>(p->m->master)};
+    else return Weights<T>{p->m, reinterpret_cast<const T*>(p->wpack)};
+}
+
+template <typename TO>
+static int run_layernorm(hipStream_t s, const float* x, const float* w, const float* b, TO* out, float* out32, int rows, int E, float eps) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (E) {
+        case 192: hipLaunchKernelGGL((layernorm_kernel<TO, 192>), grid, block, 0, s, x, w, b, out, out32, rows, eps); break;
+        case 384: hipLaunchKernelGGL((layernorm_kernel<TO, 384>), grid, block, 0, s, x, w, b, out, out32, rows, eps); break;
+        case 768: hipLaunchKernelGGL((layernorm_kernel<TO, 768>), grid, block, 0, s, x, w, b, out, out32, rows, eps); break;
+        default: return fail(PARSEQ_E_INVALID, "layernorm: E=%d not in {192, 384, 768}", E);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// GEMM dispatch: big tiles for the encoder's M = batch * 128 rows, small tiles for the decoder's M = batch (* 26).
+template <typename T, typename ALoad, typename Epi>
+static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, int N, int K, const Epi& epi) {
+    if (M >= 4096) HIPCHK((launch_gemm<T, 128, 128, 2, 2>(s, a, W, ldw, M, N, K, epi)));
+    else HIPCHK((launch_gemm<T, 64, 64, 2, 2>(s, a, W, ldw, M, N, K, epi)));
+    return 0;
+}
+
+static EpiBase epi_base(int M, int N, const float* bias) { EpiBase b; b.M = M; b.N = N; b.bias = bias; return b; }
+template <typename TO> static EpiStore<TO> epi_store(int M, int N, const float* bias, TO* out, int ldo, float scale = 1.f, int period = 0, int stride = 0, int offset = 0) {
+    EpiStore<TO> e; static_cast<EpiBase&>(e) = epi_base(M, N, bias); e.out = out; e.ldo = ldo; e.period = period; e.stride = stride; e.offset = offset; e.scale = scale; return e;
+}
+template <typename TO> static EpiGelu<TO> epi_gelu(int M, int N, const float* bias, TO* out, int ldo) {
+    EpiGelu<TO> e; static_cast<EpiBase&>(e) = epi_base(M, N, bias); e.out = out; e.ldo = ldo; return e;
+}
+static EpiResid epi_resid(int M, int N, const float* bias, float* x, int ldx) {
+    EpiResid e; static_cast<EpiBase&>(e) = epi_base(M, N, bias); e.x = x; e.ldx = ldx; return e;
+}
+static EpiAddTable epi_table(int M, int N, const float* bias, float* x, int ldx, const float* table, int ldt, int period, int offset) {
+    EpiAddTable e; static_cast<EpiBase&>(e) = epi_base(M, N, bias); e.x = x; e.ldx = ldx; e.table = table; e.ldt = ldt; e.period = period; e.offset = offset; return e;
+}
+
+template <typename T>
+static int build_tables(parseq_plan* p, hipStream_t s) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int E = c.embed_dim, npos = c.max_label_length + 1, ntok = c.num_tokens;
+    const Weights<T> W = weights_of<T>(p);
+    const std::string d = "decoder.layers.0.";
+    // content K/V table: norm_c(content(pos, tok)) @ Wkv_self^T + bkv
+    {
+        const int rows = npos * ntok;
+        const dim3 grid((rows + 3) / 4), block(256);
+        T* ln = reinterpret_cast<T*>(p->ctab_ln);
+        const float* emb = m->p("text_embed.embedding.weight"); const float* pq_ = m->p("pos_queries");
+        const float* nw = m->p(d + "norm_c.weight"); const float* nb = m->p(d + "norm_c.bias");
+        switch (E) {
+            case 192: hipLaunchKernelGGL((content_ln_kernel<T, 192>), grid, block, 0, s, emb, pq_, nw, nb, ln, npos, ntok, c.dec_ln_eps); break;
+            case 384: hipLaunchKernelGGL((content_ln_kernel<T, 384>), grid, block, 0, s, emb, pq_, nw, nb, ln, npos, ntok, c.dec_ln_eps); break;
+            default:  hipLaunchKernelGGL((content_ln_kernel<T, 768>), grid, block, 0, s, emb, pq_, nw, nb, ln, npos, ntok, c.dec_ln_eps); break;
+        }
+        HIPCHK(hipGetLastError());
+        CHK((run_gemm<T>(s, ARowMajor<T>{ln, E}, W.w(d + "self_attn.in_proj_weight") + (size_t)E * E, E, rows, 2 * E, E,
+                         epi_store<T>(rows, 2 * E, m->p(d + "self_attn.in_proj_bias") + E, reinterpret_cast<T*>(p->kvtab), 2 * E))));
+    }
+    // position-query table: (norm_q(pos_queries[i]) @ Wq_self^T + bq) / sqrt(hd)      (modules.py:90, functional.py q_scaled)
+    {
+        T* ln = reinterpret_cast<T*>(p->ctab_ln);
+        CHK((run_layernorm<T>(s, m->p("pos_queries"), m->p(d + "norm_q.weight"), m->p(d + "norm_q.bias"), ln, nullptr, npos, E, c.dec_ln_eps)));
+        const float scale = sqrtf(1.0f / (float)(E / c.dec_heads));
+        CHK((run_gemm<T>(s, ARowMajor<T>{ln, E}, W.w(d + "self_attn.in_proj_weight"), E, npos, E, E,
+                         epi_store<float>(npos, E, m->p(d + "self_attn.in_proj_bias"), p->qself, E, scale))));
+    }
+    return 0;
+}
+
+static int pack_weights(parseq_plan* p, hipStream_t s) {
+    const parseq_model* m = p->m;
+    for (const auto& ps : m->params)
+        if (!ps.set) return fail(PARSEQ_E_STATE, "parameter '%s' has not been set", ps.key.c_str());
+    if (p->precision == PARSEQ_BF16) {
+        const size_t n = m->master_elems;
+        hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<bf16_t*>(p->wpack), n);
+        HIPCHK(hipGetLastError());
+        CHK(build_tables<bf16_t>(p, s));
+    } else {
+        CHK(build_tables<float>(p, s));
+    }
+    const int npos = m->cfg.max_label_length + 1;
+    hipLaunchKernelGGL(cloze_mask_kernel, dim3(npos), dim3(LDT), 0, s, p->cloze, npos, LDT);
+    HIPCHK(hipGetLastError());
+    p->packed_version = m->version;
+    return 0;
+}
+
+extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out) {
+    if (!m || !out || max_batch <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
+    if (precision != PARSEQ_F32 && precision != PARSEQ_BF16) return fail(PARSEQ_E_INVALID, "precision %d", precision);
+    HIPCHK(hipSetDevice(m->device));
+    const parseq_config& c = m->cfg;
+    const size_t E = c.embed_dim, N = m->tokens, B = max_batch, ts = precision == PARSEQ_BF16 ? 2 : 4;
+    const size_t npos = c.max_label_length + 1, F = E * c.enc_mlp_ratio, Fd = E * c.dec_mlp_ratio;
+    const size_t rows = B * N, drows = B * npos;
+    auto* p = new parseq_plan();
+    p->m = m; p->max_batch = max_batch; p->precision = precision;
+    size_t off = 0;
+    const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : 0);
+    const size_t o_kvtab = carve(off, npos * c.num_tokens * 2 * E * ts);
+    const size_t o_qself = carve(off, npos * E * 4);
+    const size_t o_ctab = carve(off, npos * c.num_tokens * E * ts);
+    const size_t o_x = carve(off, rows * E * 4);
+    const size_t o_xn = carve(off, rows * E * ts);
+    const size_t o_q = carve(off, rows * E * ts), o_k = carve(off, rows * E * ts), o_vt = carve(off, rows * E * ts);
+    const size_t o_ao = carve(off, rows * E * ts);
+    const size_t o_h = carve(off, rows * F * ts);
+    const size_t o_kvmem = carve(off, rows * 2 * E * ts);
+    const size_t o_sa = carve(off, drows * E * ts), o_tn = carve(off, drows * E * ts), o_ca = carve(off, drows * E * ts);
+    const size_t o_hdn = carve(off, drows * Fd * ts);
+    const size_t o_t = carve(off, drows * E * 4), o_qc = carve(off, drows * E * 4);
+    const size_t o_tok = carve(off, B * LDT * 4), o_kpm = carve(off, B * LDT), o_eos = carve(off, B);
+    const size_t o_cloze = carve(off, npos * LDT), o_qmu = carve(off, npos * LDT), o_cnt = carve(off, 64);
+    p->arena_bytes = off;
+    hipError_t e = hipMalloc(&p->arena, off);
+    if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
+    unsigned char* a = p->arena;
+    p->wpack = a + o_wpack; p->kvtab = a + o_kvtab; p->qself = (float*)(a + o_qself); p->ctab_ln = a + o_ctab;
+    p->x = (float*)(a + o_x); p->xn = a + o_xn; p->q = a + o_q; p->k = a + o_k; p->vt = a + o_vt; p->ao = a + o_ao; p->h = a + o_h;
+    p->kvmem = a + o_kvmem; p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
+    p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
+    p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
+    int r = pack_weights(p, (hipStream_t)stream);
+    if (r != 0) { (void)hipFree(p->arena); delete p; return r; }
+    *out = p;
+    return 0;
+}
+
+extern "C" int parseq_plan_refresh(parseq_plan* p, void* stream) {
+    if (!p) return fail(PARSEQ_E_INVALID, "null plan");
+    return pack_weights(p, (hipStream_t)stream);
+}
+
+extern "C" void parseq_plan_destroy(parseq_plan* p) {
+    if (!p) return;
+    if (p->arena) (void)hipFree(p->arena);
+    delete p;
+}
+
+extern "C" size_t parseq_plan_workspace_bytes(const parseq_plan* p) { return p ? p->arena_bytes : 0; }
+
+extern "C" int parseq_plan_set_profiling(parseq_plan* p, int enable) {
+    if (!p) return fail(PARSEQ_E_INVALID, "null plan");
+    p->prof.reset();
+    p->prof.enabled = enable != 0;
+    return 0;
+}
+
+extern "C" int parseq_plan_get_profile(parseq_plan* p, int index, const char** name, double* total_ms, int64_t* launches) {
+    if (!p) return fail(PARSEQ_E_INVALID, "null plan");
+    if (index < 0 || index >= T_COUNT) return 1;          // past the end (not an error: lets the caller iterate)
+    p->prof.collect();
+    if (name) *name = kProfNames[index];
+    if (total_ms) *total_ms = p->prof.total_ms[index];
+    if (launches) *launches = p->prof.launches[index];
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// encoder
+// -------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads) {
+    const float scale = 1.0f / sqrtf((float)ATT_HD);
+    if constexpr (sizeof(T) == 2) {
+        hipLaunchKernelGGL(attn_mfma_kernel, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
+    } else {
+        constexpr size_t lds = (size_t)2 * ATT_N * ATT_HD * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
+        hipLaunchKernelGGL(attn_f32_kernel, dim3(bh), dim3(128), lds, s, q, k, vt, ao, heads, scale);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename T, typename TI>
+static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_out, hipStream_t s) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int E = c.embed_dim, N = m->tokens, M = B * N, H = c.enc_heads, F = E * c.enc_mlp_ratio;
+    const Weights<T> W = weights_of<T>(p);
+    T* xn = reinterpret_cast<T*>(p->xn); T* q = reinterpret_cast<T*>(p->q); T* k = reinterpret_cast<T*>(p->k);
+    T* vt = reinterpret_cast<T*>(p->vt); T* ao = reinterpret_cast<T*>(p->ao); T* h = reinterpret_cast<T*>(p->h);
+
+    // patch embedding (im2col-free) + bias + pos_embed -> x        timm PatchEmbed; forward_features `x + pos_embed`
+    APatch<T, TI> ap{images, 3, c.img_h, c.img_w, c.patch_h, c.patch_w, c.img_w / c.patch_w, N};
+    { ProfScope ps_(&p->prof, T_PATCH, s); CHK((run_gemm<T>(s, ap, W.w("encoder.patch_embed.proj.weight"), m->patch_k, M, E, m->patch_k,
+                     epi_table(M, E, m->p("encoder.patch_embed.proj.bias"), p->x, E, m->p("encoder.pos_embed"), E, N, 0)))); }
+    for (int i = 0; i < c.enc_depth; ++i) {
+        const std::string b = "encoder.blocks." + std::to_string(i) + ".";
+        { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
+        EpiQKV<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
+        eq.q = q; eq.k = k; eq.vt = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N;
+        { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
+        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H))); }
+        { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
+        { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
+        { ProfScope ps_(&p->prof, T_FC1, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "mlp.fc1.weight"), E, M, F, E, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F)))); }
+        { ProfScope ps_(&p->prof, T_FC2, s); CHK((run_gemm<T>(s, ARowMajor<T>{h, F}, W.w(b + "mlp.fc2.weight"), F, M, E, F, epi_resid(M, E, m->p(b + "mlp.fc2.bias"), p->x, E)))); }
+    }
+    // final norm -> memory (fp32 to the caller, T copy as GEMM operand), then the cross-attention K/V of memory, ONCE
+    { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p("encoder.norm.weight"), m->p("encoder.norm.bias"), xn, memory_out, M, E, c.enc_ln_eps))); }
+    const std::string d = "decoder.layers.0.cross_attn.";
+    { ProfScope ps_(&p->prof, T_KVMEM, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(d + "in_proj_weight") + (size_t)E * E, E, M, 2 * E, E,
+                     epi_store<T>(M, 2 * E, m->p(d + "in_proj_bias") + E, reinterpret_cast<T*>(p->kvmem), 2 * E)))); }
+    p->last_batch = B;
+    return 0;
+}
+
+static int check_call(parseq_plan* p, int batch, int images_dtype) {
+    if (!p) return fail(PARSEQ_E_INVALID, "null plan");
+    if (batch <= 0 || batch > p->max_batch) return fail(PARSEQ_E_INVALID, "batch %d outside (0, %d]", batch, p->max_batch);
+    if (images_dtype != PARSEQ_F32 && images_dtype != PARSEQ_BF16) return fail(PARSEQ_E_INVALID, "images_dtype %d", images_dtype);
+    if (p->packed_version != p->m->version) return fail(PARSEQ_E_STATE, "model parameters changed after the plan was packed; call parseq_plan_refresh");
+    return 0;
+}
+
+static int encode_dispatch(parseq_plan* p, const void* images, int images_dtype, int batch, float* memory_out, hipStream_t s) {
+    if (p->precision == PARSEQ_BF16) {
+        if (images_dtype == PARSEQ_F32) return encode_impl<bf16_t, float>(p, (const float*)images, batch, memory_out, s);
+        return encode_impl<bf16_t, bf16_t>(p, (const bf16_t*)images, batch, memory_out, s);
+    }
+    if (images_dtype == PARSEQ_F32) return encode_impl<float, float>(p, (const float*)images, batch, memory_out, s);
+    return encode_impl<float, bf16_t>(p, (const bf16_t*)images, batch, memory_out, s);
+}
+
+extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtype, int batch, float* memory_out, void* stream) {
+    CHK(check_call(p, batch, images_dtype));
+    if (!images) return fail(PARSEQ_E_INVALID, "null images");
+    return encode_dispatch(p, images, images_dtype, batch, memory_out, (hipStream_t)stream);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// decoder
+// -------------------------------------------------------------------------------------------------------------------
+template <typename T>
+static int run_self_attn(hipStream_t s, const parseq_plan* p, int E, int ntok, const unsigned char* qmask, const unsigned char* kpm,
+                         int Lk, int i0, int Lq, int B) {
+    const dim3 grid((B * Lq + 3) / 4), block(256);
+    const T* kvtab = reinterpret_cast<const T*>(p->kvtab); T* out = reinterpret_cast<T*>(p->sa);
+#define LAUNCH_SA(EE) hipLaunchKernelGGL((dec_self_attn_kernel<T, EE>), grid, block, 0, s, p->qself, kvtab, p->tok, LDT, ntok, qmask, LDT, kpm, LDT, Lk, i0, Lq, B, out)
+    switch (E) { case 192: LAUNCH_SA(192); break; case 384: LAUNCH_SA(384); break; default: LAUNCH_SA(768); break; }
+#undef LAUNCH_SA
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+static int run_cross_attn(hipStream_t s, const parseq_plan* p, int E, int Nk, int Lq, int B, float scale) {
+    const T* kvmem = reinterpret_cast<const T*>(p->kvmem); T* out = reinterpret_cast<T*>(p->ca);
+#define LAUNCH_CA(EE, QC) hipLaunchKernelGGL((dec_cross_attn_kernel<T, EE, QC>), dim3(B * ((Lq + QC - 1) / QC)), dim3(256), 0, s, p->qc, kvmem, Nk, Lq, scale, out)
+    if (Lq == 1) { switch (E) { case 192: LAUNCH_CA(192, 1); break; case 384: LAUNCH_CA(384, 1); break; default: LAUNCH_CA(768, 1); break; } }
+    else { switch (E) { case 192: LAUNCH_CA(192, 13); break; case 384: LAUNCH_CA(384, 13); break; default: LAUNCH_CA(768, 13); break; } }
+#undef LAUNCH_CA
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// One pass of the query stream (modules.py:55-98 with update_content=False, then decoder.norm and head) for queries
+// pos_queries[i0 : i0 + Lq] of every image against the content tokens p->tok[:, :Lk].  Writes
+// logits[b][i0 + qi][:] for qi < Lq into a [B][Ltot][C] tensor.
+template <typename T>
+static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
+                       float* logits, int Ltot) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int E = c.embed_dim, M = B * Lq, Fd = E * c.dec_mlp_ratio, C = m->classes;
+    const Weights<T> W = weights_of<T>(p);
+    const std::string d = "decoder.layers.0.";
+    T* sa = reinterpret_cast<T*>(p->sa); T* tn = reinterpret_cast<T*>(p->tn); T* ca = reinterpret_cast<T*>(p->ca); T* hdn = reinterpret_cast<T*>(p->hdn);
+    const float scale = sqrtf(1.0f / (float)(E / c.dec_heads));
+    // self-attention over the content table, out-projection, residual onto the raw position queries
+    { ProfScope ps_(&p->prof, T_DEC_SA, s); CHK((run_self_attn<T>(s, p, E, c.num_tokens, qmask, kpm, Lk, i0, Lq, B))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
+                     epi_table(M, E, m->p(d + "self_attn.out_proj.bias"), p->t, E, m->p("pos_queries"), E, Lq, i0)))); }
+    // cross-attention against memory (K/V cached in the plan)
+    { ProfScope ps_(&p->prof, T_DEC_LN, s); CHK((run_layernorm<T>(s, p->t, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), tn, nullptr, M, E, c.dec_ln_eps))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{tn, E}, W.w(d + "cross_attn.in_proj_weight"), E, M, E, E,
+                     epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
+    { ProfScope ps_(&p->prof, T_DEC_CA, s); CHK((run_cross_attn<T>(s, p, E, m->tokens, Lq, B, scale))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{ca, E}, W.w(d + "cross_attn.out_proj.weight"), E, M, E, E, epi_resid(M, E, m->p(d + "cross_attn.out_proj.bias"), p->t, E)))); }
+    // MLP
+    { ProfScope ps_(&p->prof, T_DEC_LN, s); CHK((run_layernorm<T>(s, p->t, m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), tn, nullptr, M, E, c.dec_ln_eps))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{tn, E}, W.w(d + "linear1.weight"), E, M, Fd, E, epi_gelu<T>(M, Fd, m->p(d + "linear1.bias"), hdn, Fd)))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{hdn, Fd}, W.w(d + "linear2.weight"), Fd, M, E, Fd, epi_resid(M, E, m->p(d + "linear2.bias"), p->t, E)))); }
+    // decoder.norm + head
+    { ProfScope ps_(&p->prof, T_DEC_LN, s); CHK((run_layernorm<T>(s, p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), tn, nullptr, M, E, c.dec_ln_eps))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{tn, E}, W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), logits, C, 1.f, Lq, Ltot, i0)))); }
+    return 0;
+}
+
+template <typename T>
+static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int num_steps, float* logits, int* out_len, hipStream_t s) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int C = m->classes;
+    const bool ar = flags & PARSEQ_FLAG_DECODE_AR, testing = flags & PARSEQ_FLAG_TESTING;
+    int* eos_rows = p->counters; int* ar_len = p->counters + 1;
+    hipLaunchKernelGGL(ar_init_kernel, dim3((B * LDT + 255) / 256), dim3(256), 0, s, p->tok, LDT, B, c.bos_id, c.pad_id, p->eos_seen, eos_rows, ar_len, num_steps);
+    HIPCHK(hipGetLastError());
+    if (ar) {
+        // model.py:119-147.  All num_steps steps are always run (no per-step host sync); the step at which the reference
+        // would have stopped is recorded on the device and only truncates the returned view.
+        for (int i = 0; i < num_steps; ++i) {
+            CHK((decode_pass<T>(p, s, B, i + 1, i, 1, nullptr, nullptr, logits, num_steps)));
+            if (i + 1 < num_steps) {
+                hipLaunchKernelGGL(ar_argmax_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, num_steps, C, p->tok, LDT, i, B, c.eos_id,
+                                   p->eos_seen, eos_rows, ar_len, testing ? 1 : 0);
+                HIPCHK(hipGetLastError());
+            }
+        }
+    } else {
+        // model.py:148-152: context is <bos> only, all positions queried at once
+        CHK((decode_pass<T>(p, s, B, 1, 0, num_steps, nullptr, nullptr, logits, num_steps)));
+    }
+    for (int it = 0; it < refine_iters; ++it) {
+        // model.py:154-167
+        hipLaunchKernelGGL(refine_prep_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, num_steps, C, p->tok, LDT, p->kpm, LDT, B, c.bos_id, c.eos_id, 1);
+        HIPCHK(hipGetLastError());
+        CHK((decode_pass<T>(p, s, B, num_steps, 0, num_steps, p->cloze, p->kpm, logits, num_steps)));
+    }
+    int L = num_steps;
+    if (ar && testing && refine_iters == 0) {
+        HIPCHK(hipMemcpyAsync(&L, ar_len, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    if (out_len) *out_len = L;
+    return 0;
+}
+
+extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int batch, int flags, int refine_iters,
+                              int num_steps, float* logits_out, int* out_len, void* stream) {
+    CHK(check_call(p, batch, images_dtype));
+    if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
+    const int npos = p->m->cfg.max_label_length + 1;
+    if (num_steps < 1 || num_steps > npos) return fail(PARSEQ_E_INVALID, "num_steps %d outside [1, %d]", num_steps, npos);
+    if (refine_iters < 0) return fail(PARSEQ_E_INVALID, "refine_iters %d", refine_iters);
+    hipStream_t s = (hipStream_t)stream;
+    CHK(encode_dispatch(p, images, images_dtype, batch, nullptr, s));
+    if (p->precision == PARSEQ_BF16) return forward_impl<bf16_t>(p, batch, flags, refine_iters, num_steps, logits_out, out_len, s);
+    return forward_impl<float>(p, batch, flags, refine_iters, num_steps, logits_out, out_len, s);
+}
+
+extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
+                                    const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream) {
+    if (!p || !tokens || !logits_out) return fail(PARSEQ_E_INVALID, "null argument");
+    if (batch <= 0 || batch > p->max_batch || batch != p->last_batch) return fail(PARSEQ_E_INVALID, "batch %d does not match the last parseq_encode (%d)", batch, p->last_batch);
+    const int npos = p->m->cfg.max_label_length + 1;
+    if (ctx_len < 1 || ctx_len > npos || q_start < 0 || q_len < 1 || q_start + q_len > npos) return fail(PARSEQ_E_INVALID, "bad context / query range");
+    hipStream_t s = (hipStream_t)stream;
+    // stage caller's tokens / masks into the plan's pitched arrays
+    HIPCHK(hipMemcpy2DAsync(p->tok, LDT * sizeof(int), tokens, ctx_len * sizeof(int), ctx_len * sizeof(int), batch, hipMemcpyDeviceToDevice, s));
+    const unsigned char* kpm = nullptr; const unsigned char* qm = nullptr;
+    if (key_padding_mask) {
+        HIPCHK(hipMemcpy2DAsync(p->kpm, LDT, key_padding_mask, ctx_len, ctx_len, batch, hipMemcpyDeviceToDevice, s));
+        kpm = p->kpm;
+    }
+    if (query_mask) {      // rows are relative to q_start; the kernel indexes by absolute query position
+        HIPCHK(hipMemcpy2DAsync(p->qmask_user + (size_t)q_start * LDT, LDT, query_mask, ctx_len, ctx_len, q_len, hipMemcpyDeviceToDevice, s));
+        qm = p->qmask_user;
+    }
+    if (p->precision == PARSEQ_BF16) return decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
+    return decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// single operators
+// -------------------------------------------------------------------------------------------------------------------
+extern "C" int parseq_op_layernorm(const float* x, const float* w, const float* b, void* y, int out_dtype, int rows, int E, float eps, void* stream) {
+    CHK(check_arch());
+    if (!x || !w || !b || !y || rows <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
+    if (out_dtype == PARSEQ_BF16) return run_layernorm<bf16_t>((hipStream_t)stream, x, w, b, (bf16_t*)y, nullptr, rows, E, eps);
+    return run_layernorm<float>((hipStream_t)stream, x, w, b, (float*)y, nullptr, rows, E, eps);
+}
+
+template <typename T>
+static int op_linear_impl(const T* A, const T* W, const float* bias, void* C, int act, int M, int N, int K, hipStream_t s) {
+    if (act) return run_gemm<T>(s, ARowMajor<T>{A, K}, W, K, M, N, K, epi_gelu<T>(M, N, bias, (T*)C, N));
+    return run_gemm<T>(s, ARowMajor<T>{A, K}, W, K, M, N, K, epi_store<float>(M, N, bias, (float*)C, N));
+}
+
+extern "C" int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K, void* stream) {
+    CHK(check_arch());
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || (K % 8)) return fail(PARSEQ_E_INVALID, "bad argument (K must be a multiple of 8)");
+    if (act && (N % 4)) return fail(PARSEQ_E_INVALID, "act=1 needs N %% 4 == 0");
+    if (dtype == PARSEQ_BF16) return op_linear_impl<bf16_t>((const bf16_t*)A, (const bf16_t*)W, bias, C, act, M, N, K, (hipStream_t)stream);
+    return op_linear_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, (hipStream_t)stream);
+}
+
+extern "C" int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads, void* stream) {
+    CHK(check_arch());
+    if (!q || !k || !vt || !out || bh <= 0 || heads <= 0 || bh % heads) return fail(PARSEQ_E_INVALID, "bad argument");
+    if (dtype == PARSEQ_BF16) return run_enc_attention<bf16_t>((hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, bh, heads);
+    return run_enc_attention<float>((hipStream_t)stream, (const float*)q, (const float*)k, (const float*)vt, (float*)out, bh, heads);
+}

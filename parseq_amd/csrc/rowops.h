@@ -1,0 +1,155 @@
+// Row-wise kernels: LayerNorm as a wavefront reduction, token-embedding + LayerNorm for the decoder content table,
+// greedy argmax / EOS bookkeeping, refinement token prep.  All wave64; one wave per row, 4 rows per workgroup.
+#pragma once
+#include "common.h"
+
+namespace pq {
+
+// LayerNorm over the last dim E (E = 192 * VEC, VEC in {1, 2, 4}).  x fp32 [M, E] -> out TO [M, E] and optionally a
+// second fp32 copy (the encoder's final norm is both the API's `memory` output and the decoder K/V GEMM operand).
+// torch.nn.LayerNorm semantics: biased variance, y = (x - mean) / sqrt(var + eps) * w + b  (ViT eps 1e-6, decoder 1e-5).
+template <typename TO, int E>
+__global__ __launch_bounds__(256)
+void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                      TO* __restrict__ out, float* __restrict__ out_f32, int M, float eps) {
+    constexpr int VEC = E / 192;
+    static_assert(E % 192 == 0 && (VEC == 1 || VEC == 2 || VEC == 4), "unsupported embed dim");
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * E;
+    float v[3][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { v[it][j] = xr[e0 + j]; s += v[it][j]; }
+    }
+    const float mean = wave_sum(s) * (1.0f / E);
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float d = v[it][j] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / E) + eps);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float y = (v[it][j] - mean) * rstd * w[e0 + j] + b[e0 + j];
+            out[(size_t)row * E + e0 + j] = from_f32<TO>(y);
+            if (out_f32) out_f32[(size_t)row * E + e0 + j] = y;
+        }
+    }
+}
+
+// Decoder content rows for every (position j, token id): c = (j ? pos_queries[j-1] : 0) + sqrt(E) * emb[tok], then
+// norm_c.  (model.py:97-98 + modules.py:175-176 + modules.py:91.)  Row index = j * ntok + tok.
+template <typename TO, int E>
+__global__ __launch_bounds__(256)
+void content_ln_kernel(const float* __restrict__ emb, const float* __restrict__ posq, const float* __restrict__ w,
+                       const float* __restrict__ b, TO* __restrict__ out, int npos, int ntok, float eps) {
+    constexpr int VEC = E / 192;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= npos * ntok) return;
+    const int j = row / ntok, tok = row - j * ntok;
+    const float sq = sqrtf((float)E);
+    float v[3][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj) {
+            float c = sq * emb[(size_t)tok * E + e0 + jj];
+            if (j > 0) c = posq[(size_t)(j - 1) * E + e0 + jj] + c;
+            v[it][jj] = c; s += c;
+        }
+    }
+    const float mean = wave_sum(s) * (1.0f / E);
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj) { const float d = v[it][jj] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / E) + eps);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int jj = 0; jj < VEC; ++jj)
+            out[(size_t)row * E + e0 + jj] = from_f32<TO>((v[it][jj] - mean) * rstd * w[e0 + jj] + b[e0 + jj]);
+    }
+}
+
+// Greedy pick after AR step `step` (model.py:142-145): tok[b][step + 1] = argmax_c logits[b][step][c] (first max on
+// ties, as torch.argmax), and the batch-level early-exit test kept on the device: the first step at which every row
+// holds an EOS sets *ar_len = step + 1 (the number of logit positions the reference would have produced).
+__global__ __launch_bounds__(256)
+void ar_argmax_kernel(const float* __restrict__ logits, int L, int C, int* __restrict__ tok, int ldt, int step,
+                      int B, int eos_id, unsigned char* __restrict__ eos_seen, int* __restrict__ eos_rows,
+                      int* __restrict__ ar_len, int record) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* row = logits + ((size_t)b * L + step) * C;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = row[c];
+        if (v > best) { best = v; bi = c; }      // strictly greater: keeps the lowest index inside a lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        tok[(size_t)b * ldt + step + 1] = bi;
+        if (record && bi == eos_id && !eos_seen[b]) {
+            eos_seen[b] = 1;
+            const int done = atomicAdd(eos_rows, 1) + 1;
+            if (done == B) *ar_len = step + 1;
+        }
+    }
+}
+
+// Refinement context (model.py:161-163): tok[b] = [bos, argmax(logits[b, :L-1])], and the key-padding mask
+// kpm[b][j] = (an EOS occurs at a position <= j).  One wave per image; lane p handles logits position p (L <= 64).
+__global__ __launch_bounds__(256)
+void refine_prep_kernel(const float* __restrict__ logits, int L, int C, int* __restrict__ tok, int ldt,
+                        unsigned char* __restrict__ kpm, int ldk, int B, int bos_id, int eos_id, int from_logits) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int t = bos_id;
+    if (lane >= 1 && lane < L) {
+        if (from_logits) {
+            const float* row = logits + ((size_t)b * L + (lane - 1)) * C;
+            float best = row[0]; int bi = 0;
+            for (int c = 1; c < C; ++c) { const float v = row[c]; if (v > best) { best = v; bi = c; } }
+            t = bi;
+        } else {
+            t = tok[(size_t)b * ldt + lane];      // first iteration after a full AR loop: the AR picks are the argmaxes
+        }
+    }
+    const unsigned long long eos_lanes = __ballot(lane < L && t == eos_id);
+    if (lane < L) {
+        tok[(size_t)b * ldt + lane] = t;
+        const unsigned long long upto = (lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull);
+        kpm[(size_t)b * ldk + lane] = (eos_lanes & upto) ? 1 : 0;
+    }
+}
+
+__global__ void ar_init_kernel(int* __restrict__ tok, int ldt, int B, int bos_id, int pad_id, unsigned char* __restrict__ eos_seen,
+                               int* __restrict__ eos_rows, int* __restrict__ ar_len, int num_steps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * ldt) tok[i] = (i % ldt == 0) ? bos_id : pad_id;
+    if (i < B) eos_seen[i] = 0;
+    if (i == 0) { *eos_rows = 0; *ar_len = num_steps; }
+}
+
+}  // namespace pq

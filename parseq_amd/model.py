@@ -1,0 +1,358 @@
+"""Inner PARSeq model: parameter container with the reference's state_dict layout, forward on libparseq_hip.
+
+Mirrors `strhub/models/parseq/model.py:31-169` (class `PARSeq`): same constructor arguments, same attributes
+(`decode_ar`, `refine_iters`, `max_label_length`, `encoder`, `decoder`, `head`, `text_embed`, `pos_queries`), same
+`forward(tokenizer, images, max_length=None)`, `encode(img)` and `decode(...)` entry points, and exactly the reference's
+`state_dict()` keys/shapes so released checkpoints load with `load_state_dict`.
+
+The sub-modules here only HOLD parameters (their own `forward` is never called).  All arithmetic runs in the HIP
+library through `parseq_amd._native`; on a CPU tensor or without the library the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import _native
+from .tokenizer import Tokenizer
+
+_PRECISIONS = {'bf16': _native.PARSEQ_BF16, 'fp32': _native.PARSEQ_F32, 'f32': _native.PARSEQ_F32}
+
+
+def init_weights(module: nn.Module, name: str = '', exclude: Sequence[str] = ()):
+    """Initialisation scheme of the reference (`strhub/models/utils.py:107-125`): trunc-normal(0.02) Linear / Embedding
+    weights, zero biases, unit LayerNorm, Kaiming-normal(fan_out) convolutions."""
+    if any(name.startswith(e) for e in exclude):
+        return
+    if isinstance(module, nn.Linear):
+        nn.init.trunc_normal_(module.weight, std=0.02)
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, nn.Embedding):
+        nn.init.trunc_normal_(module.weight, std=0.02)
+        if module.padding_idx is not None:
+            module.weight.data[module.padding_idx].zero_()
+    elif isinstance(module, nn.Conv2d):
+        nn.init.kaiming_normal_(module.weight, mode='fan_out', nonlinearity='relu')
+        if module.bias is not None:
+            nn.init.zeros_(module.bias)
+    elif isinstance(module, (nn.LayerNorm, nn.BatchNorm2d, nn.GroupNorm)):
+        nn.init.ones_(module.weight)
+        nn.init.zeros_(module.bias)
+
+
+class _Holder(nn.Module):
+    """A module that exists to own parameters under the reference's names."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError('parameter holder: compute runs in libparseq_hip, call the PARSeq model instead')
+
+
+class _PatchEmbed(_Holder):
+    def __init__(self, patch_size, embed_dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=tuple(patch_size), stride=tuple(patch_size))
+
+
+class _Attention(_Holder):
+    def __init__(self, dim):
+        super().__init__()
+        self.qkv = nn.Linear(dim, 3 * dim)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _Mlp(_Holder):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(_Holder):
+    def __init__(self, dim, mlp_ratio):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attention(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class Encoder(_Holder):
+    """Parameter layout of timm's VisionTransformer as the reference configures it (modules.py:128-161):
+    no class token, no head; LayerNorm eps 1e-6."""
+
+    def __init__(self, img_size, patch_size, embed_dim, depth, num_heads, mlp_ratio):
+        super().__init__()
+        self.img_size, self.patch_size = tuple(img_size), tuple(patch_size)
+        self.num_heads = num_heads
+        n_tok = (img_size[0] // patch_size[0]) * (img_size[1] // patch_size[1])
+        self.patch_embed = _PatchEmbed(patch_size, embed_dim)
+        self.pos_embed = nn.Parameter(torch.empty(1, n_tok, embed_dim))
+        self.blocks = nn.ModuleList([_Block(embed_dim, mlp_ratio) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        for m in self.modules():      # timm ViT init: trunc-normal(0.02) Linear weights, zero biases; conv keeps torch default
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                nn.init.zeros_(m.bias)
+
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+
+class DecoderLayer(_Holder):
+    """Parameter layout of the reference's two-stream pre-LN decoder layer (modules.py:27-52)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward, dropout=0.1, layer_norm_eps=1e-5):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.cross_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm2 = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm_q = nn.LayerNorm(d_model, eps=layer_norm_eps)
+        self.norm_c = nn.LayerNorm(d_model, eps=layer_norm_eps)
+
+
+class Decoder(_Holder):
+    def __init__(self, d_model, nhead, dim_feedforward, dropout, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([DecoderLayer(d_model, nhead, dim_feedforward, dropout) for _ in range(num_layers)])
+        self.num_layers = num_layers
+        self.norm = nn.LayerNorm(d_model)
+
+
+class TokenEmbedding(_Holder):
+    def __init__(self, charset_size: int, embed_dim: int):
+        super().__init__()
+        self.embedding = nn.Embedding(charset_size, embed_dim)
+        self.embed_dim = embed_dim
+
+
+def _named_apply(fn, module: nn.Module, name: str = ''):
+    for child_name, child in module.named_children():
+        full = f'{name}.{child_name}' if name else child_name
+        _named_apply(fn, child, full)
+        fn(module=child, name=full)
+
+
+class _NativeState:
+    """Device-side twin of the parameters: one parseq_model + cached plans.  Rebuilt when parameters move or change."""
+
+    def __init__(self):
+        self.model = C.c_void_p(0)
+        self.plans = {}            # precision code -> (plan handle, max_batch)
+        self.signature = None
+
+    def release(self):
+        try:
+            lib = _native.lib()
+        except Exception:
+            return
+        for plan, _ in self.plans.values():
+            lib.parseq_plan_destroy(plan)
+        self.plans = {}
+        if self.model:
+            lib.parseq_model_destroy(self.model)
+        self.model = C.c_void_p(0)
+        self.signature = None
+
+    def __del__(self):
+        self.release()
+
+
+class PARSeq(nn.Module):
+
+    def __init__(self, num_tokens: int, max_label_length: int, img_size: Sequence[int], patch_size: Sequence[int],
+                 embed_dim: int, enc_num_heads: int, enc_mlp_ratio: int, enc_depth: int, dec_num_heads: int,
+                 dec_mlp_ratio: int, dec_depth: int, decode_ar: bool, refine_iters: int, dropout: float,
+                 precision: Optional[str] = None) -> None:
+        super().__init__()
+        self.max_label_length = max_label_length
+        self.decode_ar = decode_ar
+        self.refine_iters = refine_iters
+        self.precision = precision or os.environ.get('PARSEQ_AMD_PRECISION', 'bf16')
+        self._cfg = dict(num_tokens=num_tokens, img_size=tuple(img_size), patch_size=tuple(patch_size), embed_dim=embed_dim,
+                         enc_num_heads=enc_num_heads, enc_mlp_ratio=enc_mlp_ratio, enc_depth=enc_depth,
+                         dec_num_heads=dec_num_heads, dec_mlp_ratio=dec_mlp_ratio, dec_depth=dec_depth)
+
+        self.encoder = Encoder(img_size, patch_size, embed_dim, enc_depth, enc_num_heads, enc_mlp_ratio)
+        self.decoder = Decoder(embed_dim, dec_num_heads, embed_dim * dec_mlp_ratio, dropout, dec_depth)
+        self.head = nn.Linear(embed_dim, num_tokens - 2)       # <bos> and <pad> are never predicted (model.py:62-63)
+        self.text_embed = TokenEmbedding(num_tokens, embed_dim)
+        self.pos_queries = nn.Parameter(torch.empty(1, max_label_length + 1, embed_dim))
+        _named_apply(lambda module, name: init_weights(module, name, exclude=['encoder']), self)
+        nn.init.trunc_normal_(self.pos_queries, std=0.02)
+        object.__setattr__(self, '_native_state', _NativeState())
+
+    # ---- reference surface -------------------------------------------------------------------------------------
+    @property
+    def _device(self) -> torch.device:
+        return self.head.weight.device
+
+    def no_weight_decay(self):
+        return {'text_embed.embedding.weight', 'pos_queries'} | {'encoder.' + n for n in self.encoder.no_weight_decay()}
+
+    def encode(self, img: Tensor) -> Tensor:
+        """images [B, 3, H, W] -> memory [B, tokens, E] (fp32).  model.py:83-84."""
+        img = self._check_images(img)
+        plan = self._plan(img.shape[0])
+        memory = torch.empty(img.shape[0], self.encoder.pos_embed.shape[1], self._cfg['embed_dim'],
+                             dtype=torch.float32, device=img.device)
+        _native.check(_native.lib().parseq_encode(plan, _native.ptr(img), _native.dtype_code(img.dtype), img.shape[0],
+                                                  _native.ptr(memory), _native.stream_ptr()))
+        return memory
+
+    def decode_logits(self, tgt: Tensor, q_start: int, q_len: int, tgt_padding_mask: Optional[Tensor] = None,
+                      tgt_query_mask: Optional[Tensor] = None) -> Tensor:
+        """head(decode(...)) for queries pos_queries[q_start:q_start+q_len] against the content tokens `tgt`
+        (model.py:86-103 + :138), using the memory of the most recent `encode` / `forward` on this model.
+        Per-stage parity hook; masks use torch's convention (True = masked)."""
+        B, L = tgt.shape
+        plan = self._plan(B)
+        tok = tgt.to(device=self._device, dtype=torch.int32).contiguous()
+        kpm = tgt_padding_mask.to(device=self._device, dtype=torch.uint8).contiguous() if tgt_padding_mask is not None else None
+        qm = tgt_query_mask.to(device=self._device, dtype=torch.uint8).contiguous() if tgt_query_mask is not None else None
+        if qm is not None and tuple(qm.shape) != (q_len, L):
+            raise RuntimeError(f'tgt_query_mask shape {tuple(qm.shape)} != ({q_len}, {L})')
+        out = torch.empty(B, q_len, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=self._device)
+        _native.check(_native.lib().parseq_decode_logits(plan, _native.ptr(tok), B, L, q_start, q_len, _native.ptr(qm),
+                                                         _native.ptr(kpm), _native.ptr(out), _native.stream_ptr()))
+        return out
+
+    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None) -> Tensor:
+        """model.py:105-169.  Returns logits [B, L, num_tokens - 2] (fp32)."""
+        testing = max_length is None
+        max_length = self.max_label_length if max_length is None else min(max_length, self.max_label_length)
+        num_steps = max_length + 1
+        images = self._check_images(images)
+        B = images.shape[0]
+        plan = self._plan(B)
+        if (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id) != self._special_ids(tokenizer):
+            raise RuntimeError('tokenizer special ids changed after the native model was built')
+        logits = torch.empty(B, num_steps, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=images.device)
+        flags = (_native.FLAG_DECODE_AR if self.decode_ar else 0) | (_native.FLAG_TESTING if testing else 0)
+        out_len = C.c_int(0)
+        _native.check(_native.lib().parseq_forward(plan, _native.ptr(images), _native.dtype_code(images.dtype), B, flags,
+                                                   int(self.refine_iters), num_steps, _native.ptr(logits),
+                                                   C.byref(out_len), _native.stream_ptr()))
+        return logits if out_len.value == num_steps else logits[:, :out_len.value]
+
+    def set_profiling(self, enable: bool, batch: int) -> None:
+        """Bracket every kernel launch with HIP events (per-family timing for the roofline report; perturbs throughput)."""
+        _native.check(_native.lib().parseq_plan_set_profiling(self._plan(batch), 1 if enable else 0))
+
+    def get_profile(self, batch: int) -> dict:
+        """{family: (total_ms, launches)} accumulated since set_profiling(True)."""
+        lib, plan, out, i = _native.lib(), self._plan(batch), {}, 0
+        while True:
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            status = lib.parseq_plan_get_profile(plan, i, C.byref(name), C.byref(ms), C.byref(n))
+            if status == 1:
+                break
+            _native.check(status)
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
+    # ---- native plumbing ---------------------------------------------------------------------------------------
+    def _special_ids(self, tokenizer):
+        self._tok_ids = getattr(self, '_tok_ids', None) or (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id)
+        return self._tok_ids
+
+    def _check_images(self, images: Tensor) -> Tensor:
+        if not isinstance(images, Tensor) or images.dim() != 4:
+            raise RuntimeError('images must be a [N, 3, H, W] tensor')
+        if images.device.type != 'cuda':
+            raise RuntimeError(
+                'parseq_amd runs on MI355X through libparseq_hip only; got a tensor on '
+                f"'{images.device}'. There is no CPU fallback (the CPU oracle under oracle/ is test infrastructure).")
+        if images.device != self._device:
+            raise RuntimeError(f'images on {images.device} but the model is on {self._device}')
+        h, w = self._cfg['img_size']
+        if tuple(images.shape[1:]) != (3, h, w):
+            raise RuntimeError(f'expected images of shape [N, 3, {h}, {w}], got {list(images.shape)}')
+        if images.dtype not in (torch.float32, torch.bfloat16):
+            images = images.float()
+        return images.contiguous()
+
+    def _signature(self):
+        params = list(self.parameters())
+        return (str(self._device), tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
+
+    def _sync_native(self):
+        st: _NativeState = self._native_state
+        sig = self._signature()
+        if st.signature == sig:
+            return st
+        lib = _native.lib()
+        if self._device.type != 'cuda':
+            raise RuntimeError('move the model to a ROCm device first: model.to("cuda")')
+        tok_ids = getattr(self, '_tok_ids', None)
+        if tok_ids is None:
+            n = self._cfg['num_tokens']
+            tok_ids = (n - 2, 0, n - 1)      # Tokenizer layout: [E]=0 ... [B]=n-2, [P]=n-1 (strhub/data/utils.py:107-111)
+            self._tok_ids = tok_ids
+        with torch.cuda.device(self._device):
+            fresh = (not st.model) or (st.signature is None) or st.signature[0] != sig[0]
+            if fresh:
+                st.release()
+                c = self._cfg
+                cfg = _native.ParseqConfig(
+                    img_h=c['img_size'][0], img_w=c['img_size'][1], patch_h=c['patch_size'][0], patch_w=c['patch_size'][1],
+                    embed_dim=c['embed_dim'], enc_depth=c['enc_depth'], enc_heads=c['enc_num_heads'],
+                    enc_mlp_ratio=c['enc_mlp_ratio'], dec_depth=c['dec_depth'], dec_heads=c['dec_num_heads'],
+                    dec_mlp_ratio=c['dec_mlp_ratio'], num_tokens=c['num_tokens'], max_label_length=self.max_label_length,
+                    bos_id=tok_ids[0], eos_id=tok_ids[1], pad_id=tok_ids[2], enc_ln_eps=1e-6, dec_ln_eps=1e-5)
+                handle = C.c_void_p(0)
+                _native.check(lib.parseq_model_create(C.byref(cfg), C.byref(handle)))
+                st.model = handle
+            stream = _native.stream_ptr()
+            sd = self.state_dict()
+            n_native = lib.parseq_model_num_params(st.model)
+            if n_native != len(sd):
+                raise RuntimeError(f'state_dict has {len(sd)} tensors, native model expects {n_native}')
+            keep = []
+            for key, t in sd.items():
+                t32 = t.detach().to(dtype=torch.float32).contiguous()
+                keep.append(t32)
+                _native.check(lib.parseq_model_set_param(st.model, key.encode(), _native.ptr(t32), t32.numel(), stream))
+            for plan, _ in st.plans.values():
+                _native.check(lib.parseq_plan_refresh(plan, stream))
+            torch.cuda.current_stream().synchronize()    # staging copies in `keep` must outlive the async D2D copies
+        st.signature = sig
+        return st
+
+    def _plan(self, batch: int):
+        if self.precision not in _PRECISIONS:
+            raise RuntimeError(f"precision must be one of {sorted(_PRECISIONS)}, got '{self.precision}'")
+        st = self._sync_native()
+        code = _PRECISIONS[self.precision]
+        plan, cap = st.plans.get(code, (None, 0))
+        if plan is None or batch > cap:
+            lib = _native.lib()
+            if plan is not None:
+                torch.cuda.current_stream().synchronize()
+                lib.parseq_plan_destroy(plan)
+                del st.plans[code]
+            cap = max(8, 1 << (batch - 1).bit_length())
+            handle = C.c_void_p(0)
+            with torch.cuda.device(self._device):
+                _native.check(lib.parseq_plan_create(st.model, cap, code, _native.stream_ptr(), C.byref(handle)))
+            st.plans[code] = (handle, cap)
+            plan = handle
+        return plan
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        st = getattr(self, '_native_state', None)
+        if st is not None:
+            st.signature = None if st.signature is None else (st.signature[0], (), ())   # force a re-sync
+        return out

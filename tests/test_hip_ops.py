@@ -1,0 +1,84 @@
+"""GPU parity tests, one per kernel family, each through the C ABI (parseq_op_*), against fp64 CPU references of the
+same operator on the same seeded inputs.  Tolerances are stated next to each assertion."""
+import ctypes as C
+
+import pytest
+import torch
+
+from gpu_util import DEV, native, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _gen(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize('E', [192, 384, 768])
+@pytest.mark.parametrize('rows', [1, 5, 1024])
+def test_layernorm(E, rows):
+    nat, lib = native()
+    x = _gen(rows, E, seed=1, scale=3.0) + 0.5
+    w, b = 1 + 0.1 * _gen(E, seed=2), 0.1 * _gen(E, seed=3)
+    want = torch.nn.functional.layer_norm(x.double(), (E,), w.double(), b.double(), 1e-6).float()
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    for dt, code, tol in ((torch.float32, nat.PARSEQ_F32, 2e-5), (torch.bfloat16, nat.PARSEQ_BF16, 4e-2)):
+        y = torch.empty(rows, E, dtype=dt, device=DEV)
+        nat.check(lib.parseq_op_layernorm(nat.ptr(xd), nat.ptr(wd), nat.ptr(bd), nat.ptr(y), code, rows, E, 1e-6, nat.stream_ptr()))
+        torch.cuda.synchronize()
+        err, msg = report(f'layernorm E={E} rows={rows} {dt}', y, want)
+        assert err <= tol, msg      # f32: rounding of the two reductions; bf16: one bf16 ulp at |y| <= ~5 is 2^-6
+        if dt == torch.bfloat16:    # and it must be the correctly rounded value almost everywhere
+            assert (y.float().cpu() == want.bfloat16().float()).float().mean() > 0.98
+
+
+# (M, N, K): encoder shapes (big tiles), decoder shapes (small tiles), ragged M/N (bounds), K tail (patch embed K=96)
+LINEAR_SHAPES = [(4096, 1152, 384), (4096, 384, 1536), (8192, 384, 384), (512, 384, 384), (26, 384, 384), (77, 95, 384),
+                 (512, 1536, 384), (300, 768, 192), (4096, 384, 96), (130, 200, 96), (1, 95, 192)]
+
+
+@pytest.mark.parametrize('M,N,K', LINEAR_SHAPES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_linear(M, N, K, dtype):
+    nat, lib = native()
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    code = nat.PARSEQ_F32 if dtype == 'f32' else nat.PARSEQ_BF16
+    A = _gen(M, K, seed=4).to(tdt)
+    W = (_gen(N, K, seed=5) / K ** 0.5).to(tdt)            # asymmetric operands: catches transposed / swapped layouts
+    bias = 0.1 * _gen(N, seed=6)
+    want = A.double() @ W.double().T + bias.double()
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), bias.to(DEV)
+    out = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+    nat.check(lib.parseq_op_linear(nat.ptr(Ad), nat.ptr(Wd), nat.ptr(bd), nat.ptr(out), code, 0, M, N, K, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    err, msg = report(f'linear {dtype} {M}x{N}x{K}', out, want.float())
+    assert err <= 2e-4, msg        # operands are exactly representable in `dtype`; only fp32 accumulation order differs
+    if N % 4 == 0:                 # fused exact-erf GELU epilogue, output in storage dtype
+        out2 = torch.full((M, N), float('nan'), dtype=tdt, device=DEV)
+        nat.check(lib.parseq_op_linear(nat.ptr(Ad), nat.ptr(Wd), nat.ptr(bd), nat.ptr(out2), code, 1, M, N, K, nat.stream_ptr()))
+        torch.cuda.synchronize()
+        want2 = torch.nn.functional.gelu(want)
+        err2, msg2 = report(f'linear+gelu {dtype} {M}x{N}x{K}', out2, want2.float())
+        assert err2 <= (2e-4 if dtype == 'f32' else 2e-2), msg2   # bf16: output rounding, |y| <= ~4 -> ulp 2^-6
+
+
+@pytest.mark.parametrize('heads,images', [(6, 3), (3, 2)])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_encoder_attention(heads, images, dtype):
+    nat, lib = native()
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    code = nat.PARSEQ_F32 if dtype == 'f32' else nat.PARSEQ_BF16
+    bh = heads * images
+    q = _gen(bh, 128, 64, seed=7, scale=1.5).to(tdt)
+    k = _gen(bh, 128, 64, seed=8, scale=1.5).to(tdt)
+    v = _gen(bh, 128, 64, seed=9).to(tdt)
+    want = torch.softmax(q.double() @ k.double().transpose(1, 2) * 64 ** -0.5, -1) @ v.double()     # [bh, 128, 64]
+    want = want.view(images, heads, 128, 64).permute(0, 2, 1, 3).reshape(images * 128, heads * 64)
+    vt = v.transpose(1, 2).contiguous()
+    out = torch.full((images * 128, heads * 64), float('nan'), dtype=tdt, device=DEV)
+    nat.check(lib.parseq_op_encoder_attention(nat.ptr(q.to(DEV)), nat.ptr(k.to(DEV)), nat.ptr(vt.to(DEV)), nat.ptr(out), code, bh, heads, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    err, msg = report(f'enc attention {dtype} heads={heads}', out, want.float())
+    # f32: exp/accumulation rounding.  bf16: probabilities and the output are rounded to bf16 (2^-9 relative each)
+    assert err <= (2e-5 if dtype == 'f32' else 1.5e-2), msg
