@@ -43,7 +43,9 @@ def cpu_baseline(name, sd_cpu, refine_iters, seconds=12.0, batch=64):
     from oracle import parseq_oracle as O
     from oracle.synth import CONFIGS, synth_images
     cfg = CONFIGS[name]
-    cores = os.cpu_count() or 1
+    # torch's CPU kernels on this path are small ops; beyond ~32 threads they get slower, not faster (measured on the
+    # 256-thread GPU host: 0.5 img/s with 256 threads), so the baseline uses min(host cores, 32) and says so.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     x = synth_images(batch, cfg, seed=1234)
     with torch.inference_mode():

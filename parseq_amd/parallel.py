@@ -40,13 +40,16 @@ def all_gather_logits(logits: Tensor, group=None) -> Tensor:
     bs = [int(s[0]) for s in all_sizes]
     if any(int(s[1]) != logits.shape[1] for s in all_sizes):
         raise RuntimeError('ranks produced different sequence lengths; use max_length=... or refine_iters >= 1 when sharding')
+    bmax = max(bs)
+    if logits.shape[0] < bmax:            # ragged last shards: pad to the largest shard, gather once, drop the padding
+        pad = torch.zeros((bmax - logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
+        logits = torch.cat([logits, pad], dim=0)
+    out = torch.empty((world * bmax,) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
+    dist.all_gather_into_tensor(out, logits, group=group)
     if len(set(bs)) == 1:
-        out = torch.empty((world * bs[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
-        dist.all_gather_into_tensor(out, logits, group=group)
         return out
-    parts = [torch.empty((b,) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device) for b in bs]
-    dist.all_gather(parts, logits, group=group)
-    return torch.cat(parts, dim=0)
+    out = out.view(world, bmax, *logits.shape[1:])
+    return torch.cat([out[r, :bs[r]] for r in range(world)], dim=0)
 
 
 def data_parallel_forward(model, images: Tensor, max_length: Optional[int] = None, group=None) -> Tensor:

@@ -75,9 +75,9 @@ def test_encoder_attention(heads, images, dtype):
     v = _gen(bh, 128, 64, seed=9).to(tdt)
     want = torch.softmax(q.double() @ k.double().transpose(1, 2) * 64 ** -0.5, -1) @ v.double()     # [bh, 128, 64]
     want = want.view(images, heads, 128, 64).permute(0, 2, 1, 3).reshape(images * 128, heads * 64)
-    vt = v.transpose(1, 2).contiguous()
+    qd, kd, vtd = q.to(DEV), k.to(DEV), v.transpose(1, 2).contiguous().to(DEV)     # keep the device tensors alive
     out = torch.full((images * 128, heads * 64), float('nan'), dtype=tdt, device=DEV)
-    nat.check(lib.parseq_op_encoder_attention(nat.ptr(q.to(DEV)), nat.ptr(k.to(DEV)), nat.ptr(vt.to(DEV)), nat.ptr(out), code, bh, heads, nat.stream_ptr()))
+    nat.check(lib.parseq_op_encoder_attention(nat.ptr(qd), nat.ptr(kd), nat.ptr(vtd), nat.ptr(out), code, bh, heads, nat.stream_ptr()))
     torch.cuda.synchronize()
     err, msg = report(f'enc attention {dtype} heads={heads}', out, want.float())
     # f32: exp/accumulation rounding.  bf16: probabilities and the output are rounded to bf16 (2^-9 relative each)
