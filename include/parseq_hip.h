@@ -135,6 +135,9 @@ int parseq_op_layernorm(const float* x, const float* w, const float* b, void* y,
  * C in `dtype` with exact-erf GELU applied (act = 1).  K must be a multiple of 8. */
 int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                      void* stream);
+/* Same as parseq_op_linear with an explicit tile configuration (tools/gemm_bench.py sweeps these; ids in parseq_hip.hip). */
+int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
+                         int cfg, void* stream);
 /* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;
  * out [bh / heads * 128, heads * 64] in `dtype`. */
 int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads,

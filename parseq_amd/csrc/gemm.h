@@ -20,8 +20,10 @@
 
 namespace pq {
 
-constexpr int GEMM_KB = 128;        // bytes of K per LDS stage
-constexpr int GEMM_ROWB = 144;      // padded LDS row pitch in bytes
+// Stage geometry.  KB = bytes of K per LDS stage: 128 for the encoder's M = batch*128 GEMMs (double-buffered), 768 for
+// the decoder's small-M GEMMs (K = 384 bf16 in ONE stage: one exposed load latency per GEMM instead of six; single
+// buffer).  LDS rows are padded by 16 bytes so the 16-lane groups of ds_read_b128 fall on distinct 16-byte slots.
+template <int KB> constexpr int gemm_rowb() { return KB + 16; }
 
 // ---------------------------------------------------------------------------------------------------------------
 // A-operand loaders: produce the 16-byte chunk (row m, elements [k, k + 16/sizeof(T))) of the logical A matrix.
@@ -30,9 +32,14 @@ template <typename T>
 struct ARowMajor {
     const T* A;
     int lda;
-    __device__ __forceinline__ u32x4 load(int m, int k) const {
-        return *reinterpret_cast<const u32x4*>(A + (size_t)m * lda + k);
-    }
+    static constexpr int kStatsFloats = 0;       // LDS floats per tile row the loader needs (see ALayerNorm)
+    static constexpr bool kDirect = true;        // plain row-major T: eligible for the global_load_lds main loop
+    struct Raw { u32x4 v; };
+    __device__ __forceinline__ void prepare(int, int, int, float*) {}
+    // fetch() only ISSUES the global loads; finish() turns the landed bytes into the 16-byte LDS chunk.  The kernel calls
+    // finish() after the current stage's MFMAs, so nothing between the loads and the MFMAs depends on the loaded data.
+    __device__ __forceinline__ Raw fetch(int m, int k) const { return Raw{*reinterpret_cast<const u32x4*>(A + (size_t)m * lda + k)}; }
+    __device__ __forceinline__ u32x4 finish(const Raw& r, int, int) const { return r.v; }
 };
 
 // im2col-free patch embedding: logical A[m = (b, gy, gx)][k = (c, ky, kx)] = img[b][c][gy*ph + ky][gx*pw + kx].
@@ -43,139 +50,257 @@ template <typename T, typename TI>
 struct APatch {
     const TI* img;
     int C, H, Wd, ph, pw, gw, tokens;   // tokens = gh * gw
-    __device__ __forceinline__ u32x4 load(int m, int k) const {
+    static constexpr int kStatsFloats = 0;
+    static constexpr bool kDirect = false;
+    static constexpr int kRaw = (sizeof(TI) > sizeof(T)) ? 2 : 1;       // 16-byte loads per chunk
+    struct Raw { u32x4 v[kRaw]; };
+    __device__ __forceinline__ void prepare(int, int, int, float*) {}
+    __device__ __forceinline__ Raw fetch(int m, int k) const {
         const int b = m / tokens, t = m - b * tokens;
         const int gy = t / gw, gx = t - gy * gw;
         const int c = k / (ph * pw), r = k - c * ph * pw;
         const int ky = r / pw, kx = r - ky * pw;
         const TI* src = img + (((size_t)b * C + c) * H + (gy * ph + ky)) * Wd + gx * pw + kx;
-        constexpr int n = 16 / (int)sizeof(T);
+        Raw raw;
         if constexpr (sizeof(TI) == sizeof(T)) {
-            return *reinterpret_cast<const u32x4*>(src);                 // same storage type: one 16-byte load
-        } else if constexpr (sizeof(TI) == 4) {                          // f32 image -> bf16 operand: 2 x 16-byte loads
-            const float4 lo = reinterpret_cast<const float4*>(src)[0], hi = reinterpret_cast<const float4*>(src)[1];
-            union { u32x4 u; T e[n]; } out;
-            out.e[0] = from_f32<T>(lo.x); out.e[1] = from_f32<T>(lo.y); out.e[2] = from_f32<T>(lo.z); out.e[3] = from_f32<T>(lo.w);
-            out.e[4] = from_f32<T>(hi.x); out.e[5] = from_f32<T>(hi.y); out.e[6] = from_f32<T>(hi.z); out.e[7] = from_f32<T>(hi.w);
+            raw.v[0] = *reinterpret_cast<const u32x4*>(src);                       // same storage type
+        } else if constexpr (sizeof(TI) == 4) {                                    // f32 image -> bf16 operand: 8 floats
+            raw.v[0] = reinterpret_cast<const u32x4*>(src)[0];
+            raw.v[1] = reinterpret_cast<const u32x4*>(src)[1];
+        } else {                                                                   // bf16 image -> f32 operand: 4 bf16
+            const uint2 h2 = *reinterpret_cast<const uint2*>(src);
+            raw.v[0] = u32x4{h2.x, h2.y, 0u, 0u};
+        }
+        return raw;
+    }
+    __device__ __forceinline__ u32x4 finish(const Raw& raw, int, int) const {
+        if constexpr (sizeof(TI) == sizeof(T)) {
+            return raw.v[0];
+        } else if constexpr (sizeof(TI) == 4) {
+            union { u32x4 u; T e[8]; } out;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                out.e[i] = from_f32<T>(__uint_as_float(raw.v[0][i]));
+                out.e[4 + i] = from_f32<T>(__uint_as_float(raw.v[1][i]));
+            }
             return out.u;
-        } else {                                                         // bf16 image -> f32 operand: one 8-byte load
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>(src);
-            union { u32x4 u; float e[4]; } out;
-            out.e[0] = (float)v[0]; out.e[1] = (float)v[1]; out.e[2] = (float)v[2]; out.e[3] = (float)v[3];
-            return out.u;
+        } else {
+            u32x4 out;      // bf16 -> f32 is a 16-bit shift
+            out[0] = raw.v[0][0] << 16; out[1] = raw.v[0][0] & 0xffff0000u;
+            out[2] = raw.v[0][1] << 16; out[3] = raw.v[0][1] & 0xffff0000u;
+            return out;
         }
     }
 };
 
+// LayerNorm fused into the A operand: logical A[m][k] = LayerNorm(x[m])[k] rounded to T, with x the fp32 residual
+// stream [M, E].  prepare() computes mean / rstd of the tile's rows (wave per row, two-pass, exactly like
+// layernorm_kernel) into LDS; load() normalises on the fly.  Removes a kernel boundary and the normalised-activation
+// round trip through HBM in front of every decoder GEMM that follows a LayerNorm.
+template <typename T, int E>
+struct ALayerNorm {
+    const float* x; const float* gamma; const float* beta; float eps;
+    int m0_; const float* stats_;
+    static constexpr int kStatsFloats = 2;
+    static constexpr bool kDirect = false;
+    __device__ __forceinline__ void prepare(int m0, int bm, int M, float* stats) {
+        m0_ = m0; stats_ = stats;
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        constexpr int RB = 8;                       // rows in flight per wave: RB independent load/reduce chains
+        for (int r0 = wid * RB; r0 < bm; r0 += nw * RB) {
+            float v[RB][E / 64];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const float* xr = x + (size_t)min(m0 + r0 + j, M - 1) * E;
+#pragma unroll
+                for (int i = 0; i < E / 64; ++i) v[j][i] = xr[i * 64 + lane];
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < E / 64; ++i) s += v[j][i];
+                const float mean = wave_sum(s) * (1.0f / E);
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < E / 64; ++i) { const float d = v[j][i] - mean; ss += d * d; }
+                const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / E) + eps);
+                if (lane == 0 && r0 + j < bm) { stats[2 * (r0 + j)] = mean; stats[2 * (r0 + j) + 1] = rstd; }
+            }
+        }
+    }
+    static constexpr int kRaw = 4 / (int)sizeof(T);                 // fp32 source: 2 loads for a bf16 chunk, 1 for f32
+    struct Raw { u32x4 v[kRaw]; };
+    __device__ __forceinline__ Raw fetch(int m, int k) const {
+        Raw raw;
+#pragma unroll
+        for (int i = 0; i < kRaw; ++i) raw.v[i] = reinterpret_cast<const u32x4*>(x + (size_t)m * E + k)[i];
+        return raw;
+    }
+    __device__ __forceinline__ u32x4 finish(const Raw& raw, int m, int k) const {
+        constexpr int n = 16 / (int)sizeof(T);
+        const float mean = stats_[2 * (m - m0_)], rstd = stats_[2 * (m - m0_) + 1];
+        union { u32x4 u; T e[n]; } out;
+#pragma unroll
+        for (int i = 0; i < kRaw; ++i) {
+            const float4 gv = *reinterpret_cast<const float4*>(gamma + k + 4 * i);
+            const float4 bv = *reinterpret_cast<const float4*>(beta + k + 4 * i);
+            out.e[4 * i + 0] = from_f32<T>((__uint_as_float(raw.v[i][0]) - mean) * rstd * gv.x + bv.x);
+            out.e[4 * i + 1] = from_f32<T>((__uint_as_float(raw.v[i][1]) - mean) * rstd * gv.y + bv.y);
+            out.e[4 * i + 2] = from_f32<T>((__uint_as_float(raw.v[i][2]) - mean) * rstd * gv.z + bv.z);
+            out.e[4 * i + 3] = from_f32<T>((__uint_as_float(raw.v[i][3]) - mean) * rstd * gv.w + bv.w);
+        }
+        return out.u;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
-// Epilogues.  n4(m, n, v): v[j] = C[m][n + j];  m4(m, n, v): v[j] = C[m + j][n].  Bounds are the epilogue's job.
+// Epilogues.  Two phases (the stores were the bottleneck of the first version: 8-byte-per-lane scattered stores ran the
+// encoder GEMMs store-issue-bound at ~1 TB/s; tools/gemm_bench.py, profiles/r01_gemm_sweep.md):
+//   phase 1  xform_n4(m, n, v) / xform_m4: element-wise work on the accumulators in registers (bias, GELU, scale);
+//            the kernel then parks the tile in LDS in the staging type S (the output's storage type);
+//   phase 2  store_n(m, n, chunk) / store_m: one 16-byte chunk of S per call, chunks walked row-major by consecutive
+//            threads, so global stores (and the residual stream's read-modify-write) are full-line coalesced.
+// n-form: chunk = C[m][n .. n+CH);  m-form (transposed tiles): chunk = C[m .. m+CH)[n];  CH = 16 / sizeof(S).
 // ---------------------------------------------------------------------------------------------------------------
 struct EpiBase {
     int M, N;
     const float* bias;   // [N] or nullptr
     __device__ __forceinline__ bool transposed(int) const { return false; }
-    __device__ __forceinline__ void m4(int, int, const float*) const {}
-    __device__ __forceinline__ float b(int n) const { return bias ? bias[n] : 0.f; }
+    __device__ __forceinline__ float b(int n) const { return (bias && n < N) ? bias[n] : 0.f; }
+    __device__ __forceinline__ void xform_n4(int, int n, float* v) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += b(n + j);
+    }
+    __device__ __forceinline__ void xform_m4(int, int n, float* v) const {
+        const float bb = b(n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += bb;
+    }
 };
 
-// out[m][n] = acc + bias (stored as TO), row-major with leading dimension ldo; optional row remap
-// out_row = (m / period) * stride + offset + (m % period)  (decoder head writes step/pass rows into [B, L, C]).
+template <typename S> struct Chunk { static constexpr int CH = 16 / (int)sizeof(S); };
+
+// out[row(m)][n] = (acc + bias) * scale, row-major with leading dimension ldo; optional row remap
+// row = (m / period) * stride + offset + (m % period)  (decoder head writes step/pass rows into [B, L, C]).
 template <typename TO>
 struct EpiStore : EpiBase {
+    using S = TO;
     TO* out; int ldo; int period, stride, offset; float scale;
-    __device__ __forceinline__ void n4(int m, int n, const float* v) const {
-        if (m >= M) return;
+    __device__ __forceinline__ void xform_n4(int m, int n, float* v) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (v[j] + b(n + j)) * scale;
+    }
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+        constexpr int CH = Chunk<S>::CH;
         const int row = period ? (m / period) * stride + offset + (m % period) : m;
         TO* p = out + (size_t)row * ldo + n;
-        if (n + 3 < N && (ldo & 3) == 0) {
-            float o[4] = {(v[0] + b(n)) * scale, (v[1] + b(n + 1)) * scale, (v[2] + b(n + 2)) * scale, (v[3] + b(n + 3)) * scale};
-            store4<TO>(p, o);
+        if (n + CH <= N && (ldo % CH) == 0) {
+            *reinterpret_cast<u32x4*>(p) = *reinterpret_cast<const u32x4*>(c);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (n + j < N) p[j] = from_f32<TO>((v[j] + b(n + j)) * scale);
+            for (int j = 0; j < CH; ++j) if (n + j < N) p[j] = c[j];
         }
     }
+    __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
 
 // out[m][n] = gelu(acc + bias)
 template <typename TO>
 struct EpiGelu : EpiBase {
+    using S = TO;
     TO* out; int ldo;
-    __device__ __forceinline__ void n4(int m, int n, const float* v) const {
-        if (m >= M || n + 3 >= N) return;
-        float o[4];
+    __device__ __forceinline__ void xform_n4(int m, int n, float* v) const {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = gelu_erf(v[j] + b(n + j));
-        store4<TO>(out + (size_t)m * ldo + n, o);
+        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j] + b(n + j));
     }
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+        if (n + Chunk<S>::CH <= N) *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + n) = *reinterpret_cast<const u32x4*>(c);
+    }
+    __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
 
 // x[m][n] += acc + bias   (fp32 residual stream, in place)
 struct EpiResid : EpiBase {
+    using S = float;
     float* x; int ldx;
-    __device__ __forceinline__ void n4(int m, int n, const float* v) const {
-        if (m >= M || n + 3 >= N) return;
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+        if (n + 4 > N) return;
         float4* p = reinterpret_cast<float4*>(x + (size_t)m * ldx + n);
         float4 r = *p;
-        r.x += v[0] + b(n); r.y += v[1] + b(n + 1); r.z += v[2] + b(n + 2); r.w += v[3] + b(n + 3);
+        r.x += c[0]; r.y += c[1]; r.z += c[2]; r.w += c[3];
         *p = r;
     }
+    __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
 
 // x[m][n] = acc + bias + table[(m % period) + offset][n]   (patch embed + pos_embed; decoder query + pos_queries)
 struct EpiAddTable : EpiBase {
+    using S = float;
     float* x; int ldx; const float* table; int ldt, period, offset;
-    __device__ __forceinline__ void n4(int m, int n, const float* v) const {
-        if (m >= M || n + 3 >= N) return;
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+        if (n + 4 > N) return;
         const float4 t = *reinterpret_cast<const float4*>(table + (size_t)((m % period) + offset) * ldt + n);
-        float o[4] = {v[0] + b(n) + t.x, v[1] + b(n + 1) + t.y, v[2] + b(n + 2) + t.z, v[3] + b(n + 3) + t.w};
-        store4<float>(x + (size_t)m * ldx + n, o);
+        *reinterpret_cast<float4*>(x + (size_t)m * ldx + n) = make_float4(c[0] + t.x, c[1] + t.y, c[2] + t.z, c[3] + t.w);
+    }
+    __device__ __forceinline__ void store_m(int, int, const S*) const {}
+};
+
+// Head-split projection output: N = nseg * E columns, segment s = n / E goes to seg[s] as [b][h][t][d] (row-major per
+// head) for s < tr_from and as [b][h][d][t] (transposed per head; those tiles run the m-form so that a chunk is CH
+// consecutive tokens) for s >= tr_from.  Encoder qkv: seg = {q, k, v^T}, tr_from = 2, hd = 64.  Decoder memory K/V:
+// seg = {k, v^T}, tr_from = 1, hd = 32.  hd and tokens are multiples of CH, so a chunk never straddles a head / image.
+template <typename TO>
+struct EpiHeads : EpiBase {
+    using S = TO;
+    TO* seg[3]; int E, heads, hd, tokens, tr_from;
+    __device__ __forceinline__ bool transposed(int n0) const { return n0 >= tr_from * E; }
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+        if (n + Chunk<S>::CH > N) return;
+        const int which = n / E, col = n - which * E;
+        const int h = col / hd, d = col - h * hd;
+        const int b_ = m / tokens, t = m - b_ * tokens;
+        *reinterpret_cast<u32x4*>(seg[which] + (((size_t)b_ * heads + h) * tokens + t) * hd + d) = *reinterpret_cast<const u32x4*>(c);
+    }
+    __device__ __forceinline__ void store_m(int m, int n, const S* c) const {
+        if (m + Chunk<S>::CH > M || n >= N) return;
+        const int which = n / E, col = n - which * E;
+        const int h = col / hd, d = col - h * hd;
+        const int b_ = m / tokens, t = m - b_ * tokens;
+        *reinterpret_cast<u32x4*>(seg[which] + (((size_t)b_ * heads + h) * hd + d) * tokens + t) = *reinterpret_cast<const u32x4*>(c);
     }
 };
 
-// Fused encoder qkv projection output: columns [0,E) -> q[b][h][t][d], [E,2E) -> k[b][h][t][d] (row-major per head),
-// [2E,3E) -> vt[b][h][d][t] (transposed per head; written from the m4 form so the 4 values are 4 consecutive tokens).
-template <typename TO>
-struct EpiQKV : EpiBase {
-    TO *q, *k, *vt; int E, heads, hd, tokens;
-    __device__ __forceinline__ bool transposed(int n0) const { return n0 >= 2 * E; }
-    __device__ __forceinline__ void n4(int m, int n, const float* v) const {
-        if (m >= M || n + 3 >= N) return;
-        const int which = n / E, c = n - which * E;      // 4 consecutive n never straddle a head (hd % 4 == 0)
-        const int h = c / hd, d = c - h * hd;
-        const int b_ = m / tokens, t = m - b_ * tokens;
-        TO* dst = (which == 0 ? q : k) + (((size_t)b_ * heads + h) * tokens + t) * hd + d;
-        float o[4] = {v[0] + b(n), v[1] + b(n + 1), v[2] + b(n + 2), v[3] + b(n + 3)};
-        store4<TO>(dst, o);
-    }
-    __device__ __forceinline__ void m4(int m, int n, const float* v) const {
-        if (m + 3 >= M || n >= N) return;                // M is a multiple of tokens (a multiple of 4)
-        const int c = n - 2 * E;
-        const int h = c / hd, d = c - h * hd;
-        const int b_ = m / tokens, t = m - b_ * tokens;
-        const float bb = b(n);
-        float o[4] = {v[0] + bb, v[1] + bb, v[2] + bb, v[3] + bb};
-        store4<TO>(vt + (((size_t)b_ * heads + h) * hd + d) * tokens + t, o);
-    }
+// Measurement aid (tools/gemm_bench.py): runs phase 1 and the LDS staging but stores nothing -> isolates the store cost.
+struct EpiNull : EpiBase {
+    using S = float;
+    float* sink;
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const { if (m < 0) sink[n] = c[0]; }
+    __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
 
 // ---------------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, typename ALoad, typename Epi>
+template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, bool DIRECT, typename ALoad, typename Epi>
 __global__ __launch_bounds__(WM * WN * 64)
-void gemm_kernel(const ALoad aload, const T* __restrict__ W, int ldw, int M, int N, int K, int mtiles, int ntiles,
+void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, int N, int K, int mtiles, int ntiles,
                  const Epi epi) {
     constexpr int NT = WM * WN * 64;
     constexpr int EPC = 16 / (int)sizeof(T);          // elements per 16-byte chunk
-    constexpr int BK = GEMM_KB / (int)sizeof(T);      // elements of K per stage
+    constexpr int BK = KB / (int)sizeof(T);           // elements of K per stage
+    constexpr int CPR = KB / 16;                      // 16-byte chunks per tile row
+    constexpr int GEMM_ROWB = DIRECT ? KB : gemm_rowb<KB>();   // the LDS-DMA image is lane-linear: no padding, XOR swizzle
+    static_assert(!DIRECT || (KB == 128 && NBUF == 2 && ALoad::kDirect), "direct-to-LDS loop: 128-byte stages, two buffers");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int A_IT = BM * 8 / NT, W_IT = BN * 8 / NT;
-    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile/thread mismatch");
+    constexpr int A_IT = BM * CPR / NT, W_IT = BN * CPR / NT;
+    static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/thread mismatch");
+    static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;                               // [2][BM][ROWB]
-    unsigned char* Ws = smem + 2 * BM * GEMM_ROWB;          // [2][BN][ROWB]
+    unsigned char* As = smem;                                  // [NBUF][BM][ROWB]
+    unsigned char* Ws = smem + NBUF * BM * GEMM_ROWB;          // [NBUF][BN][ROWB]
+    float* stats = reinterpret_cast<float*>(smem + NBUF * (BM + BN) * GEMM_ROWB);   // [BM][kStatsFloats]
 
     // XCD-aware tile mapping (bijective over a grid rounded up to 8 * ceil(mtiles / 8) * ntiles)
     const int id = blockIdx.x;
@@ -187,6 +312,11 @@ void gemm_kernel(const ALoad aload, const T* __restrict__ W, int ldw, int M, int
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
     const bool tr = epi.transposed(n0);
+    ALoad aload = aload_;
+    if constexpr (ALoad::kStatsFloats > 0) {
+        aload.prepare(m0, BM, M, stats);
+        __syncthreads();
+    }
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -194,72 +324,137 @@ void gemm_kernel(const ALoad aload, const T* __restrict__ W, int ldw, int M, int
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // First MFMA operand P supplies the output's register dimension (4 consecutive indices per lane), second operand Q
+    // the lane dimension.  n4 form: P = W rows (n), Q = A rows (m).  m4 form (transposed stores): P = A, Q = W.
+    // Wave tiles are square, so swapping the roles is just swapping two LDS base pointers.
+    static_assert(BM / WM == BN / WN && TM == TN, "square wave tiles required for the operand-role swap");
+    const int frow = lane & 15;
+    const int nk = (K + BK - 1) / BK;
+
+    if constexpr (DIRECT) {
+        // ---- direct-to-LDS main loop (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) ------------------
+        // One wave instruction moves 8 tile rows x 128 bytes = 1 KiB: lane l -> LDS slot (row l >> 3, 16-byte slot l & 7)
+        // of the group, fed from source chunk (l & 7) ^ (row & 7) of that row — the XOR swizzle lives on the SOURCE
+        // address because the LDS destination of the DMA is lane-linear; fragment reads apply the same XOR.
+        constexpr int NW = WM * WN;
+        constexpr int A_LI = BM / 8 / NW, W_LI = BN / 8 / NW;
+        static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row groups per wave");
+        const int wu = __builtin_amdgcn_readfirstlane(wid);
+        const int lrow = lane >> 3, lsrc = ((lane & 7) ^ lrow) * EPC;
+        const T* a_src[A_LI]; const T* w_src[W_LI];
+#pragma unroll
+        for (int it = 0; it < A_LI; ++it) {
+            const int r = m0 + (wu * A_LI + it) * 8 + lrow;
+            a_src[it] = aload_.A + (size_t)(r < M ? r : M - 1) * aload_.lda + lsrc;
+        }
+#pragma unroll
+        for (int it = 0; it < W_LI; ++it) {
+            const int r = n0 + (wu * W_LI + it) * 8 + lrow;
+            w_src[it] = W + (size_t)(r < N ? r : N - 1) * ldw + lsrc;
+        }
+#define PQ_DLOAD(buf, k0)                                                                                                  \
+        {                                                                                                                  \
+            _Pragma("unroll") for (int it = 0; it < A_LI; ++it)                                                            \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + (k0)),        \
+                    (__attribute__((address_space(3))) void*)(As + (buf) * BM * KB + (wu * A_LI + it) * 1024), 16, 0, 0);  \
+            _Pragma("unroll") for (int it = 0; it < W_LI; ++it)                                                            \
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[it] + (k0)),        \
+                    (__attribute__((address_space(3))) void*)(Ws + (buf) * BN * KB + (wu * W_LI + it) * 1024), 16, 0, 0);  \
+        }
+        PQ_DLOAD(0, 0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int g4 = lane >> 4, sx = frow & 7;
+        const int a_off = (wm * (BM / WM) + frow) * KB, w_off = (wn * (BN / WN) + frow) * KB;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) PQ_DLOAD(cur ^ 1, (kt + 1) * BK)
+            const unsigned char* Ab = As + cur * BM * KB + a_off;
+            const unsigned char* Wb = Ws + cur * BN * KB + w_off;
+            const unsigned char* Pb = tr ? Ab : Wb;
+            const unsigned char* Qb = tr ? Wb : Ab;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int so = ((kk * 4 + g4) ^ sx) * 16;
+                Frag<T> fp[TM], fq[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fp[i].v = *reinterpret_cast<const decltype(fp[i].v)*>(Pb + i * 16 * KB + so);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fq[j].v = *reinterpret_cast<const decltype(fq[j].v)*>(Qb + j * 16 * KB + so);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mma16(acc[i][j], fp[i], fq[j]);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA into the other buffer has landed
+            __syncthreads();                                     // ... and so has everybody else's; buffer `cur` is free
+        }
+#undef PQ_DLOAD
+    } else {
     // Staging: each thread owns A_IT + W_IT 16-byte chunks of a stage.  Loads are unconditional from clamped addresses
     // (no divergent control flow, everything stays in registers); out-of-range chunks are zeroed by a select.
-    u32x4 ra[A_IT], rw[W_IT];
-    int a_row[A_IT], w_row[W_IT];
+    typename ALoad::Raw ra[A_IT];
+    u32x4 rw[W_IT];
+    int a_row[A_IT], w_row[W_IT], a_col[A_IT], w_col[W_IT];
     bool a_ok[A_IT], w_ok[W_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-        const int r = m0 + ((it * NT + tid) >> 3);
-        a_ok[it] = r < M; a_row[it] = a_ok[it] ? r : M - 1;
+        const int c = it * NT + tid, r = m0 + c / CPR;
+        a_ok[it] = r < M; a_row[it] = a_ok[it] ? r : M - 1; a_col[it] = (c % CPR) * EPC;
     }
 #pragma unroll
     for (int it = 0; it < W_IT; ++it) {
-        const int r = n0 + ((it * NT + tid) >> 3);
-        w_ok[it] = r < N; w_row[it] = w_ok[it] ? r : N - 1;
+        const int c = it * NT + tid, r = n0 + c / CPR;
+        w_ok[it] = r < N; w_row[it] = w_ok[it] ? r : N - 1; w_col[it] = (c % CPR) * EPC;
     }
-    const int kc = (tid & 7) * EPC;            // NT is a multiple of 8, so the chunk column is the same for every `it`
     const int klast = K - EPC;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
+    // PQ_GLOAD only issues loads (clamped addresses, no use of the data); PQ_LSTORE — placed AFTER the stage's MFMAs —
+    // converts / zero-fills and writes LDS.  Keeping every consumer of the loaded registers behind the MFMAs is what lets
+    // the load latency overlap the matrix work (a select right after the load would force an s_waitcnt in front of them).
 #define PQ_GLOAD(k0)                                                                                  \
     {                                                                                                 \
-        const int k_ = (k0) + kc;                                                                     \
-        const bool kin_ = k_ < K;                                                                     \
-        const int kk_ = kin_ ? k_ : klast;                                                            \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                         \
-            const u32x4 v_ = aload.load(a_row[it], kk_);                                              \
-            ra[it] = (a_ok[it] && kin_) ? v_ : zero;                                                  \
+            const int k_ = (k0) + a_col[it];                                                          \
+            ra[it] = aload.fetch(a_row[it], k_ < K ? k_ : klast);                                     \
         }                                                                                             \
         _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                         \
-            const u32x4 v_ = *reinterpret_cast<const u32x4*>(W + (size_t)w_row[it] * ldw + kk_);      \
-            rw[it] = (w_ok[it] && kin_) ? v_ : zero;                                                  \
+            const int k_ = (k0) + w_col[it];                                                          \
+            rw[it] = *reinterpret_cast<const u32x4*>(W + (size_t)w_row[it] * ldw + (k_ < K ? k_ : klast)); \
         }                                                                                             \
     }
-#define PQ_LSTORE(buf)                                                                                                 \
+#define PQ_LSTORE(buf, k0)                                                                                             \
     {                                                                                                                  \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                          \
-            const int c_ = it * NT + tid;                                                                              \
-            *reinterpret_cast<u32x4*>(As + ((buf) * BM + (c_ >> 3)) * GEMM_ROWB + (c_ & 7) * 16) = ra[it];             \
+            const int c_ = it * NT + tid, k_ = (k0) + a_col[it];                                                       \
+            const u32x4 v_ = aload.finish(ra[it], a_row[it], k_ < K ? k_ : klast);                                     \
+            *reinterpret_cast<u32x4*>(As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + (c_ % CPR) * 16) =                     \
+                (a_ok[it] && k_ < K) ? v_ : zero;                                                                      \
         }                                                                                                              \
         _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                                          \
-            const int c_ = it * NT + tid;                                                                              \
-            *reinterpret_cast<u32x4*>(Ws + ((buf) * BN + (c_ >> 3)) * GEMM_ROWB + (c_ & 7) * 16) = rw[it];             \
+            const int c_ = it * NT + tid, k_ = (k0) + w_col[it];                                                       \
+            *reinterpret_cast<u32x4*>(Ws + ((buf) * BN + c_ / CPR) * GEMM_ROWB + (c_ % CPR) * 16) =                     \
+                (w_ok[it] && k_ < K) ? rw[it] : zero;                                                                  \
         }                                                                                                              \
     }
 
-    const int nk = (K + BK - 1) / BK;
     PQ_GLOAD(0)
-    PQ_LSTORE(0)
+    PQ_LSTORE(0, 0)
     __syncthreads();
 
-    // First MFMA operand P supplies the output's register dimension (4 consecutive indices per lane), second operand Q
-    // the lane dimension.  n4 form: P = W rows (n), Q = A rows (m).  m4 form (transposed stores): P = A, Q = W.
-    // Wave tiles are square (static_assert below), so swapping the roles is just swapping two LDS base pointers.
-    static_assert(BM / WM == BN / WN && TM == TN, "square wave tiles required for the operand-role swap");
-    const int frow = lane & 15, fk = (lane >> 4) * 16;
+    const int fk = (lane >> 4) * 16;
     const int a_off = (wm * (BM / WM) + frow) * GEMM_ROWB + fk;
     const int w_off = (wn * (BN / WN) + frow) * GEMM_ROWB + fk;
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (NBUF == 2) ? (kt & 1) : 0;
         if (kt + 1 < nk) PQ_GLOAD((kt + 1) * BK)
         const unsigned char* Ab = As + cur * BM * GEMM_ROWB + a_off;
         const unsigned char* Wb = Ws + cur * BN * GEMM_ROWB + w_off;
         const unsigned char* Pb = tr ? Ab : Wb;
         const unsigned char* Qb = tr ? Wb : Ab;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KB / 64; ++kk) {
             Frag<T> fp[TM], fq[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fp[i].v = *reinterpret_cast<const decltype(fp[i].v)*>(Pb + i * 16 * GEMM_ROWB + kk * 64);
@@ -270,32 +465,91 @@ void gemm_kernel(const ALoad aload, const T* __restrict__ W, int ldw, int M, int
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16(acc[i][j], fp[i], fq[j]);
         }
-        if (kt + 1 < nk) PQ_LSTORE(cur ^ 1)
+        if (kt + 1 < nk) {
+            if constexpr (NBUF == 1) __syncthreads();        // every wave has finished reading the single stage
+            PQ_LSTORE((NBUF == 2) ? (cur ^ 1) : 0, (kt + 1) * BK)
+        }
         __syncthreads();
     }
 
+    }
 #undef PQ_GLOAD
 #undef PQ_LSTORE
-    const int mb = m0 + wm * (BM / WM), nb = n0 + wn * (BN / WN);
+    // ---- epilogue: registers -> (phase 1 math) -> LDS tile in the output's storage type -> coalesced 16-byte stores.
+    // The main loop ended on a barrier, so the stage buffers are free to be reused as the staging tile.
+    using S = typename Epi::S;
+    constexpr int CH = 16 / (int)sizeof(S);
+    unsigned char* St = smem;
+    const int wmb = wm * (BM / WM), wnb = wn * (BN / WN);
+    if (!tr) {
+        constexpr int SROW = BN * (int)sizeof(S) + 16;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (!tr) epi.n4(mb + j * 16 + (lane & 15), nb + i * 16 + 4 * (lane >> 4), v);
-            else     epi.m4(mb + i * 16 + 4 * (lane >> 4), nb + j * 16 + (lane & 15), v);
+            for (int j = 0; j < TN; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const int ml = wmb + j * 16 + (lane & 15), nl = wnb + i * 16 + 4 * (lane >> 4);
+                epi.xform_n4(m0 + ml, n0 + nl, v);
+                store4<S>(reinterpret_cast<S*>(St + ml * SROW) + nl, v);
+            }
+        __syncthreads();
+        constexpr int CPRO = BN / CH;
+        for (int c = tid; c < BM * CPRO; c += NT) {
+            const int r = c / CPRO, cc = c - r * CPRO;
+            if (m0 + r < M && n0 + cc * CH < N)
+                epi.store_n(m0 + r, n0 + cc * CH, reinterpret_cast<const S*>(St + r * SROW + cc * 16));
         }
+    } else {
+        constexpr int SROW = BM * (int)sizeof(S) + 16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const int ml = wmb + i * 16 + 4 * (lane >> 4), nl = wnb + j * 16 + (lane & 15);
+                epi.xform_m4(m0 + ml, n0 + nl, v);
+                store4<S>(reinterpret_cast<S*>(St + nl * SROW) + ml, v);
+            }
+        __syncthreads();
+        constexpr int CPRO = BM / CH;
+        for (int c = tid; c < BN * CPRO; c += NT) {
+            const int r = c / CPRO, cc = c - r * CPRO;
+            if (n0 + r < N && m0 + cc * CH < M)
+                epi.store_m(m0 + cc * CH, n0 + r, reinterpret_cast<const S*>(St + r * SROW + cc * 16));
+        }
+    }
 }
 
-template <int BM, int BN>
-constexpr size_t gemm_lds_bytes() { return (size_t)2 * (BM + BN) * GEMM_ROWB; }
+template <int BM, int BN, int KB, int NBUF, int STATS, int SSZ>
+constexpr size_t gemm_lds_bytes() {
+    const size_t pipe = (size_t)NBUF * (BM + BN) * gemm_rowb<KB>() + (size_t)BM * STATS * sizeof(float);
+    const size_t stage_n = (size_t)BM * (BN * SSZ + 16), stage_m = (size_t)BN * (BM * SSZ + 16);   // epilogue staging tile
+    const size_t stage = stage_n > stage_m ? stage_n : stage_m;
+    return pipe > stage ? pipe : stage;
+}
 
-template <typename T, int BM, int BN, int WM, int WN, typename ALoad, typename Epi>
+template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, typename ALoad, typename Epi>
 inline hipError_t launch_gemm(hipStream_t s, const ALoad& aload, const T* W, int ldw, int M, int N, int K, const Epi& epi) {
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-    auto kern = gemm_kernel<T, BM, BN, WM, WN, ALoad, Epi>;
-    constexpr size_t lds = gemm_lds_bytes<BM, BN>();
+    constexpr size_t lds = gemm_lds_bytes<BM, BN, KB, NBUF, ALoad::kStatsFloats, (int)sizeof(typename Epi::S)>();
+    constexpr bool can_direct = ALoad::kDirect && KB == 128 && NBUF == 2 && (BM % (8 * WM * WN) == 0) && (BN % (8 * WM * WN) == 0);
+    if constexpr (can_direct) {
+        if (K % (KB / (int)sizeof(T)) == 0) {       // whole stages only: the DMA path cannot zero-fill a K tail
+            auto kd = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, true, ALoad, Epi>;
+            if (lds > 64 * 1024) {
+                static bool attr_done_d = false;
+                if (!attr_done_d) {
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                    if (e != hipSuccess) return e;
+                    attr_done_d = true;
+                }
+            }
+            hipLaunchKernelGGL(kd, dim3(grid), dim3(WM * WN * 64), lds, s, aload, W, ldw, M, N, K, mtiles, ntiles, epi);
+            return hipGetLastError();
+        }
+    }
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, false, ALoad, Epi>;
     if (lds > 64 * 1024) {
         static bool attr_done = false;      // one flag per template instantiation
         if (!attr_done) {

@@ -243,8 +243,10 @@ struct parseq_plan {
     float* qself = nullptr;        // [npos][E], pre-scaled
     void* ctab_ln = nullptr;       // T [npos * num_tokens][E] scratch for table build
     float* x = nullptr;            // fp32 [B*N][E]
-    void *xn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ao = nullptr, *h = nullptr, *kvmem = nullptr;
-    void *sa = nullptr, *tn = nullptr, *ca = nullptr, *hdn = nullptr;
+    void *xn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ao = nullptr, *h = nullptr;
+    void *kmem = nullptr, *vtmem = nullptr;   // cross-attention K [B][H][N][32] and V^T [B][H][32][N] of memory
+    float* stab = nullptr;         // [npos][npos][num_tokens][H] self-attention score table
+    void *sa = nullptr, *tn = nullptr, *ca = nullptr, *hdn = nullptr;   // tn: unused since LayerNorm moved into the GEMM A-loaders
     float *t = nullptr, *qc = nullptr;
     int* tok = nullptr;            // [B][LDT]
     unsigned char* kpm = nullptr;  // [B][LDT]
@@ -289,9 +291,9 @@ static int run_layernorm(hipStream_t s, const float* x, const float* w, const fl
 
 // GEMM dispatch: big tiles for the encoder's M = batch * 128 rows, small tiles for the decoder's M = batch (* 26).
 template <typename T, typename ALoad, typename Epi>
-static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, int N, int K, const Epi& epi) {
-    if (M >= 4096) HIPCHK((launch_gemm<T, 128, 128, 2, 2>(s, a, W, ldw, M, N, K, epi)));
-    else HIPCHK((launch_gemm<T, 64, 64, 2, 2>(s, a, W, ldw, M, N, K, epi)));
+static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, int N, int K, const Epi& epi, bool force_small = false) {
+    if (M >= 4096 && !force_small) HIPCHK((launch_gemm<T, 128, 128, 2, 2, 128, 2>(s, a, W, ldw, M, N, K, epi)));
+    else HIPCHK((launch_gemm<T, 64, 64, 2, 2, 768, 1>(s, a, W, ldw, M, N, K, epi)));
     return 0;
 }
 
@@ -340,6 +342,13 @@ static int build_tables(parseq_plan* p, hipStream_t s) {
         CHK((run_gemm<T>(s, ARowMajor<T>{ln, E}, W.w(d + "self_attn.in_proj_weight"), E, npos, E, E,
                          epi_store<float>(npos, E, m->p(d + "self_attn.in_proj_bias"), p->qself, E, scale))));
     }
+    // self-attention score table: every (query position, key position, key token, head) dot product
+    {
+        const size_t total = (size_t)npos * npos * ntok * (E / DEC_HD);
+        hipLaunchKernelGGL((score_table_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p->qself,
+                           reinterpret_cast<const T*>(p->kvtab), p->stab, npos, ntok, E);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -382,7 +391,8 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t o_q = carve(off, rows * E * ts), o_k = carve(off, rows * E * ts), o_vt = carve(off, rows * E * ts);
     const size_t o_ao = carve(off, rows * E * ts);
     const size_t o_h = carve(off, rows * F * ts);
-    const size_t o_kvmem = carve(off, rows * 2 * E * ts);
+    const size_t o_kmem = carve(off, rows * E * ts), o_vtmem = carve(off, rows * E * ts);
+    const size_t o_stab = carve(off, npos * npos * c.num_tokens * (E / 32) * 4);
     const size_t o_sa = carve(off, drows * E * ts), o_tn = carve(off, drows * E * ts), o_ca = carve(off, drows * E * ts);
     const size_t o_hdn = carve(off, drows * Fd * ts);
     const size_t o_t = carve(off, drows * E * 4), o_qc = carve(off, drows * E * 4);
@@ -394,7 +404,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     unsigned char* a = p->arena;
     p->wpack = a + o_wpack; p->kvtab = a + o_kvtab; p->qself = (float*)(a + o_qself); p->ctab_ln = a + o_ctab;
     p->x = (float*)(a + o_x); p->xn = a + o_xn; p->q = a + o_q; p->k = a + o_k; p->vt = a + o_vt; p->ao = a + o_ao; p->h = a + o_h;
-    p->kvmem = a + o_kvmem; p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
+    p->kmem = a + o_kmem; p->vtmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
     int r = pack_weights(p, (hipStream_t)stream);
@@ -467,8 +477,8 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     for (int i = 0; i < c.enc_depth; ++i) {
         const std::string b = "encoder.blocks." + std::to_string(i) + ".";
         { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
-        EpiQKV<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
-        eq.q = q; eq.k = k; eq.vt = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N;
+        EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
+        eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N; eq.tr_from = 2;
         { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
         { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H))); }
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
@@ -479,8 +489,14 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     // final norm -> memory (fp32 to the caller, T copy as GEMM operand), then the cross-attention K/V of memory, ONCE
     { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p("encoder.norm.weight"), m->p("encoder.norm.bias"), xn, memory_out, M, E, c.enc_ln_eps))); }
     const std::string d = "decoder.layers.0.cross_attn.";
-    { ProfScope ps_(&p->prof, T_KVMEM, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(d + "in_proj_weight") + (size_t)E * E, E, M, 2 * E, E,
-                     epi_store<T>(M, 2 * E, m->p(d + "in_proj_bias") + E, reinterpret_cast<T*>(p->kvmem), 2 * E)))); }
+    {
+        EpiHeads<T> ek; static_cast<EpiBase&>(ek) = epi_base(M, 2 * E, m->p(d + "in_proj_bias") + E);
+        ek.seg[0] = reinterpret_cast<T*>(p->kmem); ek.seg[1] = reinterpret_cast<T*>(p->vtmem); ek.seg[2] = nullptr;
+        ek.E = E; ek.heads = c.dec_heads; ek.hd = DEC_HD; ek.tokens = N; ek.tr_from = 1;
+        ProfScope ps_(&p->prof, T_KVMEM, s);
+        // the K | V^T boundary (column E) must fall on a tile edge: 64-wide tiles when E is not a multiple of 128 (PARSeq-Ti)
+        CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(d + "in_proj_weight") + (size_t)E * E, E, M, 2 * E, E, ek, E % 128 != 0)));
+    }
     p->last_batch = B;
     return 0;
 }
@@ -511,26 +527,43 @@ extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtyp
 // -------------------------------------------------------------------------------------------------------------------
 // decoder
 // -------------------------------------------------------------------------------------------------------------------
-template <typename T>
-static int run_self_attn(hipStream_t s, const parseq_plan* p, int E, int ntok, const unsigned char* qmask, const unsigned char* kpm,
-                         int Lk, int i0, int Lq, int B) {
-    const dim3 grid((B * Lq + 3) / 4), block(256);
-    const T* kvtab = reinterpret_cast<const T*>(p->kvtab); T* out = reinterpret_cast<T*>(p->sa);
-#define LAUNCH_SA(EE) hipLaunchKernelGGL((dec_self_attn_kernel<T, EE>), grid, block, 0, s, p->qself, kvtab, p->tok, LDT, ntok, qmask, LDT, kpm, LDT, Lk, i0, Lq, B, out)
-    switch (E) { case 192: LAUNCH_SA(192); break; case 384: LAUNCH_SA(384); break; default: LAUNCH_SA(768); break; }
-#undef LAUNCH_SA
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-template <typename T>
-static int run_cross_attn(hipStream_t s, const parseq_plan* p, int E, int Nk, int Lq, int B, float scale) {
-    const T* kvmem = reinterpret_cast<const T*>(p->kvmem); T* out = reinterpret_cast<T*>(p->ca);
-#define LAUNCH_CA(EE, QC) hipLaunchKernelGGL((dec_cross_attn_kernel<T, EE, QC>), dim3(B * ((Lq + QC - 1) / QC)), dim3(256), 0, s, p->qc, kvmem, Nk, Lq, scale, out)
-    if (Lq == 1) { switch (E) { case 192: LAUNCH_CA(192, 1); break; case 384: LAUNCH_CA(384, 1); break; default: LAUNCH_CA(768, 1); break; } }
-    else { switch (E) { case 192: LAUNCH_CA(192, 13); break; case 384: LAUNCH_CA(384, 13); break; default: LAUNCH_CA(768, 13); break; } }
-#undef LAUNCH_CA
-    HIPCHK(hipGetLastError());
+template <typename T, int E>
+static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
+                         float* logits, int Ltot) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int M = B * Lq, Fd = E * c.dec_mlp_ratio, C = m->classes, npos = c.max_label_length + 1, H = c.dec_heads;
+    const Weights<T> W = weights_of<T>(p);
+    const std::string d = "decoder.layers.0.";
+    T* sa = reinterpret_cast<T*>(p->sa); T* ca = reinterpret_cast<T*>(p->ca); T* hdn = reinterpret_cast<T*>(p->hdn);
+    const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vtmem = reinterpret_cast<const T*>(p->vtmem);
+    const float scale = sqrtf(1.0f / (float)DEC_HD);
+    // self-attention from the tables, out-projection, residual onto the raw position queries
+    {
+        ProfScope ps_(&p->prof, T_DEC_SA, s);
+        hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
+                           c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, sa);
+        HIPCHK(hipGetLastError());
+    }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
+                     epi_table(M, E, m->p(d + "self_attn.out_proj.bias"), p->t, E, m->p("pos_queries"), E, Lq, i0)))); }
+    // cross-attention against memory (head-split K / V^T cached in the plan); norm1 is fused into the q-projection's A operand
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), c.dec_ln_eps, 0, nullptr},
+                     W.w(d + "cross_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
+    {
+        ProfScope ps_(&p->prof, T_DEC_CA, s);
+        if (Lq == 1) hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vtmem, scale, ca);
+        else hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, p->qc, kmem, vtmem, H, Lq, scale, ca);
+        HIPCHK(hipGetLastError());
+    }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{ca, E}, W.w(d + "cross_attn.out_proj.weight"), E, M, E, E, epi_resid(M, E, m->p(d + "cross_attn.out_proj.bias"), p->t, E)))); }
+    // MLP (norm2 fused into linear1's A operand)
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps, 0, nullptr},
+                     W.w(d + "linear1.weight"), E, M, Fd, E, epi_gelu<T>(M, Fd, m->p(d + "linear1.bias"), hdn, Fd)))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{hdn, Fd}, W.w(d + "linear2.weight"), Fd, M, E, Fd, epi_resid(M, E, m->p(d + "linear2.bias"), p->t, E)))); }
+    // decoder.norm fused into the head's A operand
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps, 0, nullptr},
+                     W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), logits, C, 1.f, Lq, Ltot, i0)))); }
     return 0;
 }
 
@@ -540,31 +573,11 @@ static int run_cross_attn(hipStream_t s, const parseq_plan* p, int E, int Nk, in
 template <typename T>
 static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
                        float* logits, int Ltot) {
-    const parseq_model* m = p->m;
-    const parseq_config& c = m->cfg;
-    const int E = c.embed_dim, M = B * Lq, Fd = E * c.dec_mlp_ratio, C = m->classes;
-    const Weights<T> W = weights_of<T>(p);
-    const std::string d = "decoder.layers.0.";
-    T* sa = reinterpret_cast<T*>(p->sa); T* tn = reinterpret_cast<T*>(p->tn); T* ca = reinterpret_cast<T*>(p->ca); T* hdn = reinterpret_cast<T*>(p->hdn);
-    const float scale = sqrtf(1.0f / (float)(E / c.dec_heads));
-    // self-attention over the content table, out-projection, residual onto the raw position queries
-    { ProfScope ps_(&p->prof, T_DEC_SA, s); CHK((run_self_attn<T>(s, p, E, c.num_tokens, qmask, kpm, Lk, i0, Lq, B))); }
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
-                     epi_table(M, E, m->p(d + "self_attn.out_proj.bias"), p->t, E, m->p("pos_queries"), E, Lq, i0)))); }
-    // cross-attention against memory (K/V cached in the plan)
-    { ProfScope ps_(&p->prof, T_DEC_LN, s); CHK((run_layernorm<T>(s, p->t, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), tn, nullptr, M, E, c.dec_ln_eps))); }
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{tn, E}, W.w(d + "cross_attn.in_proj_weight"), E, M, E, E,
-                     epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
-    { ProfScope ps_(&p->prof, T_DEC_CA, s); CHK((run_cross_attn<T>(s, p, E, m->tokens, Lq, B, scale))); }
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{ca, E}, W.w(d + "cross_attn.out_proj.weight"), E, M, E, E, epi_resid(M, E, m->p(d + "cross_attn.out_proj.bias"), p->t, E)))); }
-    // MLP
-    { ProfScope ps_(&p->prof, T_DEC_LN, s); CHK((run_layernorm<T>(s, p->t, m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), tn, nullptr, M, E, c.dec_ln_eps))); }
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{tn, E}, W.w(d + "linear1.weight"), E, M, Fd, E, epi_gelu<T>(M, Fd, m->p(d + "linear1.bias"), hdn, Fd)))); }
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{hdn, Fd}, W.w(d + "linear2.weight"), Fd, M, E, Fd, epi_resid(M, E, m->p(d + "linear2.bias"), p->t, E)))); }
-    // decoder.norm + head
-    { ProfScope ps_(&p->prof, T_DEC_LN, s); CHK((run_layernorm<T>(s, p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), tn, nullptr, M, E, c.dec_ln_eps))); }
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{tn, E}, W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), logits, C, 1.f, Lq, Ltot, i0)))); }
-    return 0;
+    switch (p->m->cfg.embed_dim) {
+        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot);
+        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot);
+        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot);
+    }
 }
 
 template <typename T>
@@ -663,6 +676,39 @@ extern "C" int parseq_op_linear(const void* A, const void* W, const float* bias,
     if (act && (N % 4)) return fail(PARSEQ_E_INVALID, "act=1 needs N %% 4 == 0");
     if (dtype == PARSEQ_BF16) return op_linear_impl<bf16_t>((const bf16_t*)A, (const bf16_t*)W, bias, C, act, M, N, K, (hipStream_t)stream);
     return op_linear_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, (hipStream_t)stream);
+}
+
+// Tile-configuration sweep hook for tools/gemm_bench.py (not used by the product path, which picks via run_gemm).
+template <typename T>
+static int op_linear_cfg_impl(const T* A, const T* W, const float* bias, void* C, int act, int M, int N, int K, int cfg, hipStream_t s) {
+#define PQ_CFG(ID, BM, BN, WM, WN, KB, NBUF)                                                                                     \
+    case 100 + ID: {                                                                                                              \
+        EpiNull en; static_cast<EpiBase&>(en) = epi_base(M, N, bias); en.sink = (float*)C;                                        \
+        HIPCHK((launch_gemm<T, BM, BN, WM, WN, KB, NBUF>(s, ARowMajor<T>{A, K}, W, K, M, N, K, en)));                              \
+        return 0; }                                                                                                               \
+    case ID:                                                                                                                      \
+        if (act) HIPCHK((launch_gemm<T, BM, BN, WM, WN, KB, NBUF>(s, ARowMajor<T>{A, K}, W, K, M, N, K, epi_gelu<T>(M, N, bias, (T*)C, N)))); \
+        else HIPCHK((launch_gemm<T, BM, BN, WM, WN, KB, NBUF>(s, ARowMajor<T>{A, K}, W, K, M, N, K, epi_store<float>(M, N, bias, (float*)C, N)))); \
+        return 0;
+    switch (cfg) {
+        PQ_CFG(0, 128, 128, 2, 2, 128, 2)
+        PQ_CFG(1, 128, 128, 2, 2, 256, 1)
+        PQ_CFG(2, 256, 128, 4, 2, 128, 2)
+        PQ_CFG(3, 256, 128, 4, 2, 256, 1)
+        PQ_CFG(4, 128, 128, 2, 2, 256, 2)
+        PQ_CFG(5, 64, 64, 2, 2, 768, 1)
+        PQ_CFG(6, 128, 128, 2, 2, 128, 1)
+        PQ_CFG(7, 256, 128, 4, 2, 128, 1)
+        default: return fail(PARSEQ_E_INVALID, "unknown gemm cfg %d", cfg);
+    }
+#undef PQ_CFG
+}
+
+extern "C" int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K, int cfg, void* stream) {
+    CHK(check_arch());
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || (K % 8) || (act && (N % 4))) return fail(PARSEQ_E_INVALID, "bad argument");
+    if (dtype == PARSEQ_BF16) return op_linear_cfg_impl<bf16_t>((const bf16_t*)A, (const bf16_t*)W, bias, C, act, M, N, K, cfg, (hipStream_t)stream);
+    return op_linear_cfg_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, cfg, (hipStream_t)stream);
 }
 
 extern "C" int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads, void* stream) {
