@@ -23,6 +23,9 @@ constexpr int ATT_HD = 64;     // head dim
 constexpr int ATT_KROWB = ATT_HD * 2 + 16;    // K row pitch in LDS (bytes): 144 -> conflict-free ds_read_b128
 constexpr int ATT_VROWB = ATT_N * 2 + 8;      // V^T row pitch in LDS (bytes): 264 -> conflict-free ds_read_b64
 
+// V_ROWMAJOR: v is [B][H][N][hd] like q and k (what the LN-panel qkv kernel writes) and is transposed while it is staged
+// into LDS; otherwise v is already V^T [B][H][hd][N] (generic GEMM epilogue, m-form tiles).
+template <bool V_ROWMAJOR>
 __global__ __launch_bounds__(256)
 void attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ vt,
                       bf16_t* __restrict__ ao, int heads, float scale) {
@@ -45,9 +48,20 @@ void attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
             const uint4 kv = kg[c];
             *reinterpret_cast<uint4*>(Ks + (c >> 3) * ATT_KROWB + (c & 7) * 16) = kv;
             const uint4 vv = vg[c];
-            unsigned char* dst = Vs + (c >> 4) * ATT_VROWB + (c & 15) * 16;     // 8-byte aligned only
-            *reinterpret_cast<uint2*>(dst) = make_uint2(vv.x, vv.y);
-            *reinterpret_cast<uint2*>(dst + 8) = make_uint2(vv.z, vv.w);
+            if constexpr (V_ROWMAJOR) {
+                // chunk c = 8 consecutive d of token t = c >> 3: scatter them down a column of the V^T image
+                const int t = c >> 3, d0 = (c & 7) * 8;
+                const unsigned int w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<unsigned short*>(Vs + (d0 + 2 * i) * ATT_VROWB + t * 2) = (unsigned short)(w4[i] & 0xffffu);
+                    *reinterpret_cast<unsigned short*>(Vs + (d0 + 2 * i + 1) * ATT_VROWB + t * 2) = (unsigned short)(w4[i] >> 16);
+                }
+            } else {
+                unsigned char* dst = Vs + (c >> 4) * ATT_VROWB + (c & 15) * 16;     // 8-byte aligned only
+                *reinterpret_cast<uint2*>(dst) = make_uint2(vv.x, vv.y);
+                *reinterpret_cast<uint2*>(dst + 8) = make_uint2(vv.z, vv.w);
+            }
         }
     }
 

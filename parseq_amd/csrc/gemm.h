@@ -166,6 +166,8 @@ struct ALayerNorm {
 struct EpiBase {
     int M, N;
     const float* bias;   // [N] or nullptr
+    static constexpr bool kPrefetch = false;     // true: the kernel calls load_n() for every chunk BEFORE the staging pass
+    __device__ __forceinline__ u32x4 load_n(int, int) const { return u32x4{0u, 0u, 0u, 0u}; }
     __device__ __forceinline__ bool transposed(int) const { return false; }
     __device__ __forceinline__ float b(int n) const { return (bias && n < N) ? bias[n] : 0.f; }
     __device__ __forceinline__ void xform_n4(int, int n, float* v) const {
@@ -220,16 +222,22 @@ struct EpiGelu : EpiBase {
     __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
 
-// x[m][n] += acc + bias   (fp32 residual stream, in place)
+// x[m][n] += acc + bias   (fp32 residual stream, in place).  The old x values are fetched for ALL of a thread's chunks
+// at the start of the epilogue (kPrefetch), so their latency hides under the LDS staging pass instead of being paid
+// once per chunk in a load -> add -> store chain (that chain ran proj / fc2 at 2.7 TB/s).
 struct EpiResid : EpiBase {
     using S = float;
+    static constexpr bool kPrefetch = true;
     float* x; int ldx;
-    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+    __device__ __forceinline__ u32x4 load_n(int m, int n) const {
+        return *reinterpret_cast<const u32x4*>(x + (size_t)m * ldx + n);
+    }
+    __device__ __forceinline__ void store_n(int m, int n, const S* c, const u32x4& old) const {
         if (n + 4 > N) return;
-        float4* p = reinterpret_cast<float4*>(x + (size_t)m * ldx + n);
-        float4 r = *p;
-        r.x += c[0]; r.y += c[1]; r.z += c[2]; r.w += c[3];
-        *p = r;
+        float4 r;
+        r.x = __uint_as_float(old[0]) + c[0]; r.y = __uint_as_float(old[1]) + c[1];
+        r.z = __uint_as_float(old[2]) + c[2]; r.w = __uint_as_float(old[3]) + c[3];
+        *reinterpret_cast<float4*>(x + (size_t)m * ldx + n) = r;
     }
     __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
@@ -483,6 +491,17 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
     const int wmb = wm * (BM / WM), wnb = wn * (BN / WN);
     if (!tr) {
         constexpr int SROW = BN * (int)sizeof(S) + 16;
+        constexpr int CPRO = BN / CH;
+        constexpr int NCH = (BM * CPRO + NT - 1) / NT;              // chunks per thread
+        u32x4 pre[Epi::kPrefetch ? NCH : 1];
+        if constexpr (Epi::kPrefetch) {
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int c = q * NT + tid, r = c / CPRO, cc = c - r * CPRO;
+                const int mm = m0 + r < M ? m0 + r : M - 1, nn = n0 + cc * CH + CH <= N ? n0 + cc * CH : 0;
+                pre[q] = epi.load_n(mm, nn);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -493,11 +512,14 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
                 store4<S>(reinterpret_cast<S*>(St + ml * SROW) + nl, v);
             }
         __syncthreads();
-        constexpr int CPRO = BN / CH;
-        for (int c = tid; c < BM * CPRO; c += NT) {
-            const int r = c / CPRO, cc = c - r * CPRO;
-            if (m0 + r < M && n0 + cc * CH < N)
-                epi.store_n(m0 + r, n0 + cc * CH, reinterpret_cast<const S*>(St + r * SROW + cc * 16));
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int c = q * NT + tid, r = c / CPRO, cc = c - r * CPRO;
+            if (c < BM * CPRO && m0 + r < M && n0 + cc * CH < N) {
+                const S* chunk = reinterpret_cast<const S*>(St + r * SROW + cc * 16);
+                if constexpr (Epi::kPrefetch) epi.store_n(m0 + r, n0 + cc * CH, chunk, pre[q]);
+                else epi.store_n(m0 + r, n0 + cc * CH, chunk);
+            }
         }
     } else {
         constexpr int SROW = BM * (int)sizeof(S) + 16;

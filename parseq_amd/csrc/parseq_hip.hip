@@ -16,6 +16,7 @@
 #include "common.h"
 #include "decoder_attn.h"
 #include "encoder_attn.h"
+#include "encoder_panel.h"
 #include "gemm.h"
 #include "rowops.h"
 
@@ -447,11 +448,13 @@ extern "C" int parseq_plan_get_profile(parseq_plan* p, int index, const char** n
 // encoder
 // -------------------------------------------------------------------------------------------------------------------
 template <typename T>
-static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads) {
+static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads, bool v_rowmajor = false) {
     const float scale = 1.0f / sqrtf((float)ATT_HD);
     if constexpr (sizeof(T) == 2) {
-        hipLaunchKernelGGL(attn_mfma_kernel, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
+        if (v_rowmajor) hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
+        else hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
     } else {
+        if (v_rowmajor) return fail(PARSEQ_E_INVALID, "f32 attention expects V^T");
         constexpr size_t lds = (size_t)2 * ATT_N * ATT_HD * sizeof(float);
         static bool attr_done = false;
         if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
@@ -474,16 +477,39 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     APatch<T, TI> ap{images, 3, c.img_h, c.img_w, c.patch_h, c.patch_w, c.img_w / c.patch_w, N};
     { ProfScope ps_(&p->prof, T_PATCH, s); CHK((run_gemm<T>(s, ap, W.w("encoder.patch_embed.proj.weight"), m->patch_k, M, E, m->patch_k,
                      epi_table(M, E, m->p("encoder.patch_embed.proj.bias"), p->x, E, m->p("encoder.pos_embed"), E, N, 0)))); }
+    // bf16 mode: LayerNorm + projection fused in the register-resident-A panel kernel (encoder_panel.h) wherever the
+    // output width is a multiple of its 128-column tile; otherwise (and in f32 mode) LayerNorm kernel + generic tile GEMM.
+    constexpr bool kBf16 = sizeof(T) == 2;
+    const bool panel_qkv = kBf16 && (E == 192 || E == 384) && (3 * E) % PN_BN == 0;
+    const bool panel_fc1 = kBf16 && (E == 192 || E == 384) && F % PN_BN == 0;
     for (int i = 0; i < c.enc_depth; ++i) {
         const std::string b = "encoder.blocks." + std::to_string(i) + ".";
-        { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
-        EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
-        eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N; eq.tr_from = 2;
-        { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
-        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H))); }
+        if (panel_qkv) {
+            if constexpr (kBf16) {
+                PanelHeads ph; ph.seg[0] = q; ph.seg[1] = k; ph.seg[2] = vt; ph.E = E; ph.heads = H; ph.hd = ATT_HD; ph.tokens = N;
+                ProfScope ps_(&p->prof, T_QKV, s);
+                if (E == 384) HIPCHK((launch_ln_panel_gemm<384>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), m->p(b + "attn.qkv.bias"), M, 3 * E, ph)));
+                else HIPCHK((launch_ln_panel_gemm<192>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), m->p(b + "attn.qkv.bias"), M, 3 * E, ph)));
+            }
+        } else {
+            { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
+            EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
+            eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N; eq.tr_from = 2;
+            { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
+        }
+        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv))); }
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
-        { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
-        { ProfScope ps_(&p->prof, T_FC1, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "mlp.fc1.weight"), E, M, F, E, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F)))); }
+        if (panel_fc1) {
+            if constexpr (kBf16) {
+                PanelGelu pg; pg.out = h; pg.ldo = F;
+                ProfScope ps_(&p->prof, T_FC1, s);
+                if (E == 384) HIPCHK((launch_ln_panel_gemm<384>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"), m->p(b + "mlp.fc1.bias"), M, F, pg)));
+                else HIPCHK((launch_ln_panel_gemm<192>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"), m->p(b + "mlp.fc1.bias"), M, F, pg)));
+            }
+        } else {
+            { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
+            { ProfScope ps_(&p->prof, T_FC1, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "mlp.fc1.weight"), E, M, F, E, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F)))); }
+        }
         { ProfScope ps_(&p->prof, T_FC2, s); CHK((run_gemm<T>(s, ARowMajor<T>{h, F}, W.w(b + "mlp.fc2.weight"), F, M, E, F, epi_resid(M, E, m->p(b + "mlp.fc2.bias"), p->x, E)))); }
     }
     // final norm -> memory (fp32 to the caller, T copy as GEMM operand), then the cross-attention K/V of memory, ONCE
