@@ -138,6 +138,10 @@ int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, i
 /* Same as parseq_op_linear with an explicit tile configuration (tools/gemm_bench.py sweeps these; ids in parseq_hip.hip). */
 int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                          int cfg, void* stream);
+/* out[M, N] (bf16) = gelu(LayerNorm(x[M, 384]; gamma, beta, eps 1e-6) W^T + bias) through the register-resident-A panel
+ * kernel; W bf16 [N, 384], N a multiple of 128.  variant 0 = the product kernel; 1..4 = ablations (tools/panel_bench.py). */
+int parseq_op_ln_linear_gelu(const float* x, const float* gamma, const float* beta, const void* W, const float* bias,
+                             void* out, int M, int N, int variant, void* stream);
 /* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;
  * out [bh / heads * 128, heads * 64] in `dtype`. */
 int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads,

@@ -737,6 +737,24 @@ extern "C" int parseq_op_linear_cfg(const void* A, const void* W, const float* b
     return op_linear_cfg_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, cfg, (hipStream_t)stream);
 }
 
+// LayerNorm + Linear + GELU through the panel kernel (E = 384), with ablation variants for tools/panel_bench.py.
+extern "C" int parseq_op_ln_linear_gelu(const float* x, const float* gamma, const float* beta, const void* W, const float* bias,
+                                        void* out, int M, int N, int variant, void* stream) {
+    CHK(check_arch());
+    if (!x || !gamma || !beta || !W || !bias || !out || M <= 0 || N <= 0 || (N % PN_BN)) return fail(PARSEQ_E_INVALID, "bad argument (N must be a multiple of 128)");
+    PanelGelu pg; pg.out = (bf16_t*)out; pg.ldo = N;
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 0: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
+        case 1: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 1>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
+        case 2: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 2>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
+        case 3: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 3>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
+        case 4: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 4>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
+        default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
+    }
+    return 0;
+}
+
 extern "C" int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads, void* stream) {
     CHK(check_arch());
     if (!q || !k || !vt || !out || bh <= 0 || heads <= 0 || bh % heads) return fail(PARSEQ_E_INVALID, "bad argument");

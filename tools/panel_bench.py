@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Ablations of the LN-panel GEMM kernel (fc1 shape 65536 x 1536 x 384 and qkv-width 1152) — run on the GPU box."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from parseq_amd import _native as nat  # noqa: E402
+
+NAMES = {0: 'full', 1: 'no global stores', 2: 'no LayerNorm prologue', 3: 'no MFMA / LDS reads', 4: 'no vmcnt waits (garbage)'}
+
+
+def main():
+    lib = nat.lib()
+    M, E = 65536, 384
+    x = torch.randn(M, E, device='cuda')
+    gamma, beta = torch.rand(E, device='cuda') + 0.5, torch.randn(E, device='cuda') * 0.1
+    for N in (1536, 1152):
+        W = (torch.randn(N, E, device='cuda') / E ** 0.5).bfloat16()
+        bias = torch.randn(N, device='cuda') * 0.1
+        out = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+        for v in range(5):
+            def run():
+                nat.check(lib.parseq_op_ln_linear_gelu(nat.ptr(x), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W), nat.ptr(bias), nat.ptr(out), M, N, v, nat.stream_ptr()))
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = 1e3 * e0.elapsed_time(e1) / 20
+            print(f'N={N} variant {v} ({NAMES[v]:26s}): {us:8.1f} us  {2.0 * M * N * E / us / 1e6:7.1f} TFLOP/s-equivalent')
+        if N == 1536:
+            ref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(x[:256], (E,), gamma, beta, 1e-6).bfloat16().float() @ W.float().T + bias)
+            nat.check(lib.parseq_op_ln_linear_gelu(nat.ptr(x), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W), nat.ptr(bias), nat.ptr(out), M, N, 0, nat.stream_ptr()))
+            torch.cuda.synchronize()
+            print('max |err| vs torch on 256 rows:', (out[:256].float() - ref).abs().max().item())
+
+
+if __name__ == '__main__':
+    main()
