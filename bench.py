@@ -32,7 +32,7 @@ def gemm_flops(family, B, cfg):
     E, M = cfg['embed_dim'], B * 128
     F = E * cfg['enc_mlp_ratio']
     return {'enc.qkv_gemm': 2.0 * M * 3 * E * E, 'enc.proj_gemm': 2.0 * M * E * E, 'enc.fc1_gelu_gemm': 2.0 * M * F * E,
-            'enc.fc2_gemm': 2.0 * M * E * F, 'dec.memory_kv_gemm': 2.0 * M * 2 * E * E,
+            'enc.fc2_gemm': 2.0 * M * E * F, 'enc.mlp_fused': 4.0 * M * E * F, 'dec.memory_kv_gemm': 2.0 * M * 2 * E * E,
             'enc.attention': 4.0 * B * cfg['enc_num_heads'] * 128 * 128 * 64}.get(family)
 
 

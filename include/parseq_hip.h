@@ -142,6 +142,13 @@ int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* 
  * kernel; W bf16 [N, 384], N a multiple of 128.  variant 0 = the product kernel; 1..4 = ablations (tools/panel_bench.py). */
 int parseq_op_ln_linear_gelu(const float* x, const float* gamma, const float* beta, const void* W, const float* bias,
                              void* out, int M, int N, int variant, void* stream);
+/* In place x[M, 384] (fp32) += fc2(gelu(fc1(LayerNorm(x; gamma, beta, eps 1e-6)))) through the fused MLP kernel:
+ * W1 bf16 [1536, 384], b1 fp32 [1536], W2 bf16 [384, 1536], b2 fp32 [384]  (timm Block: x + mlp(norm2(x))). */
+int parseq_op_mlp(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                  const float* b2, int M, void* stream);
+/* Ablation variants of parseq_op_mlp for tools/panel_bench.py (variant 0 = the product kernel). */
+int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                          const float* b2, int M, int variant, void* stream);
 /* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;
  * out [bh / heads * 128, heads * 64] in `dtype`. */
 int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads,

@@ -1,0 +1,347 @@
+// Fused encoder MLP block (bf16 throughput mode, E = 384):
+//
+//     x[m] += fc2( gelu( fc1( LayerNorm(x[m]) ) ) )                 x: fp32 residual stream [M, E], updated in place
+//
+// i.e. timm Block's `x = x + mlp(norm2(x))` as ONE kernel.  The 4E-wide hidden activation
+// never leaves the CU: in the unfused pipeline it was a 201 MB write plus a 201 MB read per layer at batch 512, and its
+// store drain (about 9 B/clk per CU) serialised with the MFMA phases of the fc1 kernel (profiles/r01_panel_ablation.log).
+//
+// Structure (one workgroup = 128 rows, 4 waves x 32 rows, ONE wave per SIMD so that each wave may use the whole
+// 512-entry register file):
+//   * LayerNorm'd rows live in registers as MFMA operand fragments for the whole K = E depth (as in encoder_panel.h).
+//   * The hidden dimension is walked in chunks of 64 units (acc1 = 32 accumulator registers; with 128-unit chunks the
+//     accumulator file is exactly full and VGPR spills go to scratch instead of to spare AGPRs).  Per chunk:
+//       GEMM1  acc1[64 hidden x 32 rows] = W1[chunk] . LN(x)^T           3 ring slots of W1 (each: 64 rows x two 64-k stages)
+//       GELU   + bias, packed to bf16 IN PLACE as the operand fragments of GEMM2: the pair-permuted row order in which
+//              the W1 rows are laid out in LDS makes a lane's 8 outputs of a tile pair exactly the 8 consecutive k-slots
+//              (hidden units) that its lane group feeds to one MFMA k-step — no LDS round trip, no cross-lane traffic.
+//       GEMM2  acc2[384 out x 32 rows] += W2[:, chunk] . H^T               3 ring slots of W2 (128 out rows x 64 k each)
+//   * W1 / W2 stages stream through an 8-slot LDS ring (16 KiB each) by global_load_lds, 7 stages in flight, counted vmcnt
+//     across raw barriers; there are no global stores inside the loop, so the counts are loads only.
+//   * Epilogue: x += acc2 + b2, read-modify-write with the 8-lanes-per-row arrangement (half-row DPP swap) so every
+//     load / store instruction touches complete 128-byte lines.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+#include "encoder_panel.h"
+
+namespace pq {
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+constexpr int MLP_BM = 128, MLP_NST = 8, MLP_DIST = 7, MLP_STAGE_BYTES = 128 * 128, MLP_HC = 64;
+
+// VARIANT (ablations, tools/panel_bench.py): 0 product; 1 no weight stream inside the loop (stale LDS); 2 no GELU (bias + convert
+// only); 3 no LDS reads / MFMAs; 4 no barriers and no vmcnt waits (garbage); 5 no LayerNorm prologue.
+template <int E, int VARIANT = 0>
+__global__ __launch_bounds__(256, 1)
+void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                      const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+                      const float* __restrict__ b2, int M, unsigned long long* __restrict__ dbg = nullptr) {
+    constexpr int F = 4 * E;                  // hidden width
+    constexpr int KSTEPS = E / 32;            // MFMA k-steps over E
+    constexpr int KS1 = E / 128;              // W1 ring slots per chunk: slot t holds k-stages 2t (LDS rows 0-63) and 2t+1 (rows 64-127)
+    constexpr int NG = E / 128;               // 128-row groups of W2 (output columns)
+    constexpr int KS2 = NG;                   // W2 ring slots per chunk (the chunk's 64 hidden units = one 64-k stage per row group)
+    constexpr int SPC = KS1 + KS2;            // stages per chunk
+    constexpr int NCH = F / MLP_HC;           // chunks
+    constexpr int S = NCH * SPC;              // total stages
+    static_assert(E % 128 == 0, "E must be a multiple of 128");
+    static_assert(S > MLP_DIST, "stream shorter than the prefetch distance");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;                                                // [MLP_NST][128 rows][128 B], XOR-swizzled
+    float* sb1 = reinterpret_cast<float*>(smem + MLP_NST * MLP_STAGE_BYTES);   // [F]
+    float* sb2 = sb1 + F;                                                      // [E]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 15, g = lane >> 4;
+    const bool lo_half = rr < 8;
+    const int m0 = blockIdx.x * MLP_BM;
+    // VARIANT 6: phase time stamps (s_memtime) of workgroups 0 and 300, lane 0 of every wave -> dbg[(blk * 4 + wave) * 64 + k]
+    const bool stamp = (VARIANT == 6) && dbg && (blockIdx.x == 0 || blockIdx.x == 300) && lane == 0;
+    unsigned long long* dslot = dbg + ((blockIdx.x == 0 ? 0 : 1) * 4 + wid) * 64;
+    int nstamp = 0;
+#define MLP_STAMP() do { if (VARIANT == 6) { if (stamp) dslot[nstamp] = __builtin_amdgcn_s_memtime(); ++nstamp; } } while (0)
+    MLP_STAMP();
+
+    // ---- weight stream -----------------------------------------------------------------------------------------------
+    // ring slot contents for stage s = (chunk c = s / SPC, t = s % SPC), always 128 LDS rows x 128 bytes:
+    //   t < KS1 :  W1 rows of the chunk (64 hidden units), TWO k-stages: LDS rows [0,64) = k in [128 t, +64),
+    //              rows [64,128) = k in [128 t + 64, +64) of the SAME 64 units.  LDS row rho: unit p64(rho & 63).
+    //   t >= KS1:  ng = t - KS1: W2 rows (output columns) [128 ng, +128), k = the chunk's 64 hidden units (row pitch F).
+    //              LDS row rho: output column p128(rho).
+    // p64 / p128 are the pair permutations that make a lane's accumulators 8 consecutive units / columns per tile pair:
+    //   p128(16 i + r16) = (i>>2)*64 + ((i>>1)&1)*32 + (r16>>2)*8 + (i&1)*4 + (r16&3),   p64 = the same on 4 tiles (i < 4).
+    int p128[4], p64[4], khalf[4];
+    const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;          // XOR swizzle on the source (LDS row & 7 == lane >> 3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rho = (wid * 4 + q) * 8 + (lane >> 3);
+        const int i = rho >> 4, r16 = rho & 15;
+        p128[q] = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
+        const int i4 = i & 3;
+        p64[q] = ((i4 >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i4 & 1) * 4 + (r16 & 3);
+        khalf[q] = (rho >> 6) * 64;
+    }
+    auto issue_stage = [&](int c, int t, int slot) {
+        unsigned char* dst = ring + slot * MLP_STAGE_BYTES + wid * 4096;
+        if (t < KS1) {
+            const bf16_t* base = W1 + (size_t)c * MLP_HC * E + t * 128 + src_chunk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + p64[q] * E + khalf[q]),
+                                                 (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+        } else {
+            const int ng = t - KS1;
+            const bf16_t* base = W2 + (size_t)ng * 128 * F + c * MLP_HC + src_chunk;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (size_t)p128[q] * F),
+                                                 (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
+        }
+    };
+    // biases to LDS first: an ordinary load issued behind the DMA prefetch would make the compiler drain all of it (vmcnt(0))
+    for (int i = tid; i < F; i += 256) sb1[i] = b1[i];
+    for (int i = tid; i < E; i += 256) sb2[i] = b2[i];
+    MLP_STAMP();      // 1: biases in LDS
+#pragma unroll
+    for (int s = 0; s < MLP_DIST; ++s) issue_stage(s / SPC, s % SPC, s % MLP_NST);
+    MLP_STAMP();      // 2: prefetch issued
+
+    // ---- LayerNorm'd A fragments (identical to encoder_panel.h) ------------------------------------------------------
+    bf16x8 afrag[2][KSTEPS];
+    if constexpr (VARIANT == 5) {
+        const bf16x8 f = *reinterpret_cast<const bf16x8*>(W1 + lane * 8);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) { afrag[0][ks] = f; afrag[1][ks] = f; }
+    } else
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = m0 + wid * 32 + j * 16 + (rr & 7);
+        const float* xlo = x + (size_t)min(rbase, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+        const float* xhi = x + (size_t)min(rbase + 8, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+        float4 xa[KSTEPS], xb[KSTEPS];
+        u32x4 raw0[KSTEPS], raw1[KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            raw0[ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);            // a piece of row (r16 & 7)
+            raw1[ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);            // a piece of row (r16 & 7) + 8
+        }
+        __builtin_amdgcn_sched_barrier(0);     // all 2 * KSTEPS row loads in flight before the first one is consumed
+        if (VARIANT == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MLP_STAMP(); }   // 3 / 5: row loads landed
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 p0 = raw0[ks], p1 = raw1[ks];
+            const u32x4 got = swap_half_rows(lo_half ? p1 : p0);
+            const u32x4 ev = lo_half ? p0 : got, od = lo_half ? got : p1;
+            xa[ks] = make_float4(__uint_as_float(ev[0]), __uint_as_float(ev[1]), __uint_as_float(ev[2]), __uint_as_float(ev[3]));
+            xb[ks] = make_float4(__uint_as_float(od[0]), __uint_as_float(od[1]), __uint_as_float(od[2]), __uint_as_float(od[3]));
+        }
+        float s1 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) s1 += ((xa[ks].x + xa[ks].y) + (xa[ks].z + xa[ks].w)) + ((xb[ks].x + xb[ks].y) + (xb[ks].z + xb[ks].w));
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 * (1.0f / E);
+        float s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const float d0 = xa[ks].x - mean, d1 = xa[ks].y - mean, d2 = xa[ks].z - mean, d3 = xa[ks].w - mean;
+            const float d4 = xb[ks].x - mean, d5 = xb[ks].y - mean, d6 = xb[ks].z - mean, d7 = xb[ks].w - mean;
+            s2 += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+        }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = __builtin_amdgcn_rsqf(s2 * (1.0f / E) + eps);       // v_rsq_f32, 1 ulp
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const float4 a = xa[ks], b = xb[ks];
+            const float4 ga = *reinterpret_cast<const float4*>(gamma + ks * 32 + 8 * g), gb = *reinterpret_cast<const float4*>(gamma + ks * 32 + 8 * g + 4);
+            const float4 ba = *reinterpret_cast<const float4*>(beta + ks * 32 + 8 * g), bb = *reinterpret_cast<const float4*>(beta + ks * 32 + 8 * g + 4);
+            bf16x8 f;
+            f[0] = static_cast<bf16_t>((a.x - mean) * rstd * ga.x + ba.x); f[1] = static_cast<bf16_t>((a.y - mean) * rstd * ga.y + ba.y);
+            f[2] = static_cast<bf16_t>((a.z - mean) * rstd * ga.z + ba.z); f[3] = static_cast<bf16_t>((a.w - mean) * rstd * ga.w + ba.w);
+            f[4] = static_cast<bf16_t>((b.x - mean) * rstd * gb.x + bb.x); f[5] = static_cast<bf16_t>((b.y - mean) * rstd * gb.y + bb.y);
+            f[6] = static_cast<bf16_t>((b.z - mean) * rstd * gb.z + bb.z); f[7] = static_cast<bf16_t>((b.w - mean) * rstd * gb.w + bb.w);
+            afrag[j][ks] = f;
+        }
+        MLP_STAMP();  // 4 / 6: row tile j normalised
+    }
+
+    MLP_STAMP();      // 7: LayerNorm prologue done
+    // ---- main loop ---------------------------------------------------------------------------------------------------
+    f32x4 acc2[NG * 8][2];
+#pragma unroll
+    for (int i = 0; i < NG * 8; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int sx = rr & 7;
+    const int frag_off = rr * 128;
+    const int so0 = (g ^ sx) * 16, so1 = ((4 + g) ^ sx) * 16;
+
+    for (int c = 0; c < NCH; ++c) {
+        if (c == 1 || c == 2 || c == NCH - 1) MLP_STAMP();     // 2,3: chunk boundaries; 4: start of last chunk
+        f32x4 acc1[4][2];
+        bf16x8 hfrag[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        static_for<0, SPC>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int s = c * SPC + t;
+            // stage s landed for this wave once at most 4 * min(DIST-1, stages after s) loads are outstanding
+            if constexpr (VARIANT != 4) {
+                const int rem = S - 1 - s;
+                if (rem >= MLP_DIST - 1) wait_vmcnt<4 * (MLP_DIST - 1)>();
+                else if (rem == 5) wait_vmcnt<20>();
+                else if (rem == 4) wait_vmcnt<16>();
+                else if (rem == 3) wait_vmcnt<12>();
+                else if (rem == 2) wait_vmcnt<8>();
+                else if (rem == 1) wait_vmcnt<4>();
+                else wait_vmcnt<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (VARIANT != 4) __builtin_amdgcn_s_barrier();   // stage s complete in LDS for everyone; the slot of stage s-1 is free
+            asm volatile("" ::: "memory");
+            {
+                // stage s + DIST goes into the slot stage s - 1 just vacated:  (s + DIST) % NST == (s - 1) % NST
+                constexpr int tn = (t + MLP_DIST) % SPC, cadd = (t + MLP_DIST) / SPC;
+                if constexpr (VARIANT != 1) { if (s + MLP_DIST < S) issue_stage(c + cadd, tn, (s + MLP_DIST) & (MLP_NST - 1)); }
+            }
+            const unsigned char* st = ring + (s & (MLP_NST - 1)) * MLP_STAGE_BYTES + frag_off;
+            if constexpr (VARIANT != 3) {
+            bf16x8 wf0[8], wf1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(st + i * 2048 + so0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(st + i * 2048 + so1);
+            if constexpr (t < KS1) {
+                // tiles 0-3: k-stage 2t, tiles 4-7: k-stage 2t+1 of the same 64 hidden units
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[0][(2 * t + (i >> 2)) * 2], acc1[i & 3][0], 0, 0, 0);
+                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[1][(2 * t + (i >> 2)) * 2], acc1[i & 3][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[0][(2 * t + (i >> 2)) * 2 + 1], acc1[i & 3][0], 0, 0, 0);
+                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[1][(2 * t + (i >> 2)) * 2 + 1], acc1[i & 3][1], 0, 0, 0);
+                }
+            } else {
+                constexpr int ng = t - KS1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], hfrag[0][0], acc2[ng * 8 + i][0], 0, 0, 0);
+                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], hfrag[1][0], acc2[ng * 8 + i][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], hfrag[0][1], acc2[ng * 8 + i][0], 0, 0, 0);
+                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], hfrag[1][1], acc2[ng * 8 + i][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+
+            if constexpr (t == KS1 - 1) {
+                // hidden chunk complete: + bias, exact-erf GELU, bf16 -> operand fragments of GEMM2.
+                // lane (r16, g), tile pair pr: hidden units c*64 + 32 pr + 8 g + [0, 8)  ==  k-slots of k-step pr
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const float* bp = sb1 + c * MLP_HC + 32 * pr + 8 * g;
+                        bf16x8 f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (VARIANT == 2) {
+                                f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp[r]);
+                                f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp[4 + r]);
+                            } else {
+                                f[r] = static_cast<bf16_t>(gelu_erf(acc1[2 * pr][j][r] + bp[r]));
+                                f[4 + r] = static_cast<bf16_t>(gelu_erf(acc1[2 * pr + 1][j][r] + bp[4 + r]));
+                            }
+                        }
+                        hfrag[j][pr] = f;
+                    }
+            }
+        });
+    }
+
+    MLP_STAMP();      // 5: main loop done
+    // ---- epilogue: x += acc2 + b2  (fp32, in place; 8 lanes per row via the half-row swap) --------------------------
+    // lane (r16, g), row tile j, 32-column group q32 (tile pair): columns cg = 32 q32 + 8 g + [0, 8) as piece A = [0,4), B = [4,8)
+    // All old x values of a row tile are requested before the first store (the compiler cannot hoist a load above a store
+    // to the same array: the naive load -> add -> store chain cost 19 us per workgroup in s_memtime stamps).
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mrow = m0 + wid * 32 + j * 16;
+        const int r_first = mrow + (rr & 7), r_second = r_first + 8;
+        const int rf = min(r_first, M - 1), rs = min(r_second, M - 1);
+        const int cbase = 8 * g + (lo_half ? 0 : 4);
+        float4 old1[E / 32], old2[E / 32];
+#pragma unroll
+        for (int q32 = 0; q32 < E / 32; ++q32) {
+            old1[q32] = *reinterpret_cast<const float4*>(x + (size_t)rf * E + 32 * q32 + cbase);
+            old2[q32] = *reinterpret_cast<const float4*>(x + (size_t)rs * E + 32 * q32 + cbase);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q32 = 0; q32 < E / 32; ++q32) {
+            const int ng = q32 >> 2, pr = q32 & 3;
+            const int cg = 32 * q32 + 8 * g;
+            const f32x4 ta = acc2[ng * 8 + 2 * pr][j], tb = acc2[ng * 8 + 2 * pr + 1][j];
+            u32x4 pa, pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[r] = __float_as_uint(ta[r] + sb2[cg + r]);
+                pb[r] = __float_as_uint(tb[r] + sb2[cg + 4 + r]);
+            }
+            const u32x4 got = swap_half_rows(lo_half ? pb : pa);
+            const u32x4 first = lo_half ? pa : got, second = lo_half ? got : pb;
+            const int col = 32 * q32 + cbase;
+            if (r_first < M) {
+                float4 o = old1[q32];
+                o.x += __uint_as_float(first[0]); o.y += __uint_as_float(first[1]); o.z += __uint_as_float(first[2]); o.w += __uint_as_float(first[3]);
+                *reinterpret_cast<float4*>(x + (size_t)r_first * E + col) = o;
+            }
+            if (r_second < M) {
+                float4 o = old2[q32];
+                o.x += __uint_as_float(second[0]); o.y += __uint_as_float(second[1]); o.z += __uint_as_float(second[2]); o.w += __uint_as_float(second[3]);
+                *reinterpret_cast<float4*>(x + (size_t)r_second * E + col) = o;
+            }
+        }
+    }
+    MLP_STAMP();      // 6: epilogue done
+#undef MLP_STAMP
+}
+
+template <int E, int VARIANT = 0>
+inline hipError_t launch_fused_mlp(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1,
+                                   const float* b1, const bf16_t* W2, const float* b2, int M, unsigned long long* dbg = nullptr) {
+    const size_t lds = (size_t)MLP_NST * MLP_STAGE_BYTES + (size_t)(5 * E) * sizeof(float);
+    auto kern = fused_mlp_kernel<E, VARIANT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((M + MLP_BM - 1) / MLP_BM), dim3(256), lds, s, x, gamma, beta, eps, W1, b1, W2, b2, M, dbg);
+    return hipGetLastError();
+}
+
+}  // namespace pq

@@ -132,11 +132,10 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + w_rowoff[q]),
                                              (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
     };
+    for (int i = tid; i < N; i += 256) sbias[i] = bias[i];     // before the DMA prefetch (ordinary loads behind it drain it)
     issue_stage(0);
     if (S > 1) issue_stage(1);
     if (S > 2) issue_stage(2);
-
-    for (int i = tid; i < N; i += 256) sbias[i] = bias[i];
 
     // ---- A panel: LayerNorm'd rows of this wave as MFMA fragments in registers --------------------------------------
     // lane (r16, g) of row tile j holds row m0 + 32 wid + 16 j + r16, elements [32 ks + 8 g, +8) for every k-step ks.
@@ -157,10 +156,16 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
         const float* xlo = x + (size_t)min(rbase, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
         const float* xhi = x + (size_t)min(rbase + 8, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
         float4 xa[KSTEPS], xb[KSTEPS];
+        u32x4 raw0[KSTEPS], raw1[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 p0 = *reinterpret_cast<const u32x4*>(xlo + ks * 32);      // a piece of row (r16 & 7)
-            const u32x4 p1 = *reinterpret_cast<const u32x4*>(xhi + ks * 32);      // a piece of row (r16 & 7) + 8
+            raw0[ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);            // a piece of row (r16 & 7)
+            raw1[ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);            // a piece of row (r16 & 7) + 8
+        }
+        __builtin_amdgcn_sched_barrier(0);     // all 2 * KSTEPS row loads in flight before the first one is consumed
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 p0 = raw0[ks], p1 = raw1[ks];
             // lanes < 8 own the first row: keep p0 (even piece), give p1; lanes >= 8 own the second: keep p1 (odd piece), give p0
             const u32x4 got = swap_half_rows(lo_half ? p1 : p0);
             const u32x4 ev = lo_half ? p0 : got, od = lo_half ? got : p1;          // even piece 2g, odd piece 2g+1 of MY row
@@ -183,7 +188,7 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
         }
         s2 += __shfl_xor(s2, 16, 64);
         s2 += __shfl_xor(s2, 32, 64);
-        const float rstd = 1.0f / sqrtf(s2 * (1.0f / E) + eps);
+        const float rstd = __builtin_amdgcn_rsqf(s2 * (1.0f / E) + eps);       // v_rsq_f32, 1 ulp
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const float4 a = xa[ks], b = xb[ks];

@@ -17,6 +17,7 @@
 #include "decoder_attn.h"
 #include "encoder_attn.h"
 #include "encoder_panel.h"
+#include "encoder_mlp.h"
 #include "gemm.h"
 #include "rowops.h"
 
@@ -47,9 +48,9 @@ static int fail(int code, const char* fmt, ...) {
 // -------------------------------------------------------------------------------------------------------------------
 // optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
 // -------------------------------------------------------------------------------------------------------------------
-enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_COUNT };
+enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_COUNT };
 static const char* const kProfNames[T_COUNT] = {"enc.patch_embed_gemm", "enc.layernorm", "enc.qkv_gemm", "enc.attention", "enc.proj_gemm",
-                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
+                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "enc.mlp_fused", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
                                                 "dec.cross_attention", "dec.layernorm", "dec.misc"};
 struct Profiler {
     bool enabled = false;
@@ -482,6 +483,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     constexpr bool kBf16 = sizeof(T) == 2;
     const bool panel_qkv = kBf16 && (E == 192 || E == 384) && (3 * E) % PN_BN == 0;
     const bool panel_fc1 = kBf16 && (E == 192 || E == 384) && F % PN_BN == 0;
+    const bool fused_mlp = kBf16 && E == 384 && c.enc_mlp_ratio == 4;      // encoder_mlp.h: LayerNorm + fc1 + GELU + fc2 + residual in one kernel
     for (int i = 0; i < c.enc_depth; ++i) {
         const std::string b = "encoder.blocks." + std::to_string(i) + ".";
         if (panel_qkv) {
@@ -499,6 +501,14 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         }
         { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv))); }
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
+        if (fused_mlp) {
+            if constexpr (kBf16) {
+                ProfScope ps_(&p->prof, T_MLP, s);
+                HIPCHK((launch_fused_mlp<384>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
+                                              m->p(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), m->p(b + "mlp.fc2.bias"), M)));
+            }
+            continue;
+        }
         if (panel_fc1) {
             if constexpr (kBf16) {
                 PanelGelu pg; pg.out = h; pg.ldo = F;
@@ -735,6 +745,34 @@ extern "C" int parseq_op_linear_cfg(const void* A, const void* W, const float* b
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || (K % 8) || (act && (N % 4))) return fail(PARSEQ_E_INVALID, "bad argument");
     if (dtype == PARSEQ_BF16) return op_linear_cfg_impl<bf16_t>((const bf16_t*)A, (const bf16_t*)W, bias, C, act, M, N, K, cfg, (hipStream_t)stream);
     return op_linear_cfg_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, cfg, (hipStream_t)stream);
+}
+
+// x += fc2(gelu(fc1(LayerNorm(x)))) through the fused MLP kernel (E = 384, hidden 1536, bf16 weights).
+extern "C" int parseq_op_mlp(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                             const float* b2, int M, void* stream) {
+    CHK(check_arch());
+    if (!x || !gamma || !beta || !W1 || !b1 || !W2 || !b2 || M <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
+    HIPCHK((launch_fused_mlp<384>((hipStream_t)stream, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M)));
+    return 0;
+}
+
+extern "C" int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
+                                     const float* b2, int M, int variant, void* stream) {
+    CHK(check_arch());
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 0: HIPCHK((launch_fused_mlp<384, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 1: HIPCHK((launch_fused_mlp<384, 1>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 2: HIPCHK((launch_fused_mlp<384, 2>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 3: HIPCHK((launch_fused_mlp<384, 3>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 4: HIPCHK((launch_fused_mlp<384, 4>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 5: HIPCHK((launch_fused_mlp<384, 5>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 6: {   // phase time stamps: the LAST 4096 bytes of x's allocation are not touched (caller passes M smaller than the buffer)
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
+            HIPCHK((launch_fused_mlp<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }
+        default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
+    }
+    return 0;
 }
 
 // LayerNorm + Linear + GELU through the panel kernel (E = 384), with ablation variants for tools/panel_bench.py.

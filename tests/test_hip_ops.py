@@ -82,3 +82,28 @@ def test_encoder_attention(heads, images, dtype):
     err, msg = report(f'enc attention {dtype} heads={heads}', out, want.float())
     # f32: exp/accumulation rounding.  bf16: probabilities and the output are rounded to bf16 (2^-9 relative each)
     assert err <= (2e-5 if dtype == 'f32' else 1.5e-2), msg
+
+
+@pytest.mark.parametrize('M', [128, 1000, 4096])
+def test_fused_mlp(M):
+    """encoder_mlp.h: x += fc2(gelu(fc1(LN(x)))) in one kernel, against an fp64 reference with the same bf16 rounding points
+    (LayerNorm output, weights, GELU output)."""
+    nat, lib = native()
+    E, F = 384, 1536
+    x = _gen(M, E, seed=11, scale=1.5) + 0.2
+    gamma, beta = 1 + 0.1 * _gen(E, seed=12), 0.1 * _gen(E, seed=13)
+    W1 = (_gen(F, E, seed=14) / E ** 0.5).bfloat16()
+    W2 = (_gen(E, F, seed=15) / F ** 0.5).bfloat16()
+    b1, b2 = 0.1 * _gen(F, seed=16), 0.1 * _gen(E, seed=17)
+    ln = torch.nn.functional.layer_norm(x.double(), (E,), gamma.double(), beta.double(), 1e-6).float().bfloat16().double()
+    hidden = torch.nn.functional.gelu(ln @ W1.double().T + b1.double()).float().bfloat16().double()
+    want = (x.double() + hidden @ W2.double().T + b2.double()).float()
+    xd = x.to(DEV).clone()
+    dev = [t.to(DEV) for t in (gamma, beta, W1, b1, W2, b2)]
+    nat.check(lib.parseq_op_mlp(nat.ptr(xd), nat.ptr(dev[0]), nat.ptr(dev[1]), nat.ptr(dev[2]), nat.ptr(dev[3]), nat.ptr(dev[4]),
+                                nat.ptr(dev[5]), M, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    err, msg = report(f'fused mlp M={M}', xd, want)
+    # residual: bf16 re-rounding of LN / GELU values that land within fp32 noise of a rounding boundary (2^-9 relative on
+    # a few of 1536 terms of magnitude <= 0.1) plus fp32 accumulation order
+    assert err <= 5e-3, msg

@@ -41,5 +41,54 @@ def main():
             print('max |err| vs torch on 256 rows:', (out[:256].float() - ref).abs().max().item())
 
 
+def mlp():
+    lib = nat.lib()
+    M, E, F = 65536, 384, 1536
+    names = {0: 'full', 1: 'no weight stream in loop', 2: 'no GELU', 3: 'no LDS reads / MFMA', 4: 'no barriers / waits', 5: 'no LayerNorm prologue'}
+    x = torch.randn(M, E, device='cuda')
+    gamma, beta = torch.rand(E, device='cuda') + 0.5, torch.randn(E, device='cuda') * 0.1
+    W1 = (torch.randn(F, E, device='cuda') / E ** 0.5).bfloat16(); W2 = (torch.randn(E, F, device='cuda') / F ** 0.5).bfloat16()
+    b1, b2 = torch.randn(F, device='cuda') * 0.1, torch.randn(E, device='cuda') * 0.1
+    for v in range(6):
+        def run():
+            nat.check(lib.parseq_op_mlp_variant(nat.ptr(x), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W1), nat.ptr(b1), nat.ptr(W2), nat.ptr(b2), M, v, nat.stream_ptr()))
+        x.normal_()
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        x.normal_()
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / 10
+        print(f'fused MLP variant {v} ({names[v]:26s}): {us:8.1f} us  {4.0 * M * E * F / us / 1e6:7.1f} TFLOP/s-equivalent')
+
+
+def mlp_stamps():
+    lib = nat.lib()
+    M, E, F = 65536, 384, 1536
+    xbuf = torch.randn(M * E + 1024, device='cuda')          # 4 KB of stamp space behind the matrix
+    gamma, beta = torch.rand(E, device='cuda') + 0.5, torch.randn(E, device='cuda') * 0.1
+    W1 = (torch.randn(F, E, device='cuda') / E ** 0.5).bfloat16(); W2 = (torch.randn(E, F, device='cuda') / F ** 0.5).bfloat16()
+    b1, b2 = torch.randn(F, device='cuda') * 0.1, torch.randn(E, device='cuda') * 0.1
+    for _ in range(3):
+        nat.check(lib.parseq_op_mlp_variant(nat.ptr(xbuf), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W1), nat.ptr(b1), nat.ptr(W2), nat.ptr(b2), M, 6, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    st = xbuf[M * E:].view(torch.int64).cpu().view(-1)[:8 * 64].view(2, 4, 64)
+    names = ['start', 'bias', 'prefetch issued', 'x0 landed', 'j0 done', 'x1 landed', 'j1 done', 'LN done', 'chunk1', 'chunk2', 'last chunk', 'loop done', 'epilogue done']
+    for blk in range(2):
+        for w in range(4):
+            v = st[blk, w, :13].tolist()
+            print(f'block {"0" if blk == 0 else "300"} wave {w}: ' + ', '.join(f'{n} {(b - v[0]) / 100.0:.1f}' for n, b in zip(names, v)) + '   (us if s_memtime ticks at 100 MHz)')
+
+
 if __name__ == '__main__':
-    main()
+    if 'stamps' in sys.argv:
+        mlp_stamps()
+    elif 'mlp' in sys.argv:
+        mlp()
+    else:
+        main()
