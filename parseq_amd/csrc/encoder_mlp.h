@@ -110,15 +110,42 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
                                                  (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, 0, 0);
         }
     };
-    // biases to LDS first: an ordinary load issued behind the DMA prefetch would make the compiler drain all of it (vmcnt(0))
-    for (int i = tid; i < F; i += 256) sb1[i] = b1[i];
-    for (int i = tid; i < E; i += 256) sb2[i] = b2[i];
-    MLP_STAMP();      // 1: biases in LDS
+    // ---- prologue: ONE memory round trip ------------------------------------------------------------------------------
+    // Under load a dependent global round trip costs 2-3 us, and the first version chained eight of them (bias loop, row
+    // tile 0, its gamma/beta, row tile 1, ...: 31 us per workgroup in s_memtime stamps).  Everything the prologue needs is
+    // requested back to back — both row tiles of x, biases, LayerNorm affine parameters — then the weight prefetch.
+    float* sgam = sb2 + E;                   // [E] LayerNorm weight
+    float* sbet = sgam + E;                  // [E] LayerNorm bias
+    constexpr int PVN = F + 3 * E;           // b1 | b2 | gamma | beta, contiguous in LDS
+    constexpr int PV = (PVN + 255) / 256;    // floats per thread
+    float pv[PV];
+#pragma unroll
+    for (int i = 0; i < PV; ++i) {
+        const int e = min(i * 256 + tid, PVN - 1);
+        pv[i] = e < F ? b1[e] : (e < F + E ? b2[e - F] : (e < F + 2 * E ? gamma[e - F - E] : beta[e - F - 2 * E]));
+    }
+    u32x4 raw0[2][KSTEPS], raw1[2][KSTEPS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = m0 + wid * 32 + j * 16 + (rr & 7);
+        const float* xlo = x + (size_t)min(rbase, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+        const float* xhi = x + (size_t)min(rbase + 8, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            raw0[j][ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);        // a piece of row (r16 & 7)
+            raw1[j][ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);        // a piece of row (r16 & 7) + 8
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < MLP_DIST; ++s) issue_stage(s / SPC, s % SPC, s % MLP_NST);
-    MLP_STAMP();      // 2: prefetch issued
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < PV; ++i) if (i * 256 + tid < PVN) sb1[i * 256 + tid] = pv[i];   // sb1 | sb2 | sgam | sbet are contiguous
+    __syncthreads();
 
-    // ---- LayerNorm'd A fragments (identical to encoder_panel.h) ------------------------------------------------------
+    // ---- LayerNorm'd A fragments: lane (r16, g) of row tile j holds row 32 wid + 16 j + r16, k in [32 ks + 8 g, +8) ------
+    // (coalesced 8-lanes-per-row loads + half-row swap, see encoder_panel.h)
     bf16x8 afrag[2][KSTEPS];
     if constexpr (VARIANT == 5) {
         const bf16x8 f = *reinterpret_cast<const bf16x8*>(W1 + lane * 8);
@@ -127,21 +154,10 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int rbase = m0 + wid * 32 + j * 16 + (rr & 7);
-        const float* xlo = x + (size_t)min(rbase, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
-        const float* xhi = x + (size_t)min(rbase + 8, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
         float4 xa[KSTEPS], xb[KSTEPS];
-        u32x4 raw0[KSTEPS], raw1[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            raw0[ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);            // a piece of row (r16 & 7)
-            raw1[ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);            // a piece of row (r16 & 7) + 8
-        }
-        __builtin_amdgcn_sched_barrier(0);     // all 2 * KSTEPS row loads in flight before the first one is consumed
-        if (VARIANT == 6) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MLP_STAMP(); }   // 3 / 5: row loads landed
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 p0 = raw0[ks], p1 = raw1[ks];
+            const u32x4 p0 = raw0[j][ks], p1 = raw1[j][ks];
             const u32x4 got = swap_half_rows(lo_half ? p1 : p0);
             const u32x4 ev = lo_half ? p0 : got, od = lo_half ? got : p1;
             xa[ks] = make_float4(__uint_as_float(ev[0]), __uint_as_float(ev[1]), __uint_as_float(ev[2]), __uint_as_float(ev[3]));
@@ -166,8 +182,8 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const float4 a = xa[ks], b = xb[ks];
-            const float4 ga = *reinterpret_cast<const float4*>(gamma + ks * 32 + 8 * g), gb = *reinterpret_cast<const float4*>(gamma + ks * 32 + 8 * g + 4);
-            const float4 ba = *reinterpret_cast<const float4*>(beta + ks * 32 + 8 * g), bb = *reinterpret_cast<const float4*>(beta + ks * 32 + 8 * g + 4);
+            const float4 ga = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g), gb = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g + 4);
+            const float4 ba = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g), bb = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g + 4);
             bf16x8 f;
             f[0] = static_cast<bf16_t>((a.x - mean) * rstd * ga.x + ba.x); f[1] = static_cast<bf16_t>((a.y - mean) * rstd * ga.y + ba.y);
             f[2] = static_cast<bf16_t>((a.z - mean) * rstd * ga.z + ba.z); f[3] = static_cast<bf16_t>((a.w - mean) * rstd * ga.w + ba.w);
@@ -175,10 +191,9 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
             f[6] = static_cast<bf16_t>((b.z - mean) * rstd * gb.z + bb.z); f[7] = static_cast<bf16_t>((b.w - mean) * rstd * gb.w + bb.w);
             afrag[j][ks] = f;
         }
-        MLP_STAMP();  // 4 / 6: row tile j normalised
     }
 
-    MLP_STAMP();      // 7: LayerNorm prologue done
+    MLP_STAMP();      // 1: LayerNorm prologue done
     // ---- main loop ---------------------------------------------------------------------------------------------------
     f32x4 acc2[NG * 8][2];
 #pragma unroll
@@ -332,7 +347,7 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
 template <int E, int VARIANT = 0>
 inline hipError_t launch_fused_mlp(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1,
                                    const float* b1, const bf16_t* W2, const float* b2, int M, unsigned long long* dbg = nullptr) {
-    const size_t lds = (size_t)MLP_NST * MLP_STAGE_BYTES + (size_t)(5 * E) * sizeof(float);
+    const size_t lds = (size_t)MLP_NST * MLP_STAGE_BYTES + (size_t)(7 * E) * sizeof(float);     // ring | b1 | b2 | gamma | beta
     auto kern = fused_mlp_kernel<E, VARIANT>;
     static bool attr_done = false;
     if (!attr_done) {

@@ -78,11 +78,11 @@ def mlp_stamps():
         nat.check(lib.parseq_op_mlp_variant(nat.ptr(xbuf), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W1), nat.ptr(b1), nat.ptr(W2), nat.ptr(b2), M, 6, nat.stream_ptr()))
     torch.cuda.synchronize()
     st = xbuf[M * E:].view(torch.int64).cpu().view(-1)[:8 * 64].view(2, 4, 64)
-    names = ['start', 'bias', 'prefetch issued', 'x0 landed', 'j0 done', 'x1 landed', 'j1 done', 'LN done', 'chunk1', 'chunk2', 'last chunk', 'loop done', 'epilogue done']
+    names = ['start', 'LN done', 'chunk1', 'chunk2', 'last chunk', 'loop done', 'epilogue done']
     for blk in range(2):
         for w in range(4):
-            v = st[blk, w, :13].tolist()
-            print(f'block {"0" if blk == 0 else "300"} wave {w}: ' + ', '.join(f'{n} {(b - v[0]) / 100.0:.1f}' for n, b in zip(names, v)) + '   (us if s_memtime ticks at 100 MHz)')
+            v = st[blk, w, :7].tolist()
+            print(f'block {"0" if blk == 0 else "300"} wave {w}: ' + ', '.join(f'{n} {(b - v[0]) / 2400.0:.1f}us' for n, b in zip(names, v)) + '   (s_memtime ticks / 2.4 GHz)')
 
 
 if __name__ == '__main__':
