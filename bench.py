@@ -168,10 +168,11 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # HBM bytes/launch from rocprofv3 --pmc passes, if collected
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(dom)
+            rec = json.load(open(tpath)).get(dom)
+            traffic = rec['hbm_bytes'] if rec else None    # bytes per launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE
         result['roofline'] = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': PEAK[args.precision], 'unit': 'TFLOP/s',
                               'frac': round(ach / PEAK[args.precision], 4), 'traffic': traffic,
-                              'flops_per_launch': fl, 'avg_launch_us': fam[dom]['avg_us']}
+                              'flops_per_launch': fl, 'avg_launch_us': fam[dom]['avg_us'], 'traffic_unit': 'bytes/launch (rocprofv3 --pmc, profiles/pmc_traffic.json)'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args.model, sd_cpu, args.refine_iters)
     if rank == 0:
