@@ -73,6 +73,8 @@ def main():
     ap.add_argument('--natural-exit', action='store_true', help='max_length=None (early exit); default forces 26 AR steps')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
+    ap.add_argument('--streams', type=int, default=2, help='batches in flight for `value` (independent workspaces on separate HIP streams); '
+                    'the one-call-at-a-time figure is always measured too and reported as sequential_value')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -101,31 +103,47 @@ def main():
         images = images.bfloat16()
     max_length = None if args.natural_exit else 25
 
-    def step():
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1))]
+    counter = [0]
+
+    def step(in_flight):
         with torch.inference_mode():
-            logits = model(images, max_length)
-            if dist is not None:
-                logits = all_gather_logits(logits)
+            if in_flight <= 1:
+                logits = model(images, max_length)
+                if dist is not None:
+                    logits = all_gather_logits(logits)
+            else:       # batch k runs on stream k % S with workspace k % S: its encoder overlaps batch k-1's AR decode
+                k = counter[0] % in_flight
+                counter[0] += 1
+                with torch.cuda.stream(streams[k]):
+                    logits = model(images, max_length, slot=k)
+                    if dist is not None:
+                        logits = all_gather_logits(logits)
         return logits
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(in_flight):
+        for _ in range(args.warmup):
+            step(in_flight)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out_ = step(in_flight)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out_
+
+    elapsed, out = timed(args.streams)
+    seq_elapsed, _ = timed(1) if args.streams > 1 else (elapsed, None)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
@@ -134,12 +152,14 @@ def main():
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
+        'sequential_value': round(world * B * args.steps / seq_elapsed, 1), 'sequential_ms_per_step': round(1e3 * seq_elapsed / args.steps, 4),
         'config': {'workload': f'{args.model} {args.precision}, 32x128 crops, batch={B}/GPU, AR decode '
                                f'({"natural exit" if args.natural_exit else "26 steps forced"}) + {args.refine_iters} refine iter '
                                f'(BASELINE.json configs[1]); random-init weights (reference init, seed 0); '
-                               f'inputs resident in HBM as {"bf16" if args.precision == "bf16" else "fp32"}',
+                               f'inputs resident in HBM as {"bf16" if args.precision == "bf16" else "fp32"}; '
+                               f'{args.streams} batch(es) of {B} in flight on separate HIP streams (value); sequential_value = one forward at a time',
                    'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-gather of logits' if world > 1 else ''),
-                   'output_shape': list(out.shape)},
+                   'output_shape': list(out.shape), 'batches_in_flight': args.streams},
     }
     gf = GFLOP_PER_IMG.get((args.model, args.refine_iters))
     if gf:

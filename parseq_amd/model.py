@@ -148,7 +148,7 @@ class _NativeState:
 
     def __init__(self):
         self.model = C.c_void_p(0)
-        self.plans = {}            # precision code -> (plan handle, max_batch)
+        self.plans = {}            # (precision code, slot) -> (plan handle, max_batch)
         self.signature = None
 
     def release(self):
@@ -227,14 +227,18 @@ class PARSeq(nn.Module):
                                                          _native.ptr(kpm), _native.ptr(out), _native.stream_ptr()))
         return out
 
-    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None) -> Tensor:
-        """model.py:105-169.  Returns logits [B, L, num_tokens - 2] (fp32)."""
+    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None, slot: int = 0) -> Tensor:
+        """model.py:105-169.  Returns logits [B, L, num_tokens - 2] (fp32).
+
+        `slot` selects one of several independent workspaces (plans): calls that use different slots on different
+        streams may be in flight at the same time (bench.py --streams 2 overlaps the latency-bound AR decode of one batch
+        with the encoder of the next).  The default is the reference's behaviour: one call at a time, stream-ordered."""
         testing = max_length is None
         max_length = self.max_label_length if max_length is None else min(max_length, self.max_label_length)
         num_steps = max_length + 1
         images = self._check_images(images)
         B = images.shape[0]
-        plan = self._plan(B)
+        plan = self._plan(B, slot)
         if (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id) != self._special_ids(tokenizer):
             raise RuntimeError('tokenizer special ids changed after the native model was built')
         logits = torch.empty(B, num_steps, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=images.device)
@@ -330,23 +334,23 @@ class PARSeq(nn.Module):
         st.signature = sig
         return st
 
-    def _plan(self, batch: int):
+    def _plan(self, batch: int, slot: int = 0):
         if self.precision not in _PRECISIONS:
             raise RuntimeError(f"precision must be one of {sorted(_PRECISIONS)}, got '{self.precision}'")
         st = self._sync_native()
         code = _PRECISIONS[self.precision]
-        plan, cap = st.plans.get(code, (None, 0))
+        plan, cap = st.plans.get((code, slot), (None, 0))
         if plan is None or batch > cap:
             lib = _native.lib()
             if plan is not None:
                 torch.cuda.current_stream().synchronize()
                 lib.parseq_plan_destroy(plan)
-                del st.plans[code]
+                del st.plans[(code, slot)]
             cap = max(8, 1 << (batch - 1).bit_length())
             handle = C.c_void_p(0)
             with torch.cuda.device(self._device):
                 _native.check(lib.parseq_plan_create(st.model, cap, code, _native.stream_ptr(), C.byref(handle)))
-            st.plans[code] = (handle, cap)
+            st.plans[(code, slot)] = (handle, cap)
             plan = handle
         return plan
 

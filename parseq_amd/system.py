@@ -94,9 +94,9 @@ class PARSeq(nn.Module):
     def precision(self, value: str) -> None:
         self.model.precision = value
 
-    def forward(self, images: Tensor, max_length: Optional[int] = None) -> Tensor:
-        """Inference (system.py:87-88): images [N, 3, H, W] -> logits [N, L, C]."""
-        return self.model.forward(self.tokenizer, images, max_length)
+    def forward(self, images: Tensor, max_length: Optional[int] = None, slot: int = 0) -> Tensor:
+        """Inference (system.py:87-88): images [N, 3, H, W] -> logits [N, L, C].  (`slot`: see model.PARSeq.forward.)"""
+        return self.model.forward(self.tokenizer, images, max_length, slot)
 
     # ---- evaluation glue used by the reference's test.py:121-126 ------------------------------------------------
     def _eval_step(self, batch, validation: bool):
