@@ -286,8 +286,8 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
                                 f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp[r]);
                                 f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp[4 + r]);
                             } else {
-                                f[r] = static_cast<bf16_t>(gelu_erf(acc1[2 * pr][j][r] + bp[r]));
-                                f[4 + r] = static_cast<bf16_t>(gelu_erf(acc1[2 * pr + 1][j][r] + bp[4 + r]));
+                                f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
+                                f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
                             }
                         }
                         hfrag[j][pr] = f;

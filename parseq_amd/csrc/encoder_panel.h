@@ -63,7 +63,7 @@ struct PanelGelu {           // out[m][n] = gelu(.), row-major [M, N]
     __device__ __forceinline__ u32x4 pack8(const float* v) const {
         float g8[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g8[i] = gelu_erf(v[i]);
+        for (int i = 0; i < 8; ++i) g8[i] = gelu_poly(v[i]);
         return pack_bf16x8(g8);
     }
     __device__ __forceinline__ void store_piece(int m, int n, const u32x4& piece) const {

@@ -214,7 +214,7 @@ struct EpiGelu : EpiBase {
     TO* out; int ldo;
     __device__ __forceinline__ void xform_n4(int m, int n, float* v) const {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j] + b(n + j));
+        for (int j = 0; j < 4; ++j) v[j] = gelu_for<TO>(v[j] + b(n + j));
     }
     __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
         if (n + Chunk<S>::CH <= N) *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + n) = *reinterpret_cast<const u32x4*>(c);
