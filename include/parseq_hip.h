@@ -50,7 +50,11 @@ typedef struct parseq_config {
 
 enum {
     PARSEQ_F32 = 0,    /* exact mode: f32 storage, v_mfma_f32_16x16x4_f32; parity target |dlogit| <= 1e-3 vs CPU fp32 */
-    PARSEQ_BF16 = 1    /* throughput mode: bf16 GEMM/attention operands, fp32 accumulate / residual / LayerNorm / softmax */
+    PARSEQ_BF16 = 1,   /* throughput mode: bf16 GEMM/attention operands, fp32 accumulate / residual / LayerNorm / softmax */
+    PARSEQ_U8 = 2      /* images_dtype only: raw 0..255 pixels, [batch, 3, H, W]; the patch-embed
+                        * operand loader applies the reference transform's ToTensor + Normalize(0.5, 0.5)
+                        * (strhub/data/module.py:78-81): ((v / 255) - 0.5) / 0.5 in f32, bit-identical to feeding the
+                        * normalised f32 image (then rounded to bf16 in bf16 mode) */
 };
 
 enum {
@@ -105,7 +109,8 @@ int parseq_plan_get_profile(parseq_plan* p, int index, const char** name, double
 /* ---- hot path ---------------------------------------------------------------------------------------------------- */
 
 /* model.PARSeq.encode (model.py:83-84 -> modules.py:163-165 -> timm ViT.forward_features).
- * images: device, [batch, 3, img_h, img_w], contiguous, fp32 (images_dtype = PARSEQ_F32) or bf16 (PARSEQ_BF16).
+ * images: device, [batch, 3, img_h, img_w], contiguous; normalised fp32 (images_dtype = PARSEQ_F32) or bf16 (PARSEQ_BF16),
+ * or raw uint8 pixels (PARSEQ_U8, normalised on the fly).
  * memory_out: device fp32 [batch, tokens, embed_dim], or NULL to keep the result only inside the plan. */
 int parseq_encode(parseq_plan* p, const void* images, int images_dtype, int batch, float* memory_out, void* stream);
 
@@ -125,6 +130,20 @@ int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int bat
  * (non-zero = masked, torch semantics).  logits_out: device fp32 [batch, q_len, num_tokens - 2]. */
 int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
                          const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream);
+
+/* ---- post-processing --------------------------------------------------------------- */
+
+/* Numeric half of `preds, probs = tokenizer.decode(logits.softmax(-1))` (strhub/models/base.py:132-137,
+ * strhub/data/utils.py:79-99 greedy max per position, :120-129 truncation at the first EOS) on the device, so a caller
+ * moves B*L ids + B lengths (+ probabilities) to the host instead of B*L*C probabilities and one .tolist() per row.
+ * logits: device fp32 [batch, L, C] contiguous (L <= 64).  Outputs (device):
+ *   ids_out      int32 [batch, L]  arg-max class per position (first maximum), for every position
+ *   lengths_out  int32 [batch]     index of the first position whose id is eos_id, or L: the label is ids_out[b, :len]
+ *   probs_out    fp32  [batch, L]  max soft-max probability per position (NULL to skip); the reference's per-label
+ *                                  probability tensor is probs_out[b, :min(len + 1, L)] (it keeps the EOS probability)
+ *   confidence_out fp32 [batch]    product of that tensor (base.py:137), NULL to skip */
+int parseq_postprocess(const float* logits, int batch, int L, int C, int eos_id, int32_t* ids_out, int32_t* lengths_out,
+                       float* probs_out, float* confidence_out, void* stream);
 
 /* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
 

@@ -289,3 +289,28 @@ def forward(sd: dict, cfg: OracleConfig, images: Tensor, max_length: Optional[in
                 trace.refine_tokens.append(tgt_in.clone())
                 trace.refine_logits.append(logits.clone())
     return logits
+
+
+def postprocess(logits: Tensor, eos_id: int = 0):
+    """CPU restatement of the numeric half of `tokenizer.decode(logits.softmax(-1))` (row N1).
+
+    Follows strhub/models/base.py:132-137 (`probs = logits.softmax(-1)`, `prob.prod()`), strhub/data/utils.py:90-91
+    (`probs, ids = dist.max(-1)`) and :120-129 (`_filter`: characters stop before the first EOS, the probability list keeps
+    the EOS probability).  Returns (ids [B, L] int64 for every position, lengths [B], probs [B, L], confidence [B]).
+    """
+    probs_all, ids_all = logits.float().softmax(-1).max(-1)
+    B, L = ids_all.shape
+    lengths = torch.full((B,), L, dtype=torch.long)
+    conf = torch.empty(B, dtype=torch.float32)
+    for b in range(B):
+        row = ids_all[b].tolist()
+        if eos_id in row:
+            lengths[b] = row.index(eos_id)
+        conf[b] = probs_all[b, :int(lengths[b]) + 1].prod()
+    return ids_all, lengths, probs_all, conf
+
+
+def normalize_u8(images_u8: Tensor) -> Tensor:
+    """Row N2: the numeric tail of the reference's input transform (strhub/data/module.py:78-81) on uint8 CHW pixels —
+    `T.ToTensor()` (`img.to(float32).div(255)`) followed by `T.Normalize(0.5, 0.5)` (`sub_(mean).div_(std)`)."""
+    return images_u8.to(torch.float32).div(255).sub_(0.5).div_(0.5)

@@ -13,7 +13,7 @@ from typing import Optional
 
 from . import build as _build
 
-PARSEQ_F32, PARSEQ_BF16 = 0, 1
+PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8 = 0, 1, 2
 FLAG_DECODE_AR, FLAG_TESTING = 1, 2
 ABI_VERSION = 1
 
@@ -44,6 +44,7 @@ SIGNATURES = {
     'parseq_plan_refresh': (C.c_int, [C.c_void_p, C.c_void_p]),
     'parseq_plan_destroy': (None, [C.c_void_p]),
     'parseq_plan_workspace_bytes': (C.c_size_t, [C.c_void_p]),
+    'parseq_postprocess': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_plan_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'parseq_plan_get_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'parseq_encode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -107,7 +108,9 @@ def dtype_code(t) -> int:
         return PARSEQ_F32
     if t == torch.bfloat16:
         return PARSEQ_BF16
-    raise TypeError(f'unsupported dtype {t}: libparseq_hip takes float32 or bfloat16')
+    if t == torch.uint8:
+        return PARSEQ_U8
+    raise TypeError(f'unsupported dtype {t}: libparseq_hip takes float32, bfloat16 or (images only) uint8')
 
 
 def ptr(t) -> C.c_void_p:

@@ -53,7 +53,10 @@ struct APatch {
     static constexpr int kStatsFloats = 0;
     static constexpr bool kDirect = false;
     static constexpr int kRaw = (sizeof(TI) > sizeof(T)) ? 2 : 1;       // 16-byte loads per chunk
+    static constexpr bool kU8 = sizeof(TI) == 1;                        // raw pixels: ToTensor + Normalize fused here
     struct Raw { u32x4 v[kRaw]; };
+    // strhub/data/module.py:78-81: ToTensor (v / 255 in f32) then Normalize(0.5, 0.5) ((t - 0.5) / 0.5), IEEE-exact
+    static __device__ __forceinline__ float norm_u8(unsigned v) { return ((float)v / 255.0f - 0.5f) / 0.5f; }
     __device__ __forceinline__ void prepare(int, int, int, float*) {}
     __device__ __forceinline__ Raw fetch(int m, int k) const {
         const int b = m / tokens, t = m - b * tokens;
@@ -62,7 +65,10 @@ struct APatch {
         const int ky = r / pw, kx = r - ky * pw;
         const TI* src = img + (((size_t)b * C + c) * H + (gy * ph + ky)) * Wd + gx * pw + kx;
         Raw raw;
-        if constexpr (sizeof(TI) == sizeof(T)) {
+        if constexpr (kU8) {                                                       // 16 / sizeof(T) pixels of one image row
+            if constexpr (sizeof(T) == 2) { const uint2 b8 = *reinterpret_cast<const uint2*>(src); raw.v[0] = u32x4{b8.x, b8.y, 0u, 0u}; }
+            else raw.v[0] = u32x4{*reinterpret_cast<const unsigned*>(src), 0u, 0u, 0u};
+        } else if constexpr (sizeof(TI) == sizeof(T)) {
             raw.v[0] = *reinterpret_cast<const u32x4*>(src);                       // same storage type
         } else if constexpr (sizeof(TI) == 4) {                                    // f32 image -> bf16 operand: 8 floats
             raw.v[0] = reinterpret_cast<const u32x4*>(src)[0];
@@ -74,7 +80,13 @@ struct APatch {
         return raw;
     }
     __device__ __forceinline__ u32x4 finish(const Raw& raw, int, int) const {
-        if constexpr (sizeof(TI) == sizeof(T)) {
+        if constexpr (kU8) {
+            constexpr int NE = 16 / (int)sizeof(T);
+            union { u32x4 u; T e[NE]; } out;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) out.e[i] = from_f32<T>(norm_u8((raw.v[0][i / 4] >> (8 * (i % 4))) & 0xffu));
+            return out.u;
+        } else if constexpr (sizeof(TI) == sizeof(T)) {
             return raw.v[0];
         } else if constexpr (sizeof(TI) == 4) {
             union { u32x4 u; T e[8]; } out;

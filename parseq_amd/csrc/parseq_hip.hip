@@ -540,7 +540,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
 static int check_call(parseq_plan* p, int batch, int images_dtype) {
     if (!p) return fail(PARSEQ_E_INVALID, "null plan");
     if (batch <= 0 || batch > p->max_batch) return fail(PARSEQ_E_INVALID, "batch %d outside (0, %d]", batch, p->max_batch);
-    if (images_dtype != PARSEQ_F32 && images_dtype != PARSEQ_BF16) return fail(PARSEQ_E_INVALID, "images_dtype %d", images_dtype);
+    if (images_dtype != PARSEQ_F32 && images_dtype != PARSEQ_BF16 && images_dtype != PARSEQ_U8) return fail(PARSEQ_E_INVALID, "images_dtype %d", images_dtype);
     if (p->packed_version != p->m->version) return fail(PARSEQ_E_STATE, "model parameters changed after the plan was packed; call parseq_plan_refresh");
     return 0;
 }
@@ -548,9 +548,11 @@ static int check_call(parseq_plan* p, int batch, int images_dtype) {
 static int encode_dispatch(parseq_plan* p, const void* images, int images_dtype, int batch, float* memory_out, hipStream_t s) {
     if (p->precision == PARSEQ_BF16) {
         if (images_dtype == PARSEQ_F32) return encode_impl<bf16_t, float>(p, (const float*)images, batch, memory_out, s);
+        if (images_dtype == PARSEQ_U8) return encode_impl<bf16_t, uint8_t>(p, (const uint8_t*)images, batch, memory_out, s);
         return encode_impl<bf16_t, bf16_t>(p, (const bf16_t*)images, batch, memory_out, s);
     }
     if (images_dtype == PARSEQ_F32) return encode_impl<float, float>(p, (const float*)images, batch, memory_out, s);
+    if (images_dtype == PARSEQ_U8) return encode_impl<float, uint8_t>(p, (const uint8_t*)images, batch, memory_out, s);
     return encode_impl<float, bf16_t>(p, (const bf16_t*)images, batch, memory_out, s);
 }
 
@@ -688,6 +690,20 @@ extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int b
     }
     if (p->precision == PARSEQ_BF16) return decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
     return decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// post-processing
+// -------------------------------------------------------------------------------------------------------------------
+extern "C" int parseq_postprocess(const float* logits, int batch, int L, int C, int eos_id, int32_t* ids_out, int32_t* lengths_out,
+                                  float* probs_out, float* confidence_out, void* stream) {
+    if (!logits || !ids_out || !lengths_out) return fail(PARSEQ_E_INVALID, "null logits / ids_out / lengths_out");
+    if (batch <= 0 || L < 1 || L > 64 || C < 1) return fail(PARSEQ_E_INVALID, "bad shape: batch %d, L %d (1..64), C %d", batch, L, C);
+    if (eos_id < 0 || eos_id >= C) return fail(PARSEQ_E_INVALID, "eos_id %d outside [0, %d)", eos_id, C);
+    hipLaunchKernelGGL(postprocess_kernel, dim3((batch + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, batch, L, C, eos_id, ids_out,
+                       lengths_out, probs_out, confidence_out);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // -------------------------------------------------------------------------------------------------------------------

@@ -152,4 +152,52 @@ __global__ void ar_init_kernel(int* __restrict__ tok, int ldt, int B, int bos_id
     if (i == 0) { *eos_rows = 0; *ar_len = num_steps; }
 }
 
+// Device-side numeric half of `Tokenizer.decode(logits.softmax(-1))` (strhub/models/base.py:132-135,
+// strhub/data/utils.py:79-99 greedy max per position, :120-129 cut at the first EOS keeping the EOS probability).
+// One wave per image, lane l ends up owning position l (L <= 64):
+//   ids[b][l]   = argmax_c logits[b][l][c]  (first maximum; soft-max is monotone, so this is the arg-max of the probabilities)
+//   probs[b][l] = max_c softmax(logits[b][l])[c] = 1 / sum_c exp(logit_c - max)
+//   lengths[b]  = index of the first EOS, or L            (number of characters)
+//   conf[b]     = prod_{l < min(lengths[b] + 1, L)} probs[b][l]   (base.py:137 `prob.prod()`)
+__global__ __launch_bounds__(256)
+void postprocess_kernel(const float* __restrict__ logits, int B, int L, int C, int eos_id, int* __restrict__ ids,
+                        int* __restrict__ lengths, float* __restrict__ probs, float* __restrict__ conf) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float my_p = 1.0f; int my_id = -1;
+    for (int l = 0; l < L; ++l) {
+        const float* row = logits + ((size_t)b * L + l) * C;
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = row[c];
+            if (v > best) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += expf(row[c] - best);
+        sum = wave_sum(sum);
+        if (lane == l) { my_p = 1.0f / sum; my_id = bi; }
+    }
+    const unsigned long long eos_lanes = __ballot(lane < L && my_id == eos_id);
+    const int eos_idx = eos_lanes ? __builtin_ctzll(eos_lanes) : L;
+    const int n_probs = min(eos_idx + 1, L);
+    float prod = lane < n_probs ? my_p : 1.0f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) prod *= __shfl_xor(prod, o, 64);
+    if (lane < L) {
+        ids[(size_t)b * L + lane] = my_id;
+        if (probs) probs[(size_t)b * L + lane] = my_p;
+    }
+    if (lane == 0) {
+        lengths[b] = eos_idx;
+        if (conf) conf[b] = prod;
+    }
+}
+
 }  // namespace pq

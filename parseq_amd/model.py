@@ -283,7 +283,9 @@ class PARSeq(nn.Module):
         h, w = self._cfg['img_size']
         if tuple(images.shape[1:]) != (3, h, w):
             raise RuntimeError(f'expected images of shape [N, 3, {h}, {w}], got {list(images.shape)}')
-        if images.dtype not in (torch.float32, torch.bfloat16):
+        # uint8 = raw pixels: the reference transform's ToTensor + Normalize(0.5, 0.5) (strhub/data/module.py:78-81) is
+        # applied inside the patch-embed kernel (row N2); float tensors are taken as already normalised
+        if images.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
             images = images.float()
         return images.contiguous()
 

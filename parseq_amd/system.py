@@ -105,12 +105,12 @@ class PARSeq(nn.Module):
             raise NotImplementedError('validation loss (training path) is out of scope; use test_step')
         with torch.inference_mode():
             logits = self.forward(images)
-            probs = logits.softmax(-1)
-        preds, probs = self.tokenizer.decode(probs)
+            # base.py:132-137 on the device: soft-max, greedy pick, first-EOS cut and prob.prod() in one kernel (row N1)
+            preds, confs = self.tokenizer.read(logits)
         correct = total = label_length = 0
         ned = confidence = 0.0
-        for pred, prob, gt in zip(preds, probs, labels):
-            confidence += prob.prod().item()
+        for pred, conf, gt in zip(preds, confs.tolist(), labels):
+            confidence += conf
             pred = self.charset_adapter(pred)
             ned += edit_distance(pred, gt) / max(len(pred), len(gt), 1)
             correct += int(pred == gt)

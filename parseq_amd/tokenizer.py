@@ -3,8 +3,9 @@
 Mirrors the interface of the reference's `strhub/data/utils.py` (`CharsetAdapter` :26-43, `BaseTokenizer` :46-99,
 `Tokenizer` :102-129): same class and method names, same id assignment ([E] = 0, characters 1..len(charset),
 [B], [P] last), same greedy decode + truncate-at-first-EOS rule — string parity with the reference is judged on the
-output of `Tokenizer.decode`.  Written from scratch; CPU-side post-processing (a device-side version is row N1 of
-SURVEY.md section 8f).
+output of `Tokenizer.decode`.  Written from scratch.  `decode` is the reference's host-side routine;
+`decode_logits` / `read` give the same result from raw logits with the numeric part (soft-max, greedy pick, first-EOS cut,
+confidence product) done by the HIP post-processing kernel (`parseq_postprocess`).
 """
 from __future__ import annotations
 
@@ -93,3 +94,37 @@ class Tokenizer(BaseTokenizer):
             eos_idx = len(ids)
         # characters stop before the first EOS; the probability list keeps the EOS probability itself
         return probs[:eos_idx + 1], ids[:eos_idx]
+
+    # ---- device-side post-processing (row N1) ---------------------------------------------------------------------
+    def _postprocess(self, logits: Tensor):
+        """logits: CUDA fp32 [N, L, C].  Returns device tensors (ids int32 [N, L], lengths int32 [N], probs [N, L], conf [N])."""
+        from . import _native
+        if not logits.is_cuda:
+            raise RuntimeError('decode_logits / read run on the GPU (no CPU fallback); use decode(logits.softmax(-1)) on the host')
+        logits = logits.float().contiguous()
+        n, length, classes = logits.shape
+        dev = logits.device
+        ids = torch.empty((n, length), dtype=torch.int32, device=dev)
+        lengths = torch.empty((n,), dtype=torch.int32, device=dev)
+        probs = torch.empty((n, length), dtype=torch.float32, device=dev)
+        conf = torch.empty((n,), dtype=torch.float32, device=dev)
+        if n:
+            _native.check(_native.lib().parseq_postprocess(_native.ptr(logits), n, length, classes, self.eos_id,
+                                                           _native.ptr(ids), _native.ptr(lengths), _native.ptr(probs), _native.ptr(conf),
+                                                           _native.stream_ptr()))
+        return ids, lengths, probs, conf
+
+    def decode_logits(self, logits: Tensor) -> Tuple[List[str], List[Tensor]]:
+        """Drop-in for `decode(logits.softmax(-1))`: same labels, same per-label probability tensors (views of one device
+        tensor), with one small device->host copy (ids + lengths) instead of a [N, L, C] soft-max and a .tolist() per row."""
+        ids, lengths, probs, _ = self._postprocess(logits)
+        ids_h, len_h = ids.cpu().numpy(), lengths.cpu().tolist()
+        width = ids_h.shape[1] if ids_h.ndim == 2 else 0
+        labels = [self._ids2tok(row[:k].tolist()) for row, k in zip(ids_h, len_h)]
+        return labels, [probs[i, :min(k + 1, width)] for i, k in enumerate(len_h)]
+
+    def read(self, logits: Tensor) -> Tuple[List[str], Tensor]:
+        """(labels, confidence [N] on the host): what `read.py` / `_eval_step` consume (`prob.prod()` per label)."""
+        ids, lengths, _, conf = self._postprocess(logits)
+        ids_h, len_h = ids.cpu().numpy(), lengths.cpu().tolist()
+        return [self._ids2tok(row[:k].tolist()) for row, k in zip(ids_h, len_h)], conf.cpu()

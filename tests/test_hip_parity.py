@@ -193,3 +193,25 @@ def test_test_step_contract(name, models, golden):
     assert res.num_samples == 8 and 0 <= res.correct <= 8 and res.loss is None
     want_conf = sum(meta['modes']['ar1']['confidence'])
     assert abs(res.confidence - want_conf) <= 1e-2 * max(1.0, want_conf)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_uint8_input_is_normalised_in_the_patch_embed(name, models, precision):
+    """Row N2: raw uint8 pixels through parseq_forward(images_dtype=PARSEQ_U8) == the reference transform's
+    ToTensor + Normalize(0.5, 0.5) (oracle.normalize_u8) fed as a float tensor, bit for bit (every pixel value occurs)."""
+    m = models[precision]
+    m.model.decode_ar, m.model.refine_iters = True, 1
+    g = torch.Generator().manual_seed(99)
+    u8 = torch.randint(0, 256, (9, 3, 32, 128), generator=g, dtype=torch.uint8)
+    u8[0].view(-1)[:256] = torch.arange(256, dtype=torch.uint8)
+    ref_in = O.normalize_u8(u8)
+    if precision == 'bf16':
+        ref_in = ref_in.bfloat16()
+    with torch.inference_mode():
+        got = m(u8.to(DEV), 25).float().cpu()
+        want = m(ref_in.to(DEV), 25).float().cpu()
+    assert torch.equal(got, want)
+    with torch.inference_mode():
+        mem_u8 = m.model.encode(u8.to(DEV)).cpu()
+        mem_f = m.model.encode(ref_in.to(DEV)).cpu()
+    assert torch.equal(mem_u8, mem_f)
