@@ -1,0 +1,369 @@
+// Fused AR decoder step (bf16 mode, one query per image): modules.py:55-98 query stream + decoder.norm + head
+// (+ model.py:142-145 greedy pick) in TWO launches around the cross-attention instead of eight.
+//
+// Every decoder op except the cross-attention is local to one (image, query) row, so a workgroup that owns 16 rows (one
+// MFMA M tile) carries them through a whole chain of GEMMs with the activations parked in LDS:
+//
+//   dec_step_pre_kernel   self-attention from the (position, token) tables -> out_proj + pos_queries residual ->
+//                         norm1 -> cross-attention q-projection                                  writes t, qc
+//   (dec_cross_attn_ar_kernel streams the image's K/V: the one part that needs the whole chip's HBM bandwidth)
+//   dec_step_post_kernel  cross out_proj + residual -> norm2 -> linear1 + GELU -> linear2 + residual -> decoder.norm
+//                         -> head -> arg-max / EOS bookkeeping                                   writes logits, tok
+//
+// At 512 rows an AR step is 32 workgroups: far too few to fill 256 CUs, but the step is a latency chain, not a throughput
+// problem (1.9 GFLOP).  What the fusion removes is seven launch + drain + fill gaps per step (26 steps per batch), three
+// dependent HBM round trips inside each small GEMM, and the round trips of t / xn / hdn between them.  The price is that
+// every workgroup streams ALL decoder weights (0.6 MB pre, 3.0 MB post) through one CU, so the weight stream must run near
+// the per-CU fill rate (tools/microbench/l2_fill.hip: 115-135 GB/s with global_load_lds rings, a third of that through
+// register loads).  Each wave therefore owns a private ring of 1-KB LDS slots: `global_load_lds` copies the wave's next
+// W fragments (lane l's 16 bytes land at slot + 16 l, exactly where lane l reads its MFMA operand back) while the wave
+// multiplies — no block-level barrier inside a GEMM, only counted `s_waitcnt vmcnt`.
+// Rounding points are the generic path's (decode_pass_e): bf16 GEMM operands, fp32 accumulation, fp32 residual stream.
+#pragma once
+#include "common.h"
+#include "decoder_attn.h"
+#include "encoder_mlp.h"        // static_for, wait_vmcnt
+
+namespace pq {
+
+constexpr int DS_ROWS = 16;     // rows per workgroup
+constexpr int DS_NW = 8;        // waves per workgroup; 16-wide output column tiles are dealt round-robin to waves
+constexpr int DS_RING = 8;      // 1-KB LDS slots per wave (7 fragment loads in flight per wave, 56 KB per CU)
+
+// Fragment-ordered weights.  A [N][K] row-major weight is re-packed once per weight set (frag_pack_kernel) into
+//   Wp[tile = n / 16][kp = k / 64][half][lane = (n & 15) + 16 g][8]  =  W[16 tile + (lane & 15)][64 kp + 16 g + 8 half + 0..7]
+// i.e. unit (tile, kp, half) is the 1-KB MFMA operand fragment of one wave, contiguous in memory, and the units of one
+// tile follow each other: a wave's whole weight stream is one linear run of 1-KB `global_load_lds` copies.  (Read in
+// place from the row-major weight the same fragment is 16 half-used cache lines: measured 4x slower end to end.)
+// k is walked 64 at a time: lane group g takes k = 64 kp + 16 g + [0, 16) as the k-slots of TWO MFMAs (the slot
+// assignment is free as long as both operands agree).  Rows past N are zero in the packed copy.
+__global__ __launch_bounds__(256)
+void frag_pack_kernel(const bf16_t* __restrict__ W, int N, int K, int ldw, bf16_t* __restrict__ out, int tiles) {
+    const int KP = K / 64;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece per thread
+    if (idx >= (size_t)tiles * KP * 2 * 64) return;
+    const int lane = (int)(idx & 63), half = (int)((idx >> 6) & 1);
+    const int kp = (int)((idx >> 7) % KP), tile = (int)((idx >> 7) / KP);
+    const int n = tile * 16 + (lane & 15), k = 64 * kp + 16 * (lane >> 4) + 8 * half;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (n < N) v = *reinterpret_cast<const u32x4*>(W + (size_t)n * ldw + k);
+    *reinterpret_cast<u32x4*>(out + idx * 8) = v;
+}
+constexpr size_t frag_pack_elems(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K; }
+
+// acc[t] += Wp[tile (w + DS_NW t)] (16 x K)  x  A^T (K x 16 rows).  Result layout: lane (m = lane & 15, g = lane >> 4)
+// holds columns n = 16 tile + 4 g + r (r = 0..3) of row m.  Tiles past `tiles` recompute the last tile (discarded).
+// Unit u = ((kp * TN) + t) * 2 + half is one 1-KB fragment; unit u lives in the wave's ring slot u % DS_RING.
+template <int K, int TN>
+__device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const bf16_t* __restrict__ Wp, int tiles,
+                                             int wave, unsigned char* wring, f32x4 (&acc)[TN]) {
+    const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
+    constexpr int KP = K / 64, U = KP * TN * 2, DIST = DS_RING - 1, PRE = U < DIST ? U : DIST;
+    const bf16_t* wp[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+        int tile = wave + DS_NW * t;
+        tile = tile < tiles ? tile : tiles - 1;
+        wp[t] = Wp + (size_t)tile * KP * 1024 + lane * 8;
+    }
+    const bf16_t* ap = a_lds + r16 * lda + 16 * g;
+    auto issue = [&](auto uc) {
+        constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[t] + (kp * 2 + half) * 512),
+                                         (__attribute__((address_space(3))) void*)(wring + (u % DS_RING) * 1024), 16, 0, 0);
+    };
+    static_for<0, PRE>(issue);
+    Frag<bf16_t> a0, a1;
+    static_for<0, U>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
+        if constexpr (t == 0 && half == 0) {
+            a0.v = *reinterpret_cast<const bf16x8*>(ap + 64 * kp);
+            a1.v = *reinterpret_cast<const bf16x8*>(ap + 64 * kp + 8);
+        }
+        // units issued so far: min(U, u + DIST); all but the (issued - u - 1) newest must have landed
+        constexpr int issued = (u + DIST < U) ? u + DIST : U;
+        wait_vmcnt<issued - u - 1>();
+        Frag<bf16_t> w;
+        w.v = *reinterpret_cast<const bf16x8*>(wring + (u % DS_RING) * 1024 + lane * 16);
+        mma16(acc[t], w, half ? a1 : a0);
+        // refill: unit u + DIST goes to slot (u + DIST) % DS_RING = (u - 1) % DS_RING, whose ds_read was consumed by the
+        // previous unit's MFMA (program order pinned by the scheduling barrier), so the slot is free
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (u + DIST < U) issue(std::integral_constant<int, u + DIST>{});
+    });
+}
+
+// LayerNorm of rows 2w, 2w + 1 of the fp32 residual tile (pitch PT) into the bf16 A buffer (pitch PA).
+template <int E>
+__device__ __forceinline__ void ds_layernorm_rows(const float* tl, int PT, bf16_t* abuf, int PA, const float* __restrict__ gw,
+                                                  const float* __restrict__ gb, float eps, int wave) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
+        const int row = wave * (DS_ROWS / DS_NW) + rr;
+        float v[E / 64], s = 0.f;
+#pragma unroll
+        for (int i = 0; i < E / 64; ++i) { v[i] = tl[row * PT + lane + 64 * i]; s += v[i]; }
+        const float mean = wave_sum(s) * (1.0f / E);
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < E / 64; ++i) { const float d = v[i] - mean; ss += d * d; }
+        const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * (1.0f / E) + eps);
+#pragma unroll
+        for (int i = 0; i < E / 64; ++i) {
+            const int c = lane + 64 * i;
+            abuf[row * PA + c] = from_f32<bf16_t>((v[i] - mean) * rstd * gw[c] + gb[c]);
+        }
+    }
+}
+
+template <int E> constexpr size_t dec_step_pre_lds() { return (size_t)DS_ROWS * ((E + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024; }
+template <int E> constexpr size_t dec_step_post_lds() {
+    return (size_t)DS_ROWS * ((E + 8) * 2 + (4 * E + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
+}
+
+// ---- before the cross-attention ---------------------------------------------------------------------------------------
+// tok [M][ldt]; keys j < Lk are the content tokens; query position `pos` for every row (AR step: Lq == 1, no masks).
+// Wo, Wq: fragment-packed (Wq = first E rows of cross_attn.in_proj_weight; bq its first E biases).  t_out, qc_out: fp32 [M][E].
+template <int E>
+__global__ __launch_bounds__(64 * DS_NW)
+void dec_step_pre_kernel(const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, const int* __restrict__ tok, int ldt,
+                         int ntok, int npos, int Lk, int pos, const bf16_t* __restrict__ Wo, const float* __restrict__ bo,
+                         const float* __restrict__ posq, const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+                         const bf16_t* __restrict__ Wq, const float* __restrict__ bq, float* __restrict__ t_out,
+                         float* __restrict__ qc_out, int M) {
+    constexpr int H = E / DEC_HD, PA = E + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
+    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
+    float* tl = reinterpret_cast<float*>(abuf + DS_ROWS * PA);         // [DS_ROWS][PT]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
+    const int row0 = blockIdx.x * DS_ROWS;
+
+    // self-attention of rows 2w, 2w + 1 (decoder_attn.h: dec_self_attn_kernel), one wave per row, registers only:
+    // lane l works for head h = l >> 2: it scores keys j = (l & 3) + 4 c, the quad reduces max / sum over DPP, and the same
+    // lane then mixes value columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.
+    static_assert(DEC_HD == 32 && DEC_MAXL == 32, "lane mapping assumes 32-wide heads and <= 32 keys");
+#pragma unroll 1
+    for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
+        const int row = wave * (DS_ROWS / DS_NW) + rr;
+        const int b = min(row0 + row, M - 1);
+        const int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
+        const int h = lane >> 2, q = lane & 3;
+        const bool live = h < H;
+        float sc[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int j = q + 4 * c;
+            const int tj = __shfl(tokv, j, 64);
+            sc[c] = (live && j < Lk) ? stab[(((size_t)pos * npos + j) * ntok + tj) * H + h] : -INFINITY;
+            mx = fmaxf(mx, sc[c]);
+        }
+        mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+        mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { sc[c] = (q + 4 * c < Lk) ? expf(sc[c] - mx) : 0.f; sum += sc[c]; }
+        sum += dpp_mov<0xB1>(sum);
+        sum += dpp_mov<0x4E>(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sc[c] *= inv;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int d0 = live ? 8 * lane : 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            // key j = 4 c + qq: its probability sits in lane (quad base + qq), register sc[c]
+            const float pq4[4] = {dpp_mov<0x00>(sc[c]), dpp_mov<0x55>(sc[c]), dpp_mov<0xAA>(sc[c]), dpp_mov<0xFF>(sc[c])};
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int j = 4 * c + qq;
+                if (j < Lk) {
+                    const int tj = __builtin_amdgcn_readlane(tokv, j);
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+                }
+            }
+        }
+        if (live) {
+            bf16x8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
+            *reinterpret_cast<bf16x8*>(abuf + row * PA + d0) = o;
+        }
+    }
+    __syncthreads();
+
+    // t = pos_queries[pos] + sa @ Wo^T + bo
+    {
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<E, TN>(abuf, PA, Wo, TILES, wave, wring, acc);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(bo + n);
+                const float4 pv = *reinterpret_cast<const float4*>(posq + n);
+                f32x4 o = {acc[t][0] + bv.x + pv.x, acc[t][1] + bv.y + pv.y, acc[t][2] + bv.z + pv.z, acc[t][3] + bv.w + pv.w};
+                *reinterpret_cast<f32x4*>(tl + r16 * PT + n) = o;
+                if (row0 + r16 < M) *reinterpret_cast<f32x4*>(t_out + (size_t)(row0 + r16) * E + n) = o;
+            }
+        }
+    }
+    __syncthreads();
+    ds_layernorm_rows<E>(tl, PT, abuf, PA, ln_w, ln_b, eps, wave);
+    __syncthreads();
+    // qc = norm1(t) @ Wq^T + bq
+    {
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<E, TN>(abuf, PA, Wq, TILES, wave, wring, acc);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES && row0 + r16 < M) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(bq + n);
+                f32x4 o = {acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w};
+                *reinterpret_cast<f32x4*>(qc_out + (size_t)(row0 + r16) * E + n) = o;
+            }
+        }
+    }
+}
+
+// ---- after the cross-attention ----------------------------------------------------------------------------------------
+// ca bf16 [M][E]; t fp32 [M][E] (from the pre kernel); Wco, W1, W2, Wh fragment-packed; logits fp32 [M][Ltot][C] at position `pos`.
+// argmax_mode: 0 = none, 1 = write tok[b][pos + 1], 2 = also keep the batch-level EOS bookkeeping (rowops.h: ar_argmax_kernel).
+template <int E>
+__global__ __launch_bounds__(64 * DS_NW)
+void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict__ t_in, const bf16_t* __restrict__ Wco,
+                          const float* __restrict__ bco, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b,
+                          const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+                          const float* __restrict__ b2, const float* __restrict__ lnf_w, const float* __restrict__ lnf_b, float eps,
+                          const bf16_t* __restrict__ Wh, const float* __restrict__ bh, int C, float* __restrict__ logits, int Ltot,
+                          int pos, int M, int argmax_mode, int* __restrict__ tok, int ldt, int eos_id,
+                          unsigned char* __restrict__ eos_seen, int* __restrict__ eos_rows, int* __restrict__ ar_len) {
+    constexpr int F = 4 * E, PA = E + 8, PH = F + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW;
+    constexpr int TN1 = F / 16 / DS_NW;                       // linear1: column tiles per wave
+    constexpr int PL = 128;                                  // logits tile pitch (C <= 128); aliases hbuf after linear2
+    static_assert(F % (16 * DS_NW) == 0, "linear1 width must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
+    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
+    bf16_t* hbuf = abuf + DS_ROWS * PA;                                // [DS_ROWS][PH]
+    float* tl = reinterpret_cast<float*>(hbuf + DS_ROWS * PH);         // [DS_ROWS][PT]
+    float* lg = reinterpret_cast<float*>(hbuf);                        // [DS_ROWS][PL]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
+    const int row0 = blockIdx.x * DS_ROWS;
+
+    // stage the 16 rows of ca (bf16) and t (fp32)
+    for (int i = threadIdx.x; i < DS_ROWS * (E / 8); i += 64 * DS_NW) {
+        const int row = i / (E / 8), c = (i - row * (E / 8)) * 8;
+        const int gr = min(row0 + row, M - 1);
+        *reinterpret_cast<bf16x8*>(abuf + row * PA + c) = *reinterpret_cast<const bf16x8*>(ca + (size_t)gr * E + c);
+    }
+    for (int i = threadIdx.x; i < DS_ROWS * (E / 4); i += 64 * DS_NW) {
+        const int row = i / (E / 4), c = (i - row * (E / 4)) * 4;
+        const int gr = min(row0 + row, M - 1);
+        *reinterpret_cast<f32x4*>(tl + row * PT + c) = *reinterpret_cast<const f32x4*>(t_in + (size_t)gr * E + c);
+    }
+    __syncthreads();
+    // t += ca @ Wco^T + bco
+    {
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<E, TN>(abuf, PA, Wco, TILES, wave, wring, acc);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(bco + n);
+                f32x4* p = reinterpret_cast<f32x4*>(tl + r16 * PT + n);
+                f32x4 o = *p;
+                o[0] += acc[t][0] + bv.x; o[1] += acc[t][1] + bv.y; o[2] += acc[t][2] + bv.z; o[3] += acc[t][3] + bv.w;
+                *p = o;
+            }
+        }
+    }
+    __syncthreads();
+    ds_layernorm_rows<E>(tl, PT, abuf, PA, ln2_w, ln2_b, eps, wave);
+    __syncthreads();
+    // h = gelu(norm2(t) @ W1^T + b1)
+    {
+        f32x4 acc[TN1] = {};
+        ds_wave_gemm<E, TN1>(abuf, PA, W1, F / 16, wave, wring, acc);
+#pragma unroll
+        for (int t = 0; t < TN1; ++t) {
+            const int n = (wave + DS_NW * t) * 16 + 4 * g;
+            const float4 bv = *reinterpret_cast<const float4*>(b1 + n);
+            const float o[4] = {gelu_poly(acc[t][0] + bv.x), gelu_poly(acc[t][1] + bv.y), gelu_poly(acc[t][2] + bv.z), gelu_poly(acc[t][3] + bv.w)};
+            store4<bf16_t>(hbuf + r16 * PH + n, o);
+        }
+    }
+    __syncthreads();
+    // t += h @ W2^T + b2
+    {
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<F, TN>(hbuf, PH, W2, TILES, wave, wring, acc);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(b2 + n);
+                f32x4* p = reinterpret_cast<f32x4*>(tl + r16 * PT + n);
+                f32x4 o = *p;
+                o[0] += acc[t][0] + bv.x; o[1] += acc[t][1] + bv.y; o[2] += acc[t][2] + bv.z; o[3] += acc[t][3] + bv.w;
+                *p = o;
+            }
+        }
+    }
+    __syncthreads();
+    ds_layernorm_rows<E>(tl, PT, abuf, PA, lnf_w, lnf_b, eps, wave);
+    __syncthreads();
+    // logits = decoder.norm(t) @ Wh^T + bh   (C <= 128 classes: one column tile per wave); hbuf is free: lg aliases it
+    {
+        f32x4 acc[1] = {};
+        ds_wave_gemm<E, 1>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc);
+        const int n = wave * 16 + 4 * g;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r < C) {
+                const float v = acc[0][r] + bh[n + r];
+                lg[r16 * PL + n + r] = v;
+                if (row0 + r16 < M) logits[((size_t)(row0 + r16) * Ltot + pos) * C + n + r] = v;
+            }
+        }
+    }
+    if (argmax_mode == 0) return;
+    __syncthreads();
+    // greedy pick (first maximum, as torch.argmax) + batch-level EOS bookkeeping
+#pragma unroll 1
+    for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
+        const int row = wave * (DS_ROWS / DS_NW) + rr, b = row0 + row;
+        if (b >= M) continue;
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int c = lane; c < C; c += 64) {
+            const float v = lg[row * PL + c];
+            if (v > best) { best = v; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            tok[(size_t)b * ldt + pos + 1] = bi;
+            if (argmax_mode == 2 && bi == eos_id && !eos_seen[b]) {
+                eos_seen[b] = 1;
+                const int done = atomicAdd(eos_rows, 1) + 1;
+                if (done == M) *ar_len = pos + 1;
+            }
+        }
+    }
+}
+
+}  // namespace pq

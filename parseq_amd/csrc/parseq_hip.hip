@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -15,6 +16,7 @@
 
 #include "common.h"
 #include "decoder_attn.h"
+#include "decoder_step.h"
 #include "encoder_attn.h"
 #include "encoder_panel.h"
 #include "encoder_mlp.h"
@@ -48,10 +50,10 @@ static int fail(int code, const char* fmt, ...) {
 // -------------------------------------------------------------------------------------------------------------------
 // optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
 // -------------------------------------------------------------------------------------------------------------------
-enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_COUNT };
+enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_DEC_PRE, T_DEC_POST, T_COUNT };
 static const char* const kProfNames[T_COUNT] = {"enc.patch_embed_gemm", "enc.layernorm", "enc.qkv_gemm", "enc.attention", "enc.proj_gemm",
                                                 "enc.fc1_gelu_gemm", "enc.fc2_gemm", "enc.mlp_fused", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
-                                                "dec.cross_attention", "dec.layernorm", "dec.misc"};
+                                                "dec.cross_attention", "dec.layernorm", "dec.misc", "dec.step_pre", "dec.step_post"};
 struct Profiler {
     bool enabled = false;
     std::vector<hipEvent_t> pool;          // events, used pairwise
@@ -241,6 +243,8 @@ struct parseq_plan {
     size_t arena_bytes = 0;
     // carved pointers (typed at use)
     void* wpack = nullptr;         // all parameters in storage type T (bf16 mode only; f32 mode aliases the master)
+    bf16_t* wstep[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fragment-packed decoder weights (decoder_step.h):
+                                   // self out_proj, cross q-proj, cross out_proj, linear1, linear2, head; bf16 mode, E <= 384
     void* kvtab = nullptr;         // T [npos][num_tokens][2E]
     float* qself = nullptr;        // [npos][E], pre-scaled
     void* ctab_ln = nullptr;       // T [npos * num_tokens][E] scratch for table build
@@ -257,6 +261,7 @@ struct parseq_plan {
     unsigned char* qmask_user = nullptr;  // [npos][LDT] staging for parseq_decode_logits
     int* counters = nullptr;       // [0] eos_rows, [1] ar_len
     int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
+    bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
     Profiler prof;
 };
 constexpr int LDT = 32;            // row pitch of token / mask arrays
@@ -363,6 +368,22 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
         hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<bf16_t*>(p->wpack), n);
         HIPCHK(hipGetLastError());
         CHK(build_tables<bf16_t>(p, s));
+        if (p->wstep[0]) {       // decoder weights in MFMA-fragment order for the fused AR step
+            const int E = m->cfg.embed_dim, Fd = E * m->cfg.dec_mlp_ratio;
+            const Weights<bf16_t> W = weights_of<bf16_t>(p);
+            const std::string d = "decoder.layers.0.";
+            struct { const bf16_t* w; int N, K; } src[6] = {
+                {W.w(d + "self_attn.out_proj.weight"), E, E}, {W.w(d + "cross_attn.in_proj_weight"), E, E},
+                {W.w(d + "cross_attn.out_proj.weight"), E, E}, {W.w(d + "linear1.weight"), Fd, E},
+                {W.w(d + "linear2.weight"), E, Fd}, {W.w("head.weight"), m->classes, E}};
+            for (int i = 0; i < 6; ++i) {
+                const int tiles = (src[i].N + 15) / 16;
+                const size_t pieces = (size_t)tiles * (src[i].K / 64) * 128;
+                hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, src[i].w, src[i].N, src[i].K,
+                                   src[i].K, p->wstep[i], tiles);
+                HIPCHK(hipGetLastError());
+            }
+        }
     } else {
         CHK(build_tables<float>(p, s));
     }
@@ -385,6 +406,11 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->m = m; p->max_batch = max_batch; p->precision = precision;
     size_t off = 0;
     const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : 0);
+    const bool step_ok = precision == PARSEQ_BF16 && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
+    const size_t step_elems[6] = {frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(Fd, E),
+                                  frag_pack_elems(E, Fd), frag_pack_elems(m->classes, E)};
+    size_t o_wstep[6];
+    for (int i = 0; i < 6; ++i) o_wstep[i] = carve(off, step_ok ? step_elems[i] * 2 : 0);
     const size_t o_kvtab = carve(off, npos * c.num_tokens * 2 * E * ts);
     const size_t o_qself = carve(off, npos * E * 4);
     const size_t o_ctab = carve(off, npos * c.num_tokens * E * ts);
@@ -404,6 +430,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     hipError_t e = hipMalloc(&p->arena, off);
     if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
     unsigned char* a = p->arena;
+    if (step_ok) for (int i = 0; i < 6; ++i) p->wstep[i] = reinterpret_cast<bf16_t*>(a + o_wstep[i]);
     p->wpack = a + o_wpack; p->kvtab = a + o_kvtab; p->qself = (float*)(a + o_qself); p->ctab_ln = a + o_ctab;
     p->x = (float*)(a + o_x); p->xn = a + o_xn; p->q = a + o_q; p->k = a + o_k; p->vt = a + o_vt; p->ao = a + o_ao; p->h = a + o_h;
     p->kmem = a + o_kmem; p->vtmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
@@ -567,7 +594,7 @@ extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtyp
 // -------------------------------------------------------------------------------------------------------------------
 template <typename T, int E>
 static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
-                         float* logits, int Ltot) {
+                         float* logits, int Ltot, int argmax_mode) {
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
     const int M = B * Lq, Fd = E * c.dec_mlp_ratio, C = m->classes, npos = c.max_label_length + 1, H = c.dec_heads;
@@ -576,6 +603,44 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     T* sa = reinterpret_cast<T*>(p->sa); T* ca = reinterpret_cast<T*>(p->ca); T* hdn = reinterpret_cast<T*>(p->hdn);
     const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vtmem = reinterpret_cast<const T*>(p->vtmem);
     const float scale = sqrtf(1.0f / (float)DEC_HD);
+    int* eos_rows = p->counters; int* ar_len = p->counters + 1;
+    if constexpr (sizeof(T) == 2 && E <= 384) {
+        // AR step (one unmasked query per image): two fused row-block kernels around the cross-attention (decoder_step.h)
+        if (Lq == 1 && !qmask && !kpm && C <= 128 && p->fused_step && p->wstep[0]) {
+            const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
+            static const bool attr_set = [] {
+                return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_pre_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)dec_step_pre_lds<E>()) == hipSuccess &&
+                       hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_post_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)dec_step_post_lds<E>()) == hipSuccess;
+            }();
+            if (!attr_set) return fail(PARSEQ_E_HIP, "hipFuncSetAttribute(dec_step kernels) failed");
+            {
+                ProfScope ps_(&p->prof, T_DEC_PRE, s);
+                hipLaunchKernelGGL((dec_step_pre_kernel<E>), grid, block, dec_step_pre_lds<E>(), s, p->stab, reinterpret_cast<const bf16_t*>(p->kvtab),
+                                   p->tok, LDT, c.num_tokens, npos, Lk, i0, p->wstep[0], m->p(d + "self_attn.out_proj.bias"),
+                                   m->p("pos_queries") + (size_t)i0 * E, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), c.dec_ln_eps,
+                                   p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), p->t, p->qc, M);
+                HIPCHK(hipGetLastError());
+            }
+            {
+                ProfScope ps_(&p->prof, T_DEC_CA, s);
+                hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vtmem, scale, ca);
+                HIPCHK(hipGetLastError());
+            }
+            {
+                ProfScope ps_(&p->prof, T_DEC_POST, s);
+                hipLaunchKernelGGL((dec_step_post_kernel<E>), grid, block, dec_step_post_lds<E>(), s, reinterpret_cast<const bf16_t*>(ca), p->t,
+                                   p->wstep[2], m->p(d + "cross_attn.out_proj.bias"), m->p(d + "norm2.weight"),
+                                   m->p(d + "norm2.bias"), p->wstep[3], m->p(d + "linear1.bias"), p->wstep[4],
+                                   m->p(d + "linear2.bias"), m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps,
+                                   p->wstep[5], m->p("head.bias"), C, logits, Ltot, i0, M, argmax_mode, p->tok, LDT, c.eos_id,
+                                   p->eos_seen, eos_rows, ar_len);
+                HIPCHK(hipGetLastError());
+            }
+            return 0;
+        }
+    }
     // self-attention from the tables, out-projection, residual onto the raw position queries
     {
         ProfScope ps_(&p->prof, T_DEC_SA, s);
@@ -602,6 +667,11 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     // decoder.norm fused into the head's A operand
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps, 0, nullptr},
                      W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), logits, C, 1.f, Lq, Ltot, i0)))); }
+    if (argmax_mode) {       // only meaningful for Lq == 1: greedy pick of position i0 into tok[:, i0 + 1]
+        hipLaunchKernelGGL(ar_argmax_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, Ltot, C, p->tok, LDT, i0, B, c.eos_id,
+                           p->eos_seen, eos_rows, ar_len, argmax_mode == 2 ? 1 : 0);
+        HIPCHK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -610,11 +680,11 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
 // logits[b][i0 + qi][:] for qi < Lq into a [B][Ltot][C] tensor.
 template <typename T>
 static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
-                       float* logits, int Ltot) {
+                       float* logits, int Ltot, int argmax_mode = 0) {
     switch (p->m->cfg.embed_dim) {
-        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot);
-        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot);
-        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot);
+        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode);
+        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode);
+        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode);
     }
 }
 
@@ -631,12 +701,8 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
         // model.py:119-147.  All num_steps steps are always run (no per-step host sync); the step at which the reference
         // would have stopped is recorded on the device and only truncates the returned view.
         for (int i = 0; i < num_steps; ++i) {
-            CHK((decode_pass<T>(p, s, B, i + 1, i, 1, nullptr, nullptr, logits, num_steps)));
-            if (i + 1 < num_steps) {
-                hipLaunchKernelGGL(ar_argmax_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, num_steps, C, p->tok, LDT, i, B, c.eos_id,
-                                   p->eos_seen, eos_rows, ar_len, testing ? 1 : 0);
-                HIPCHK(hipGetLastError());
-            }
+            // greedy pick of position i into tok[:, i + 1] (+ EOS bookkeeping) rides on the step; the last step needs none
+            CHK((decode_pass<T>(p, s, B, i + 1, i, 1, nullptr, nullptr, logits, num_steps, i + 1 < num_steps ? (testing ? 2 : 1) : 0)));
         }
     } else {
         // model.py:148-152: context is <bos> only, all positions queried at once
