@@ -10,9 +10,9 @@
 // so an AR step's self-attention is: gather <= 26 x H scores, soft-max, mix <= 26 gathered V rows.
 //
 // Cross-attention.  K/V of `memory` are projected ONCE per image by the encoder tail (the reference re-projects them
-// on each of its 26 + refine_iters decoder calls) and stored head-split:  kmem[b][h][key][32], vtmem[b][h][32][key].
+// on each of its 26 + refine_iters decoder calls) and stored head-split:  kmem[b][h][key][32], vmem[b][h][key][32].
 //   * AR step (one query per image): dec_cross_attn_ar_kernel — memory-bound streaming of the image's 2 x 96 KB of K/V
-//     with 16-byte loads, one workgroup of E threads per image.
+//     as contiguous 1-KB wave loads, one workgroup of E threads per image.
 //   * refinement / NAR (all <= 32 positions at once): dec_cross_attn_multi_kernel — one workgroup per (image, head), K
 //     and V^T staged in LDS as fp32, scores and the value mix as register-blocked FMA loops (2.6 GFLOP per 512 images:
 //     not worth an MFMA pipeline).
@@ -84,58 +84,84 @@ void dec_self_attn_kernel(const float* __restrict__ stab, const T* __restrict__ 
 }
 
 // AR-step cross-attention: one workgroup of E threads per image, ONE query.  qc fp32 [B][E] un-scaled projected query;
-// kmem T [B][H][Nk][32]; vtmem T [B][H][32][Nk]; out T [B][E].  Nk = 128 memory tokens.
+// kmem, vmem T [B][H][Nk][32] (head-split, key rows of 32 contiguous d); out T [B][E].  Nk = 128 memory tokens.
+// Pure streaming of the image's K and V (196 KB in bf16): every wave-level load is one contiguous 1 KB — lane
+// (kl = lane / LPR, dl = lane % LPR) takes the 16-byte piece dl of key row (16 c + kl) — and all 16 loads of a head are
+// issued before the first score is needed.  A wave owns a head at a time: partial dot products are reduced over the LPR
+// lanes of a key row with DPP, the soft-max over the 128 keys and the value mix over the key lanes with DPP rotations
+// inside a 16-lane row and two cross-row shuffles.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) { return v + dpp_mov<CTRL>(v); }
+template <int CTRL> __device__ __forceinline__ float dpp_max(float v) { return fmaxf(v, dpp_mov<CTRL>(v)); }
+
 template <typename T, int E>
 __global__ __launch_bounds__(E)
-void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict__ kmem, const T* __restrict__ vtmem,
+void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict__ kmem, const T* __restrict__ vmem,
                               float scale, T* __restrict__ out) {
     constexpr int H = E / DEC_HD, NK = 128;
-    constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte chunk
-    __shared__ __attribute__((aligned(16))) float sq[E];
-    __shared__ __attribute__((aligned(16))) float sp[H][NK];
-    const int t = threadIdx.x, b = blockIdx.x;
-    sq[t] = qc[(size_t)b * E + t] * scale;
-    __syncthreads();
-    // scores: H * NK (head, key) pairs, consecutive threads take consecutive keys of one head -> consecutive 64-byte rows
-    for (int pair = t; pair < H * NK; pair += E) {
-        const int h = pair / NK, key = pair - h * NK;
-        const T* kr = kmem + (((size_t)b * H + h) * NK + key) * DEC_HD;
-        float s = 0.f;
+    constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte piece: 8 (bf16) or 4 (f32)
+    constexpr int LPR = DEC_HD / EPC;                  // lanes per key row: 4 or 8
+    constexpr int KPL = 64 / LPR;                      // key rows per wave-level load: 16 or 8
+    constexpr int NL = NK / KPL;                       // loads per head and operand: 8 or 16
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = E / 64, b = blockIdx.x;
+    const int kl = lane / LPR, dl = lane % LPR;
+    // sum / max over the lanes that hold the same d piece (all kl): rotations by multiples of LPR inside the 16-lane row,
+    // then the other three rows
+    auto over_keys_sum = [](float v) {
+        if constexpr (LPR == 4) v = dpp_add<0x124>(v);     // row_ror:4
+        v = dpp_add<0x128>(v);                             // row_ror:8
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+    auto over_keys_max = [](float v) {
+        if constexpr (LPR == 4) v = dpp_max<0x124>(v);
+        v = dpp_max<0x128>(v);
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        return v;
+    };
+    for (int h = wid; h < H; h += nw) {
+        const T* kb = kmem + (((size_t)b * H + h) * NK + kl) * DEC_HD + dl * EPC;
+        const T* vb = vmem + (((size_t)b * H + h) * NK + kl) * DEC_HD + dl * EPC;
+        union Piece { u32x4 u; T e[EPC]; };
+        Piece kr[NL], vr[NL];
 #pragma unroll
-        for (int c = 0; c < DEC_HD / EPC; ++c) {
-            union { u32x4 u; T e[EPC]; } kv;
-            kv.u = *reinterpret_cast<const u32x4*>(kr + c * EPC);
+        for (int c = 0; c < NL; ++c) kr[c].u = *reinterpret_cast<const u32x4*>(kb + (size_t)c * KPL * DEC_HD);
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) s = fmaf(sq[h * DEC_HD + c * EPC + i], to_f32(kv.e[i]), s);
-        }
-        sp[h][key] = s;
-    }
-    __syncthreads();
-    // soft-max over the 128 keys of each head: wave w handles heads w, w + nwaves, ...; lane owns keys lane and lane + 64
-    {
-        const int lane = t & 63, wid = t >> 6, nw = E / 64;
-        for (int h = wid; h < H; h += nw) {
-            const float a = sp[h][lane], c = sp[h][lane + 64];
-            const float mx = wave_max(fmaxf(a, c));
-            const float pa = expf(a - mx), pc = expf(c - mx);
-            const float inv = 1.0f / wave_sum(pa + pc);
-            sp[h][lane] = pa * inv; sp[h][lane + 64] = pc * inv;
-        }
-    }
-    __syncthreads();
-    // value mix: thread t = (h, d) walks its V^T row (128 keys, contiguous) against the head's probabilities
-    {
-        const int h = t / DEC_HD;
-        const T* vr = vtmem + ((size_t)b * E + t) * NK;          // ((b * H + h) * 32 + d) * NK with h * 32 + d == t
-        float acc = 0.f;
-#pragma unroll 4
-        for (int c = 0; c < NK / EPC; ++c) {
-            union { u32x4 u; T e[EPC]; } vv;
-            vv.u = *reinterpret_cast<const u32x4*>(vr + c * EPC);
+        for (int c = 0; c < NL; ++c) vr[c].u = *reinterpret_cast<const u32x4*>(vb + (size_t)c * KPL * DEC_HD);
+        float qv[EPC];
 #pragma unroll
-            for (int i = 0; i < EPC; ++i) acc = fmaf(sp[h][c * EPC + i], to_f32(vv.e[i]), acc);
+        for (int i = 0; i < EPC; ++i) qv[i] = qc[(size_t)b * E + h * DEC_HD + dl * EPC + i] * scale;
+        float s[NL], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) d = fmaf(qv[i], to_f32(kr[c].e[i]), d);
+            d = dpp_add<0xB1>(d);                              // quad: lanes of one key row (LPR = 4) ...
+            d = dpp_add<0x4E>(d);
+            if constexpr (LPR == 8) d = dpp_add<0x141>(d);     // ... or two quads (row_half_mirror)
+            s[c] = d;
+            mx = fmaxf(mx, d);
         }
-        out[(size_t)b * E + t] = from_f32<T>(acc);
+        mx = over_keys_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) { s[c] = expf(s[c] - mx); sum += s[c]; }
+        const float inv = 1.0f / over_keys_sum(sum);
+        float acc[EPC];
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+            const float pc = s[c] * inv;
+#pragma unroll
+            for (int i = 0; i < EPC; ++i) acc[i] = fmaf(pc, to_f32(vr[c].e[i]), acc[i]);
+        }
+        Piece o;
+#pragma unroll
+        for (int i = 0; i < EPC; ++i) o.e[i] = from_f32<T>(over_keys_sum(acc[i]));
+        if (kl == 0) *reinterpret_cast<u32x4*>(out + (size_t)b * E + h * DEC_HD + dl * EPC) = o.u;
     }
 }
 
@@ -143,7 +169,7 @@ void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict_
 // qc fp32 [B*Lq][E]; out T [B*Lq][E].
 template <typename T>
 __global__ __launch_bounds__(128)
-void dec_cross_attn_multi_kernel(const float* __restrict__ qc, const T* __restrict__ kmem, const T* __restrict__ vtmem,
+void dec_cross_attn_multi_kernel(const float* __restrict__ qc, const T* __restrict__ kmem, const T* __restrict__ vmem,
                                  int H, int Lq, float scale, T* __restrict__ out) {
     constexpr int NK = 128, QP = DEC_MAXL;
     __shared__ float sk[NK][DEC_HD + 1];        // K rows, +1 pad: thread-per-key row reads hit distinct banks
@@ -153,10 +179,10 @@ void dec_cross_attn_multi_kernel(const float* __restrict__ qc, const T* __restri
     const int t = threadIdx.x;
     const int bh = blockIdx.x, b = bh / H, h = bh - b * H, E = H * DEC_HD;
     const T* kg = kmem + (size_t)bh * NK * DEC_HD;
-    const T* vg = vtmem + (size_t)bh * DEC_HD * NK;
+    const T* vg = vmem + (size_t)bh * NK * DEC_HD;
     for (int i = t; i < NK * DEC_HD; i += 128) {
         sk[i / DEC_HD][i % DEC_HD] = to_f32(kg[i]);
-        sv[i / NK][i % NK] = to_f32(vg[i]);
+        sv[i % DEC_HD][i / DEC_HD] = to_f32(vg[i]);        // V rows arrive [key][d]; the mix wants d-major
     }
     for (int i = t; i < Lq * DEC_HD; i += 128) {
         const int qi = i / DEC_HD, d = i - qi * DEC_HD;
@@ -193,6 +219,129 @@ void dec_cross_attn_multi_kernel(const float* __restrict__ qc, const T* __restri
 #pragma unroll 8
             for (int key = 0; key < NK; ++key) acc = fmaf(sp[qi][key], sv[d][key], acc);
             out[((size_t)b * Lq + qi) * E + h * DEC_HD + d] = from_f32<T>(acc);
+        }
+    }
+}
+
+// Multi-query cross-attention on the matrix cores (bf16 storage): one WAVE per (image, head), Lq <= 32 queries.
+//   S^T[key][query] = K Q^T   (16x16x32 MFMA: 8 key tiles x 2 query tiles, the 32-wide head is exactly one k-step)
+//   soft-max over the 128 keys of a query: 32 values in the lane + the other three lane groups (two shuffles)
+//   O^T[d][query]   = V^T P^T (k-slot s of lane group g in k-step kk is key 32 kk + 16 (s >> 2) + 4 g + (s & 3), which is
+//                     where the S^T accumulators already hold the probabilities; V^T fragments are gathered from an LDS copy)
+// Queries and probabilities are fp32 quantities in this decoder: each is fed to the bf16 MFMA as a
+// hi + lo pair (x = bf16(x) + bf16(x - bf16(x)), two MFMAs), which keeps ~16 mantissa bits instead of 8.
+__global__ __launch_bounds__(256)
+void dec_cross_attn_multi_mfma_kernel(const float* __restrict__ qc, const bf16_t* __restrict__ kmem, const bf16_t* __restrict__ vmem,
+                                      int H, int Lq, float scale, bf16_t* __restrict__ out, int BH) {
+    constexpr int NK = 128, VP = DEC_HD + 2;               // LDS pitch of a V row (elements): odd word count spreads banks
+    __shared__ __attribute__((aligned(16))) bf16_t sv[4][NK * VP];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x * 4 + wid;
+    if (bh >= BH) return;
+    const int b = bh / H, h = bh - b * H, E = H * DEC_HD;
+    const bf16_t* kg = kmem + (size_t)bh * NK * DEC_HD;
+    const bf16_t* vg = vmem + (size_t)bh * NK * DEC_HD;
+    // K fragments straight from global (a key tile is 16 rows x 64 B = one contiguous KB); V staged to LDS
+    Frag<bf16_t> kf[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) kf[kt].v = *reinterpret_cast<const bf16x8*>(kg + (kt * 16 + r16) * DEC_HD + 8 * g);
+    bf16x8 vraw[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) vraw[c] = *reinterpret_cast<const bf16x8*>(vg + (size_t)c * 512 + lane * 8);
+    // queries: lane (query = 16 qt + r16, g) takes d = 8 g .. 8 g + 7, scaled, split hi / lo
+    Frag<bf16_t> qhi[2], qlo[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = 16 * qt + r16;
+        float qv[8];
+        if (qi < Lq) {
+            const float4* src = reinterpret_cast<const float4*>(qc + ((size_t)b * Lq + qi) * E + h * DEC_HD + 8 * g);
+            const float4 x0 = src[0], x1 = src[1];
+            qv[0] = x0.x; qv[1] = x0.y; qv[2] = x0.z; qv[3] = x0.w; qv[4] = x1.x; qv[5] = x1.y; qv[6] = x1.z; qv[7] = x1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = qv[i] * scale;
+            const bf16_t hi = from_f32<bf16_t>(x);
+            qhi[qt].v[i] = hi;
+            qlo[qt].v[i] = from_f32<bf16_t>(x - to_f32(hi));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                       // key row 16 c + lane / 4, piece lane % 4
+        bf16_t* dst = &sv[wid][(16 * c + (lane >> 2)) * VP + 8 * (lane & 3)];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = vraw[c][i];
+    }
+    f32x4 accs[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            accs[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(accs[qt][kt], kf[kt], qhi[qt]);
+            mma16(accs[qt][kt], kf[kt], qlo[qt]);
+        }
+    // soft-max per query (lane column): 32 keys here, the rest in lanes l ^ 16, l ^ 32, l ^ 48
+    Frag<bf16_t> phi[2][4], plo[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, accs[qt][kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(accs[qt][kt][r] - mx); accs[qt][kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const float pv = accs[qt][2 * kk + (sl >> 2)][sl & 3] * inv;
+                const bf16_t hi = from_f32<bf16_t>(pv);
+                phi[qt][kk].v[sl] = hi;
+                plo[qt][kk].v[sl] = from_f32<bf16_t>(pv - to_f32(hi));
+            }
+    }
+    __builtin_amdgcn_wave_barrier();                    // this wave's V tile is in LDS (wave-private region)
+    f32x4 acco[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) acco[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            Frag<bf16_t> vt;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) vt.v[sl] = sv[wid][(32 * kk + 16 * (sl >> 2) + 4 * g + (sl & 3)) * VP + 16 * dt + r16];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                mma16(acco[qt][dt], vt, phi[qt][kk]);
+                mma16(acco[qt][dt], vt, plo[qt][kk]);
+            }
+        }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = 16 * qt + r16;
+        if (qi < Lq) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float o[4] = {acco[qt][dt][0], acco[qt][dt][1], acco[qt][dt][2], acco[qt][dt][3]};
+                store4<bf16_t>(out + ((size_t)b * Lq + qi) * E + h * DEC_HD + 16 * dt + 4 * g, o);
+            }
         }
     }
 }

@@ -250,7 +250,7 @@ struct parseq_plan {
     void* ctab_ln = nullptr;       // T [npos * num_tokens][E] scratch for table build
     float* x = nullptr;            // fp32 [B*N][E]
     void *xn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ao = nullptr, *h = nullptr;
-    void *kmem = nullptr, *vtmem = nullptr;   // cross-attention K [B][H][N][32] and V^T [B][H][32][N] of memory
+    void *kmem = nullptr, *vmem = nullptr;   // cross-attention K and V of memory, head-split [B][H][N][32]
     float* stab = nullptr;         // [npos][npos][num_tokens][H] self-attention score table
     void *sa = nullptr, *tn = nullptr, *ca = nullptr, *hdn = nullptr;   // tn: unused since LayerNorm moved into the GEMM A-loaders
     float *t = nullptr, *qc = nullptr;
@@ -433,7 +433,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     if (step_ok) for (int i = 0; i < 6; ++i) p->wstep[i] = reinterpret_cast<bf16_t*>(a + o_wstep[i]);
     p->wpack = a + o_wpack; p->kvtab = a + o_kvtab; p->qself = (float*)(a + o_qself); p->ctab_ln = a + o_ctab;
     p->x = (float*)(a + o_x); p->xn = a + o_xn; p->q = a + o_q; p->k = a + o_k; p->vt = a + o_vt; p->ao = a + o_ao; p->h = a + o_h;
-    p->kmem = a + o_kmem; p->vtmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
+    p->kmem = a + o_kmem; p->vmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
     int r = pack_weights(p, (hipStream_t)stream);
@@ -554,10 +554,10 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const std::string d = "decoder.layers.0.cross_attn.";
     {
         EpiHeads<T> ek; static_cast<EpiBase&>(ek) = epi_base(M, 2 * E, m->p(d + "in_proj_bias") + E);
-        ek.seg[0] = reinterpret_cast<T*>(p->kmem); ek.seg[1] = reinterpret_cast<T*>(p->vtmem); ek.seg[2] = nullptr;
-        ek.E = E; ek.heads = c.dec_heads; ek.hd = DEC_HD; ek.tokens = N; ek.tr_from = 1;
+        ek.seg[0] = reinterpret_cast<T*>(p->kmem); ek.seg[1] = reinterpret_cast<T*>(p->vmem); ek.seg[2] = nullptr;
+        ek.E = E; ek.heads = c.dec_heads; ek.hd = DEC_HD; ek.tokens = N; ek.tr_from = 2;      // K and V both [b][h][key][32]
         ProfScope ps_(&p->prof, T_KVMEM, s);
-        // the K | V^T boundary (column E) must fall on a tile edge: 64-wide tiles when E is not a multiple of 128 (PARSeq-Ti)
+        // the K | V boundary (column E) must fall on a tile edge: 64-wide tiles when E is not a multiple of 128 (PARSeq-Ti)
         CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(d + "in_proj_weight") + (size_t)E * E, E, M, 2 * E, E, ek, E % 128 != 0)));
     }
     p->last_batch = B;
@@ -601,7 +601,7 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     const Weights<T> W = weights_of<T>(p);
     const std::string d = "decoder.layers.0.";
     T* sa = reinterpret_cast<T*>(p->sa); T* ca = reinterpret_cast<T*>(p->ca); T* hdn = reinterpret_cast<T*>(p->hdn);
-    const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vtmem = reinterpret_cast<const T*>(p->vtmem);
+    const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
     if constexpr (sizeof(T) == 2 && E <= 384) {
@@ -625,7 +625,7 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
             }
             {
                 ProfScope ps_(&p->prof, T_DEC_CA, s);
-                hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vtmem, scale, ca);
+                hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vmem, scale, ca);
                 HIPCHK(hipGetLastError());
             }
             {
@@ -655,8 +655,10 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
                      W.w(d + "cross_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
     {
         ProfScope ps_(&p->prof, T_DEC_CA, s);
-        if (Lq == 1) hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vtmem, scale, ca);
-        else hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, p->qc, kmem, vtmem, H, Lq, scale, ca);
+        if (Lq == 1) hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vmem, scale, ca);
+        else if constexpr (sizeof(T) == 2)
+            hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca, B * H);
+        else hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca);
         HIPCHK(hipGetLastError());
     }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{ca, E}, W.w(d + "cross_attn.out_proj.weight"), E, M, E, E, epi_resid(M, E, m->p(d + "cross_attn.out_proj.bias"), p->t, E)))); }
