@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libparseq_hip.so')
 SOURCES = ['parseq_hip.hip']
-HEADERS = ['common.h', 'gemm.h', 'encoder_attn.h', 'decoder_attn.h', 'rowops.h', os.path.join('..', '..', 'include', 'parseq_hip.h')]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'parseq_hip.h')]
 
 
 def _hipcc() -> str:

@@ -28,7 +28,8 @@ namespace pq {
 
 constexpr int DS_ROWS = 16;     // rows per workgroup
 constexpr int DS_NW = 8;        // waves per workgroup; 16-wide output column tiles are dealt round-robin to waves
-constexpr int DS_RING = 8;      // 1-KB LDS slots per wave (7 fragment loads in flight per wave, 56 KB per CU)
+constexpr int DS_RING = 8;      // 1-KB LDS slots per wave: fragment copies in flight (64 KB per CU)
+constexpr int DS_LA = 2;        // fragments read ahead from LDS into registers (hides the ds_read latency behind MFMAs)
 
 // Fragment-ordered weights.  A [N][K] row-major weight is re-packed once per weight set (frag_pack_kernel) into
 //   Wp[tile = n / 16][kp = k / 64][half][lane = (n & 15) + 16 g][8]  =  W[16 tile + (lane & 15)][64 kp + 16 g + 8 half + 0..7]
@@ -54,11 +55,27 @@ constexpr size_t frag_pack_elems(int N, int K) { return (size_t)((N + 15) / 16) 
 // acc[t] += Wp[tile (w + DS_NW t)] (16 x K)  x  A^T (K x 16 rows).  Result layout: lane (m = lane & 15, g = lane >> 4)
 // holds columns n = 16 tile + 4 g + r (r = 0..3) of row m.  Tiles past `tiles` recompute the last tile (discarded).
 // Unit u = ((kp * TN) + t) * 2 + half is one 1-KB fragment; unit u lives in the wave's ring slot u % DS_RING.
+// ds_prefetch<K, TN> issues the first DS_RING copies of a GEMM's weight stream; it may run as soon as the previous GEMM
+// of the wave has consumed its last fragment (the weights do not depend on activations), i.e. before the epilogue,
+// the block barrier and the LayerNorm that separate two GEMMs.  ds_wave_gemm<..., true> then skips its own prologue.
 template <int K, int TN>
+__device__ __forceinline__ void ds_prefetch(const bf16_t* __restrict__ Wp, int tiles, int wave, unsigned char* wring) {
+    const int lane = threadIdx.x & 63;
+    constexpr int KP = K / 64, U = KP * TN * 2, PRE = U < DS_RING ? U : DS_RING;
+    static_for<0, PRE>([&](auto uc) {
+        constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
+        int tile = wave + DS_NW * t;
+        tile = tile < tiles ? tile : tiles - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (size_t)tile * KP * 1024 + lane * 8 + (kp * 2 + half) * 512),
+                                         (__attribute__((address_space(3))) void*)(wring + (u % DS_RING) * 1024), 16, 0, 0);
+    });
+}
+
+template <int K, int TN, bool PREFETCHED = false>
 __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const bf16_t* __restrict__ Wp, int tiles,
                                              int wave, unsigned char* wring, f32x4 (&acc)[TN]) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
-    constexpr int KP = K / 64, U = KP * TN * 2, DIST = DS_RING - 1, PRE = U < DIST ? U : DIST;
+    constexpr int KP = K / 64, U = KP * TN * 2, PRE = U < DS_RING ? U : DS_RING;
     const bf16_t* wp[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
@@ -72,7 +89,17 @@ __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[t] + (kp * 2 + half) * 512),
                                          (__attribute__((address_space(3))) void*)(wring + (u % DS_RING) * 1024), 16, 0, 0);
     };
-    static_for<0, PRE>(issue);
+    // Software pipeline per wave: unit u + DS_RING is copied global -> LDS while unit u + DS_LA is read LDS -> registers
+    // and unit u is multiplied.  Before step u the copies of units < min(U, u + DS_RING) have been issued; reading unit v
+    // needs all but the (issued - v - 1) newest of them landed.
+    Frag<bf16_t> wbuf[DS_LA + 1];
+    auto fetch = [&](auto vc, auto issued_c) {
+        constexpr int v = decltype(vc)::value, issued = decltype(issued_c)::value;
+        wait_vmcnt<issued - v - 1>();
+        wbuf[v % (DS_LA + 1)].v = *reinterpret_cast<const bf16x8*>(wring + (v % DS_RING) * 1024 + lane * 16);
+    };
+    if constexpr (!PREFETCHED) static_for<0, PRE>(issue);
+    static_for<0, (DS_LA < U ? DS_LA : U)>([&](auto vc) { fetch(vc, std::integral_constant<int, PRE>{}); });
     Frag<bf16_t> a0, a1;
     static_for<0, U>([&](auto uc) {
         constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
@@ -80,16 +107,12 @@ __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const
             a0.v = *reinterpret_cast<const bf16x8*>(ap + 64 * kp);
             a1.v = *reinterpret_cast<const bf16x8*>(ap + 64 * kp + 8);
         }
-        // units issued so far: min(U, u + DIST); all but the (issued - u - 1) newest must have landed
-        constexpr int issued = (u + DIST < U) ? u + DIST : U;
-        wait_vmcnt<issued - u - 1>();
-        Frag<bf16_t> w;
-        w.v = *reinterpret_cast<const bf16x8*>(wring + (u % DS_RING) * 1024 + lane * 16);
-        mma16(acc[t], w, half ? a1 : a0);
-        // refill: unit u + DIST goes to slot (u + DIST) % DS_RING = (u - 1) % DS_RING, whose ds_read was consumed by the
-        // previous unit's MFMA (program order pinned by the scheduling barrier), so the slot is free
+        constexpr int issued = (u + DS_RING < U) ? u + DS_RING : U;
+        if constexpr (u + DS_LA < U) fetch(std::integral_constant<int, u + DS_LA>{}, std::integral_constant<int, issued>{});
+        mma16(acc[t], wbuf[u % (DS_LA + 1)], half ? a1 : a0);
+        // slot u % DS_RING is free once unit u's fragment has been consumed by the MFMA above (order pinned below)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (u + DIST < U) issue(std::integral_constant<int, u + DIST>{});
+        if constexpr (u + DS_RING < U) issue(std::integral_constant<int, u + DS_RING>{});
     });
 }
 
@@ -144,7 +167,8 @@ void dec_step_pre_kernel(const float* __restrict__ stab, const bf16_t* __restric
     // lane l works for head h = l >> 2: it scores keys j = (l & 3) + 4 c, the quad reduces max / sum over DPP, and the same
     // lane then mixes value columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.
     static_assert(DEC_HD == 32 && DEC_MAXL == 32, "lane mapping assumes 32-wide heads and <= 32 keys");
-#pragma unroll 1
+    ds_prefetch<E, TN>(Wo, TILES, wave, wring);
+#pragma unroll
     for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
         const int row = wave * (DS_ROWS / DS_NW) + rr;
         const int b = min(row0 + row, M - 1);
@@ -199,7 +223,8 @@ void dec_step_pre_kernel(const float* __restrict__ stab, const bf16_t* __restric
     // t = pos_queries[pos] + sa @ Wo^T + bo
     {
         f32x4 acc[TN] = {};
-        ds_wave_gemm<E, TN>(abuf, PA, Wo, TILES, wave, wring, acc);
+        ds_wave_gemm<E, TN, true>(abuf, PA, Wo, TILES, wave, wring, acc);
+        ds_prefetch<E, TN>(Wq, TILES, wave, wring);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -219,7 +244,7 @@ void dec_step_pre_kernel(const float* __restrict__ stab, const bf16_t* __restric
     // qc = norm1(t) @ Wq^T + bq
     {
         f32x4 acc[TN] = {};
-        ds_wave_gemm<E, TN>(abuf, PA, Wq, TILES, wave, wring, acc);
+        ds_wave_gemm<E, TN, true>(abuf, PA, Wq, TILES, wave, wring, acc);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -258,6 +283,7 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
     unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
     const int row0 = blockIdx.x * DS_ROWS;
 
+    ds_prefetch<E, TN>(Wco, TILES, wave, wring);
     // stage the 16 rows of ca (bf16) and t (fp32)
     for (int i = threadIdx.x; i < DS_ROWS * (E / 8); i += 64 * DS_NW) {
         const int row = i / (E / 8), c = (i - row * (E / 8)) * 8;
@@ -273,7 +299,8 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
     // t += ca @ Wco^T + bco
     {
         f32x4 acc[TN] = {};
-        ds_wave_gemm<E, TN>(abuf, PA, Wco, TILES, wave, wring, acc);
+        ds_wave_gemm<E, TN, true>(abuf, PA, Wco, TILES, wave, wring, acc);
+        ds_prefetch<E, TN1>(W1, F / 16, wave, wring);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -293,7 +320,8 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
     // h = gelu(norm2(t) @ W1^T + b1)
     {
         f32x4 acc[TN1] = {};
-        ds_wave_gemm<E, TN1>(abuf, PA, W1, F / 16, wave, wring, acc);
+        ds_wave_gemm<E, TN1, true>(abuf, PA, W1, F / 16, wave, wring, acc);
+        ds_prefetch<F, TN>(W2, TILES, wave, wring);
 #pragma unroll
         for (int t = 0; t < TN1; ++t) {
             const int n = (wave + DS_NW * t) * 16 + 4 * g;
@@ -306,7 +334,8 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
     // t += h @ W2^T + b2
     {
         f32x4 acc[TN] = {};
-        ds_wave_gemm<F, TN>(hbuf, PH, W2, TILES, wave, wring, acc);
+        ds_wave_gemm<F, TN, true>(hbuf, PH, W2, TILES, wave, wring, acc);
+        ds_prefetch<E, 1>(Wh, (C + 15) / 16, wave, wring);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -326,7 +355,7 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
     // logits = decoder.norm(t) @ Wh^T + bh   (C <= 128 classes: one column tile per wave); hbuf is free: lg aliases it
     {
         f32x4 acc[1] = {};
-        ds_wave_gemm<E, 1>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc);
+        ds_wave_gemm<E, 1, true>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc);
         const int n = wave * 16 + 4 * g;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
