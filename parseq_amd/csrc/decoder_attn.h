@@ -83,6 +83,69 @@ void dec_self_attn_kernel(const float* __restrict__ stab, const T* __restrict__ 
     out[(size_t)w * E + t] = from_f32<T>(acc);
 }
 
+// Wave-per-row variant of dec_self_attn_kernel for bf16 storage and <= 16 heads: no LDS, no block barriers.
+// Lane l works for head h = l >> 2: it scores keys j = (l & 3) + 4 c (c < 8), the quad reduces max / sum over DPP, and the
+// same lane then mixes value columns d = 8 l .. 8 l + 7 (which belong to head l >> 2), probabilities quad-broadcast.
+template <int E>
+__global__ __launch_bounds__(256)
+void dec_self_attn_wave_kernel(const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, const int* __restrict__ tok,
+                               int ldt, int ntok, int npos, const unsigned char* __restrict__ qmask, int ldq,
+                               const unsigned char* __restrict__ kpm, int ldk, int Lk, int i0, int Lq, bf16_t* __restrict__ out,
+                               int rows) {
+    constexpr int H = E / DEC_HD;
+    static_assert(H <= 16 && DEC_HD == 32 && DEC_MAXL == 32, "lane mapping: <= 16 heads of 32, <= 32 keys");
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= rows) return;
+    const int b = w / Lq, qi = w - b * Lq, pos = i0 + qi;
+    const int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
+    const int h = lane >> 2, q = lane & 3;
+    const bool live = h < H;
+    float sc[8], mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int j = q + 4 * c;
+        const int tj = __shfl(tokv, j, 64);
+        bool ok = live && j < Lk;
+        if (ok && qmask && qmask[(size_t)pos * ldq + j]) ok = false;
+        if (ok && kpm && kpm[(size_t)b * ldk + j]) ok = false;
+        sc[c] = ok ? stab[(((size_t)pos * npos + j) * ntok + tj) * H + h] : -INFINITY;
+        mx = fmaxf(mx, sc[c]);
+    }
+    mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+    mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] = (sc[c] == -INFINITY) ? 0.f : expf(sc[c] - mx); sum += sc[c]; }
+    sum += dpp_mov<0xB1>(sum);
+    sum += dpp_mov<0x4E>(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sc[c] *= inv;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int d0 = live ? 8 * lane : 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float pq4[4] = {dpp_mov<0x00>(sc[c]), dpp_mov<0x55>(sc[c]), dpp_mov<0xAA>(sc[c]), dpp_mov<0xFF>(sc[c])};
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int j = 4 * c + qq;
+            if (j < Lk) {
+                const int tj = __builtin_amdgcn_readlane(tokv, j);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+            }
+        }
+    }
+    if (live) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
+        *reinterpret_cast<bf16x8*>(out + (size_t)w * E + d0) = o;
+    }
+}
+
 // AR-step cross-attention: one workgroup of E threads per image, ONE query.  qc fp32 [B][E] un-scaled projected query;
 // kmem, vmem T [B][H][Nk][32] (head-split, key rows of 32 contiguous d); out T [B][E].  Nk = 128 memory tokens.
 // Pure streaming of the image's K and V (196 KB in bf16): every wave-level load is one contiguous 1 KB — lane

@@ -644,8 +644,12 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     // self-attention from the tables, out-projection, residual onto the raw position queries
     {
         ProfScope ps_(&p->prof, T_DEC_SA, s);
-        hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
-                           c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, sa);
+        if constexpr (sizeof(T) == 2 && E <= 512)
+            hipLaunchKernelGGL((dec_self_attn_wave_kernel<E>), dim3((M + 3) / 4), dim3(256), 0, s, p->stab, reinterpret_cast<const bf16_t*>(p->kvtab),
+                               p->tok, LDT, c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, reinterpret_cast<bf16_t*>(sa), M);
+        else
+            hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
+                               c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, sa);
         HIPCHK(hipGetLastError());
     }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
