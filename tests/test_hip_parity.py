@@ -215,3 +215,33 @@ def test_uint8_input_is_normalised_in_the_patch_embed(name, models, precision):
         mem_u8 = m.model.encode(u8.to(DEV)).cpu()
         mem_f = m.model.encode(ref_in.to(DEV)).cpu()
     assert torch.equal(mem_u8, mem_f)
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_config3_batch_1024_ar_two_refinements(golden, precision):
+    """BASELINE configs[3]: PARSeq-S, 94-char set, max_label_length 25, AR + 2 refinement iterations, batch 1024 on one GPU.
+    128 copies of the 8 golden crops: fp32 mode against the reference's own logits (bar 1e-3), bf16 against its batch-8 run."""
+    g, _ = golden('parseq')
+    m = make_model('parseq', precision)
+    big = _run(m, g['images'].repeat(128, 1, 1, 1).to(DEV), 'ar2')
+    assert big.shape == (1024, 26, 95)
+    want = g['logits.ar2'] if precision == 'fp32' else _run(m, g['images'].to(DEV), 'ar2')
+    d = (big.view(128, 8, 26, 95) - want.unsqueeze(0)).abs().max().item()
+    print(f'[config3 {precision}] batch 1024 AR+2: max|d| {d:.3e}')
+    assert d <= (1e-3 if precision == 'fp32' else 1e-5)
+    if precision == 'fp32':
+        assert torch.equal(big.view(128, 8, 26, 95).argmax(-1), want.argmax(-1).unsqueeze(0).expand(128, -1, -1))
+
+
+@pytest.mark.parametrize('batch', [1, 7, 17, 100, 333])
+def test_ragged_batch_sizes_bf16(name, models, golden, batch):
+    """Row tails of every kernel (16-row step tiles, 64 / 128-row GEMM tiles, 4-images-per-block row ops): image i of a
+    ragged batch must equal the same crop's result in the 8-crop batch."""
+    g, _ = golden(name)
+    m = models['bf16']
+    idx = torch.arange(batch) % 8
+    small = _run(m, g['images'].to(DEV), 'ar1')
+    got = _run(m, g['images'][idx].to(DEV), 'ar1')
+    d = (got - small[idx]).abs().max().item()
+    print(f'[{name} ragged batch {batch}] max|d| {d:.3e}')
+    assert d <= 1e-5
