@@ -131,6 +131,24 @@ int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int bat
 int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
                          const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream);
 
+/* ---- input resize ------------------------------------------------------------------- */
+
+/* One RGB image, HWC uint8: `data` is a DEVICE pointer, row_stride in bytes (>= 3 * width). */
+typedef struct {
+    const uint8_t* data;
+    int32_t height, width;
+    int64_t row_stride;
+} parseq_image_desc;
+
+/* The resize step of the reference's input transform, T.Resize(img_size, BICUBIC) on a PIL image
+ * (strhub/data/module.py:77, read.py:41-43): Pillow's 8-bit ImagingResample, bit-exact (double-precision weights, 22-bit
+ * fixed point, horizontal pass stored as uint8 before the vertical pass).  images: HOST array of `batch` descriptors
+ * (image sizes may differ); out: device uint8 [batch, 3, out_h, out_w] — exactly the PARSEQ_U8 input of parseq_forward /
+ * parseq_encode, which applies ToTensor + Normalize(0.5, 0.5) in its patch-embed loader; workspace: device scratch of
+ * parseq_resize_workspace_bytes(batch) bytes (the descriptors are copied there on `stream`). */
+size_t parseq_resize_workspace_bytes(int batch);
+int parseq_resize_bicubic(const parseq_image_desc* images, int batch, int out_h, int out_w, uint8_t* out, void* workspace, void* stream);
+
 /* ---- post-processing --------------------------------------------------------------- */
 
 /* Numeric half of `preds, probs = tokenizer.decode(logits.softmax(-1))` (strhub/models/base.py:132-137,

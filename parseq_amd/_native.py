@@ -25,6 +25,10 @@ class ParseqConfig(C.Structure):
     _fields_ += [('enc_ln_eps', C.c_float), ('dec_ln_eps', C.c_float)]
 
 
+class ImageDesc(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('height', C.c_int32), ('width', C.c_int32), ('row_stride', C.c_int64)]
+
+
 class NativeError(RuntimeError):
     """A libparseq_hip entry point returned a non-zero status."""
 
@@ -44,6 +48,8 @@ SIGNATURES = {
     'parseq_plan_refresh': (C.c_int, [C.c_void_p, C.c_void_p]),
     'parseq_plan_destroy': (None, [C.c_void_p]),
     'parseq_plan_workspace_bytes': (C.c_size_t, [C.c_void_p]),
+    'parseq_resize_workspace_bytes': (C.c_size_t, [C.c_int]),
+    'parseq_resize_bicubic': (C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_postprocess': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_plan_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'parseq_plan_get_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +19,7 @@
 #include "common.h"
 #include "decoder_attn.h"
 #include "decoder_step.h"
+#include "resize.h"
 #include "encoder_attn.h"
 #include "encoder_panel.h"
 #include "encoder_mlp.h"
@@ -762,6 +765,40 @@ extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int b
     }
     if (p->precision == PARSEQ_BF16) return decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
     return decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// input resize
+// -------------------------------------------------------------------------------------------------------------------
+static int resize_taps(int in_size, int out_size) {
+    const double scale = (double)in_size / (double)out_size;
+    const double support = 2.0 * (scale < 1.0 ? 1.0 : scale);
+    return (int)ceil(support) * 2 + 1;
+}
+
+extern "C" size_t parseq_resize_workspace_bytes(int batch) { return batch > 0 ? (size_t)batch * sizeof(ImageDesc) : 0; }
+
+extern "C" int parseq_resize_bicubic(const parseq_image_desc* images, int batch, int out_h, int out_w, uint8_t* out, void* workspace,
+                                     void* stream) {
+    static_assert(sizeof(parseq_image_desc) == sizeof(ImageDesc), "descriptor layouts must match");
+    if (!images || !out || !workspace) return fail(PARSEQ_E_INVALID, "null images / out / workspace");
+    if (batch <= 0 || out_h <= 0 || out_w <= 0) return fail(PARSEQ_E_INVALID, "bad shape: batch %d, output %dx%d", batch, out_h, out_w);
+    int ksh = 1, ksv = 1;
+    for (int i = 0; i < batch; ++i) {
+        const parseq_image_desc& d = images[i];
+        if (!d.data || d.height <= 0 || d.width <= 0 || d.row_stride < (int64_t)d.width * 3)
+            return fail(PARSEQ_E_INVALID, "image %d: bad descriptor (%dx%d, row stride %lld)", i, d.height, d.width, (long long)d.row_stride);
+        ksh = std::max(ksh, resize_taps(d.width, out_w));
+        ksv = std::max(ksv, resize_taps(d.height, out_h));
+    }
+    const size_t lds = sizeof(int) * ((size_t)out_w * ksh + (size_t)out_h * ksv + 2 * (size_t)(out_w + out_h));
+    if (lds > 150 * 1024) return fail(PARSEQ_E_INVALID, "an image is too large for the on-chip weight tables (%zu bytes of LDS needed)", lds);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(workspace, images, (size_t)batch * sizeof(ImageDesc), hipMemcpyHostToDevice, s));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_bicubic_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(resize_bicubic_kernel, dim3(batch), dim3(256), lds, s, reinterpret_cast<const ImageDesc*>(workspace), out_h, out_w, ksh, ksv, out);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // -------------------------------------------------------------------------------------------------------------------
