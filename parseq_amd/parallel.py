@@ -20,8 +20,12 @@ def shard_bounds(n: int, world: int, rank: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_logits(logits: Tensor, group=None) -> Tensor:
+def all_gather_logits(logits: Tensor, group=None, uniform: bool = False) -> Tensor:
     """[b_local, L, C] on every rank -> [sum b_local, L, C] on every rank (rank order).
+
+    uniform=True: the caller guarantees identical shapes on every rank (fixed per-GPU batch, forced steps or
+    refine_iters >= 1) — ONE all-gather and no host synchronisation, which is what a throughput loop wants.  Otherwise
+    the shapes are exchanged first (a second small collective and a device->host read).
 
     Shards may differ in batch size (ragged last shard) and, with refine_iters == 0 and early exit, in L: each shard can
     stop earlier than the whole batch would.  The single-device result has L = max over shards (the reference's
@@ -34,6 +38,10 @@ def all_gather_logits(logits: Tensor, group=None) -> Tensor:
     if world == 1:
         return logits
     logits = logits.contiguous()
+    if uniform:
+        out = torch.empty((world * logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(out, logits, group=group)
+        return out
     sizes = torch.tensor([logits.shape[0], logits.shape[1]], dtype=torch.int64, device=logits.device)
     all_sizes = [torch.empty_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)

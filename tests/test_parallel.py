@@ -56,7 +56,11 @@ def _worker(rank, world, port, n_images, q):
             ok3 = False
         except RuntimeError:
             ok3 = True
-        q.put((rank, ok1, ok2, ok3))
+        # uniform fast path (what bench.py's multi-GPU loop uses): one collective, rank order preserved
+        mine = torch.full((3, 26, 95), float(rank))
+        both = all_gather_logits(mine, uniform=True)
+        ok4 = both.shape == (3 * world, 26, 95) and all(bool((both[3 * r:3 * r + 3] == r).all()) for r in range(world))
+        q.put((rank, ok1, ok2, ok3 and ok4))
     finally:
         dist.destroy_process_group()
 
