@@ -79,21 +79,27 @@ def main():
     ap.add_argument('--candidates', type=int, default=96)
     ap.add_argument('--keep', type=int, default=8)
     ap.add_argument('--seed', type=int, default=0)
+    ap.add_argument('--only', default=None, help='mint one configuration only')
     args = ap.parse_args()
     from safetensors.torch import save_file
     torch.manual_seed(0)
     os.makedirs(args.out, exist_ok=True)
 
     for name, cfg in CONFIGS.items():
+        if args.only and name != args.only:
+            continue
+        # the 224 x 224 configuration keeps 2 of 64 candidates: its crops are 37x larger and it shares every kernel but
+        # the attention ones with the 32 x 128 models
+        n_cand, n_keep = (64, 2) if cfg.num_patches != 128 else (args.candidates, args.keep)
         sd = synth_state_dict(cfg, seed=args.seed)
         model, tok = build_reference(args.ref, cfg, sd)
         n_params = sum(p.numel() for p in model.parameters())
-        cand = synth_images(args.candidates, cfg, seed=1234)
+        cand = synth_images(n_cand, cfg, seed=1234)
         # rank candidates by the worst decision margin over every mode
-        worst = torch.full((args.candidates,), float('inf'))
+        worst = torch.full((n_cand,), float('inf'))
         for mode in ('nar0', 'ar0_full', 'ar1', 'ar2', 'nar1'):
             worst = torch.minimum(worst, min_margin(run_mode(model, tok, cand, mode)))
-        order = worst.argsort(descending=True)[:args.keep].sort().values
+        order = worst.argsort(descending=True)[:n_keep].sort().values
         images = cand[order].contiguous()
         out = {'images': images}
         meta = {'model': name, 'seed': args.seed, 'num_params': n_params, 'candidate_ids': order.tolist(),

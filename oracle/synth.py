@@ -127,4 +127,6 @@ CONFIGS = {
     'parseq': OracleConfig(),
     # configs/experiment/parseq-tiny.yaml:5-9
     'parseq-tiny': OracleConfig(embed_dim=192, enc_num_heads=3, dec_num_heads=6),
+    # configs/experiment/parseq-patch16-224.yaml:5-7 (row N4): 14 x 14 = 196 visual tokens, 768-wide patches
+    'parseq-patch16-224': OracleConfig(img_size=(224, 224), patch_size=(16, 16)),
 }

@@ -286,6 +286,68 @@ void dec_cross_attn_multi_kernel(const float* __restrict__ qc, const T* __restri
     }
 }
 
+// Cross-attention against any number of memory tokens (row N4: 196 for parseq-patch16-224), 1 <= Lq <= 32 queries per
+// (image, head): dec_cross_attn_multi_kernel with a run-time key count and dynamic LDS.  Correctness path for NK != 128.
+// LDS floats: NK * 33 (K) + 32 * (NK + 1) (V^T) + 32 * 32 (q) + 32 * (NK + 1) (p).
+inline size_t dec_cross_attn_generic_lds(int NK) { return sizeof(float) * ((size_t)NK * (DEC_HD + 1) + 2 * (size_t)DEC_MAXL * (NK + 1) + DEC_MAXL * DEC_HD); }
+template <typename T>
+__global__ __launch_bounds__(128)
+void dec_cross_attn_generic_kernel(const float* __restrict__ qc, const T* __restrict__ kmem, const T* __restrict__ vmem,
+                                   int H, int Lq, int NK, float scale, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cag[];
+    const int KP = DEC_HD + 1, NP = NK + 1;
+    float* sk = reinterpret_cast<float*>(smem_cag);         // [NK][KP]
+    float* sv = sk + (size_t)NK * KP;                        // [32][NP]  (d-major)
+    float* sp = sv + (size_t)DEC_HD * NP;                    // [32][NP]
+    float* sq = sp + (size_t)DEC_MAXL * NP;                  // [32][32]
+    const int t = threadIdx.x;
+    const int bh = blockIdx.x, b = bh / H, h = bh - b * H, E = H * DEC_HD;
+    const T* kg = kmem + (size_t)bh * NK * DEC_HD;
+    const T* vg = vmem + (size_t)bh * NK * DEC_HD;
+    for (int i = t; i < NK * DEC_HD; i += 128) {
+        sk[(i / DEC_HD) * KP + (i % DEC_HD)] = to_f32(kg[i]);
+        sv[(i % DEC_HD) * NP + (i / DEC_HD)] = to_f32(vg[i]);
+    }
+    for (int i = t; i < Lq * DEC_HD; i += 128) {
+        const int qi = i / DEC_HD, d = i - qi * DEC_HD;
+        sq[qi * DEC_HD + d] = qc[((size_t)b * Lq + qi) * E + h * DEC_HD + d] * scale;
+    }
+    __syncthreads();
+    for (int key = t; key < NK; key += 128) {
+        float kr[DEC_HD];
+#pragma unroll
+        for (int d = 0; d < DEC_HD; ++d) kr[d] = sk[key * KP + d];
+        for (int qi = 0; qi < Lq; ++qi) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < DEC_HD; ++d) s = fmaf(sq[qi * DEC_HD + d], kr[d], s);
+            sp[qi * NP + key] = s;
+        }
+    }
+    __syncthreads();
+    {   // soft-max per query: wave w takes queries w, w + 2, ...; lanes stride the keys
+        const int lane = t & 63, wid = t >> 6;
+        for (int qi = wid; qi < Lq; qi += 2) {
+            float mx = -INFINITY;
+            for (int key = lane; key < NK; key += 64) mx = fmaxf(mx, sp[qi * NP + key]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int key = lane; key < NK; key += 64) { const float e = expf(sp[qi * NP + key] - mx); sp[qi * NP + key] = e; sum += e; }
+            const float inv = 1.0f / wave_sum(sum);
+            for (int key = lane; key < NK; key += 64) sp[qi * NP + key] *= inv;
+        }
+    }
+    __syncthreads();
+    {
+        const int d = t & 31, g = t >> 5;
+        for (int qi = g; qi < Lq; qi += 4) {
+            float acc = 0.f;
+            for (int key = 0; key < NK; ++key) acc = fmaf(sp[qi * NP + key], sv[d * NP + key], acc);
+            out[((size_t)b * Lq + qi) * E + h * DEC_HD + d] = from_f32<T>(acc);
+        }
+    }
+}
+
 // Multi-query cross-attention on the matrix cores (bf16 storage): one WAVE per (image, head), Lq <= 32 queries.
 //   S^T[key][query] = K Q^T   (16x16x32 MFMA: 8 key tiles x 2 query tiles, the 32-wide head is exactly one k-step)
 //   soft-max over the 128 keys of a query: 32 values in the lane + the other three lane groups (two shuffles)

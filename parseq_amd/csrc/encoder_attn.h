@@ -196,4 +196,54 @@ void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, c
         og[i] = make_float4(acc[4 * i] * inv, acc[4 * i + 1] * inv, acc[4 * i + 2] * inv, acc[4 * i + 3] * inv);
 }
 
+// Any token count (parseq-patch16-224 has 14 x 14 = 196 visual tokens): thread = query,
+// K and V rows ([N][64], row-major per head) broadcast-read from an fp32 LDS copy, two passes (row max, then exp / sum /
+// weighted V with the scores recomputed instead of stored).  Correctness path for N != 128; the 128-token kernels above
+// are the tuned ones.  q, k, v: T [B][H][N][64]; out: T [B*N][E].  Launch: grid B*H, block ATTG_THREADS >= N.
+constexpr int ATTG_THREADS = 256;
+template <typename T>
+__global__ __launch_bounds__(ATTG_THREADS)
+void attn_generic_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ out,
+                         int heads, int N, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_attg[];
+    float* Ks = reinterpret_cast<float*>(smem_attg);      // [N][64]
+    float* Vs = Ks + (size_t)N * ATT_HD;                   // [N][64]
+    const int tid = threadIdx.x, bh = blockIdx.x, b = bh / heads, h = bh - b * heads, E = heads * ATT_HD;
+    const T* kg = k + (size_t)bh * N * ATT_HD;
+    const T* vg = v + (size_t)bh * N * ATT_HD;
+    for (int i = tid; i < N * ATT_HD; i += ATTG_THREADS) { Ks[i] = to_f32(kg[i]); Vs[i] = to_f32(vg[i]); }
+    __syncthreads();
+    if (tid >= N) return;
+    float qv[ATT_HD];
+    const T* qg = q + ((size_t)bh * N + tid) * ATT_HD;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) qv[d] = to_f32(qg[d]) * scale;
+    float mx = -INFINITY;
+    for (int j = 0; j < N; ++j) {
+        const float* kr = Ks + j * ATT_HD;
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < ATT_HD; ++d) sc = fmaf(qv[d], kr[d], sc);
+        mx = fmaxf(mx, sc);
+    }
+    float acc[ATT_HD], sum = 0.f;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) acc[d] = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const float* kr = Ks + j * ATT_HD;
+        float sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < ATT_HD; ++d) sc = fmaf(qv[d], kr[d], sc);
+        const float pj = expf(sc - mx);
+        sum += pj;
+        const float* vr = Vs + j * ATT_HD;
+#pragma unroll
+        for (int d = 0; d < ATT_HD; ++d) acc[d] = fmaf(pj, vr[d], acc[d]);
+    }
+    const float inv = 1.0f / sum;
+    T* og = out + ((size_t)b * N + tid) * E + h * ATT_HD;
+#pragma unroll
+    for (int d = 0; d < ATT_HD; ++d) og[d] = from_f32<T>(acc[d] * inv);
+}
+
 }  // namespace pq

@@ -147,7 +147,9 @@ extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {
     if (c->patch_h <= 0 || c->patch_w <= 0 || c->img_h % c->patch_h || c->img_w % c->patch_w || c->patch_w % 8)
         return fail(PARSEQ_E_INVALID, "unsupported image/patch geometry %dx%d / %dx%d", c->img_h, c->img_w, c->patch_h, c->patch_w);
     const int tokens = (c->img_h / c->patch_h) * (c->img_w / c->patch_w);
-    if (tokens != ATT_N) return fail(PARSEQ_E_INVALID, "%d visual tokens: this build of the encoder attention kernel handles exactly %d (32x128 crops, 4x8 patches)", tokens, ATT_N);
+    // 128 tokens (32x128 crops, 4x8 patches) run the tuned attention kernels; any other count up to ATTG_THREADS (e.g. the 196
+    // of parseq-patch16-224) the token-count-generic ones
+    if (tokens < 1 || tokens > ATTG_THREADS) return fail(PARSEQ_E_INVALID, "%d visual tokens: supported range is [1, %d]", tokens, ATTG_THREADS);
     if (c->max_label_length < 1 || c->max_label_length + 1 > DEC_MAXL) return fail(PARSEQ_E_INVALID, "max_label_length=%d outside [1, %d]", c->max_label_length, DEC_MAXL - 1);
     if (c->num_tokens < 3) return fail(PARSEQ_E_INVALID, "num_tokens=%d", c->num_tokens);
 
@@ -479,8 +481,16 @@ extern "C" int parseq_plan_get_profile(parseq_plan* p, int index, const char** n
 // encoder
 // -------------------------------------------------------------------------------------------------------------------
 template <typename T>
-static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads, bool v_rowmajor = false) {
+static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads, bool v_rowmajor = false, int tokens = ATT_N) {
     const float scale = 1.0f / sqrtf((float)ATT_HD);
+    if (tokens != ATT_N) {
+        if (!v_rowmajor) return fail(PARSEQ_E_INVALID, "token-count-generic attention expects row-major V");
+        const size_t lds = (size_t)2 * tokens * ATT_HD * sizeof(float);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(bh), dim3(ATTG_THREADS), lds, s, q, k, vt, ao, heads, tokens, scale);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if constexpr (sizeof(T) == 2) {
         if (v_rowmajor) hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
         else hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
@@ -526,10 +536,11 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         } else {
             { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
             EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
-            eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N; eq.tr_from = 2;
+            eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N;
+            eq.tr_from = N == ATT_N ? 2 : 3;      // the 128-token kernels of this path read V^T, the generic one row-major V
             { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
         }
-        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv))); }
+        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv || N != ATT_N, N))); }
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
         if (fused_mlp) {
             if constexpr (kBf16) {
@@ -595,6 +606,27 @@ extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtyp
 // -------------------------------------------------------------------------------------------------------------------
 // decoder
 // -------------------------------------------------------------------------------------------------------------------
+// Cross-attention of Lq queries per image against the plan's cached memory K / V: tuned kernels for 128 memory tokens
+// (streaming AR kernel, MFMA multi-query kernel), the key-count-generic kernel otherwise.
+template <typename T, int E>
+static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca) {
+    const int H = p->m->cfg.dec_heads, NK = p->m->tokens;
+    const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
+    if (NK != 128) {
+        const size_t lds = dec_cross_attn_generic_lds(NK);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((dec_cross_attn_generic_kernel<T>), dim3(B * H), dim3(128), lds, s, p->qc, kmem, vmem, H, Lq, NK, scale, ca);
+    } else if (Lq == 1) {
+        hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vmem, scale, ca);
+    } else if constexpr (sizeof(T) == 2) {
+        hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca, B * H);
+    } else {
+        hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 template <typename T, int E>
 static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
                          float* logits, int Ltot, int argmax_mode) {
@@ -628,8 +660,7 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
             }
             {
                 ProfScope ps_(&p->prof, T_DEC_CA, s);
-                hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vmem, scale, ca);
-                HIPCHK(hipGetLastError());
+                CHK((run_cross_attention<T, E>(p, s, B, 1, scale, ca)));
             }
             {
                 ProfScope ps_(&p->prof, T_DEC_POST, s);
@@ -662,11 +693,7 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
                      W.w(d + "cross_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
     {
         ProfScope ps_(&p->prof, T_DEC_CA, s);
-        if (Lq == 1) hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vmem, scale, ca);
-        else if constexpr (sizeof(T) == 2)
-            hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca, B * H);
-        else hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca);
-        HIPCHK(hipGetLastError());
+        CHK((run_cross_attention<T, E>(p, s, B, Lq, scale, ca)));
     }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{ca, E}, W.w(d + "cross_attn.out_proj.weight"), E, M, E, E, epi_resid(M, E, m->p(d + "cross_attn.out_proj.bias"), p->t, E)))); }
     // MLP (norm2 fused into linear1's A operand)

@@ -18,7 +18,7 @@ def test_hub_entrypoints_and_signatures():
     assert hubconf.dependencies == ['torch']
 
 
-@pytest.mark.parametrize('name', ['parseq', 'parseq-tiny'])
+@pytest.mark.parametrize('name', ['parseq', 'parseq-tiny', 'parseq-patch16-224'])
 def test_state_dict_layout_matches_reference(name):
     from parseq_amd import create_model
     m = create_model(name)

@@ -13,7 +13,7 @@ MODES = {  # name: (decode_ar, refine_iters, max_length) — mirrors oracle/make
 }
 
 
-@pytest.fixture(scope='module', params=['parseq', 'parseq-tiny'])
+@pytest.fixture(scope='module', params=['parseq', 'parseq-tiny', 'parseq-patch16-224'])
 def setup(request, golden):
     name = request.param
     cfg = CONFIGS[name]
@@ -65,7 +65,7 @@ def test_output_length_rules(setup):
     assert meta['modes']['ar0']['shape'][1] < 26          # the synthetic weights do trigger early exit
     assert meta['modes']['ar0_full']['shape'][1] == 26
     assert meta['modes']['ar0_len7']['shape'][1] == 8
-    assert meta['modes']['ar1']['shape'] == [8, 26, 95]
+    assert meta['modes']['ar1']['shape'] == [g['images'].shape[0], 26, 95]
     with torch.inference_mode():
         lo = O.forward(sd, cfg, g['images'][:1], 99, decode_ar=True, refine_iters=0)
     assert lo.shape == (1, 26, 95)
@@ -87,7 +87,7 @@ def test_ar_loop_equals_teacher_forced_single_pass(setup):
         tr = O.Trace()
         lo = O.forward(sd, cfg, images, 25, decode_ar=True, refine_iters=0, trace=tr)
         causal = torch.triu(torch.ones(26, 26, dtype=torch.bool), 1)
-        pos_q = sd['pos_queries'].expand(4, -1, -1)
+        pos_q = sd['pos_queries'].expand(images.shape[0], -1, -1)
         one = O.head(sd, O.decode(sd, cfg, tr.ar_tokens, tr.memory, causal, None, pos_q, causal))
     torch.testing.assert_close(one, lo, rtol=0, atol=2e-5)
 
