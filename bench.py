@@ -28,12 +28,13 @@ PEAK = {'bf16': 2500.0, 'fp32': 157.3}    # dense MFMA TFLOP/s, /opt/skills/guid
 
 
 def gemm_flops(family, B, cfg):
-    """Algorithmic FLOPs of one launch of an encoder GEMM family (M = B * 128 rows)."""
-    E, M = cfg['embed_dim'], B * 128
+    """Algorithmic FLOPs of one launch of an encoder GEMM family (M = B * tokens rows)."""
+    tokens = (cfg['img_size'][0] // cfg['patch_size'][0]) * (cfg['img_size'][1] // cfg['patch_size'][1])
+    E, M = cfg['embed_dim'], B * tokens
     F = E * cfg['enc_mlp_ratio']
     return {'enc.qkv_gemm': 2.0 * M * 3 * E * E, 'enc.proj_gemm': 2.0 * M * E * E, 'enc.fc1_gelu_gemm': 2.0 * M * F * E,
             'enc.fc2_gemm': 2.0 * M * E * F, 'enc.mlp_fused': 4.0 * M * E * F, 'dec.memory_kv_gemm': 2.0 * M * 2 * E * E,
-            'enc.attention': 4.0 * B * cfg['enc_num_heads'] * 128 * 128 * 64}.get(family)
+            'enc.attention': 4.0 * B * cfg['enc_num_heads'] * tokens * tokens * 64}.get(family)
 
 
 def cpu_baseline(name, sd_cpu, refine_iters, seconds=12.0, batch=64):
@@ -98,7 +99,8 @@ def main():
     model = model.eval().to(dev)
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
-    images = (torch.rand(B, 3, 32, 128, generator=g) * 2 - 1).to(dev)      # already resident in HBM when timing starts
+    ih, iw = model.hparams.img_size
+    images = (torch.rand(B, 3, ih, iw, generator=g) * 2 - 1).to(dev)      # already resident in HBM when timing starts
     if args.precision == 'bf16':
         images = images.bfloat16()
     max_length = None if args.natural_exit else 25
@@ -148,12 +150,12 @@ def main():
     value = world * B * args.steps / elapsed
 
     result = {
-        'metric': 'images/sec (32x128 crops) PARSeq-S AR+refine', 'value': round(value, 1), 'unit': 'images/s',
+        'metric': 'images/sec (32x128 crops) PARSeq-S AR+refine' if args.model == 'parseq' else f'images/sec ({ih}x{iw} crops) {args.model} AR+refine', 'value': round(value, 1), 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'sequential_value': round(world * B * args.steps / seq_elapsed, 1), 'sequential_ms_per_step': round(1e3 * seq_elapsed / args.steps, 4),
-        'config': {'workload': f'{args.model} {args.precision}, 32x128 crops, batch={B}/GPU, AR decode '
+        'config': {'workload': f'{args.model} {args.precision}, {ih}x{iw} crops, batch={B}/GPU, AR decode '
                                f'({"natural exit" if args.natural_exit else "26 steps forced"}) + {args.refine_iters} refine iter '
                                f'(BASELINE.json configs[1]); random-init weights (reference init, seed 0); '
                                f'inputs resident in HBM as {"bf16" if args.precision == "bf16" else "fp32"}; '
