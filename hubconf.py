@@ -43,3 +43,11 @@ def parseq_patch16_224(pretrained: bool = False, decode_ar: bool = True, refine_
     forward() raises until row N4 of SURVEY.md section 8f lands.
     """
     return create_model('parseq-patch16-224', pretrained, decode_ar=decode_ar, refine_iters=refine_iters, **kwargs)
+
+
+def vitstr(pretrained: bool = False, **kwargs):
+    """
+    ViTSTR small model (img_size=32x128, patch_size=4x8, d_model=384)
+    @param pretrained: (bool) Use pretrained weights
+    """
+    return create_model('vitstr', pretrained, **kwargs)

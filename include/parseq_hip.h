@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 1
+#define PARSEQ_ABI_VERSION 2
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -46,7 +46,13 @@ typedef struct parseq_config {
     int32_t max_label_length;      /* 25 */
     int32_t bos_id, eos_id, pad_id;/* 95, 0, 96  (strhub/data/utils.py:107-111) */
     float enc_ln_eps, dec_ln_eps;  /* 1e-6 (timm ViT), 1e-5 (nn.LayerNorm default) */
+    int32_t arch;                  /* PARSEQ_ARCH_PARSEQ (0) or PARSEQ_ARCH_VITSTR (1): the ViT encoder
+                                    * with a class token and a per-token head (strhub/models/vitstr/model.py:20-28), no decoder;
+                                    * the dec_* fields are ignored and the parameter keys are timm's (cls_token, pos_embed,
+                                    * patch_embed.proj.*, blocks.N.*, norm.*, head.*) */
 } parseq_config;
+
+enum { PARSEQ_ARCH_PARSEQ = 0, PARSEQ_ARCH_VITSTR = 1 };
 
 enum {
     PARSEQ_F32 = 0,    /* exact mode: f32 storage, v_mfma_f32_16x16x4_f32; parity target |dlogit| <= 1e-3 vs CPU fp32 */
@@ -130,6 +136,12 @@ int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int bat
  * (non-zero = masked, torch semantics).  logits_out: device fp32 [batch, q_len, num_tokens - 2]. */
 int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
                          const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream);
+
+/* ViTSTR.forward (strhub/models/vitstr/system.py:76-82 -> vitstr/model.py:20-28) for a model created with
+ * arch = PARSEQ_ARCH_VITSTR: encoder with class token, head on tokens [1, num_steps], i.e. logits_out fp32
+ * [batch, num_steps, num_tokens - 2] with num_steps = min(max_length, max_label_length) + 1.  images as parseq_forward. */
+int parseq_vitstr_forward(parseq_plan* p, const void* images, int images_dtype, int batch, int num_steps, float* logits_out,
+                          void* stream);
 
 /* ---- input resize ------------------------------------------------------------------- */
 

@@ -92,19 +92,22 @@ def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 # encoder  (timm VisionTransformer.forward_features, class_token=False, global_pool='')
 # ----------------------------------------------------------------------------------------------------------
 
-def encode(sd: dict, cfg: OracleConfig, images: Tensor, rounding: Optional[str] = None) -> Tensor:
-    """images [B,3,H,W] fp32 -> memory [B, N, E].  model.py:83-84, modules.py:163-165."""
+def vit_features(sd: dict, prefix: str, cfg: OracleConfig, images: Tensor, rounding: Optional[str] = None) -> Tensor:
+    """timm VisionTransformer.forward_features with the parameters under `prefix` ('encoder.' for PARSeq, '' for ViTSTR).
+    A class token is prepended (before the position embedding is added) iff `prefix + 'cls_token'` exists."""
     E, H = cfg.embed_dim, cfg.enc_num_heads
     hd = E // H
     B = images.shape[0]
     # PatchEmbed: Conv2d(k = stride = patch) then flatten(2).transpose(1, 2); token t = gy * grid_w + gx
-    x = F.conv2d(_r(images, rounding), _r(sd['encoder.patch_embed.proj.weight'], rounding),
-                 sd['encoder.patch_embed.proj.bias'], stride=tuple(cfg.patch_size))
+    x = F.conv2d(_r(images, rounding), _r(sd[prefix + 'patch_embed.proj.weight'], rounding),
+                 sd[prefix + 'patch_embed.proj.bias'], stride=tuple(cfg.patch_size))
     x = x.flatten(2).transpose(1, 2)
-    x = x + sd['encoder.pos_embed']
+    if prefix + 'cls_token' in sd:
+        x = torch.cat([sd[prefix + 'cls_token'].expand(B, -1, -1), x], dim=1)
+    x = x + sd[prefix + 'pos_embed']
     N = x.shape[1]
     for i in range(cfg.enc_depth):
-        p = f'encoder.blocks.{i}.'
+        p = f'{prefix}blocks.{i}.'
         h = _ln(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], cfg.enc_ln_eps)
         qkv = _linear(h, sd[p + 'attn.qkv.weight'], sd[p + 'attn.qkv.bias'], rounding)
         qkv = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
@@ -124,7 +127,12 @@ def encode(sd: dict, cfg: OracleConfig, images: Tensor, rounding: Optional[str] 
         h = _ln(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], cfg.enc_ln_eps)
         h = F.gelu(_linear(h, sd[p + 'mlp.fc1.weight'], sd[p + 'mlp.fc1.bias'], rounding))
         x = x + _linear(h, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], rounding)
-    return _ln(x, sd['encoder.norm.weight'], sd['encoder.norm.bias'], cfg.enc_ln_eps)
+    return _ln(x, sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias'], cfg.enc_ln_eps)
+
+
+def encode(sd: dict, cfg: OracleConfig, images: Tensor, rounding: Optional[str] = None) -> Tensor:
+    """images [B,3,H,W] fp32 -> memory [B, N, E].  model.py:83-84, modules.py:163-165."""
+    return vit_features(sd, 'encoder.', cfg, images, rounding)
 
 
 # ----------------------------------------------------------------------------------------------------------

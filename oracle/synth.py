@@ -73,21 +73,21 @@ def _key_seed(seed: int, key: str) -> int:
     return int.from_bytes(h[:7], 'little')
 
 
-def synth_state_dict(cfg: OracleConfig, seed: int = 0, eos_bias: float = 2.5, gain: float = 1.0) -> 'OrderedDict[str, torch.Tensor]':
+def synth_state_dict(cfg: OracleConfig, seed: int = 0, eos_bias: float = 2.5, gain: float = 1.0, spec=None) -> 'OrderedDict[str, torch.Tensor]':
     """Per-key seeded weights in a 'trained-like' regime: Linear/Conv weights ~ N(0, gain/sqrt(fan_in)) so that
     activations stay O(1) and attention is far from uniform; biases ~ N(0, 0.1); LayerNorm weight ~ 1 + N(0, 0.1),
     bias ~ N(0, 0.1); embeddings / positional tables ~ N(0, 0.5 or 0.05).  `eos_bias` lifts the [E] logit so that
     end-of-sequence actually occurs at mixed positions (exercises early exit and the refinement padding mask).
     CPU generator => identical bits on every x86 box with the same torch build."""
     sd = OrderedDict()
-    for key, shape in state_dict_spec(cfg).items():
+    for key, shape in (spec if spec is not None else state_dict_spec(cfg)).items():
         g = torch.Generator(device='cpu').manual_seed(_key_seed(seed, key))
         n = torch.randn(shape, generator=g, dtype=torch.float32)
         leaf = key.rsplit('.', 1)[-1]
-        is_norm = any(t in key for t in ('norm1', 'norm2', 'norm_q', 'norm_c', '.norm.', 'encoder.norm', 'decoder.norm'))
+        is_norm = any(t in key for t in ('norm1', 'norm2', 'norm_q', 'norm_c', '.norm.', 'encoder.norm', 'decoder.norm')) or key.startswith('norm.')
         if key == 'pos_queries':
             t = 0.5 * n
-        elif key == 'encoder.pos_embed':
+        elif key in ('encoder.pos_embed', 'pos_embed', 'cls_token'):
             t = 0.3 * n
         elif key == 'text_embed.embedding.weight':
             t = 0.05 * n          # multiplied by sqrt(E) ~ 19.6 in TokenEmbedding

@@ -1,4 +1,4 @@
-"""Minimal in-memory stand-in for the three `timm` symbols the reference PARSeq model imports.
+"""Minimal in-memory stand-in for the three `timm` symbols the reference PARSeq / ViTSTR models import.
 
 TEST INFRASTRUCTURE ONLY.  Used by `oracle/make_golden.py` (in the build container, where
 `/root/reference` exists) so that the reference's *own* `strhub/models/parseq/model.py` and
@@ -106,23 +106,36 @@ class Block(nn.Module):
 
 
 class VisionTransformer(nn.Module):
+    """Two configurations are restated (timm 0.9.16 `vision_transformer.py`):
+      * the PARSeq encoder: num_classes=0, global_pool='', class_token=False (no head, no class token);
+      * ViTSTR (strhub/models/vitstr/system.py:51-60): the constructor defaults class_token=True, global_pool='token',
+        num_classes > 0 — a learned `cls_token[1, 1, E]` is prepended to the patch tokens BEFORE `pos_embed[1, N + 1, E]`
+        is added (`_pos_embed` with `no_embed_class=False`), `norm` is the final LayerNorm (`fc_norm` is only used with
+        average pooling) and `head = Linear(E, num_classes)`.  ViTSTR overrides `forward` and calls `forward_features`
+        and `head` itself, so `forward_head` / pooling is never reached.
+    """
+
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, global_pool='token',
                  embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0, qkv_bias=True, class_token=True,
                  drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0, embed_layer=PatchEmbed, **_unused):
         super().__init__()
-        assert num_classes == 0 and global_pool == '' and not class_token, \
-            'stand-in covers only the configuration the reference PARSeq encoder uses'
-        assert drop_rate == 0 and attn_drop_rate == 0 and drop_path_rate == 0
+        assert (num_classes == 0 and global_pool == '' and not class_token) or (num_classes > 0 and global_pool == 'token' and class_token), \
+            'stand-in covers only the PARSeq-encoder and the ViTSTR configurations'
+        assert drop_rate == 0 and attn_drop_rate == 0 and drop_path_rate == 0 and qkv_bias
         norm_layer = partial(nn.LayerNorm, eps=1e-6)
+        self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
-        self.cls_token = None
-        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches, embed_dim) * 0.02)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim)) if class_token else None
+        self.pos_embed = nn.Parameter(torch.randn(1, self.patch_embed.num_patches + (1 if class_token else 0), embed_dim) * 0.02)
         self.blocks = nn.Sequential(*[
             Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)
         ])
         self.norm = norm_layer(embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        if self.cls_token is not None:
+            nn.init.normal_(self.cls_token, std=1e-6)
         named_apply(self._init_vit, self)
 
     @staticmethod
@@ -137,6 +150,8 @@ class VisionTransformer(nn.Module):
 
     def forward_features(self, x):
         x = self.patch_embed(x)
+        if self.cls_token is not None:
+            x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1)
         x = x + self.pos_embed
         x = self.blocks(x)
         return self.norm(x)

@@ -14,15 +14,16 @@ from typing import Optional
 from . import build as _build
 
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8 = 0, 1, 2
+ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING = 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ParseqConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         'img_h', 'img_w', 'patch_h', 'patch_w', 'embed_dim', 'enc_depth', 'enc_heads', 'enc_mlp_ratio',
         'dec_depth', 'dec_heads', 'dec_mlp_ratio', 'num_tokens', 'max_label_length', 'bos_id', 'eos_id', 'pad_id')]
-    _fields_ += [('enc_ln_eps', C.c_float), ('dec_ln_eps', C.c_float)]
+    _fields_ += [('enc_ln_eps', C.c_float), ('dec_ln_eps', C.c_float), ('arch', C.c_int32)]
 
 
 class ImageDesc(C.Structure):
@@ -56,6 +57,7 @@ SIGNATURES = {
     'parseq_encode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'parseq_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                  C.POINTER(C.c_int), C.c_void_p]),
+    'parseq_vitstr_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'parseq_decode_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_op_layernorm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -51,7 +51,22 @@ EXPERIMENTS = {
 }
 
 
+# configs/model/vitstr.yaml:1-14 over configs/main.yaml:7-17 and the 94-char charset; configs/experiment/vitstr.yaml:5-7
+# overrides the model's 224 x 224 / 16 x 16 defaults with the 32 x 128 crops and 4 x 8 patches every released model uses
+_VITSTR = {
+    '_convert_': 'all', 'img_size': [32, 128], 'max_label_length': 25, 'charset_train': CHARSET_94_FULL,
+    'charset_test': '0123456789abcdefghijklmnopqrstuvwxyz', 'batch_size': 384, 'weight_decay': 0.0, 'warmup_pct': 0.075,
+    'name': 'vitstr', '_target_': 'strhub.models.vitstr.system.ViTSTR', 'patch_size': [4, 8], 'embed_dim': 384, 'num_heads': 6,
+    'lr': 8.9e-4,
+}
+
+
 def get_config(experiment: str, **kwargs) -> dict:
+    if experiment == 'vitstr':
+        config = copy.deepcopy(_VITSTR)
+        config.update(kwargs)
+        config['lr'] = float(config['lr'])
+        return config
     if experiment not in EXPERIMENTS:
         raise FileNotFoundError(experiment)
     config = copy.deepcopy(_BASE)

@@ -106,7 +106,10 @@ struct ParamSpec { std::string key; int64_t numel; size_t offset; bool set; };
 struct parseq_model {
     parseq_config cfg;
     int device = 0;
-    int tokens = 0;           // visual tokens per image
+    int tokens = 0;           // encoder sequence length per image (patch tokens + the class token of ViTSTR)
+    int patch_tokens = 0;     // patch tokens per image
+    bool vitstr = false;      // cfg.arch == PARSEQ_ARCH_VITSTR: class token + per-token head, no decoder
+    std::string enc;          // key prefix of the encoder parameters: "encoder." (PARSeq) or "" (ViTSTR)
     int patch_k = 0;          // 3 * patch_h * patch_w
     int classes = 0;          // num_tokens - 2
     std::vector<ParamSpec> params;
@@ -140,32 +143,41 @@ extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {
     if (!c || !out) return fail(PARSEQ_E_INVALID, "null argument");
     CHK(check_arch());
     const int E = c->embed_dim;
-    if (c->dec_depth != 1) return fail(PARSEQ_E_INVALID, "dec_depth=%d: only the reference's dec_depth == 1 is supported", c->dec_depth);
+    const bool vitstr = c->arch == PARSEQ_ARCH_VITSTR;
+    if (c->arch != PARSEQ_ARCH_PARSEQ && !vitstr) return fail(PARSEQ_E_INVALID, "arch=%d", c->arch);
+    if (!vitstr && c->dec_depth != 1) return fail(PARSEQ_E_INVALID, "dec_depth=%d: only the reference's dec_depth == 1 is supported", c->dec_depth);
     if (E != 192 && E != 384 && E != 768) return fail(PARSEQ_E_INVALID, "embed_dim=%d not in {192, 384, 768}", E);
     if (c->enc_heads <= 0 || E / c->enc_heads != ATT_HD || E % c->enc_heads) return fail(PARSEQ_E_INVALID, "encoder head_dim must be 64 (embed_dim %d / heads %d)", E, c->enc_heads);
-    if (c->dec_heads <= 0 || E / c->dec_heads != 32 || E % c->dec_heads) return fail(PARSEQ_E_INVALID, "decoder head_dim must be 32 (embed_dim %d / heads %d)", E, c->dec_heads);
+    if (!vitstr && (c->dec_heads <= 0 || E / c->dec_heads != 32 || E % c->dec_heads)) return fail(PARSEQ_E_INVALID, "decoder head_dim must be 32 (embed_dim %d / heads %d)", E, c->dec_heads);
     if (c->patch_h <= 0 || c->patch_w <= 0 || c->img_h % c->patch_h || c->img_w % c->patch_w || c->patch_w % 8)
         return fail(PARSEQ_E_INVALID, "unsupported image/patch geometry %dx%d / %dx%d", c->img_h, c->img_w, c->patch_h, c->patch_w);
-    const int tokens = (c->img_h / c->patch_h) * (c->img_w / c->patch_w);
-    // 128 tokens (32x128 crops, 4x8 patches) run the tuned attention kernels; any other count up to ATTG_THREADS (e.g. the 196
-    // of parseq-patch16-224) the token-count-generic ones
-    if (tokens < 1 || tokens > ATTG_THREADS) return fail(PARSEQ_E_INVALID, "%d visual tokens: supported range is [1, %d]", tokens, ATTG_THREADS);
+    const int patch_tokens = (c->img_h / c->patch_h) * (c->img_w / c->patch_w);
+    const int tokens = patch_tokens + (vitstr ? 1 : 0);
+    // 128 tokens (32x128 crops, 4x8 patches) run the tuned attention kernels; any other count up to ATTG_THREADS (the 196 of
+    // parseq-patch16-224, the 129 of ViTSTR) the token-count-generic ones
+    if (tokens < 1 || tokens > ATTG_THREADS) return fail(PARSEQ_E_INVALID, "%d encoder tokens: supported range is [1, %d]", tokens, ATTG_THREADS);
     if (c->max_label_length < 1 || c->max_label_length + 1 > DEC_MAXL) return fail(PARSEQ_E_INVALID, "max_label_length=%d outside [1, %d]", c->max_label_length, DEC_MAXL - 1);
+    if (vitstr && c->max_label_length + 2 > tokens) return fail(PARSEQ_E_INVALID, "max_label_length=%d needs %d tokens, the encoder has %d", c->max_label_length, c->max_label_length + 2, tokens);
     if (c->num_tokens < 3) return fail(PARSEQ_E_INVALID, "num_tokens=%d", c->num_tokens);
 
     auto* m = new parseq_model();
     m->cfg = *c;
     HIPCHK(hipGetDevice(&m->device));
     m->tokens = tokens;
+    m->patch_tokens = patch_tokens;
+    m->vitstr = vitstr;
+    m->enc = vitstr ? "" : "encoder.";
     m->patch_k = 3 * c->patch_h * c->patch_w;
     m->classes = c->num_tokens - 2;
     const int64_t F = (int64_t)E * c->enc_mlp_ratio, Fd = (int64_t)E * c->dec_mlp_ratio;
-    add_param(m, "pos_queries", (int64_t)(c->max_label_length + 1) * E);
-    add_param(m, "encoder.pos_embed", (int64_t)tokens * E);
-    add_param(m, "encoder.patch_embed.proj.weight", (int64_t)E * m->patch_k);
-    add_param(m, "encoder.patch_embed.proj.bias", E);
+    const std::string& pe = m->enc;
+    if (vitstr) add_param(m, "cls_token", E);                 // timm VisionTransformer key order (class token first)
+    else add_param(m, "pos_queries", (int64_t)(c->max_label_length + 1) * E);
+    add_param(m, pe + "pos_embed", (int64_t)tokens * E);
+    add_param(m, pe + "patch_embed.proj.weight", (int64_t)E * m->patch_k);
+    add_param(m, pe + "patch_embed.proj.bias", E);
     for (int i = 0; i < c->enc_depth; ++i) {
-        const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+        const std::string p = pe + "blocks." + std::to_string(i) + ".";
         add_param(m, p + "norm1.weight", E); add_param(m, p + "norm1.bias", E);
         add_param(m, p + "attn.qkv.weight", (int64_t)3 * E * E); add_param(m, p + "attn.qkv.bias", 3 * E);
         add_param(m, p + "attn.proj.weight", (int64_t)E * E); add_param(m, p + "attn.proj.bias", E);
@@ -173,8 +185,8 @@ extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {
         add_param(m, p + "mlp.fc1.weight", F * E); add_param(m, p + "mlp.fc1.bias", F);
         add_param(m, p + "mlp.fc2.weight", E * F); add_param(m, p + "mlp.fc2.bias", E);
     }
-    add_param(m, "encoder.norm.weight", E); add_param(m, "encoder.norm.bias", E);
-    {
+    add_param(m, pe + "norm.weight", E); add_param(m, pe + "norm.bias", E);
+    if (!vitstr) {
         const std::string p = "decoder.layers.0.";
         for (const char* a : {"self_attn.", "cross_attn."}) {
             add_param(m, p + a + "in_proj_weight", (int64_t)3 * E * E); add_param(m, p + a + "in_proj_bias", 3 * E);
@@ -183,10 +195,10 @@ extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {
         add_param(m, p + "linear1.weight", Fd * E); add_param(m, p + "linear1.bias", Fd);
         add_param(m, p + "linear2.weight", E * Fd); add_param(m, p + "linear2.bias", E);
         for (const char* n : {"norm1.", "norm2.", "norm_q.", "norm_c."}) { add_param(m, p + n + "weight", E); add_param(m, p + n + "bias", E); }
+        add_param(m, "decoder.norm.weight", E); add_param(m, "decoder.norm.bias", E);
     }
-    add_param(m, "decoder.norm.weight", E); add_param(m, "decoder.norm.bias", E);
     add_param(m, "head.weight", (int64_t)m->classes * E); add_param(m, "head.bias", m->classes);
-    add_param(m, "text_embed.embedding.weight", (int64_t)c->num_tokens * E);
+    if (!vitstr) add_param(m, "text_embed.embedding.weight", (int64_t)c->num_tokens * E);
     hipError_t e = hipMalloc(&m->master, m->master_elems * sizeof(float));
     if (e != hipSuccess) { delete m; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) failed: %s", m->master_elems * sizeof(float), hipGetErrorString(e)); }
     *out = m;
@@ -237,6 +249,23 @@ __global__ void cloze_mask_kernel(unsigned char* __restrict__ mask, int n, int l
     // model.py:117,157: causal triu(1) with triu(2) cleared -> query i may not see key i + 1 only
     const int i = blockIdx.x, j = threadIdx.x;
     if (i < n && j < ld) mask[i * ld + j] = (j == i + 1) ? 1 : 0;
+}
+
+// ViTSTR sequence assembly: x[b][0] = cls_token + pos_embed[0]; x[b][1 + t] = xp[b][t] (patch rows, pos_embed already added).
+__global__ void insert_cls_kernel(const float* __restrict__ xp, const float* __restrict__ cls, const float* __restrict__ pos0,
+                                  float* __restrict__ x, int B, int Np, int E) {
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t e4 = E / 4, per_img = (size_t)(Np + 1) * e4;
+    if (i4 >= (size_t)B * per_img) return;
+    const size_t b = i4 / per_img, r = i4 - b * per_img, t = r / e4, c4 = r - t * e4;
+    float4 v;
+    if (t == 0) {
+        const float4 a = reinterpret_cast<const float4*>(cls)[c4], q = reinterpret_cast<const float4*>(pos0)[c4];
+        v = make_float4(a.x + q.x, a.y + q.y, a.z + q.z, a.w + q.w);
+    } else {
+        v = reinterpret_cast<const float4*>(xp)[(b * Np + (t - 1)) * e4 + c4];
+    }
+    reinterpret_cast<float4*>(x)[i4] = v;
 }
 
 struct parseq_plan {
@@ -372,7 +401,7 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
         const size_t n = m->master_elems;
         hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<bf16_t*>(p->wpack), n);
         HIPCHK(hipGetLastError());
-        CHK(build_tables<bf16_t>(p, s));
+        if (!m->vitstr) CHK(build_tables<bf16_t>(p, s));
         if (p->wstep[0]) {       // decoder weights in MFMA-fragment order for the fused AR step
             const int E = m->cfg.embed_dim, Fd = E * m->cfg.dec_mlp_ratio;
             const Weights<bf16_t> W = weights_of<bf16_t>(p);
@@ -390,7 +419,7 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
             }
         }
     } else {
-        CHK(build_tables<float>(p, s));
+        if (!m->vitstr) CHK(build_tables<float>(p, s));
     }
     const int npos = m->cfg.max_label_length + 1;
     hipLaunchKernelGGL(cloze_mask_kernel, dim3(npos), dim3(LDT), 0, s, p->cloze, npos, LDT);
@@ -411,7 +440,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->m = m; p->max_batch = max_batch; p->precision = precision;
     size_t off = 0;
     const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : 0);
-    const bool step_ok = precision == PARSEQ_BF16 && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
+    const bool step_ok = !m->vitstr && precision == PARSEQ_BF16 && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
     const size_t step_elems[6] = {frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(Fd, E),
                                   frag_pack_elems(E, Fd), frag_pack_elems(m->classes, E)};
     size_t o_wstep[6];
@@ -515,9 +544,25 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     T* vt = reinterpret_cast<T*>(p->vt); T* ao = reinterpret_cast<T*>(p->ao); T* h = reinterpret_cast<T*>(p->h);
 
     // patch embedding (im2col-free) + bias + pos_embed -> x        timm PatchEmbed; forward_features `x + pos_embed`
-    APatch<T, TI> ap{images, 3, c.img_h, c.img_w, c.patch_h, c.patch_w, c.img_w / c.patch_w, N};
-    { ProfScope ps_(&p->prof, T_PATCH, s); CHK((run_gemm<T>(s, ap, W.w("encoder.patch_embed.proj.weight"), m->patch_k, M, E, m->patch_k,
-                     epi_table(M, E, m->p("encoder.patch_embed.proj.bias"), p->x, E, m->p("encoder.pos_embed"), E, N, 0)))); }
+    const std::string& pe = m->enc;
+    const int Np = m->patch_tokens, Mp = B * Np;
+    APatch<T, TI> ap{images, 3, c.img_h, c.img_w, c.patch_h, c.patch_w, c.img_w / c.patch_w, Np};
+    if (!m->vitstr) {
+        ProfScope ps_(&p->prof, T_PATCH, s);
+        CHK((run_gemm<T>(s, ap, W.w(pe + "patch_embed.proj.weight"), m->patch_k, Mp, E, m->patch_k,
+                         epi_table(Mp, E, m->p(pe + "patch_embed.proj.bias"), p->x, E, m->p(pe + "pos_embed"), E, Np, 0))));
+    } else {
+        // ViTSTR (timm class_token=True): x[b] = [cls_token; patches] + pos_embed[0 .. Np].  The patch rows (with pos_embed[1..])
+        // go to a scratch tile first (the idle MLP hidden buffer), then one pass interleaves the class-token rows
+        float* xp = reinterpret_cast<float*>(p->h);
+        ProfScope ps_(&p->prof, T_PATCH, s);
+        CHK((run_gemm<T>(s, ap, W.w(pe + "patch_embed.proj.weight"), m->patch_k, Mp, E, m->patch_k,
+                         epi_table(Mp, E, m->p(pe + "patch_embed.proj.bias"), xp, E, m->p(pe + "pos_embed") + E, E, Np, 0))));
+        const size_t total4 = (size_t)M * E / 4;
+        hipLaunchKernelGGL(insert_cls_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, xp, m->p("cls_token"), m->p(pe + "pos_embed"),
+                           p->x, B, Np, E);
+        HIPCHK(hipGetLastError());
+    }
     // bf16 mode: LayerNorm + projection fused in the register-resident-A panel kernel (encoder_panel.h) wherever the
     // output width is a multiple of its 128-column tile; otherwise (and in f32 mode) LayerNorm kernel + generic tile GEMM.
     constexpr bool kBf16 = sizeof(T) == 2;
@@ -525,7 +570,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const bool panel_fc1 = kBf16 && (E == 192 || E == 384) && F % PN_BN == 0;
     const bool fused_mlp = kBf16 && E == 384 && c.enc_mlp_ratio == 4;      // encoder_mlp.h: LayerNorm + fc1 + GELU + fc2 + residual in one kernel
     for (int i = 0; i < c.enc_depth; ++i) {
-        const std::string b = "encoder.blocks." + std::to_string(i) + ".";
+        const std::string b = pe + "blocks." + std::to_string(i) + ".";
         if (panel_qkv) {
             if constexpr (kBf16) {
                 PanelHeads ph; ph.seg[0] = q; ph.seg[1] = k; ph.seg[2] = vt; ph.E = E; ph.heads = H; ph.hd = ATT_HD; ph.tokens = N;
@@ -564,7 +609,9 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         { ProfScope ps_(&p->prof, T_FC2, s); CHK((run_gemm<T>(s, ARowMajor<T>{h, F}, W.w(b + "mlp.fc2.weight"), F, M, E, F, epi_resid(M, E, m->p(b + "mlp.fc2.bias"), p->x, E)))); }
     }
     // final norm -> memory (fp32 to the caller, T copy as GEMM operand), then the cross-attention K/V of memory, ONCE
-    { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p("encoder.norm.weight"), m->p("encoder.norm.bias"), xn, memory_out, M, E, c.enc_ln_eps))); }
+    { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(pe + "norm.weight"), m->p(pe + "norm.bias"), xn, memory_out, M, E, c.enc_ln_eps))); }
+    p->last_batch = B;
+    if (m->vitstr) return 0;          // no decoder: the head reads xn (parseq_vitstr_forward)
     const std::string d = "decoder.layers.0.cross_attn.";
     {
         EpiHeads<T> ek; static_cast<EpiBase&>(ek) = epi_base(M, 2 * E, m->p(d + "in_proj_bias") + E);
@@ -759,9 +806,37 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     return 0;
 }
 
+// ViTSTR: strhub/models/vitstr/system.py:76-82 + vitstr/model.py:20-28.
+extern "C" int parseq_vitstr_forward(parseq_plan* p, const void* images, int images_dtype, int batch, int num_steps, float* logits_out,
+                                     void* stream) {
+    CHK(check_call(p, batch, images_dtype));
+    if (!p->m->vitstr) return fail(PARSEQ_E_INVALID, "parseq_vitstr_forward on a PARSeq model (arch 0)");
+    if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
+    const parseq_model* m = p->m;
+    const int npos = m->cfg.max_label_length + 1, N = m->tokens, C = m->classes, E = m->cfg.embed_dim;
+    if (num_steps < 1 || num_steps > npos) return fail(PARSEQ_E_INVALID, "num_steps %d outside [1, %d]", num_steps, npos);
+    hipStream_t s = (hipStream_t)stream;
+    CHK(encode_dispatch(p, images, images_dtype, batch, nullptr, s));
+    // model.forward(images, seqlen = num_steps + 1): head over the first seqlen tokens, then [:, 1:] drops the class-token position.
+    // The head runs over every token row of the batch (one plain GEMM on the normalised features); the wanted rows are sliced out.
+    float* all = reinterpret_cast<float*>(p->h);           // [batch * N][C] scratch (the MLP hidden buffer is idle here)
+    const int M = batch * N;
+    if (p->precision == PARSEQ_BF16) {
+        const Weights<bf16_t> W = weights_of<bf16_t>(p);
+        CHK((run_gemm<bf16_t>(s, ARowMajor<bf16_t>{reinterpret_cast<const bf16_t*>(p->xn), E}, W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), all, C))));
+    } else {
+        const Weights<float> W = weights_of<float>(p);
+        CHK((run_gemm<float>(s, ARowMajor<float>{reinterpret_cast<const float*>(p->xn), E}, W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), all, C))));
+    }
+    HIPCHK(hipMemcpy2DAsync(logits_out, (size_t)num_steps * C * sizeof(float), all + (size_t)C, (size_t)N * C * sizeof(float),
+                            (size_t)num_steps * C * sizeof(float), batch, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int batch, int flags, int refine_iters,
                               int num_steps, float* logits_out, int* out_len, void* stream) {
     CHK(check_call(p, batch, images_dtype));
+    if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "parseq_forward on a ViTSTR model: use parseq_vitstr_forward");
     if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
     const int npos = p->m->cfg.max_label_length + 1;
     if (num_steps < 1 || num_steps > npos) return fail(PARSEQ_E_INVALID, "num_steps %d outside [1, %d]", num_steps, npos);
@@ -775,6 +850,7 @@ extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dty
 extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
                                     const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream) {
     if (!p || !tokens || !logits_out) return fail(PARSEQ_E_INVALID, "null argument");
+    if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
     if (batch <= 0 || batch > p->max_batch || batch != p->last_batch) return fail(PARSEQ_E_INVALID, "batch %d does not match the last parseq_encode (%d)", batch, p->last_batch);
     const int npos = p->m->cfg.max_label_length + 1;
     if (ctx_len < 1 || ctx_len > npos || q_start < 0 || q_len < 1 || q_start + q_len > npos) return fail(PARSEQ_E_INVALID, "bad context / query range");

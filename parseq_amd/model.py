@@ -168,7 +168,118 @@ class _NativeState:
         self.release()
 
 
-class PARSeq(nn.Module):
+class _NativeBacked(nn.Module):
+    """A parameter container whose arithmetic lives in libparseq_hip: keeps a device-side twin of the parameters
+    (`parseq_model`) and cached workspaces (`parseq_plan`) in step with the module's tensors.  Subclasses provide
+    `_cfg` (dict with at least 'img_size'), `precision`, and `_make_native_config()`."""
+
+    @property
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    def _make_native_config(self):  # pragma: no cover
+        raise NotImplementedError
+
+    def set_profiling(self, enable: bool, batch: int) -> None:
+        """Bracket every kernel launch with HIP events (per-family timing for the roofline report; perturbs throughput)."""
+        _native.check(_native.lib().parseq_plan_set_profiling(self._plan(batch), 1 if enable else 0))
+
+    def get_profile(self, batch: int) -> dict:
+        """{family: (total_ms, launches)} accumulated since set_profiling(True)."""
+        lib, plan, out, i = _native.lib(), self._plan(batch), {}, 0
+        while True:
+            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
+            status = lib.parseq_plan_get_profile(plan, i, C.byref(name), C.byref(ms), C.byref(n))
+            if status == 1:
+                break
+            _native.check(status)
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
+
+    def _check_images(self, images: Tensor) -> Tensor:
+        if not isinstance(images, Tensor) or images.dim() != 4:
+            raise RuntimeError('images must be a [N, 3, H, W] tensor')
+        if images.device.type != 'cuda':
+            raise RuntimeError(
+                'parseq_amd runs on MI355X through libparseq_hip only; got a tensor on '
+                f"'{images.device}'. There is no CPU fallback (the CPU oracle under oracle/ is test infrastructure).")
+        if images.device != self._device:
+            raise RuntimeError(f'images on {images.device} but the model is on {self._device}')
+        h, w = self._cfg['img_size']
+        if tuple(images.shape[1:]) != (3, h, w):
+            raise RuntimeError(f'expected images of shape [N, 3, {h}, {w}], got {list(images.shape)}')
+        # uint8 = raw pixels: the reference transform's ToTensor + Normalize(0.5, 0.5) (strhub/data/module.py:78-81) is
+        # applied inside the patch-embed kernel (row N2); float tensors are taken as already normalised
+        if images.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
+            images = images.float()
+        return images.contiguous()
+
+    def _signature(self):
+        params = list(self.parameters())
+        return (str(self._device), tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
+
+    def _sync_native(self):
+        st: _NativeState = self._native_state
+        sig = self._signature()
+        if st.signature == sig:
+            return st
+        lib = _native.lib()
+        if self._device.type != 'cuda':
+            raise RuntimeError('move the model to a ROCm device first: model.to("cuda")')
+        with torch.cuda.device(self._device):
+            fresh = (not st.model) or (st.signature is None) or st.signature[0] != sig[0]
+            if fresh:
+                st.release()
+                cfg = self._make_native_config()
+                handle = C.c_void_p(0)
+                _native.check(lib.parseq_model_create(C.byref(cfg), C.byref(handle)))
+                st.model = handle
+            stream = _native.stream_ptr()
+            sd = self.state_dict()
+            n_native = lib.parseq_model_num_params(st.model)
+            if n_native != len(sd):
+                raise RuntimeError(f'state_dict has {len(sd)} tensors, native model expects {n_native}')
+            keep = []
+            for key, t in sd.items():
+                t32 = t.detach().to(dtype=torch.float32).contiguous()
+                keep.append(t32)
+                _native.check(lib.parseq_model_set_param(st.model, key.encode(), _native.ptr(t32), t32.numel(), stream))
+            for plan, _ in st.plans.values():
+                _native.check(lib.parseq_plan_refresh(plan, stream))
+            torch.cuda.current_stream().synchronize()    # staging copies in `keep` must outlive the async D2D copies
+        st.signature = sig
+        return st
+
+    def _plan(self, batch: int, slot: int = 0):
+        if self.precision not in _PRECISIONS:
+            raise RuntimeError(f"precision must be one of {sorted(_PRECISIONS)}, got '{self.precision}'")
+        st = self._sync_native()
+        code = _PRECISIONS[self.precision]
+        plan, cap = st.plans.get((code, slot), (None, 0))
+        if plan is None or batch > cap:
+            lib = _native.lib()
+            if plan is not None:
+                torch.cuda.current_stream().synchronize()
+                lib.parseq_plan_destroy(plan)
+                del st.plans[(code, slot)]
+            cap = max(8, 1 << (batch - 1).bit_length())
+            handle = C.c_void_p(0)
+            with torch.cuda.device(self._device):
+                _native.check(lib.parseq_plan_create(st.model, cap, code, _native.stream_ptr(), C.byref(handle)))
+            st.plans[(code, slot)] = (handle, cap)
+            plan = handle
+        return plan
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        st = getattr(self, '_native_state', None)
+        if st is not None:
+            st.signature = None if st.signature is None else (st.signature[0], (), ())   # force a re-sync
+        return out
+
+
+class PARSeq(_NativeBacked):
 
     def __init__(self, num_tokens: int, max_label_length: int, img_size: Sequence[int], patch_size: Sequence[int],
                  embed_dim: int, enc_num_heads: int, enc_mlp_ratio: int, enc_depth: int, dec_num_heads: int,
@@ -249,116 +360,22 @@ class PARSeq(nn.Module):
                                                    C.byref(out_len), _native.stream_ptr()))
         return logits if out_len.value == num_steps else logits[:, :out_len.value]
 
-    def set_profiling(self, enable: bool, batch: int) -> None:
-        """Bracket every kernel launch with HIP events (per-family timing for the roofline report; perturbs throughput)."""
-        _native.check(_native.lib().parseq_plan_set_profiling(self._plan(batch), 1 if enable else 0))
-
-    def get_profile(self, batch: int) -> dict:
-        """{family: (total_ms, launches)} accumulated since set_profiling(True)."""
-        lib, plan, out, i = _native.lib(), self._plan(batch), {}, 0
-        while True:
-            name, ms, n = C.c_char_p(), C.c_double(), C.c_int64()
-            status = lib.parseq_plan_get_profile(plan, i, C.byref(name), C.byref(ms), C.byref(n))
-            if status == 1:
-                break
-            _native.check(status)
-            out[name.value.decode()] = (ms.value, n.value)
-            i += 1
-        return out
-
     # ---- native plumbing ---------------------------------------------------------------------------------------
     def _special_ids(self, tokenizer):
         self._tok_ids = getattr(self, '_tok_ids', None) or (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id)
         return self._tok_ids
 
-    def _check_images(self, images: Tensor) -> Tensor:
-        if not isinstance(images, Tensor) or images.dim() != 4:
-            raise RuntimeError('images must be a [N, 3, H, W] tensor')
-        if images.device.type != 'cuda':
-            raise RuntimeError(
-                'parseq_amd runs on MI355X through libparseq_hip only; got a tensor on '
-                f"'{images.device}'. There is no CPU fallback (the CPU oracle under oracle/ is test infrastructure).")
-        if images.device != self._device:
-            raise RuntimeError(f'images on {images.device} but the model is on {self._device}')
-        h, w = self._cfg['img_size']
-        if tuple(images.shape[1:]) != (3, h, w):
-            raise RuntimeError(f'expected images of shape [N, 3, {h}, {w}], got {list(images.shape)}')
-        # uint8 = raw pixels: the reference transform's ToTensor + Normalize(0.5, 0.5) (strhub/data/module.py:78-81) is
-        # applied inside the patch-embed kernel (row N2); float tensors are taken as already normalised
-        if images.dtype not in (torch.float32, torch.bfloat16, torch.uint8):
-            images = images.float()
-        return images.contiguous()
-
-    def _signature(self):
-        params = list(self.parameters())
-        return (str(self._device), tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
-
-    def _sync_native(self):
-        st: _NativeState = self._native_state
-        sig = self._signature()
-        if st.signature == sig:
-            return st
-        lib = _native.lib()
-        if self._device.type != 'cuda':
-            raise RuntimeError('move the model to a ROCm device first: model.to("cuda")')
+    def _make_native_config(self):
         tok_ids = getattr(self, '_tok_ids', None)
         if tok_ids is None:
             n = self._cfg['num_tokens']
             tok_ids = (n - 2, 0, n - 1)      # Tokenizer layout: [E]=0 ... [B]=n-2, [P]=n-1 (strhub/data/utils.py:107-111)
             self._tok_ids = tok_ids
-        with torch.cuda.device(self._device):
-            fresh = (not st.model) or (st.signature is None) or st.signature[0] != sig[0]
-            if fresh:
-                st.release()
-                c = self._cfg
-                cfg = _native.ParseqConfig(
-                    img_h=c['img_size'][0], img_w=c['img_size'][1], patch_h=c['patch_size'][0], patch_w=c['patch_size'][1],
-                    embed_dim=c['embed_dim'], enc_depth=c['enc_depth'], enc_heads=c['enc_num_heads'],
-                    enc_mlp_ratio=c['enc_mlp_ratio'], dec_depth=c['dec_depth'], dec_heads=c['dec_num_heads'],
-                    dec_mlp_ratio=c['dec_mlp_ratio'], num_tokens=c['num_tokens'], max_label_length=self.max_label_length,
-                    bos_id=tok_ids[0], eos_id=tok_ids[1], pad_id=tok_ids[2], enc_ln_eps=1e-6, dec_ln_eps=1e-5)
-                handle = C.c_void_p(0)
-                _native.check(lib.parseq_model_create(C.byref(cfg), C.byref(handle)))
-                st.model = handle
-            stream = _native.stream_ptr()
-            sd = self.state_dict()
-            n_native = lib.parseq_model_num_params(st.model)
-            if n_native != len(sd):
-                raise RuntimeError(f'state_dict has {len(sd)} tensors, native model expects {n_native}')
-            keep = []
-            for key, t in sd.items():
-                t32 = t.detach().to(dtype=torch.float32).contiguous()
-                keep.append(t32)
-                _native.check(lib.parseq_model_set_param(st.model, key.encode(), _native.ptr(t32), t32.numel(), stream))
-            for plan, _ in st.plans.values():
-                _native.check(lib.parseq_plan_refresh(plan, stream))
-            torch.cuda.current_stream().synchronize()    # staging copies in `keep` must outlive the async D2D copies
-        st.signature = sig
-        return st
-
-    def _plan(self, batch: int, slot: int = 0):
-        if self.precision not in _PRECISIONS:
-            raise RuntimeError(f"precision must be one of {sorted(_PRECISIONS)}, got '{self.precision}'")
-        st = self._sync_native()
-        code = _PRECISIONS[self.precision]
-        plan, cap = st.plans.get((code, slot), (None, 0))
-        if plan is None or batch > cap:
-            lib = _native.lib()
-            if plan is not None:
-                torch.cuda.current_stream().synchronize()
-                lib.parseq_plan_destroy(plan)
-                del st.plans[(code, slot)]
-            cap = max(8, 1 << (batch - 1).bit_length())
-            handle = C.c_void_p(0)
-            with torch.cuda.device(self._device):
-                _native.check(lib.parseq_plan_create(st.model, cap, code, _native.stream_ptr(), C.byref(handle)))
-            st.plans[(code, slot)] = (handle, cap)
-            plan = handle
-        return plan
-
-    def _apply(self, fn, *args, **kwargs):
-        out = super()._apply(fn, *args, **kwargs)
-        st = getattr(self, '_native_state', None)
-        if st is not None:
-            st.signature = None if st.signature is None else (st.signature[0], (), ())   # force a re-sync
-        return out
+        c = self._cfg
+        return _native.ParseqConfig(
+            img_h=c['img_size'][0], img_w=c['img_size'][1], patch_h=c['patch_size'][0], patch_w=c['patch_size'][1],
+            embed_dim=c['embed_dim'], enc_depth=c['enc_depth'], enc_heads=c['enc_num_heads'],
+            enc_mlp_ratio=c['enc_mlp_ratio'], dec_depth=c['dec_depth'], dec_heads=c['dec_num_heads'],
+            dec_mlp_ratio=c['dec_mlp_ratio'], num_tokens=c['num_tokens'], max_label_length=self.max_label_length,
+            bos_id=tok_ids[0], eos_id=tok_ids[1], pad_id=tok_ids[2], enc_ln_eps=1e-6, dec_ln_eps=1e-5,
+            arch=_native.ARCH_PARSEQ)

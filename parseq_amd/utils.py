@@ -12,11 +12,12 @@ class InvalidModelError(RuntimeError):
     """Exception raised for any model-related error (creation, loading)"""
 
 
-# strhub/models/utils.py:14-17 (PARSeq entries only; the other model families are out of scope)
+# strhub/models/utils.py:14-20 (PARSeq and ViTSTR entries; ABINet / TRBA / CRNN are out of scope)
 _WEIGHTS_URL = {
     'parseq-tiny': 'https://github.com/baudm/parseq/releases/download/v1.0.0/parseq_tiny-e7a21b54.pt',
     'parseq-patch16-224': 'https://github.com/baudm/parseq/releases/download/v1.0.0/parseq_small_patch16_224-fcf06f5a.pt',
     'parseq': 'https://github.com/baudm/parseq/releases/download/v1.0.0/parseq-bb5792a6.pt',
+    'vitstr': 'https://github.com/baudm/parseq/releases/download/v1.0.0/vitstr-26d0fcf4.pt',     # utils.py:20
 }
 
 
@@ -24,7 +25,10 @@ def _get_model_class(key: str):
     if 'parseq' in key:
         from .system import PARSeq as ModelClass
         return ModelClass
-    raise InvalidModelError(f"Unable to find model class for '{key}' (only the PARSeq family is implemented here)")
+    if 'vitstr' in key:                                   # utils.py:58-59
+        from .vitstr import ViTSTR as ModelClass
+        return ModelClass
+    raise InvalidModelError(f"Unable to find model class for '{key}' (PARSeq and ViTSTR are implemented here)")
 
 
 def get_pretrained_weights(experiment: str):
