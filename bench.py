@@ -30,6 +30,8 @@ PEAK = {'bf16': 2500.0, 'fp32': 157.3}    # dense MFMA TFLOP/s, /opt/skills/guid
 def gemm_flops(family, B, cfg):
     """Algorithmic FLOPs of one launch of an encoder GEMM family (M = B * tokens rows)."""
     tokens = (cfg['img_size'][0] // cfg['patch_size'][0]) * (cfg['img_size'][1] // cfg['patch_size'][1])
+    if 'enc_num_heads' not in cfg:
+        tokens += 1                                           # ViTSTR: class token
     E, M = cfg['embed_dim'], B * tokens
     F = E * cfg['enc_mlp_ratio']
     return {'enc.qkv_gemm': 2.0 * M * 3 * E * E, 'enc.proj_gemm': 2.0 * M * E * E, 'enc.fc1_gelu_gemm': 2.0 * M * F * E,
@@ -184,6 +186,8 @@ def main():
                    'share': round(ms / total, 4)} for k, (ms, n) in prof.items() if n}
         result['kernel_families'] = fam
         cfg = dict(model.hparams)
+        cfg.setdefault('enc_mlp_ratio', 4)                      # ViTSTR: fixed in vitstr/system.py:54-56
+        cfg.setdefault('enc_num_heads', cfg.get('num_heads'))
         dom = max((k for k in fam if gemm_flops(k, B, cfg)), key=lambda k: fam[k]['share'])
         fl = gemm_flops(dom, B, cfg)
         ach = fl / (fam[dom]['avg_us'] * 1e-6) / 1e12

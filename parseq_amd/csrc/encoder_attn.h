@@ -142,6 +142,120 @@ void attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
         }
 }
 
+// attn_mfma_kernel for any token count N <= 32 * NT32 (129 tokens for ViTSTR, 196 for
+// parseq-patch16-224): NT32 waves per workgroup, wave w owns queries 32 w .. 32 w + 31; K and V^T are zero-padded to
+// 32 * NT32 keys in LDS and the padded keys are excluded from the soft-max.  q, k, v: [B][H][N][64] (row-major V).
+template <int NT32>
+__global__ __launch_bounds__(64 * NT32)
+void attn_mfma_n_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                        bf16_t* __restrict__ ao, int heads, int N, float scale) {
+    constexpr int NP = 32 * NT32, NTHR = 64 * NT32;
+    constexpr int VROWB = NP * 2 + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn[];
+    unsigned char* Ks = smem_attn;                          // [NP][ATT_KROWB]
+    unsigned char* Vs = smem_attn + NP * ATT_KROWB;          // [64][VROWB]  (V^T)
+
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t base = (size_t)bh * N * ATT_HD;
+    const int E = heads * ATT_HD;
+
+    for (int c = tid; c < NP * 8; c += NTHR) {              // 16-byte chunk c = 8 consecutive d of token t = c >> 3
+        const int t = c >> 3, d0 = (c & 7) * 8;
+        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = make_uint4(0u, 0u, 0u, 0u);
+        if (t < N) {
+            kv = reinterpret_cast<const uint4*>(k + base)[c];
+            vv = reinterpret_cast<const uint4*>(v + base)[c];
+        }
+        *reinterpret_cast<uint4*>(Ks + t * ATT_KROWB + (c & 7) * 16) = kv;
+        const unsigned int w4[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<unsigned short*>(Vs + (d0 + 2 * i) * VROWB + t * 2) = (unsigned short)(w4[i] & 0xffffu);
+            *reinterpret_cast<unsigned short*>(Vs + (d0 + 2 * i + 1) * VROWB + t * 2) = (unsigned short)(w4[i] >> 16);
+        }
+    }
+
+    const int qi = lane & 31, hi = lane >> 5;
+    const int q0 = wid * 32;
+    const int qrow_i = min(q0 + qi, N - 1);
+    bf16x8 qf[4];
+    {
+        const bf16_t* qrow = q + base + (size_t)qrow_i * ATT_HD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+    }
+    __syncthreads();
+
+    // S^T tiles: st[t][r] = score(key = 32 t + (r & 3) + 8 (r >> 2) + 4 hi, query = qi)
+    f32x16 st[NT32];
+#pragma unroll
+    for (int t = 0; t < NT32; ++t) {
+        st[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned char* kb = Ks + (t * 32 + qi) * ATT_KROWB + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + ks * 32);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[t], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= N) st[t][r] = -INFINITY;
+            mx = fmaxf(mx, st[t][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c = scale * 1.44269504088896340736f;
+    const float mc = mx * c;
+    float sum = 0.f;
+    bf16x8 pf[NT32][2];
+#pragma unroll
+    for (int t = 0; t < NT32; ++t)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = exp2f(st[t][m2 * 8 + j] * c - mc);      // exp2(-inf) = 0 for the padded keys
+                sum += p;
+                pf[t][m2][j] = static_cast<bf16_t>(p);
+            }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        ot[nt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned char* vb = Vs + (nt * 32 + qi) * VROWB + hi * 8;
+#pragma unroll
+        for (int t = 0; t < NT32; ++t)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const unsigned char* p0 = vb + (t * 32 + m2 * 16) * 2;
+                union { bf16x8 v; uint2 u[2]; } vf;
+                vf.u[0] = *reinterpret_cast<const uint2*>(p0);
+                vf.u[1] = *reinterpret_cast<const uint2*>(p0 + 16);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf[t][m2], ot[nt], 0, 0, 0);
+            }
+    }
+    if (q0 + qi < N) {
+        bf16_t* orow = ao + ((size_t)b * N + q0 + qi) * E + h * ATT_HD + 4 * hi;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float o[4] = {ot[nt][rg * 4 + 0] * inv, ot[nt][rg * 4 + 1] * inv, ot[nt][rg * 4 + 2] * inv, ot[nt][rg * 4 + 3] * inv};
+                store4<bf16_t>(orow + nt * 32 + rg * 8, o);
+            }
+    }
+}
+template <int NT32> constexpr size_t attn_mfma_n_lds() { return (size_t)32 * NT32 * ATT_KROWB + (size_t)ATT_HD * (32 * NT32 * 2 + 8); }
+
 // Exact-f32 attention: 128 threads, thread = query; K [128][64] and V^T [64][128] broadcast-read from LDS.
 __global__ __launch_bounds__(128)
 void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vt,

@@ -514,6 +514,20 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
     const float scale = 1.0f / sqrtf((float)ATT_HD);
     if (tokens != ATT_N) {
         if (!v_rowmajor) return fail(PARSEQ_E_INVALID, "token-count-generic attention expects row-major V");
+        if constexpr (sizeof(T) == 2) {
+            // bf16: the MFMA kernel padded to a multiple of 32 keys, one wave per 32 queries (ViTSTR: 5 waves, patch16-224: 7)
+            const int nt32 = (tokens + 31) / 32;
+#define PQ_ATTN_N(NT)                                                                                                                   \
+            if (nt32 == NT) {                                                                                                           \
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_n_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)attn_mfma_n_lds<NT>()));                                                                \
+                hipLaunchKernelGGL((attn_mfma_n_kernel<NT>), dim3(bh), dim3(64 * NT), attn_mfma_n_lds<NT>(), s, q, k, vt, ao, heads, tokens, scale); \
+                HIPCHK(hipGetLastError());                                                                                              \
+                return 0;                                                                                                               \
+            }
+            PQ_ATTN_N(1) PQ_ATTN_N(2) PQ_ATTN_N(3) PQ_ATTN_N(4) PQ_ATTN_N(5) PQ_ATTN_N(6) PQ_ATTN_N(7) PQ_ATTN_N(8)
+#undef PQ_ATTN_N
+        }
         const size_t lds = (size_t)2 * tokens * ATT_HD * sizeof(float);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(bh), dim3(ATTG_THREADS), lds, s, q, k, vt, ao, heads, tokens, scale);
