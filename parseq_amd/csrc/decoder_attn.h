@@ -189,9 +189,11 @@ void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict_
         union Piece { u32x4 u; T e[EPC]; };
         Piece kr[NL], vr[NL];
 #pragma unroll
-        for (int c = 0; c < NL; ++c) kr[c].u = *reinterpret_cast<const u32x4*>(kb + (size_t)c * KPL * DEC_HD);
+        // streamed once per step and 100 MB per launch: non-temporal, so that the 3.6 MB of decoder weights the step
+        // kernels re-read every step are not evicted from L2 in between
+        for (int c = 0; c < NL; ++c) kr[c].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)c * KPL * DEC_HD));
 #pragma unroll
-        for (int c = 0; c < NL; ++c) vr[c].u = *reinterpret_cast<const u32x4*>(vb + (size_t)c * KPL * DEC_HD);
+        for (int c = 0; c < NL; ++c) vr[c].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)c * KPL * DEC_HD));
         float qv[EPC];
 #pragma unroll
         for (int i = 0; i < EPC; ++i) qv[i] = qc[(size_t)b * E + h * DEC_HD + dl * EPC + i] * scale;
