@@ -216,6 +216,8 @@ class _NativeBacked(nn.Module):
         return images.contiguous()
 
     def _signature(self):
+        # device, storage addresses and autograd versions of every parameter: load_state_dict, .to(), optimiser steps and
+        # in-place ops (also under no_grad) change it; writes through `param.data` do not bump the version and are NOT seen
         params = list(self.parameters())
         return (str(self._device), tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
 

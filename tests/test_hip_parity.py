@@ -245,3 +245,52 @@ def test_ragged_batch_sizes_bf16(name, models, golden, batch):
     d = (got - small[idx]).abs().max().item()
     print(f'[{name} ragged batch {batch}] max|d| {d:.3e}')
     assert d <= 1e-5
+
+
+def test_weight_update_refreshes_native_state(golden):
+    """load_state_dict / in-place edits after the first forward must reach the device twin (packed weights, decoder tables,
+    fragment-packed step weights): change the weights, compare with the oracle on the NEW weights."""
+    g, _ = golden('parseq')
+    for precision, tol in (('fp32', 1e-3), ('bf16', 6e-2)):
+        m = make_model('parseq', precision)
+        images = g['images'].to(DEV)
+        before = _run(m, images, 'ar1')
+        sd2 = synth_state_dict(CONFIGS['parseq'], 5)                     # a different weight set
+        m.model.load_state_dict(sd2)
+        after = _run(m, images, 'ar1')
+        with torch.inference_mode():
+            want = O.forward(sd2, CONFIGS['parseq'], g['images'], None, decode_ar=True, refine_iters=1)
+        assert (before - after).abs().max() > 0.1                        # the update is visible ...
+        d, msg = report(f'after load_state_dict {precision}', after, want)
+        assert d <= tol, msg                                             # ... and complete
+        with torch.no_grad():
+            m.model.head.bias.add_(1.0)                                  # in-place edit of one tensor
+        shifted = _run(m, images, 'nar0')
+        with torch.no_grad():
+            m.model.head.bias.sub_(1.0)          # (edits through `.data` do not bump the tensor version and are not tracked)
+        base = _run(m, images, 'nar0')
+        assert torch.allclose(shifted - base, torch.ones_like(base), atol=2e-2 if precision == 'bf16' else 1e-5)
+
+
+def test_slots_and_streams_give_identical_results(models, golden, name):
+    """`slot=k` workspaces on separate streams (bench.py --streams 2) must not interfere: two batches in flight reproduce the
+    one-at-a-time results bit for bit."""
+    g, _ = golden(name)
+    m = models['bf16']
+    m.model.decode_ar, m.model.refine_iters = True, 1
+    a = g['images'].repeat(8, 1, 1, 1).to(DEV)
+    b = a.flip(0).contiguous()
+    with torch.inference_mode():
+        ref_a, ref_b = m(a, 25).clone(), m(b, 25).clone()
+        torch.cuda.synchronize()          # the reference runs used slot 0 on the default stream: drain before reusing it elsewhere
+        s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for it in range(3):
+            with torch.cuda.stream(s0):
+                oa = m(a, 25, slot=0)
+            with torch.cuda.stream(s1):
+                ob = m(b, 25, slot=1)
+            outs.append((oa, ob))
+        torch.cuda.synchronize()
+    for oa, ob in outs:
+        assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
