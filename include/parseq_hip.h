@@ -175,6 +175,13 @@ int parseq_resize_bicubic(const parseq_image_desc* images, int batch, int out_h,
 int parseq_postprocess(const float* logits, int batch, int L, int C, int eos_id, int32_t* ids_out, int32_t* lengths_out,
                        float* probs_out, float* confidence_out, void* stream);
 
+/* Validation loss of strhub/models/base.py:194-201 (CrossEntropySystem.forward_logits_loss):
+ * F.cross_entropy(logits.flatten(end_dim=1), targets.flatten(), ignore_index) with mean reduction, and the number of
+ * non-ignored targets.  logits: device fp32 [rows, C]; targets: device int32 [rows] (class index or ignore_index);
+ * loss_out / numel_out: device scalars; workspace: device, `rows` floats.  Deterministic (fixed summation order). */
+int parseq_cross_entropy(const float* logits, const int32_t* targets, int rows, int C, int ignore_index, float* loss_out,
+                         int32_t* numel_out, float* workspace, void* stream);
+
 /* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
 
 /* y = LayerNorm(x) over the last dim `E` (192 | 384 | 768); x fp32 [rows, E]; y in out_dtype. */

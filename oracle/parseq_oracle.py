@@ -322,3 +322,10 @@ def normalize_u8(images_u8: Tensor) -> Tensor:
     """Row N2: the numeric tail of the reference's input transform (strhub/data/module.py:78-81) on uint8 CHW pixels —
     `T.ToTensor()` (`img.to(float32).div(255)`) followed by `T.Normalize(0.5, 0.5)` (`sub_(mean).div_(std)`)."""
     return images_u8.to(torch.float32).div(255).sub_(0.5).div_(0.5)
+
+
+def validation_loss(logits: Tensor, targets: Tensor, pad_id: int):
+    """strhub/models/base.py:199-200: (F.cross_entropy(logits.flatten(end_dim=1), targets.flatten(), ignore_index=pad_id),
+    (targets != pad_id).sum()) — `targets` is tokenizer.encode(labels)[:, 1:]."""
+    loss = F.cross_entropy(logits.float().flatten(end_dim=1), targets.flatten(), ignore_index=pad_id)
+    return loss, (targets != pad_id).sum()

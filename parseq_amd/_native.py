@@ -51,6 +51,7 @@ SIGNATURES = {
     'parseq_plan_workspace_bytes': (C.c_size_t, [C.c_void_p]),
     'parseq_resize_workspace_bytes': (C.c_size_t, [C.c_int]),
     'parseq_resize_bicubic': (C.c_int, [C.POINTER(ImageDesc), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'parseq_cross_entropy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_postprocess': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_plan_set_profiling': (C.c_int, [C.c_void_p, C.c_int]),
     'parseq_plan_get_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

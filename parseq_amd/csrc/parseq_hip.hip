@@ -932,6 +932,18 @@ extern "C" int parseq_postprocess(const float* logits, int batch, int L, int C, 
     return 0;
 }
 
+extern "C" int parseq_cross_entropy(const float* logits, const int32_t* targets, int rows, int C, int ignore_index, float* loss_out,
+                                    int32_t* numel_out, float* workspace, void* stream) {
+    if (!logits || !targets || !loss_out || !numel_out || !workspace) return fail(PARSEQ_E_INVALID, "null argument");
+    if (rows <= 0 || C <= 0) return fail(PARSEQ_E_INVALID, "bad shape: rows %d, C %d", rows, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ce_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, logits, targets, rows, C, ignore_index, workspace);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, workspace, targets, rows, ignore_index, loss_out, numel_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // -------------------------------------------------------------------------------------------------------------------
 // single operators
 // -------------------------------------------------------------------------------------------------------------------

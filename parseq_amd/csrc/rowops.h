@@ -200,4 +200,42 @@ void postprocess_kernel(const float* __restrict__ logits, int B, int L, int C, i
     }
 }
 
+// Validation loss (strhub/models/base.py:194-201, CrossEntropySystem.forward_logits_loss):
+//   F.cross_entropy(logits.flatten(end_dim=1), targets.flatten(), ignore_index=pad_id)  — mean over the non-ignored rows.
+// Pass 1: one wave per row, row_loss[r] = logsumexp(logits[r]) - logits[r][target[r]] (0 for ignored rows).
+// Pass 2: one workgroup sums the rows in a fixed order (deterministic) and writes the mean and the count.
+__global__ __launch_bounds__(256)
+void ce_rows_kernel(const float* __restrict__ logits, const int* __restrict__ targets, int rows, int C, int ignore_index,
+                    float* __restrict__ row_loss) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int tgt = targets[r];
+    if (tgt == ignore_index) { if (lane == 0) row_loss[r] = 0.f; return; }
+    const float* row = logits + (size_t)r * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(row[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) row_loss[r] = (mx + logf(sum)) - row[tgt];
+}
+
+__global__ __launch_bounds__(256)
+void ce_reduce_kernel(const float* __restrict__ row_loss, const int* __restrict__ targets, int rows, int ignore_index,
+                      float* __restrict__ loss_out, int* __restrict__ numel_out) {
+    __shared__ float ssum[256];
+    __shared__ int scnt[256];
+    float s = 0.f; int n = 0;
+    for (int r = threadIdx.x; r < rows; r += 256) { s += row_loss[r]; n += targets[r] != ignore_index; }
+    ssum[threadIdx.x] = s; scnt[threadIdx.x] = n;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { ssum[threadIdx.x] += ssum[threadIdx.x + o]; scnt[threadIdx.x] += scnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *loss_out = ssum[0] / (float)scnt[0]; *numel_out = scnt[0]; }   // 0 / 0 = NaN, as torch
+}
+
 }  // namespace pq

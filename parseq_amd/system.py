@@ -57,6 +57,48 @@ def edit_distance(a: str, b: str) -> int:
     return prev[-1]
 
 
+def forward_logits_loss(system, images: Tensor, labels):
+    """CrossEntropySystem.forward_logits_loss (strhub/models/base.py:194-201): logits for max_len = longest label, the mean
+    cross-entropy over non-<pad> targets and their count, the loss computed on the device (`parseq_cross_entropy`)."""
+    from . import _native
+    targets = system.tokenizer.encode(labels, images.device)[:, 1:]           # discard <bos>
+    max_len = targets.shape[1] - 1                                             # exclude <eos> from the count
+    logits = system.forward(images, max_len)
+    if logits.shape[1] != targets.shape[1]:
+        raise RuntimeError(f'labels longer than max_label_length: targets {targets.shape[1]} positions, logits {logits.shape[1]}')
+    flat = logits.float().contiguous().view(-1, logits.shape[-1])
+    tgt = targets.to(torch.int32).contiguous().view(-1)
+    loss = torch.empty((), dtype=torch.float32, device=images.device)
+    numel = torch.empty((), dtype=torch.int32, device=images.device)
+    ws = torch.empty(flat.shape[0], dtype=torch.float32, device=images.device)
+    _native.check(_native.lib().parseq_cross_entropy(_native.ptr(flat), _native.ptr(tgt), flat.shape[0], flat.shape[1], system.pad_id,
+                                                     _native.ptr(loss), _native.ptr(numel), _native.ptr(ws), _native.stream_ptr()))
+    return logits, loss, numel
+
+
+def eval_step(system, batch, validation: bool):
+    """BaseSystem._eval_step (strhub/models/base.py:112-143) for any system with `.forward`, `.tokenizer`, `.charset_adapter`."""
+    images, labels = batch
+    with torch.inference_mode():
+        if validation:
+            logits, loss, loss_numel = forward_logits_loss(system, images, labels)
+        else:
+            # at test time no max_length is given (base.py:123-130): the test charset may shorten the labels
+            logits, loss, loss_numel = system.forward(images), None, None
+        # base.py:132-137 on the device: soft-max, greedy pick, first-EOS cut and prob.prod() in one kernel (row N1)
+        preds, confs = system.tokenizer.read(logits)
+    correct = total = label_length = 0
+    ned = confidence = 0.0
+    for pred, conf, gt in zip(preds, confs.tolist(), labels):
+        confidence += conf
+        pred = system.charset_adapter(pred)
+        ned += edit_distance(pred, gt) / max(len(pred), len(gt), 1)
+        correct += int(pred == gt)
+        total += 1
+        label_length += len(pred)
+    return dict(output=BatchResult(total, correct, ned, confidence, label_length, loss, loss_numel))
+
+
 class PARSeq(nn.Module):
 
     def __init__(self, charset_train: str, charset_test: str, max_label_length: int, batch_size: int, lr: float,
@@ -100,23 +142,13 @@ class PARSeq(nn.Module):
 
     # ---- evaluation glue used by the reference's test.py:121-126 ------------------------------------------------
     def _eval_step(self, batch, validation: bool):
-        images, labels = batch
-        if validation:
-            raise NotImplementedError('validation loss (training path) is out of scope; use test_step')
-        with torch.inference_mode():
-            logits = self.forward(images)
-            # base.py:132-137 on the device: soft-max, greedy pick, first-EOS cut and prob.prod() in one kernel (row N1)
-            preds, confs = self.tokenizer.read(logits)
-        correct = total = label_length = 0
-        ned = confidence = 0.0
-        for pred, conf, gt in zip(preds, confs.tolist(), labels):
-            confidence += conf
-            pred = self.charset_adapter(pred)
-            ned += edit_distance(pred, gt) / max(len(pred), len(gt), 1)
-            correct += int(pred == gt)
-            total += 1
-            label_length += len(pred)
-        return dict(output=BatchResult(total, correct, ned, confidence, label_length, None, None))
+        return eval_step(self, batch, validation)
+
+    def forward_logits_loss(self, images: Tensor, labels):
+        return forward_logits_loss(self, images, labels)
+
+    def validation_step(self, batch, batch_idx):
+        return self._eval_step(batch, True)
 
     def test_step(self, batch, batch_idx):
         return self._eval_step(batch, False)

@@ -17,7 +17,7 @@ from torch import Tensor
 
 from . import _native
 from .model import _Block, _NativeBacked, _NativeState, _PatchEmbed, init_weights
-from .system import AttributeDict, BatchResult, edit_distance  # noqa: F401
+from .system import AttributeDict, eval_step, forward_logits_loss
 from .tokenizer import CharsetAdapter, Tokenizer
 
 
@@ -135,21 +135,13 @@ class ViTSTR(nn.Module):
         return self.model.forward_sliced(images, max_length + 1, slot)
 
     def _eval_step(self, batch, validation: bool):
-        images, labels = batch
-        if validation:
-            raise NotImplementedError('validation loss (training path) is out of scope; use test_step')
-        with torch.inference_mode():
-            preds, confs = self.tokenizer.read(self.forward(images))
-        correct = total = label_length = 0
-        ned = confidence = 0.0
-        for pred, conf, gt in zip(preds, confs.tolist(), labels):
-            confidence += conf
-            pred = self.charset_adapter(pred)
-            ned += edit_distance(pred, gt) / max(len(pred), len(gt), 1)
-            correct += int(pred == gt)
-            total += 1
-            label_length += len(pred)
-        return dict(output=BatchResult(total, correct, ned, confidence, label_length, None, None))
+        return eval_step(self, batch, validation)
+
+    def forward_logits_loss(self, images: Tensor, labels):
+        return forward_logits_loss(self, images, labels)
+
+    def validation_step(self, batch, batch_idx):
+        return self._eval_step(batch, True)
 
     def test_step(self, batch, batch_idx):
         return self._eval_step(batch, False)

@@ -294,3 +294,36 @@ def test_slots_and_streams_give_identical_results(models, golden, name):
         torch.cuda.synchronize()
     for oa, ob in outs:
         assert torch.equal(oa, ref_a) and torch.equal(ob, ref_b)
+
+
+def test_validation_step_loss(golden):
+    """base.py:112-143 with validation=True: forward_logits_loss (base.py:194-201) = logits for max_len = longest label, mean
+    cross-entropy over non-<pad> targets (device kernel), loss_numel; checked against the oracle's logits + F.cross_entropy."""
+    g, meta = golden('parseq')
+    m = make_model('parseq', 'fp32')
+    labels = ['hello', 'MI355X', 'a', 'parseq-amd', 'x' * 25, '0123', 'Zz', '!?']
+    images = g['images'].to(DEV)
+    logits, loss, numel = m.forward_logits_loss(images, labels)
+    torch.cuda.synchronize()
+    targets = m.tokenizer.encode(labels)[:, 1:]
+    assert logits.shape == (8, targets.shape[1], 95) and int(numel) == sum(len(s) + 1 for s in labels)
+    with torch.inference_mode():
+        want_logits = O.forward(synth_state_dict(CONFIGS['parseq'], 0), CONFIGS['parseq'], g['images'], targets.shape[1] - 1,
+                                decode_ar=True, refine_iters=1)
+    want_loss, want_numel = O.validation_loss(want_logits, targets, m.pad_id)
+    assert (logits.cpu() - want_logits).abs().max() <= 1e-3
+    assert abs(float(loss) - float(want_loss)) <= 1e-4 * max(1.0, float(want_loss)) and int(want_numel) == int(numel)
+    # the kernel alone, bit-level semantics: ignored rows, every row ignored -> NaN like torch
+    lg = torch.randn(40, 95) * 3
+    tg = torch.randint(0, 95, (40,))
+    tg[::3] = 96
+    from parseq_amd import _native
+    out_l, out_n = torch.empty((), device=DEV), torch.empty((), dtype=torch.int32, device=DEV)
+    ws = torch.empty(40, device=DEV)
+    lgd, tgd = lg.to(DEV), tg.to(torch.int32).to(DEV)
+    _native.check(_native.lib().parseq_cross_entropy(_native.ptr(lgd), _native.ptr(tgd), 40, 95, 96, _native.ptr(out_l), _native.ptr(out_n),
+                                                     _native.ptr(ws), _native.stream_ptr()))
+    ref = torch.nn.functional.cross_entropy(lg, tg, ignore_index=96)
+    assert abs(float(out_l) - float(ref)) <= 2e-6 * float(ref) + 1e-6 and int(out_n) == int((tg != 96).sum())
+    res = m.validation_step((images, labels), 0)['output']
+    assert res.num_samples == 8 and abs(float(res.loss) - float(want_loss)) <= 1e-4 * max(1.0, float(want_loss)) and int(res.loss_numel) == int(numel)
