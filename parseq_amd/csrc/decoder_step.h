@@ -58,30 +58,34 @@ constexpr size_t frag_pack_elems(int N, int K) { return (size_t)((N + 15) / 16) 
 // ds_prefetch<K, TN> issues the first DS_RING copies of a GEMM's weight stream; it may run as soon as the previous GEMM
 // of the wave has consumed its last fragment (the weights do not depend on activations), i.e. before the epilogue,
 // the block barrier and the LayerNorm that separate two GEMMs.  ds_wave_gemm<..., true> then skips its own prologue.
+// kp0 / tile_kp: multiply against the k-slice [64 kp0, 64 kp0 + K) of a matrix packed with tile_kp k-chunks per tile
+// (0 = the whole matrix, K / 64 chunks per tile).
 template <int K, int TN>
-__device__ __forceinline__ void ds_prefetch(const bf16_t* __restrict__ Wp, int tiles, int wave, unsigned char* wring) {
+__device__ __forceinline__ void ds_prefetch(const bf16_t* __restrict__ Wp, int tiles, int wave, unsigned char* wring, int kp0 = 0, int tile_kp = 0) {
     const int lane = threadIdx.x & 63;
     constexpr int KP = K / 64, U = KP * TN * 2, PRE = U < DS_RING ? U : DS_RING;
+    if (tile_kp == 0) tile_kp = KP;
     static_for<0, PRE>([&](auto uc) {
         constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
         int tile = wave + DS_NW * t;
         tile = tile < tiles ? tile : tiles - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (size_t)tile * KP * 1024 + lane * 8 + (kp * 2 + half) * 512),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (size_t)tile * tile_kp * 1024 + lane * 8 + ((kp0 + kp) * 2 + half) * 512),
                                          (__attribute__((address_space(3))) void*)(wring + (u % DS_RING) * 1024), 16, 0, 0);
     });
 }
 
 template <int K, int TN, bool PREFETCHED = false>
 __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const bf16_t* __restrict__ Wp, int tiles,
-                                             int wave, unsigned char* wring, f32x4 (&acc)[TN]) {
+                                             int wave, unsigned char* wring, f32x4 (&acc)[TN], int kp0 = 0, int tile_kp = 0) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
     constexpr int KP = K / 64, U = KP * TN * 2, PRE = U < DS_RING ? U : DS_RING;
+    if (tile_kp == 0) tile_kp = KP;
     const bf16_t* wp[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         int tile = wave + DS_NW * t;
         tile = tile < tiles ? tile : tiles - 1;
-        wp[t] = Wp + (size_t)tile * KP * 1024 + lane * 8;
+        wp[t] = Wp + (size_t)tile * tile_kp * 1024 + (size_t)kp0 * 1024 + lane * 8;
     }
     const bf16_t* ap = a_lds + r16 * lda + 16 * g;
     auto issue = [&](auto uc) {
@@ -140,6 +144,62 @@ __device__ __forceinline__ void ds_layernorm_rows(const float* tl, int PT, bf16_
     }
 }
 
+// Table self-attention of ONE row by one wave, registers only (decoder_attn.h: dec_self_attn_kernel): lane l works for head
+// h = l >> 2: it scores keys j = (l & 3) + 4 c, the quad reduces max / sum over DPP, and the same lane then mixes value
+// columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.  tokv: lane j holds token j
+// of the row's context (j < Lk).  Result: bf16 row of E values at `arow` (LDS).
+template <int E>
+__device__ __forceinline__ void ds_self_attn_row(const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, int tokv, int ntok,
+                                                 int npos, int Lk, int pos, bf16_t* arow) {
+    static_assert(DEC_HD == 32 && DEC_MAXL == 32, "lane mapping assumes 32-wide heads and <= 32 keys");
+    constexpr int H = E / DEC_HD;
+    const int lane = threadIdx.x & 63;
+    const int h = lane >> 2, q = lane & 3;
+    const bool live = h < H;
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int j = q + 4 * c;
+        const int tj = __shfl(tokv, j, 64);
+        sc[c] = (live && j < Lk) ? stab[(((size_t)pos * npos + j) * ntok + tj) * H + h] : -INFINITY;
+        mx = fmaxf(mx, sc[c]);
+    }
+    mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+    mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sc[c] = (q + 4 * c < Lk) ? expf(sc[c] - mx) : 0.f; sum += sc[c]; }
+    sum += dpp_mov<0xB1>(sum);
+    sum += dpp_mov<0x4E>(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sc[c] *= inv;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int d0 = live ? 8 * lane : 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        // key j = 4 c + qq: its probability sits in lane (quad base + qq), register sc[c]
+        const float pq4[4] = {dpp_mov<0x00>(sc[c]), dpp_mov<0x55>(sc[c]), dpp_mov<0xAA>(sc[c]), dpp_mov<0xFF>(sc[c])};
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            const int j = 4 * c + qq;
+            if (j < Lk) {
+                const int tj = __builtin_amdgcn_readlane(tokv, j);
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+            }
+        }
+    }
+    if (live) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
+        *reinterpret_cast<bf16x8*>(arow + d0) = o;
+    }
+}
+
 template <int E> constexpr size_t dec_step_pre_lds() { return (size_t)DS_ROWS * ((E + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024; }
 template <int E> constexpr size_t dec_step_post_lds() {
     return (size_t)DS_ROWS * ((E + 8) * 2 + (4 * E + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
@@ -163,60 +223,14 @@ void dec_step_pre_kernel(const float* __restrict__ stab, const bf16_t* __restric
     unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
     const int row0 = blockIdx.x * DS_ROWS;
 
-    // self-attention of rows 2w, 2w + 1 (decoder_attn.h: dec_self_attn_kernel), one wave per row, registers only:
-    // lane l works for head h = l >> 2: it scores keys j = (l & 3) + 4 c, the quad reduces max / sum over DPP, and the same
-    // lane then mixes value columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.
-    static_assert(DEC_HD == 32 && DEC_MAXL == 32, "lane mapping assumes 32-wide heads and <= 32 keys");
+    // self-attention of rows 2w, 2w + 1, one wave per row
     ds_prefetch<E, TN>(Wo, TILES, wave, wring);
 #pragma unroll
     for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
         const int row = wave * (DS_ROWS / DS_NW) + rr;
         const int b = min(row0 + row, M - 1);
         const int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
-        const int h = lane >> 2, q = lane & 3;
-        const bool live = h < H;
-        float sc[8];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const int j = q + 4 * c;
-            const int tj = __shfl(tokv, j, 64);
-            sc[c] = (live && j < Lk) ? stab[(((size_t)pos * npos + j) * ntok + tj) * H + h] : -INFINITY;
-            mx = fmaxf(mx, sc[c]);
-        }
-        mx = fmaxf(mx, dpp_mov<0xB1>(mx));
-        mx = fmaxf(mx, dpp_mov<0x4E>(mx));
-        float sum = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { sc[c] = (q + 4 * c < Lk) ? expf(sc[c] - mx) : 0.f; sum += sc[c]; }
-        sum += dpp_mov<0xB1>(sum);
-        sum += dpp_mov<0x4E>(sum);
-        const float inv = 1.0f / sum;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) sc[c] *= inv;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int d0 = live ? 8 * lane : 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            // key j = 4 c + qq: its probability sits in lane (quad base + qq), register sc[c]
-            const float pq4[4] = {dpp_mov<0x00>(sc[c]), dpp_mov<0x55>(sc[c]), dpp_mov<0xAA>(sc[c]), dpp_mov<0xFF>(sc[c])};
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int j = 4 * c + qq;
-                if (j < Lk) {
-                    const int tj = __builtin_amdgcn_readlane(tokv, j);
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
-                }
-            }
-        }
-        if (live) {
-            bf16x8 o;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
-            *reinterpret_cast<bf16x8*>(abuf + row * PA + d0) = o;
-        }
+        ds_self_attn_row<E>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + row * PA);
     }
     __syncthreads();
 
@@ -390,6 +404,245 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
                 eos_seen[b] = 1;
                 const int done = atomicAdd(eos_rows, 1) + 1;
                 if (done == M) *ar_len = pos + 1;
+            }
+        }
+    }
+}
+
+// =====================================================================================================================
+// AR loop, second arrangement (forward_impl): the step boundary moves to the cross-attention.
+//
+//   dec_step_mid_kernel   finishes step i-1 (linear2 partial sums + residual -> decoder.norm -> head -> logits, greedy pick,
+//                         EOS bookkeeping) AND starts step i (self-attention with the token it has just picked ->
+//                         out_proj -> norm1 -> q-projection), 16 rows per workgroup
+//   dec_cross_attn_ar_kernel (step i)
+//   dec_step_mlp_kernel   cross out_proj + residual -> norm2 -> linear1 + GELU -> linear2 for HALF of the hidden units per
+//                         workgroup (DS_SPLIT workgroups per row tile): each streams 0.3 + 0.6 + 0.6 MB of weights instead
+//                         of 3 MB; the partial products of linear2 go to global memory and are summed, in a fixed order, by
+//                         the next mid kernel
+// Same three launches per step as the pre / post arrangement, but the longest weight stream per CU drops from 3.0 MB to
+// 1.5 MB and the token never leaves the workgroup between the pick and the next self-attention.
+// =====================================================================================================================
+constexpr int DS_SPLIT = 2;
+
+template <int E> constexpr size_t dec_step_mid_lds() { return (size_t)DS_ROWS * ((E + 8) * 2 + (E + 4) * 4 + 128 * 4) + (size_t)DS_NW * DS_RING * 1024; }
+template <int E> constexpr size_t dec_step_mlp_lds() {
+    return (size_t)DS_ROWS * ((E + 8) * 2 + (4 * E / DS_SPLIT + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
+}
+
+// tq: fp32 [M][E], t' of the step being finished (written by dec_step_mlp_kernel split 0); partial: fp32 [DS_SPLIT][M][E].
+// pos: the step being started (its query position); the step being finished is pos - 1.  Lk = pos + 1 context tokens.
+template <int E>
+__global__ __launch_bounds__(64 * DS_NW)
+void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
+                         // finish
+                         const float* __restrict__ tq, const float* __restrict__ partial, const float* __restrict__ b2,
+                         const float* __restrict__ lnf_w, const float* __restrict__ lnf_b, float eps, const bf16_t* __restrict__ Wh,
+                         const float* __restrict__ bh, int C, float* __restrict__ logits, int Ltot, int argmax_mode, int eos_id,
+                         unsigned char* __restrict__ eos_seen, int* __restrict__ eos_rows, int* __restrict__ ar_len,
+                         // start
+                         const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, int* __restrict__ tok, int ldt, int ntok,
+                         int npos, const bf16_t* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ pos_queries,
+                         const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16_t* __restrict__ Wq,
+                         const float* __restrict__ bq, float* __restrict__ t_out, float* __restrict__ qc_out) {
+    constexpr int PA = E + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW, PL = 128, RPW = DS_ROWS / DS_NW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
+    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
+    float* tl = reinterpret_cast<float*>(abuf + DS_ROWS * PA);         // [DS_ROWS][PT]
+    float* lg = tl + DS_ROWS * PT;                                     // [DS_ROWS][PL]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    unsigned char* wring = reinterpret_cast<unsigned char*>(lg + DS_ROWS * PL) + wave * DS_RING * 1024;
+    const int row0 = blockIdx.x * DS_ROWS;
+    int picked[RPW];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) picked[rr] = -1;
+
+    if (do_finish) {
+        ds_prefetch<E, 1>(Wh, (C + 15) / 16, wave, wring);
+        // t'' = t' + b2 + partial[0] + partial[1] + ...   (fixed order: deterministic)
+        for (int i = threadIdx.x; i < DS_ROWS * (E / 4); i += 64 * DS_NW) {
+            const int row = i / (E / 4), c = (i - row * (E / 4)) * 4;
+            const size_t gr = (size_t)min(row0 + row, M - 1) * E + c;
+            f32x4 v = *reinterpret_cast<const f32x4*>(tq + gr);
+            const float4 bv = *reinterpret_cast<const float4*>(b2 + c);
+            v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+#pragma unroll
+            for (int sp = 0; sp < DS_SPLIT; ++sp) v += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * M * E + gr);
+            *reinterpret_cast<f32x4*>(tl + row * PT + c) = v;
+        }
+        __syncthreads();
+        ds_layernorm_rows<E>(tl, PT, abuf, PA, lnf_w, lnf_b, eps, wave);
+        __syncthreads();
+        {
+            f32x4 acc[1] = {};
+            ds_wave_gemm<E, 1, true>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc);
+            if (do_start) ds_prefetch<E, TN>(Wo, TILES, wave, wring);
+            const int n = wave * 16 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r < C) {
+                    const float v = acc[0][r] + bh[n + r];
+                    lg[r16 * PL + n + r] = v;
+                    if (row0 + r16 < M) logits[((size_t)(row0 + r16) * Ltot + (pos - 1)) * C + n + r] = v;
+                }
+            }
+        }
+        __syncthreads();                                     // lg complete; abuf free for the next step's self-attention
+        if (argmax_mode) {
+#pragma unroll
+            for (int rr = 0; rr < RPW; ++rr) {
+                const int row = wave * RPW + rr, b = row0 + row;
+                float best = -INFINITY; int bi = 0x7fffffff;
+                for (int c = lane; c < C; c += 64) {
+                    const float v = lg[row * PL + c];
+                    if (v > best) { best = v; bi = c; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                picked[rr] = bi;
+                if (lane == 0 && b < M) {
+                    tok[(size_t)b * ldt + pos] = bi;
+                    if (argmax_mode == 2 && bi == eos_id && !eos_seen[b]) {
+                        eos_seen[b] = 1;
+                        const int done = atomicAdd(eos_rows, 1) + 1;
+                        if (done == M) *ar_len = pos;       // = (finished step) + 1
+                    }
+                }
+            }
+        }
+    } else if (do_start) {
+        ds_prefetch<E, TN>(Wo, TILES, wave, wring);
+    }
+    if (!do_start) return;
+
+    const int Lk = pos + 1;
+    // self-attention of rows 2w, 2w + 1: context tokens from global, the newest one straight from the pick above
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
+        const int b = min(row0 + row, M - 1);
+        int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
+        if (picked[rr] >= 0 && lane == pos) tokv = picked[rr];
+        ds_self_attn_row<E>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + row * PA);
+    }
+    __syncthreads();
+    {   // t = pos_queries[pos] + sa @ Wo^T + bo
+        const float* posq = pos_queries + (size_t)pos * E;
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<E, TN, true>(abuf, PA, Wo, TILES, wave, wring, acc);
+        ds_prefetch<E, TN>(Wq, TILES, wave, wring);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(bo + n);
+                const float4 pv = *reinterpret_cast<const float4*>(posq + n);
+                f32x4 o = {acc[t][0] + bv.x + pv.x, acc[t][1] + bv.y + pv.y, acc[t][2] + bv.z + pv.z, acc[t][3] + bv.w + pv.w};
+                *reinterpret_cast<f32x4*>(tl + r16 * PT + n) = o;
+                if (row0 + r16 < M) *reinterpret_cast<f32x4*>(t_out + (size_t)(row0 + r16) * E + n) = o;
+            }
+        }
+    }
+    __syncthreads();
+    ds_layernorm_rows<E>(tl, PT, abuf, PA, ln1_w, ln1_b, eps, wave);
+    __syncthreads();
+    {   // qc = norm1(t) @ Wq^T + bq
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<E, TN, true>(abuf, PA, Wq, TILES, wave, wring, acc);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES && row0 + r16 < M) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(bq + n);
+                f32x4 o = {acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w};
+                *reinterpret_cast<f32x4*>(qc_out + (size_t)(row0 + r16) * E + n) = o;
+            }
+        }
+    }
+}
+
+// grid: row tiles x DS_SPLIT.  ca bf16 [M][E]; t_in fp32 [M][E] (from the mid kernel); tq_out fp32 [M][E] receives
+// t' = t + ca @ Wco^T + bco (split 0 only); partial fp32 [DS_SPLIT][M][E] receives this split's share of h @ W2^T.
+template <int E>
+__global__ __launch_bounds__(64 * DS_NW)
+void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict__ t_in, const bf16_t* __restrict__ Wco,
+                         const float* __restrict__ bco, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float eps,
+                         const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
+                         float* __restrict__ tq_out, float* __restrict__ partial, int M) {
+    constexpr int F = 4 * E, FS = F / DS_SPLIT, PA = E + 8, PH = FS + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW;
+    constexpr int TN1 = FS / 16 / DS_NW;                      // linear1: column tiles per wave in this split
+    static_assert(FS % (16 * DS_NW) == 0 && FS % 64 == 0, "hidden width must split evenly over the workgroups and waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
+    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
+    bf16_t* hbuf = abuf + DS_ROWS * PA;                                // [DS_ROWS][PH]
+    float* tl = reinterpret_cast<float*>(hbuf + DS_ROWS * PH);         // [DS_ROWS][PT]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
+    const int rt = blockIdx.x / DS_SPLIT, sp = blockIdx.x - rt * DS_SPLIT;
+    const int row0 = rt * DS_ROWS;
+
+    ds_prefetch<E, TN>(Wco, TILES, wave, wring);
+    for (int i = threadIdx.x; i < DS_ROWS * (E / 8); i += 64 * DS_NW) {
+        const int row = i / (E / 8), c = (i - row * (E / 8)) * 8;
+        const int gr = min(row0 + row, M - 1);
+        *reinterpret_cast<bf16x8*>(abuf + row * PA + c) = *reinterpret_cast<const bf16x8*>(ca + (size_t)gr * E + c);
+    }
+    for (int i = threadIdx.x; i < DS_ROWS * (E / 4); i += 64 * DS_NW) {
+        const int row = i / (E / 4), c = (i - row * (E / 4)) * 4;
+        const int gr = min(row0 + row, M - 1);
+        *reinterpret_cast<f32x4*>(tl + row * PT + c) = *reinterpret_cast<const f32x4*>(t_in + (size_t)gr * E + c);
+    }
+    __syncthreads();
+    {   // t' = t + ca @ Wco^T + bco   (every split needs it for norm2; split 0 publishes it)
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<E, TN, true>(abuf, PA, Wco, TILES, wave, wring, acc);
+        ds_prefetch<E, TN1>(W1 + (size_t)sp * (FS / 16) * (E / 64) * 1024, FS / 16, wave, wring);
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES) {
+                const int n = tile * 16 + 4 * g;
+                const float4 bv = *reinterpret_cast<const float4*>(bco + n);
+                f32x4* p = reinterpret_cast<f32x4*>(tl + r16 * PT + n);
+                f32x4 o = *p;
+                o[0] += acc[t][0] + bv.x; o[1] += acc[t][1] + bv.y; o[2] += acc[t][2] + bv.z; o[3] += acc[t][3] + bv.w;
+                *p = o;
+                if (sp == 0 && row0 + r16 < M) *reinterpret_cast<f32x4*>(tq_out + (size_t)(row0 + r16) * E + n) = o;
+            }
+        }
+    }
+    __syncthreads();
+    ds_layernorm_rows<E>(tl, PT, abuf, PA, ln2_w, ln2_b, eps, wave);
+    __syncthreads();
+    {   // h[:, split] = gelu(norm2(t') @ W1[split]^T + b1[split])
+        f32x4 acc[TN1] = {};
+        ds_wave_gemm<E, TN1, true>(abuf, PA, W1 + (size_t)sp * (FS / 16) * (E / 64) * 1024, FS / 16, wave, wring, acc);
+        ds_prefetch<FS, TN>(W2, TILES, wave, wring, sp * (FS / 64), F / 64);
+#pragma unroll
+        for (int t = 0; t < TN1; ++t) {
+            const int n = (wave + DS_NW * t) * 16 + 4 * g;
+            const float4 bv = *reinterpret_cast<const float4*>(b1 + sp * FS + n);
+            const float o[4] = {gelu_poly(acc[t][0] + bv.x), gelu_poly(acc[t][1] + bv.y), gelu_poly(acc[t][2] + bv.z), gelu_poly(acc[t][3] + bv.w)};
+            store4<bf16_t>(hbuf + r16 * PH + n, o);
+        }
+    }
+    __syncthreads();
+    {   // partial[split] = h[:, split] @ W2[:, split]^T
+        f32x4 acc[TN] = {};
+        ds_wave_gemm<FS, TN, true>(hbuf, PH, W2, TILES, wave, wring, acc, sp * (FS / 64), F / 64);
+        float* dst = partial + (size_t)sp * M * E;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int tile = wave + DS_NW * t;
+            if (tile < TILES && row0 + r16 < M) {
+                const int n = tile * 16 + 4 * g;
+                *reinterpret_cast<f32x4*>(dst + (size_t)(row0 + r16) * E + n) = acc[t];
             }
         }
     }

@@ -785,6 +785,57 @@ static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int
     }
 }
 
+// The whole AR loop with the mid / cross-attention / mlp arrangement of decoder_step.h (bf16, E <= 384): step i's logits are
+// produced by the mid kernel of step i + 1 (and by one trailing finish-only launch after the last step).
+template <int E>
+static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int M = B, C = m->classes, npos = c.max_label_length + 1;
+    const std::string d = "decoder.layers.0.";
+    int* eos_rows = p->counters; int* ar_len = p->counters + 1;
+    bf16_t* ca = reinterpret_cast<bf16_t*>(p->ca);
+    float* partial = reinterpret_cast<float*>(p->hdn);          // [DS_SPLIT][M][E] (the generic path's MLP hidden buffer is idle here)
+    float* tq = p->qc;                                          // t' lives in the q-projection buffer once the cross-attention has consumed it
+    const float scale = sqrtf(1.0f / (float)DEC_HD);
+    const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
+    static const bool attr_set = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_mid_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dec_step_mid_lds<E>()) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_mlp_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)dec_step_mlp_lds<E>()) == hipSuccess;
+    }();
+    if (!attr_set) return fail(PARSEQ_E_HIP, "hipFuncSetAttribute(dec_step mid / mlp kernels) failed");
+    for (int i = 0; i <= num_steps; ++i) {
+        const int do_finish = i > 0, do_start = i < num_steps;
+        // the pick of position i - 1 feeds step i: needed while there is a step to start
+        const int argmax_mode = do_start ? (testing ? 2 : 1) : 0;
+        {
+            ProfScope ps_(&p->prof, T_DEC_PRE, s);
+            hipLaunchKernelGGL((dec_step_mid_kernel<E>), grid, block, dec_step_mid_lds<E>(), s, do_finish, do_start, i, M,
+                               tq, partial, m->p(d + "linear2.bias"), m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps,
+                               p->wstep[5], m->p("head.bias"), C, logits, num_steps, argmax_mode, c.eos_id, p->eos_seen, eos_rows, ar_len,
+                               p->stab, reinterpret_cast<const bf16_t*>(p->kvtab), p->tok, LDT, c.num_tokens, npos, p->wstep[0],
+                               m->p(d + "self_attn.out_proj.bias"), m->p("pos_queries"), m->p(d + "norm1.weight"), m->p(d + "norm1.bias"),
+                               p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), p->t, p->qc);
+            HIPCHK(hipGetLastError());
+        }
+        if (!do_start) break;
+        {
+            ProfScope ps_(&p->prof, T_DEC_CA, s);
+            CHK((run_cross_attention<bf16_t, E>(p, s, B, 1, scale, ca)));
+        }
+        {
+            ProfScope ps_(&p->prof, T_DEC_POST, s);
+            hipLaunchKernelGGL((dec_step_mlp_kernel<E>), dim3(grid.x * DS_SPLIT), block, dec_step_mlp_lds<E>(), s, ca, p->t, p->wstep[2],
+                               m->p(d + "cross_attn.out_proj.bias"), m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps,
+                               p->wstep[3], m->p(d + "linear1.bias"), p->wstep[4], tq, partial, M);
+            HIPCHK(hipGetLastError());
+        }
+    }
+    return 0;
+}
+
 template <typename T>
 static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int num_steps, float* logits, int* out_len, hipStream_t s) {
     const parseq_model* m = p->m;
@@ -797,7 +848,14 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     if (ar) {
         // model.py:119-147.  All num_steps steps are always run (no per-step host sync); the step at which the reference
         // would have stopped is recorded on the device and only truncates the returned view.
-        for (int i = 0; i < num_steps; ++i) {
+        bool done = false;
+        if constexpr (sizeof(T) == 2) {
+            if (p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4 && !getenv("PARSEQ_STEP_PREPOST")) {
+                if (c.embed_dim == 384) { CHK((ar_loop_fused<384>(p, s, B, num_steps, logits, testing))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192>(p, s, B, num_steps, logits, testing))); done = true; }
+            }
+        }
+        for (int i = 0; !done && i < num_steps; ++i) {
             // greedy pick of position i into tok[:, i + 1] (+ EOS bookkeeping) rides on the step; the last step needs none
             CHK((decode_pass<T>(p, s, B, i + 1, i, 1, nullptr, nullptr, logits, num_steps, i + 1 < num_steps ? (testing ? 2 : 1) : 0)));
         }
