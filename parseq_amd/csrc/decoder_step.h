@@ -416,18 +416,18 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
 //                         EOS bookkeeping) AND starts step i (self-attention with the token it has just picked ->
 //                         out_proj -> norm1 -> q-projection), 16 rows per workgroup
 //   dec_cross_attn_ar_kernel (step i)
-//   dec_step_mlp_kernel   cross out_proj + residual -> norm2 -> linear1 + GELU -> linear2 for HALF of the hidden units per
-//                         workgroup (DS_SPLIT workgroups per row tile): each streams 0.3 + 0.6 + 0.6 MB of weights instead
+//   dec_step_mlp_kernel   cross out_proj + residual -> norm2 -> linear1 + GELU -> linear2 for a QUARTER of the hidden units per
+//                         workgroup (ds_split<E>() workgroups per row tile): each streams 3 x 0.3 MB of weights instead
 //                         of 3 MB; the partial products of linear2 go to global memory and are summed, in a fixed order, by
 //                         the next mid kernel
 // Same three launches per step as the pre / post arrangement, but the longest weight stream per CU drops from 3.0 MB to
-// 1.5 MB and the token never leaves the workgroup between the pick and the next self-attention.
+// 0.9 MB and the token never leaves the workgroup between the pick and the next self-attention.
 // =====================================================================================================================
-constexpr int DS_SPLIT = 2;
+template <int E> constexpr int ds_split() { return E >= 384 ? 4 : 2; }   // workgroups per row tile in dec_step_mlp_kernel
 
 template <int E> constexpr size_t dec_step_mid_lds() { return (size_t)DS_ROWS * ((E + 8) * 2 + (E + 4) * 4 + 128 * 4) + (size_t)DS_NW * DS_RING * 1024; }
 template <int E> constexpr size_t dec_step_mlp_lds() {
-    return (size_t)DS_ROWS * ((E + 8) * 2 + (4 * E / DS_SPLIT + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
+    return (size_t)DS_ROWS * ((E + 8) * 2 + (4 * E / ds_split<E>() + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
 }
 
 // tq: fp32 [M][E], t' of the step being finished (written by dec_step_mlp_kernel split 0); partial: fp32 [DS_SPLIT][M][E].
@@ -446,6 +446,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                          const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16_t* __restrict__ Wq,
                          const float* __restrict__ bq, float* __restrict__ t_out, float* __restrict__ qc_out) {
     constexpr int PA = E + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW, PL = 128, RPW = DS_ROWS / DS_NW;
+    constexpr int DS_SPLIT = ds_split<E>();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
     bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
     float* tl = reinterpret_cast<float*>(abuf + DS_ROWS * PA);         // [DS_ROWS][PT]
@@ -575,6 +576,7 @@ void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict_
                          const float* __restrict__ bco, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float eps,
                          const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
                          float* __restrict__ tq_out, float* __restrict__ partial, int M) {
+    constexpr int DS_SPLIT = ds_split<E>();
     constexpr int F = 4 * E, FS = F / DS_SPLIT, PA = E + 8, PH = FS + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW;
     constexpr int TN1 = FS / 16 / DS_NW;                      // linear1: column tiles per wave in this split
     static_assert(FS % (16 * DS_NW) == 0 && FS % 64 == 0, "hidden width must split evenly over the workgroups and waves");

@@ -795,7 +795,7 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, fl
     const std::string d = "decoder.layers.0.";
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
     bf16_t* ca = reinterpret_cast<bf16_t*>(p->ca);
-    float* partial = reinterpret_cast<float*>(p->hdn);          // [DS_SPLIT][M][E] (the generic path's MLP hidden buffer is idle here)
+    float* partial = reinterpret_cast<float*>(p->hdn);          // [ds_split][M][E] (the generic path's MLP hidden buffer is idle here)
     float* tq = p->qc;                                          // t' lives in the q-projection buffer once the cross-attention has consumed it
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
@@ -827,7 +827,7 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, fl
         }
         {
             ProfScope ps_(&p->prof, T_DEC_POST, s);
-            hipLaunchKernelGGL((dec_step_mlp_kernel<E>), dim3(grid.x * DS_SPLIT), block, dec_step_mlp_lds<E>(), s, ca, p->t, p->wstep[2],
+            hipLaunchKernelGGL((dec_step_mlp_kernel<E>), dim3(grid.x * ds_split<E>()), block, dec_step_mlp_lds<E>(), s, ca, p->t, p->wstep[2],
                                m->p(d + "cross_attn.out_proj.bias"), m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps,
                                p->wstep[3], m->p(d + "linear1.bias"), p->wstep[4], tq, partial, M);
             HIPCHK(hipGetLastError());
