@@ -1,10 +1,11 @@
-"""torch.hub entrypoints with the reference's names and signatures (reference `hubconf.py:6-33`).
+"""torch.hub entrypoints: the names, positional order and defaults of the reference's `hubconf.py:6-58` for the model
+families this repository implements (PARSeq small / tiny / patch16-224, ViTSTR).
 
     torch.hub.load('<repo dir>', 'parseq', source='local', pretrained=False, decode_ar=True, refine_iters=1)
 
-Only the PARSeq family is provided (the path this repository accelerates); `dependencies` lists just torch, because
-`torch.hub` refuses to load a hubconf whose dependencies are not importable and this backend needs neither
-pytorch_lightning nor timm.  Extra keyword `precision='bf16'|'fp32'` selects the arithmetic mode of the HIP library.
+`dependencies` names torch alone: `torch.hub` refuses a hubconf whose dependencies cannot be imported, and this backend
+needs neither pytorch_lightning nor timm.  One keyword goes beyond the reference: `precision='bf16' | 'fp32'` picks the
+arithmetic mode of the HIP library.
 """
 import os
 import sys
@@ -16,38 +17,28 @@ from parseq_amd.utils import create_model  # noqa: E402
 dependencies = ['torch']
 
 
-def parseq_tiny(pretrained: bool = False, decode_ar: bool = True, refine_iters: int = 1, **kwargs):
-    """
-    PARSeq tiny model (img_size=128x32, patch_size=8x4, d_model=192)
-    @param pretrained: (bool) Use pretrained weights
-    @param decode_ar: (bool) use AR decoding
-    @param refine_iters: (int) number of refinement iterations to use
-    """
-    return create_model('parseq-tiny', pretrained, decode_ar=decode_ar, refine_iters=refine_iters, **kwargs)
+def _parseq_entry(experiment: str, summary: str):
+    def entry(pretrained: bool = False, decode_ar: bool = True, refine_iters: int = 1, **kwargs):
+        return create_model(experiment, pretrained, decode_ar=decode_ar, refine_iters=refine_iters, **kwargs)
+
+    entry.__doc__ = (f'{summary}\n\n'
+                     'pretrained   -- download and load the released checkpoint of this experiment\n'
+                     'decode_ar    -- autoregressive decoding (True) or one non-autoregressive pass (False)\n'
+                     'refine_iters -- number of cloze refinement passes after decoding\n'
+                     'precision    -- "bf16" (default) or "fp32", arithmetic mode of libparseq_hip\n'
+                     'Any other keyword overrides the experiment configuration, as in the reference.')
+    return entry
 
 
-def parseq(pretrained: bool = False, decode_ar: bool = True, refine_iters: int = 1, **kwargs):
-    """
-    PARSeq base model (img_size=128x32, patch_size=8x4, d_model=384)
-    @param pretrained: (bool) Use pretrained weights
-    @param decode_ar: (bool) use AR decoding
-    @param refine_iters: (int) number of refinement iterations to use
-    """
-    return create_model('parseq', pretrained, decode_ar=decode_ar, refine_iters=refine_iters, **kwargs)
-
-
-def parseq_patch16_224(pretrained: bool = False, decode_ar: bool = True, refine_iters: int = 1, **kwargs):
-    """
-    PARSeq base model (img_size=224x224, patch_size=16x16, d_model=384)
-    Constructible (parameters, state_dict); its 196-token encoder is not yet covered by the gfx950 attention kernel, so
-    forward() raises until row N4 of SURVEY.md section 8f lands.
-    """
-    return create_model('parseq-patch16-224', pretrained, decode_ar=decode_ar, refine_iters=refine_iters, **kwargs)
+parseq_tiny = _parseq_entry('parseq-tiny', 'PARSeq-Ti: 32x128 crops, 4x8 patches, width 192 (6.0 M parameters).')
+parseq = _parseq_entry('parseq', 'PARSeq-S: 32x128 crops, 4x8 patches, width 384 (23.8 M parameters).')
+parseq_patch16_224 = _parseq_entry('parseq-patch16-224', 'PARSeq-S on 224x224 crops with 16x16 patches (196 visual tokens).')
+for _name in ('parseq_tiny', 'parseq', 'parseq_patch16_224'):
+    globals()[_name].__name__ = globals()[_name].__qualname__ = _name
 
 
 def vitstr(pretrained: bool = False, **kwargs):
-    """
-    ViTSTR small model (img_size=32x128, patch_size=4x8, d_model=384)
-    @param pretrained: (bool) Use pretrained weights
-    """
+    """ViTSTR-S: ViT encoder with a class token and a per-token head; 32x128 crops, 4x8 patches, width 384.
+
+    pretrained -- download and load the released checkpoint; other keywords override the experiment configuration."""
     return create_model('vitstr', pretrained, **kwargs)

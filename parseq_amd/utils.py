@@ -32,47 +32,52 @@ def _get_model_class(key: str):
 
 
 def get_pretrained_weights(experiment: str):
-    try:
-        url = _WEIGHTS_URL[experiment]
-    except KeyError:
-        raise InvalidModelError(f"No pretrained weights found for '{experiment}'") from None
+    """State dict of the released checkpoint of `experiment` (downloaded through torch.hub's cache)."""
+    url = _WEIGHTS_URL.get(experiment)
+    if url is None:
+        raise InvalidModelError(f"No pretrained weights found for '{experiment}'")
     return torch.hub.load_state_dict_from_url(url=url, map_location='cpu', check_hash=True)
 
 
 def create_model(experiment: str, pretrained: bool = False, **kwargs):
+    """Build the system object of an experiment (`strhub/models/utils.py:73-83`); keyword arguments override its configuration."""
     try:
         config = get_config(experiment, **kwargs)
     except FileNotFoundError:
         raise InvalidModelError(f"No configuration found for '{experiment}'") from None
-    ModelClass = _get_model_class(experiment)
-    model = ModelClass(**config)
+    system = _get_model_class(experiment)(**config)
     if pretrained:
-        model.model.load_state_dict(get_pretrained_weights(experiment))
-    return model
+        system.model.load_state_dict(get_pretrained_weights(experiment))
+    return system
 
 
 def load_from_checkpoint(checkpoint_path: str, **kwargs):
-    if checkpoint_path.startswith('pretrained='):
-        model_id = checkpoint_path.split('=', maxsplit=1)[1]
-        return create_model(model_id, True, **kwargs)
-    ModelClass = _get_model_class(checkpoint_path)
-    # A Lightning checkpoint: {'state_dict': {'model.<key>': tensor, ...}, 'hyper_parameters': {...}} (train.py:86-92)
+    """`pretrained=<experiment>` or the path of a Lightning checkpoint (`strhub/models/utils.py:86-93`).
+
+    A Lightning checkpoint is {'state_dict': {'model.<key>': tensor, ...}, 'hyper_parameters': {...}} (written by
+    train.py:86-92); the class is chosen from the file name, the hyper-parameters (overridden by `kwargs`) rebuild the system
+    and the state dict is loaded with the system-level 'model.' prefix."""
+    prefix = 'pretrained='
+    if checkpoint_path.startswith(prefix):
+        return create_model(checkpoint_path[len(prefix):], True, **kwargs)
+    system_class = _get_model_class(checkpoint_path)
     ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
     if 'state_dict' not in ckpt:                       # a bare inner-model state_dict, as released on GitHub
         raise InvalidModelError(f"'{checkpoint_path}' is not a Lightning checkpoint; use create_model(...).model.load_state_dict")
-    hparams = dict(ckpt.get('hyper_parameters', {}))
-    hparams.update(kwargs)
-    model = ModelClass(**hparams)
-    model.load_state_dict(ckpt['state_dict'])
-    return model
+    hparams = {**ckpt.get('hyper_parameters', {}), **kwargs}
+    system = system_class(**hparams)
+    system.load_state_dict(ckpt['state_dict'])
+    return system
+
+
+_ARG_TYPES = {'int': int, 'float': float, 'str': str, 'bool': lambda text: text.lower() == 'true'}
 
 
 def parse_model_args(args):
-    kwargs = {}
-    arg_types = {t.__name__: t for t in [int, float, str]}
-    arg_types['bool'] = lambda v: v.lower() == 'true'
-    for arg in args:
-        name, value = arg.split('=', maxsplit=1)
-        name, arg_type = name.split(':', maxsplit=1)
-        kwargs[name] = arg_types[arg_type](value)
-    return kwargs
+    """['name:type=value', ...] -> {name: typed value} with type in int / float / str / bool (`strhub/models/utils.py:96-104`)."""
+    parsed = {}
+    for item in args:
+        key, text = item.split('=', maxsplit=1)
+        name, type_name = key.split(':', maxsplit=1)
+        parsed[name] = _ARG_TYPES[type_name](text)
+    return parsed
