@@ -211,6 +211,9 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
         static_for<0, SPC>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int s = c * SPC + t;
+#ifdef MLP_FINE_STAMPS
+            if (c < 2) MLP_STAMP();
+#endif
             // Issue schedule of the weight stream (per chunk c, for chunk c + 1's six stages; slot = stage index & 7):
             //   A: stages (c+1, 0..3) in the GELU gap of chunk c   (their slots held stages (c-1,4), (c-1,5), (c,0), (c,1))
             //   B: stage  (c+1, 4) at the start of stage (c, 4)    (slot of (c, 2))

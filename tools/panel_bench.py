@@ -78,6 +78,12 @@ def mlp_stamps():
         nat.check(lib.parseq_op_mlp_variant(nat.ptr(xbuf), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W1), nat.ptr(b1), nat.ptr(W2), nat.ptr(b2), M, 6, nat.stream_ptr()))
     torch.cuda.synchronize()
     st = xbuf[M * E:].view(torch.int64).cpu().view(-1)[:8 * 64].view(2, 4, 64)
+    if 'fine' in sys.argv:      # library built with -DMLP_FINE_STAMPS: a stamp at every stage start of chunks 0 and 1
+        names = ['start', 'LN done'] + [f'c0t{t}' for t in range(6)] + ['chunk1'] + [f'c1t{t}' for t in range(6)] + ['chunk2', 'last chunk', 'loop done', 'epilogue done']
+        for blk in range(2):
+            v = st[blk, 0, :len(names)].tolist()
+            print(f'block {"0" if blk == 0 else "300"} wave 0: ' + ', '.join(f'{n} {(b - v[0]) / 2400.0:.2f}' for n, b in zip(names, v)))
+        return
     names = ['start', 'LN done', 'chunk1', 'chunk2', 'last chunk', 'loop done', 'epilogue done']
     for blk in range(2):
         for w in range(4):
