@@ -83,3 +83,28 @@ def test_read_pipeline_uint8_images_to_strings():
     assert torch.equal(got, want)
     labels, conf = m.tokenizer.read(got.to(DEV))
     assert len(labels) == 4 and conf.shape == (4,)
+
+
+@pytest.mark.gpu
+def test_read_files_matches_reference_transform_pipeline(tmp_path):
+    """read.py's read_files (files -> device resize -> uint8 forward -> device post-processing) prints the strings the reference pipeline
+    (PIL resize -> ToTensor -> Normalize -> model -> tokenizer.decode) gives with the same weights (fp32 mode)."""
+    Image = pytest.importorskip('PIL.Image')
+    import read as read_cli
+    from gpu_util import DEV, make_model
+    from oracle import parseq_oracle as O
+    files, tensors = [], []
+    for i, (h, w) in enumerate([(40, 150), (32, 128), (64, 200)]):
+        img = make_input(h, w, 1 - i % 2)
+        f = tmp_path / f'crop{i}.png'
+        Image.fromarray(img, 'RGB').save(f)
+        files.append(str(f))
+        ref = np.asarray(Image.fromarray(img, 'RGB').resize((128, 32), Image.BICUBIC))
+        tensors.append(torch.from_numpy(ref.copy()).permute(2, 0, 1))
+    m = make_model('parseq', 'fp32')
+    out = read_cli.read_files(m, files, DEV)
+    with torch.inference_mode():
+        logits = m(O.normalize_u8(torch.stack(tensors)).to(DEV))
+    want, probs = m.tokenizer.decode(logits.softmax(-1))
+    assert [o[1] for o in out] == want
+    assert all(abs(o[2] - float(p.prod())) <= 1e-4 * max(float(p.prod()), 1e-6) for o, p in zip(out, probs))
