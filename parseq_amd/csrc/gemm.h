@@ -274,19 +274,20 @@ template <typename TO>
 struct EpiHeads : EpiBase {
     using S = TO;
     TO* seg[3]; int E, heads, hd, tokens, tr_from;
+    int m_off = 0;                 // global row of the GEMM's row 0 (a call on the tail rows of a larger activation matrix)
     __device__ __forceinline__ bool transposed(int n0) const { return n0 >= tr_from * E; }
     __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
         if (n + Chunk<S>::CH > N) return;
         const int which = n / E, col = n - which * E;
         const int h = col / hd, d = col - h * hd;
-        const int b_ = m / tokens, t = m - b_ * tokens;
+        const int b_ = (m + m_off) / tokens, t = (m + m_off) - b_ * tokens;
         *reinterpret_cast<u32x4*>(seg[which] + (((size_t)b_ * heads + h) * tokens + t) * hd + d) = *reinterpret_cast<const u32x4*>(c);
     }
     __device__ __forceinline__ void store_m(int m, int n, const S* c) const {
         if (m + Chunk<S>::CH > M || n >= N) return;
         const int which = n / E, col = n - which * E;
         const int h = col / hd, d = col - h * hd;
-        const int b_ = m / tokens, t = m - b_ * tokens;
+        const int b_ = (m + m_off) / tokens, t = (m + m_off) - b_ * tokens;
         *reinterpret_cast<u32x4*>(seg[which] + (((size_t)b_ * heads + h) * hd + d) * tokens + t) = *reinterpret_cast<const u32x4*>(c);
     }
 };

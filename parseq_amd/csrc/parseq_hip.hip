@@ -295,6 +295,7 @@ struct parseq_plan {
     unsigned char* qmask_user = nullptr;  // [npos][LDT] staging for parseq_decode_logits
     int* counters = nullptr;       // [0] eos_rows, [1] ar_len
     int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
+    int num_cus = 256;             // compute units of the device (tail-round avoidance of the one- and two-workgroup-per-CU kernels)
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
     Profiler prof;
 };
@@ -438,6 +439,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t rows = B * N, drows = B * npos;
     auto* p = new parseq_plan();
     p->m = m; p->max_batch = max_batch; p->precision = precision;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount; }
     size_t off = 0;
     const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : 0);
     const bool step_ok = !m->vitstr && precision == PARSEQ_BF16 && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
@@ -583,14 +585,29 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const bool panel_qkv = kBf16 && (E == 192 || E == 384) && (3 * E) % PN_BN == 0;
     const bool panel_fc1 = kBf16 && (E == 192 || E == 384) && F % PN_BN == 0;
     const bool fused_mlp = kBf16 && E == 384 && c.enc_mlp_ratio == 4;      // encoder_mlp.h: LayerNorm + fc1 + GELU + fc2 + residual in one kernel
+    // A kernel that holds `per_cu` workgroups of 128 rows per CU finishes in whole rounds of per_cu * CUs row tiles.  When
+    // the row count leaves a few tiles over (ViTSTR: 512 x 129 rows = 516 tiles on 256 CUs), those tiles would cost a whole
+    // extra round; instead the leading whole rounds go to the fused kernel and the tail rows to the generic kernels.
+    auto main_rows = [&](int per_cu) {
+        const int tiles = (M + 127) / 128, slots = per_cu * p->num_cus, rem = tiles % slots;
+        return (tiles > slots && rem > 0 && rem <= slots / 16) ? (tiles - rem) * 128 : M;
+    };
+    const int Mq = panel_qkv ? main_rows(2) : M, Mm = fused_mlp ? main_rows(1) : M;
     for (int i = 0; i < c.enc_depth; ++i) {
         const std::string b = pe + "blocks." + std::to_string(i) + ".";
         if (panel_qkv) {
             if constexpr (kBf16) {
                 PanelHeads ph; ph.seg[0] = q; ph.seg[1] = k; ph.seg[2] = vt; ph.E = E; ph.heads = H; ph.hd = ATT_HD; ph.tokens = N;
                 ProfScope ps_(&p->prof, T_QKV, s);
-                if (E == 384) HIPCHK((launch_ln_panel_gemm<384>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), m->p(b + "attn.qkv.bias"), M, 3 * E, ph)));
-                else HIPCHK((launch_ln_panel_gemm<192>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), m->p(b + "attn.qkv.bias"), M, 3 * E, ph)));
+                if (E == 384) HIPCHK((launch_ln_panel_gemm<384>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), m->p(b + "attn.qkv.bias"), Mq, 3 * E, ph)));
+                else HIPCHK((launch_ln_panel_gemm<192>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), m->p(b + "attn.qkv.bias"), Mq, 3 * E, ph)));
+                if (Mq < M) {        // tail rows: LayerNorm kernel + generic GEMM, same head-split row-major outputs
+                    const int Mt = M - Mq;
+                    CHK((run_layernorm<T>(s, p->x + (size_t)Mq * E, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn + (size_t)Mq * E, nullptr, Mt, E, c.enc_ln_eps)));
+                    EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(Mt, 3 * E, m->p(b + "attn.qkv.bias"));
+                    eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N; eq.tr_from = 3; eq.m_off = Mq;
+                    CHK((run_gemm<T>(s, ARowMajor<T>{xn + (size_t)Mq * E, E}, W.w(b + "attn.qkv.weight"), E, Mt, 3 * E, E, eq)));
+                }
             }
         } else {
             { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
@@ -605,7 +622,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             if constexpr (kBf16) {
                 ProfScope ps_(&p->prof, T_MLP, s);
                 HIPCHK((launch_fused_mlp<384>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
-                                              m->p(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), m->p(b + "mlp.fc2.bias"), M)));
+                                              m->p(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), m->p(b + "mlp.fc2.bias"), Mm)));
+                if (Mm < M) {        // tail rows through the per-op kernels (same rounding points)
+                    const int Mt = M - Mm;
+                    CHK((run_layernorm<T>(s, p->x + (size_t)Mm * E, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), xn + (size_t)Mm * E, nullptr, Mt, E, c.enc_ln_eps)));
+                    CHK((run_gemm<T>(s, ARowMajor<T>{xn + (size_t)Mm * E, E}, W.w(b + "mlp.fc1.weight"), E, Mt, F, E, epi_gelu<T>(Mt, F, m->p(b + "mlp.fc1.bias"), h + (size_t)Mm * F, F))));
+                    CHK((run_gemm<T>(s, ARowMajor<T>{h + (size_t)Mm * F, F}, W.w(b + "mlp.fc2.weight"), F, Mt, E, F, epi_resid(Mt, E, m->p(b + "mlp.fc2.bias"), p->x + (size_t)Mm * E, E))));
+                }
             }
             continue;
         }
