@@ -473,4 +473,135 @@ void dec_cross_attn_multi_mfma_kernel(const float* __restrict__ qc, const bf16_t
     }
 }
 
+// dec_cross_attn_multi_mfma_kernel for any key count NK <= 16 * NT16 (row N4: 196 memory tokens for parseq-patch16-224) and
+// 1 <= Lq <= 32 queries: keys padded to NT16 tiles of 16 (scores) / to a multiple of 32 (value mix) with the padded keys
+// masked out of the soft-max and zero V rows.  One wave per (image, head); V staged in LDS ([NKP][34] bf16 per wave).
+template <int NT16>
+__global__ __launch_bounds__(128)
+void dec_cross_attn_mfma_n_kernel(const float* __restrict__ qc, const bf16_t* __restrict__ kmem, const bf16_t* __restrict__ vmem,
+                                  int H, int Lq, int NK, float scale, bf16_t* __restrict__ out, int BH) {
+    constexpr int NKP = ((NT16 + 1) / 2) * 32, KK = NKP / 32, VP = DEC_HD + 2, WAVES = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_cam[];
+    bf16_t* sv_all = reinterpret_cast<bf16_t*>(smem_cam);              // [WAVES][NKP][VP]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x * WAVES + wid;
+    if (bh >= BH) return;
+    bf16_t* sv = sv_all + (size_t)wid * NKP * VP;
+    const int b = bh / H, h = bh - b * H, E = H * DEC_HD;
+    const bf16_t* kg = kmem + (size_t)bh * NK * DEC_HD;
+    const bf16_t* vg = vmem + (size_t)bh * NK * DEC_HD;
+    Frag<bf16_t> kf[NT16];
+#pragma unroll
+    for (int kt = 0; kt < NT16; ++kt) {
+        const int key = min(kt * 16 + r16, NK - 1);                    // padded keys read a valid row; their scores are masked
+        kf[kt].v = *reinterpret_cast<const bf16x8*>(kg + (size_t)key * DEC_HD + 8 * g);
+    }
+    for (int c = lane; c < NKP * 4; c += 64) {                         // 16-byte piece c: key c >> 2, d 8 (c & 3)
+        const int key = c >> 2;
+        bf16x8 v = {};
+        if (key < NK) v = *reinterpret_cast<const bf16x8*>(vg + (size_t)c * 8);
+        bf16_t* dst = sv + key * VP + 8 * (c & 3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = v[i];
+    }
+    Frag<bf16_t> qhi[2], qlo[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = 16 * qt + r16;
+        float qv[8];
+        if (qi < Lq) {
+            const float4* src = reinterpret_cast<const float4*>(qc + ((size_t)b * Lq + qi) * E + h * DEC_HD + 8 * g);
+            const float4 x0 = src[0], x1 = src[1];
+            qv[0] = x0.x; qv[1] = x0.y; qv[2] = x0.z; qv[3] = x0.w; qv[4] = x1.x; qv[5] = x1.y; qv[6] = x1.z; qv[7] = x1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = qv[i] * scale;
+            const bf16_t hi = from_f32<bf16_t>(x);
+            qhi[qt].v[i] = hi;
+            qlo[qt].v[i] = from_f32<bf16_t>(x - to_f32(hi));
+        }
+    }
+    const int nqt = Lq > 16 ? 2 : 1;
+    f32x4 accs[2][2 * KK];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 2 * KK; ++kt) {
+            accs[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt < NT16 && qt < nqt) {
+                mma16(accs[qt][kt], kf[kt < NT16 ? kt : 0], qhi[qt]);
+                mma16(accs[qt][kt], kf[kt < NT16 ? kt : 0], qlo[qt]);
+            }
+        }
+    Frag<bf16_t> phi[2][KK], plo[2][KK];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2 * KK; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (16 * kt + 4 * g + r >= NK) accs[qt][kt][r] = -INFINITY;
+                mx = fmaxf(mx, accs[qt][kt][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2 * KK; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(accs[qt][kt][r] - mx); accs[qt][kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const float pv = accs[qt][2 * kk + (sl >> 2)][sl & 3] * inv;
+                const bf16_t hi = from_f32<bf16_t>(pv);
+                phi[qt][kk].v[sl] = hi;
+                plo[qt][kk].v[sl] = from_f32<bf16_t>(pv - to_f32(hi));
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x4 acco[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) acco[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            Frag<bf16_t> vt;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) vt.v[sl] = sv[(32 * kk + 16 * (sl >> 2) + 4 * g + (sl & 3)) * VP + 16 * dt + r16];
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                if (qt < nqt) {
+                    mma16(acco[qt][dt], vt, phi[qt][kk]);
+                    mma16(acco[qt][dt], vt, plo[qt][kk]);
+                }
+            }
+        }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = 16 * qt + r16;
+        if (qi < Lq) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const float o[4] = {acco[qt][dt][0], acco[qt][dt][1], acco[qt][dt][2], acco[qt][dt][3]};
+                store4<bf16_t>(out + ((size_t)b * Lq + qi) * E + h * DEC_HD + 16 * dt + 4 * g, o);
+            }
+        }
+    }
+}
+template <int NT16> constexpr size_t dec_cross_attn_mfma_n_lds() { return (size_t)2 * (((NT16 + 1) / 2) * 32) * (DEC_HD + 2) * sizeof(bf16_t); }
+
 }  // namespace pq
+

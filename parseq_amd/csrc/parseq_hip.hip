@@ -697,6 +697,20 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
     const int H = p->m->cfg.dec_heads, NK = p->m->tokens;
     const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
     if (NK != 128) {
+        if constexpr (sizeof(T) == 2) {
+            const int nt16 = (NK + 15) / 16;
+#define PQ_CAM_N(NT)                                                                                                                      \
+            if (nt16 > NT - 2 && nt16 <= NT) {                                                                                           \
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_mfma_n_kernel<NT>),                              \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_cross_attn_mfma_n_lds<NT>()));           \
+                hipLaunchKernelGGL((dec_cross_attn_mfma_n_kernel<NT>), dim3((B * H + 1) / 2), dim3(128), dec_cross_attn_mfma_n_lds<NT>(), s, \
+                                   p->qc, kmem, vmem, H, Lq, NK, scale, ca, B * H);                                                      \
+                HIPCHK(hipGetLastError());                                                                                                \
+                return 0;                                                                                                                 \
+            }
+            PQ_CAM_N(2) PQ_CAM_N(4) PQ_CAM_N(6) PQ_CAM_N(8) PQ_CAM_N(10) PQ_CAM_N(12) PQ_CAM_N(14) PQ_CAM_N(16)
+#undef PQ_CAM_N
+        }
         const size_t lds = dec_cross_attn_generic_lds(NK);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((dec_cross_attn_generic_kernel<T>), dim3(B * H), dim3(128), lds, s, p->qc, kmem, vmem, H, Lq, NK, scale, ca);
