@@ -266,6 +266,12 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
         // complete 128-byte lines (the 4-lanes-per-row form ran the store path at 2.3 TB/s, profiles/r01_panel_ablation.log).
         int ntr = nt + rot; if (ntr >= ntiles) ntr -= ntiles;
         const int n0 = ntr * PN_BN;
+        // lane-derived values of the epilogue are re-derived here from an opaque lane id: kept live across the MFMA stages they
+        // were spilled to scratch, and a scratch reload in the epilogue has to wait (in-order VMEM return) for the weight
+        // stages in flight
+        int lane_e;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+        const int rr = lane_e & 15, g = lane_e >> 4;
         const bool lo = rr < 8;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
