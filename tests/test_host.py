@@ -91,3 +91,24 @@ def test_cpu_forward_is_refused():
 def test_edit_distance():
     from parseq_amd.system import edit_distance
     assert edit_distance('kitten', 'sitting') == 3 and edit_distance('', 'abc') == 3 and edit_distance('abc', 'abc') == 0
+
+
+def test_product_code_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+    Nothing under parseq_amd/, hubconf.py or read.py may (a product path through the oracle would void every parity claim)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    product = [os.path.join(root, 'hubconf.py'), os.path.join(root, 'read.py')]
+    for d, _, files in os.walk(os.path.join(root, 'parseq_amd')):
+        product += [os.path.join(d, f) for f in files if f.endswith('.py')]
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b', re.M)
+    offenders = [p for p in product if pat.search(open(p).read())]
+    assert not offenders, offenders
+    # bench.py: the only import sits inside cpu_baseline(); __graft_entry__.py: inside smoke()
+    for name, func in (('bench.py', 'cpu_baseline'), ('__graft_entry__.py', 'smoke')):
+        src = open(os.path.join(root, name)).read()
+        for m in pat.finditer(src):
+            head = src[:m.start()]
+            last_def = re.findall(r'^def (\w+)\(', head, re.M)[-1]
+            assert last_def == func, (name, last_def)
