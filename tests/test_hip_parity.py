@@ -340,3 +340,24 @@ def test_batch_520_tail_tiles_bf16(golden):
     d = (got - small[idx]).abs().amax(dim=(1, 2))
     assert d[:512].max().item() <= 1e-5
     assert d[512:].max().item() <= 6e-2
+
+
+@pytest.mark.parametrize('model_name,batch', [('parseq', 512), ('parseq', 333), ('parseq-tiny', 512), ('vitstr', 512), ('parseq-patch16-224', 40)])
+def test_repeated_runs_are_bit_identical(model_name, batch):
+    """Every kernel synchronises its LDS rings with counted `s_waitcnt vmcnt` and barriers it places itself; a missing wait
+    would show up as run-to-run differences long before it shows up as a visible error.  Eight runs, same input, bf16."""
+    if model_name == 'vitstr':
+        from oracle import vitstr_oracle as V
+        from parseq_amd import create_model
+        m = create_model('vitstr', precision='bf16')
+        m.model.load_state_dict(V.synth_state_dict(V.vitstr_config(), 0))
+        m = m.eval().to(DEV)
+        size = (32, 128)
+    else:
+        m = make_model(model_name, 'bf16')
+        size = tuple(CONFIGS[model_name].img_size)
+    x = (torch.rand(batch, 3, *size, generator=torch.Generator().manual_seed(3)) * 2 - 1).to(DEV)
+    with torch.inference_mode():
+        first = m(x, 25).clone()
+        for _ in range(7):
+            assert torch.equal(m(x, 25), first)
