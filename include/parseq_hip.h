@@ -137,6 +137,13 @@ int parseq_forward(parseq_plan* p, const void* images, int images_dtype, int bat
 int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
                          const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream);
 
+/* model.PARSeq.decode (model.py:86-103): the same pass as parseq_decode_logits, additionally returning what `decode`
+ * returns in the reference — the decoder output after decoder.norm (modules.py:124), fp32 [batch, q_len, embed_dim] — so that
+ * `model.head(model.decode(...))` keeps working.  logits_out is written too (head of the same pass, library arithmetic). */
+int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
+                         const uint8_t* query_mask, const uint8_t* key_padding_mask, float* hidden_out, float* logits_out,
+                         void* stream);
+
 /* ViTSTR.forward (strhub/models/vitstr/system.py:76-82 -> vitstr/model.py:20-28) for a model created with
  * arch = PARSEQ_ARCH_VITSTR: encoder with class token, head on tokens [1, num_steps], i.e. logits_out fp32
  * [batch, num_steps, num_tokens - 2] with num_steps = min(max_length, max_label_length) + 1.  images as parseq_forward. */

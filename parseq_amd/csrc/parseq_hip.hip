@@ -727,7 +727,7 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
 
 template <typename T, int E>
 static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
-                         float* logits, int Ltot, int argmax_mode) {
+                         float* logits, int Ltot, int argmax_mode, bool keep_t = false) {
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
     const int M = B * Lq, Fd = E * c.dec_mlp_ratio, C = m->classes, npos = c.max_label_length + 1, H = c.dec_heads;
@@ -739,7 +739,7 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
     if constexpr (sizeof(T) == 2 && E <= 384) {
         // AR step (one unmasked query per image): two fused row-block kernels around the cross-attention (decoder_step.h)
-        if (Lq == 1 && !qmask && !kpm && C <= 128 && p->fused_step && p->wstep[0]) {
+        if (Lq == 1 && !qmask && !kpm && C <= 128 && p->fused_step && p->wstep[0] && !keep_t) {
             const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
             static const bool attr_set = [] {
                 return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_pre_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -814,11 +814,11 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
 // logits[b][i0 + qi][:] for qi < Lq into a [B][Ltot][C] tensor.
 template <typename T>
 static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
-                       float* logits, int Ltot, int argmax_mode = 0) {
+                       float* logits, int Ltot, int argmax_mode = 0, bool keep_t = false) {
     switch (p->m->cfg.embed_dim) {
-        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode);
-        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode);
-        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode);
+        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t);
+        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t);
+        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t);
     }
 }
 
@@ -956,8 +956,8 @@ extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dty
     return forward_impl<float>(p, batch, flags, refine_iters, num_steps, logits_out, out_len, s);
 }
 
-extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
-                                    const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream) {
+static int decode_entry(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len, const uint8_t* query_mask,
+                        const uint8_t* key_padding_mask, float* logits_out, float* hidden_out, void* stream) {
     if (!p || !tokens || !logits_out) return fail(PARSEQ_E_INVALID, "null argument");
     if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
     if (batch <= 0 || batch > p->max_batch || batch != p->last_batch) return fail(PARSEQ_E_INVALID, "batch %d does not match the last parseq_encode (%d)", batch, p->last_batch);
@@ -975,8 +975,27 @@ extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int b
         HIPCHK(hipMemcpy2DAsync(p->qmask_user + (size_t)q_start * LDT, LDT, query_mask, ctx_len, ctx_len, q_len, hipMemcpyDeviceToDevice, s));
         qm = p->qmask_user;
     }
-    if (p->precision == PARSEQ_BF16) return decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
-    return decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len);
+    const bool keep_t = hidden_out != nullptr;
+    if (p->precision == PARSEQ_BF16) CHK((decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t)));
+    else CHK((decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t)));
+    if (hidden_out) {      // model.decode's return value: decoder.norm of the query stream (modules.py:124), fp32
+        const parseq_model* m = p->m;
+        CHK((run_layernorm<float>(s, p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), hidden_out, nullptr, batch * q_len,
+                                  m->cfg.embed_dim, m->cfg.dec_ln_eps)));
+    }
+    return 0;
+}
+
+extern "C" int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
+                                    const uint8_t* query_mask, const uint8_t* key_padding_mask, float* logits_out, void* stream) {
+    return decode_entry(p, tokens, batch, ctx_len, q_start, q_len, query_mask, key_padding_mask, logits_out, nullptr, stream);
+}
+
+extern "C" int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
+                                    const uint8_t* query_mask, const uint8_t* key_padding_mask, float* hidden_out, float* logits_out,
+                                    void* stream) {
+    if (!hidden_out) return fail(PARSEQ_E_INVALID, "null hidden_out");
+    return decode_entry(p, tokens, batch, ctx_len, q_start, q_len, query_mask, key_padding_mask, logits_out, hidden_out, stream);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

@@ -143,6 +143,22 @@ def _named_apply(fn, module: nn.Module, name: str = ''):
         fn(module=child, name=full)
 
 
+class _Head(nn.Linear):
+    """`model.head` (model.py:63): a Linear whose forward runs on the HIP library (fp32 GEMM), so that the reference idiom
+    `model.head(model.decode(...))` works; parameters under the reference keys `head.weight` / `head.bias`."""
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not x.is_cuda:
+            raise RuntimeError('parseq_amd runs on MI355X through libparseq_hip only (no CPU fallback)')
+        a = x.detach().to(torch.float32).contiguous().view(-1, self.in_features)
+        out = torch.empty(a.shape[0], self.out_features, dtype=torch.float32, device=x.device)
+        w = self.weight.detach().to(torch.float32).contiguous()
+        b = self.bias.detach().to(torch.float32).contiguous()
+        _native.check(_native.lib().parseq_op_linear(_native.ptr(a), _native.ptr(w), _native.ptr(b), _native.ptr(out), _native.PARSEQ_F32, 0,
+                                                     a.shape[0], self.out_features, self.in_features, _native.stream_ptr()))
+        return out.view(*x.shape[:-1], self.out_features)
+
+
 class _NativeState:
     """Device-side twin of the parameters: one parseq_model + cached plans.  Rebuilt when parameters move or change."""
 
@@ -298,7 +314,7 @@ class PARSeq(_NativeBacked):
 
         self.encoder = Encoder(img_size, patch_size, embed_dim, enc_depth, enc_num_heads, enc_mlp_ratio)
         self.decoder = Decoder(embed_dim, dec_num_heads, embed_dim * dec_mlp_ratio, dropout, dec_depth)
-        self.head = nn.Linear(embed_dim, num_tokens - 2)       # <bos> and <pad> are never predicted (model.py:62-63)
+        self.head = _Head(embed_dim, num_tokens - 2)           # <bos> and <pad> are never predicted (model.py:62-63)
         self.text_embed = TokenEmbedding(num_tokens, embed_dim)
         self.pos_queries = nn.Parameter(torch.empty(1, max_label_length + 1, embed_dim))
         _named_apply(lambda module, name: init_weights(module, name, exclude=['encoder']), self)
@@ -322,6 +338,40 @@ class PARSeq(_NativeBacked):
         _native.check(_native.lib().parseq_encode(plan, _native.ptr(img), _native.dtype_code(img.dtype), img.shape[0],
                                                   _native.ptr(memory), _native.stream_ptr()))
         return memory
+
+    def decode(self, tgt: Tensor, memory: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,
+               tgt_padding_mask: Optional[Tensor] = None, tgt_query: Optional[Tensor] = None,
+               tgt_query_mask: Optional[Tensor] = None) -> Tensor:
+        """model.py:86-103: decoder output (after decoder.norm) [N, Lq, E] for the context tokens `tgt`.
+
+        Restrictions of this backend: `memory` is the encoder output of the most recent `encode` / `forward` on this model
+        (its cross-attention K / V are cached on the device; the argument is accepted for signature compatibility only);
+        `tgt_query` is None (all positions `pos_queries[:, :L]`) or a view `pos_queries[:, i:j]` (what `forward` and the
+        training step pass); `tgt_mask` only feeds the content-stream update, which a depth-1 decoder never runs
+        (modules.py:116-118), so it is ignored exactly as the reference ignores it."""
+        B, L = tgt.shape
+        E = self._cfg['embed_dim']
+        if tgt_query is None:
+            q_start, q_len = 0, L
+        else:
+            pq = self.pos_queries
+            off = (tgt_query.data_ptr() - pq.data_ptr()) // pq.element_size()
+            q_len = tgt_query.shape[1]
+            if (tgt_query.device != pq.device or tgt_query.dtype != pq.dtype or off < 0 or off % E or tgt_query.shape[-1] != E or
+                    off // E + q_len > pq.shape[1] or tgt_query.stride(-1) != 1 or tgt_query.stride(-2) != E):
+                raise NotImplementedError('tgt_query must be None or a slice pos_queries[:, i:j] of this model')
+            q_start = off // E
+        plan = self._plan(B)
+        tok = tgt.to(device=self._device, dtype=torch.int32).contiguous()
+        kpm = tgt_padding_mask.to(device=self._device, dtype=torch.uint8).contiguous() if tgt_padding_mask is not None else None
+        qm = tgt_query_mask.to(device=self._device, dtype=torch.uint8).contiguous() if tgt_query_mask is not None else None
+        if qm is not None and tuple(qm.shape) != (q_len, L):
+            raise RuntimeError(f'tgt_query_mask shape {tuple(qm.shape)} != ({q_len}, {L})')
+        hidden = torch.empty(B, q_len, E, dtype=torch.float32, device=self._device)
+        logits = torch.empty(B, q_len, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=self._device)
+        _native.check(_native.lib().parseq_decode_hidden(plan, _native.ptr(tok), B, L, q_start, q_len, _native.ptr(qm), _native.ptr(kpm),
+                                                         _native.ptr(hidden), _native.ptr(logits), _native.stream_ptr()))
+        return hidden
 
     def decode_logits(self, tgt: Tensor, q_start: int, q_len: int, tgt_padding_mask: Optional[Tensor] = None,
                       tgt_query_mask: Optional[Tensor] = None) -> Tensor:

@@ -361,3 +361,33 @@ def test_repeated_runs_are_bit_identical(model_name, batch):
         first = m(x, 25).clone()
         for _ in range(7):
             assert torch.equal(m(x, 25), first)
+
+
+def test_decode_and_head_reference_idiom(name, models, golden):
+    """`model.head(model.decode(tgt, memory, ...))` — the reference's own call pattern (model.py:138,152,167; system.py:149-150):
+    decoder output after decoder.norm and a callable head, against the oracle; single-position and sliced-query forms too."""
+    g, _ = golden(name)
+    cfg, sd = CONFIGS[name], synth_state_dict(CONFIGS[name], 0)
+    images = g['images'][:4]
+    m = models['fp32']
+    with torch.inference_mode():
+        tr = O.Trace()
+        O.forward(sd, cfg, images, 25, decode_ar=True, refine_iters=0, trace=tr)
+        mem_o = O.encode(sd, cfg, images)
+        causal = torch.triu(torch.ones(26, 26, dtype=torch.bool), 1)
+        pos_q = sd['pos_queries'].expand(4, -1, -1)
+        want_h = O.decode(sd, cfg, tr.ar_tokens, mem_o, causal, None, pos_q, causal)
+        memory = m.model.encode(images.to(DEV))
+        tgt = tr.ar_tokens.to(DEV)
+        hid = m.model.decode(tgt, memory, tgt_mask=causal.to(DEV), tgt_query_mask=causal.to(DEV))
+        logits = m.model.head(hid)
+        assert hid.shape == (4, 26, cfg.embed_dim)
+        assert (hid.cpu() - want_h).abs().max() <= 1e-3
+        assert (logits.cpu() - O.head(sd, want_h)).abs().max() <= 1e-3
+        assert (logits - m.model.decode_logits(tr.ar_tokens, 0, 26, None, causal)).abs().max() <= 1e-4
+        # AR-step form: context tgt[:, :j], one query pos_queries[:, i:j] with its mask row (model.py:126-137)
+        i, j = 5, 6
+        hid1 = m.model.decode(tgt[:, :j], memory, tgt_query=m.model.pos_queries[:, i:j], tgt_query_mask=causal[i:j, :j].to(DEV))
+        assert hid1.shape == (4, 1, cfg.embed_dim) and (hid1[:, 0] - hid[:, i]).abs().max() <= 1e-4
+        with pytest.raises(NotImplementedError):
+            m.model.decode(tgt, memory, tgt_query=torch.zeros(4, 26, cfg.embed_dim, device=DEV))
