@@ -50,11 +50,14 @@ __device__ __forceinline__ u32x4 pack_bf16x8(const float* v) {
 struct PanelHeads {          // q, k, v all as [b][h][t][d] (row-major per head), hd = 64
     bf16_t* seg[3]; int E, heads, hd, tokens;
     __device__ __forceinline__ u32x4 pack8(const float* v) const { return pack_bf16x8(v); }
+    // EC: the kernel's compile-time embedding width (== E); hd is 64.  The divisions by run-time values this function used to
+    // carry (n / E, col / hd, m / tokens: sixteen stores per column tile) were a VALU load comparable to the tile's MFMAs.
+    template <int EC>
     __device__ __forceinline__ void store_piece(int m, int n, const u32x4& piece) const {
-        const int which = n / E, col = n - which * E;
-        const int h = col / hd, d = col - h * hd;
-        const int b_ = m / tokens, t = m - b_ * tokens;
-        *reinterpret_cast<u32x4*>(seg[which] + (((size_t)b_ * heads + h) * tokens + t) * hd + d) = piece;
+        const int which = n / EC, col = n - which * EC;
+        const int h = col >> 6, d = col & 63;
+        const int b_ = tokens == 128 ? (m >> 7) : m / tokens, t = m - b_ * tokens;
+        *reinterpret_cast<u32x4*>(seg[which] + (((size_t)b_ * heads + h) * tokens + t) * 64 + d) = piece;
     }
 };
 
@@ -66,6 +69,7 @@ struct PanelGelu {           // out[m][n] = gelu(.), row-major [M, N]
         for (int i = 0; i < 8; ++i) g8[i] = gelu_poly(v[i]);
         return pack_bf16x8(g8);
     }
+    template <int EC>
     __device__ __forceinline__ void store_piece(int m, int n, const u32x4& piece) const {
         *reinterpret_cast<u32x4*>(out + (size_t)m * ldo + n) = piece;
     }
@@ -297,10 +301,10 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
                 const u32x4 first = lo ? pa : got, second = lo ? got : pb;
                 if constexpr (VARIANT == 1) {
                     asm volatile("" ::"v"(first[0]), "v"(first[3]), "v"(second[0]), "v"(second[3]));
-                    if (mrow < -5) epi.store_piece(r_first, col, first);
+                    if (mrow < -5) epi.template store_piece<E>(r_first, col, first);
                 } else {
-                    if (r_first < M) epi.store_piece(r_first, col, first);
-                    if (r_second < M) epi.store_piece(r_second, col, second);
+                    if (r_first < M) epi.template store_piece<E>(r_first, col, first);
+                    if (r_second < M) epi.template store_piece<E>(r_second, col, second);
                 }
             }
         }
