@@ -459,8 +459,8 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
     for (int rr = 0; rr < RPW; ++rr) picked[rr] = -1;
 
     if (do_finish) {
-        ds_prefetch<E, 1>(Wh, (C + 15) / 16, wave, wring);
-        // t'' = t' + b2 + partial[0] + partial[1] + ...   (fixed order: deterministic)
+        // t'' = t' + b2 + partial[0] + partial[1] + ...   (fixed order: deterministic).  These loads go out BEFORE the head's
+        // weight prefetch: vector memory returns in order, and a load queued behind eight LDS-DMA copies waits for all of them.
         for (int i = threadIdx.x; i < DS_ROWS * (E / 4); i += 64 * DS_NW) {
             const int row = i / (E / 4), c = (i - row * (E / 4)) * 4;
             const size_t gr = (size_t)min(row0 + row, M - 1) * E + c;
@@ -471,6 +471,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             for (int sp = 0; sp < DS_SPLIT; ++sp) v += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * M * E + gr);
             *reinterpret_cast<f32x4*>(tl + row * PT + c) = v;
         }
+        ds_prefetch<E, 1>(Wh, (C + 15) / 16, wave, wring);
         __syncthreads();
         ds_layernorm_rows<E>(tl, PT, abuf, PA, lnf_w, lnf_b, eps, wave);
         __syncthreads();
@@ -589,7 +590,6 @@ void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict_
     const int rt = blockIdx.x / DS_SPLIT, sp = blockIdx.x - rt * DS_SPLIT;
     const int row0 = rt * DS_ROWS;
 
-    ds_prefetch<E, TN>(Wco, TILES, wave, wring);
     for (int i = threadIdx.x; i < DS_ROWS * (E / 8); i += 64 * DS_NW) {
         const int row = i / (E / 8), c = (i - row * (E / 8)) * 8;
         const int gr = min(row0 + row, M - 1);
@@ -600,6 +600,7 @@ void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict_
         const int gr = min(row0 + row, M - 1);
         *reinterpret_cast<f32x4*>(tl + row * PT + c) = *reinterpret_cast<const f32x4*>(t_in + (size_t)gr * E + c);
     }
+    ds_prefetch<E, TN>(Wco, TILES, wave, wring);           // after the activation loads (in-order return, see the mid kernel)
     __syncthreads();
     {   // t' = t + ca @ Wco^T + bco   (every split needs it for norm2; split 0 publishes it)
         f32x4 acc[TN] = {};
