@@ -137,9 +137,13 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
                                              (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
     };
     for (int i = tid; i < N; i += 256) sbias[i] = bias[i];     // before the DMA prefetch (ordinary loads behind it drain it)
-    issue_stage(0);
-    if (S > 1) issue_stage(1);
-    if (S > 2) issue_stage(2);
+    // the first three weight stages are requested right after row tile 0's activation loads (below): vector memory returns in
+    // order, so activation rows queued behind twelve LDS-DMA copies would wait for all of them before the LayerNorm can start
+    if constexpr (VARIANT == 2) {
+        issue_stage(0);
+        if (S > 1) issue_stage(1);
+        if (S > 2) issue_stage(2);
+    }
 
     // ---- A panel: LayerNorm'd rows of this wave as MFMA fragments in registers --------------------------------------
     // lane (r16, g) of row tile j holds row m0 + 32 wid + 16 j + r16, elements [32 ks + 8 g, +8) for every k-step ks.
@@ -167,6 +171,12 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
             raw1[ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);            // a piece of row (r16 & 7) + 8
         }
         __builtin_amdgcn_sched_barrier(0);     // all 2 * KSTEPS row loads in flight before the first one is consumed
+        if (j == 0) {
+            issue_stage(0);
+            if (S > 1) issue_stage(1);
+            if (S > 2) issue_stage(2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             const u32x4 p0 = raw0[ks], p1 = raw1[ks];
