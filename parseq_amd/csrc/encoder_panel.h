@@ -31,6 +31,8 @@
 // 512 workgroups hit their epilogues together the stores arrived in 17 MB bursts: 88 us of a 194 us kernel
 // (tools/panel_bench.py ablations, profiles/r01_panel_ablation.log).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace pq {
@@ -83,6 +85,10 @@ __device__ __forceinline__ u32x4 swap_half_rows(const u32x4& v) {
     return o;
 }
 
+#ifndef PN_EARLY
+#define PN_EARLY 0        // k-steps of row tile 1 requested together with row tile 0 (measured: 0 -> 94.6 us, 6 -> 98.9, 12 -> 100.4:
+                          // the extra live registers turn into prologue spills that cost more than the latency they hide)
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // VARIANT (tools/panel_bench.py ablations): 0 full kernel; 1 no global stores; 2 no LayerNorm prologue (A fragments from
@@ -153,33 +159,31 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
         const bf16x8 f = *reinterpret_cast<const bf16x8*>(W + lane * 8);
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) { afrag[0][ks] = f; afrag[1][ks] = f; }
-    } else
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        // ONE pass over x, fully coalesced: per k-step (128 bytes of a row) the 8 lanes {(r16 & 7, g), ((r16 & 7) + 8, g)}
-        // read the 8 consecutive 16-byte pieces of ONE row — lanes r16 < 8 the even pieces 2g, lanes >= 8 the odd pieces
-        // 2g+1 — first for rows 0-7, then for rows 8-15; a DPP half-row swap then gives every lane both pieces of its own
-        // row.  (Reading each lane's own 32 bytes directly leaves 16-byte holes between lanes inside an instruction.)
+    }
+    // ONE pass over x, fully coalesced: per k-step (128 bytes of a row) the 8 lanes {(r16 & 7, g), ((r16 & 7) + 8, g)}
+    // read the 8 consecutive 16-byte pieces of ONE row — lanes r16 < 8 the even pieces 2g, lanes >= 8 the odd pieces
+    // 2g+1 — first for rows 0-7, then for rows 8-15; a DPP half-row swap then gives every lane both pieces of its own
+    // row.  (Reading each lane's own 32 bytes directly leaves 16-byte holes between lanes inside an instruction.)
+    // Row tile 1's first PN_EARLY k-steps can be requested together with row tile 0 (latency behind tile 0's LayerNorm
+    // arithmetic) — but at the 256-register budget that costs more in spills than it hides (see PN_EARLY).
+    u32x4 raw0[2][KSTEPS], raw1[2][KSTEPS];
+    auto load_rows = [&](auto jc, auto k0c, auto k1c) {
+        constexpr int j = decltype(jc)::value, k0 = decltype(k0c)::value, k1 = decltype(k1c)::value;
         const int rbase = m0 + wid * 32 + j * 16 + (rr & 7);
         const float* xlo = x + (size_t)min(rbase, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
         const float* xhi = x + (size_t)min(rbase + 8, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+#pragma unroll
+        for (int ks = k0; ks < k1; ++ks) {
+            raw0[j][ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);            // a piece of row (r16 & 7)
+            raw1[j][ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);            // a piece of row (r16 & 7) + 8
+        }
+    };
+    auto ln_rows = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
         float4 xa[KSTEPS], xb[KSTEPS];
-        u32x4 raw0[KSTEPS], raw1[KSTEPS];
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
-            raw0[ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);            // a piece of row (r16 & 7)
-            raw1[ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);            // a piece of row (r16 & 7) + 8
-        }
-        __builtin_amdgcn_sched_barrier(0);     // all 2 * KSTEPS row loads in flight before the first one is consumed
-        if (j == 0) {
-            issue_stage(0);
-            if (S > 1) issue_stage(1);
-            if (S > 2) issue_stage(2);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-            const u32x4 p0 = raw0[ks], p1 = raw1[ks];
+            const u32x4 p0 = raw0[j][ks], p1 = raw1[j][ks];
             // lanes < 8 own the first row: keep p0 (even piece), give p1; lanes >= 8 own the second: keep p1 (odd piece), give p0
             const u32x4 got = swap_half_rows(lo_half ? p1 : p0);
             const u32x4 ev = lo_half ? p0 : got, od = lo_half ? got : p1;          // even piece 2g, odd piece 2g+1 of MY row
@@ -215,6 +219,21 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
             f[6] = static_cast<bf16_t>((b.z - mean) * rstd * gb.z + bb.z); f[7] = static_cast<bf16_t>((b.w - mean) * rstd * gb.w + bb.w);
             afrag[j][ks] = f;
         }
+    };
+    if constexpr (VARIANT != 2) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using KE = std::integral_constant<int, PN_EARLY>; using KA = std::integral_constant<int, KSTEPS>;
+        load_rows(I0{}, I0{}, KA{});
+        load_rows(I1{}, I0{}, KE{});
+        __builtin_amdgcn_sched_barrier(0);     // every row load requested so far is in flight before the first one is consumed
+        issue_stage(0);
+        if (S > 1) issue_stage(1);
+        if (S > 2) issue_stage(2);
+        __builtin_amdgcn_sched_barrier(0);
+        ln_rows(I0{});
+        load_rows(I1{}, KE{}, KA{});
+        __builtin_amdgcn_sched_barrier(0);
+        ln_rows(I1{});
     }
 
     // ---- main loop over the W stream ---------------------------------------------------------------------------------
