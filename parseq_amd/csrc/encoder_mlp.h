@@ -314,19 +314,27 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     // lane (r16, g), row tile j, 32-column group q32 (tile pair): columns cg = 32 q32 + 8 g + [0, 8) as piece A = [0,4), B = [4,8)
     // All old x values of a row tile are requested before the first store (the compiler cannot hoist a load above a store
     // to the same array: the naive load -> add -> store chain cost 19 us per workgroup in s_memtime stamps).
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int mrow = m0 + wid * 32 + j * 16;
-        const int r_first = mrow + (rr & 7), r_second = r_first + 8;
-        const int rf = min(r_first, M - 1), rs = min(r_second, M - 1);
+    // Row tile 1's old values are requested piece by piece while row tile 0 is being stored (each load right after the
+    // piece of tile 0 whose registers it takes over): requested only after tile 0's 24 stores they would return behind all of
+    // them (vector memory is in order), requested all up front they do not fit (44 spills, measured slower).
+    float4 old1[E / 32], old2[E / 32], nxt1[E / 32], nxt2[E / 32];
+    {
+        const int r_first = m0 + wid * 32 + (rr & 7);
+        const int rf = min(r_first, M - 1), rs = min(r_first + 8, M - 1);
         const int cbase = 8 * g + (lo_half ? 0 : 4);
-        float4 old1[E / 32], old2[E / 32];
 #pragma unroll
         for (int q32 = 0; q32 < E / 32; ++q32) {
             old1[q32] = *reinterpret_cast<const float4*>(x + (size_t)rf * E + 32 * q32 + cbase);
             old2[q32] = *reinterpret_cast<const float4*>(x + (size_t)rs * E + 32 * q32 + cbase);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mrow = m0 + wid * 32 + j * 16;
+        const int r_first = mrow + (rr & 7), r_second = r_first + 8;
+        const int cbase = 8 * g + (lo_half ? 0 : 4);
+        const int nf = min(r_first + 16, M - 1), ns = min(r_second + 16, M - 1);
 #pragma unroll
         for (int q32 = 0; q32 < E / 32; ++q32) {
             const int ng = q32 >> 2, pr = q32 & 3;
@@ -341,13 +349,18 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
             const u32x4 got = swap_half_rows(lo_half ? pb : pa);
             const u32x4 first = lo_half ? pa : got, second = lo_half ? got : pb;
             const int col = 32 * q32 + cbase;
+            const float4 o1 = j == 0 ? old1[q32] : nxt1[q32], o2 = j == 0 ? old2[q32] : nxt2[q32];
+            if (j == 0) {
+                nxt1[q32] = *reinterpret_cast<const float4*>(x + (size_t)nf * E + col);
+                nxt2[q32] = *reinterpret_cast<const float4*>(x + (size_t)ns * E + col);
+            }
             if (r_first < M) {
-                float4 o = old1[q32];
+                float4 o = o1;
                 o.x += __uint_as_float(first[0]); o.y += __uint_as_float(first[1]); o.z += __uint_as_float(first[2]); o.w += __uint_as_float(first[3]);
                 *reinterpret_cast<float4*>(x + (size_t)r_first * E + col) = o;
             }
             if (r_second < M) {
-                float4 o = old2[q32];
+                float4 o = o2;
                 o.x += __uint_as_float(second[0]); o.y += __uint_as_float(second[1]); o.z += __uint_as_float(second[2]); o.w += __uint_as_float(second[3]);
                 *reinterpret_cast<float4*>(x + (size_t)r_second * E + col) = o;
             }
