@@ -17,6 +17,9 @@ cites the reference lines it restates (paths relative to the upstream repo root)
   decoder_layer()     strhub/models/parseq/modules.py:55-98 (forward_stream + forward, update_content=False)
   decode()            strhub/models/parseq/model.py:86-103 + modules.py:101-125 (Decoder, final LayerNorm)
   forward()           strhub/models/parseq/model.py:105-169 (AR loop, NAR branch, cloze refinement, early exit)
+  attn_masks_from_perm(), training_loss()
+                      strhub/models/parseq/system.py:152-199 (row N3: permutation masks, K-permutation loss; pinned by
+                      oracle/make_golden_train.py, which runs the reference's own system.py, loss and gradients)
 
 Pinning: `oracle/make_golden.py` executes the reference's own model.py/modules.py (on the timm stand-in)
 in the build container and freezes inputs + outputs under tests/golden/; tests/test_oracle.py requires this
@@ -329,3 +332,46 @@ def validation_loss(logits: Tensor, targets: Tensor, pad_id: int):
     (targets != pad_id).sum()) — `targets` is tokenizer.encode(labels)[:, 1:]."""
     loss = F.cross_entropy(logits.float().flatten(end_dim=1), targets.flatten(), ignore_index=pad_id)
     return loss, (targets != pad_id).sum()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# "next" row N3 (training step, forward half and — through autograd on this restatement — its gradients)
+# ----------------------------------------------------------------------------------------------------------
+
+def attn_masks_from_perm(perm: Tensor):
+    """strhub/models/parseq/system.py:152-166 (`generate_attn_masks`).  `perm` lists sequence positions in the order
+    they are generated (perm[0] == 0 is <bos>).  Position q may look at position k only when k comes earlier in `perm`;
+    the query mask additionally hides q itself.  Returns bool (content_mask [sz-1, sz-1], query_mask [sz-1, sz-1]),
+    True = masked.  Restated through the rank of every position instead of the reference's row-by-row fill."""
+    sz = perm.shape[0]
+    rank = torch.empty(sz, dtype=torch.long)
+    rank[perm] = torch.arange(sz)
+    later = rank.unsqueeze(0) > rank.unsqueeze(1)           # [q, k]: k is generated after q
+    content_mask = later[:-1, :-1].clone()
+    query_mask = (later | torch.eye(sz, dtype=torch.bool))[1:, :-1].clone()
+    return content_mask, query_mask
+
+
+def training_loss(sd: dict, cfg: OracleConfig, images: Tensor, tgt: Tensor, perms: Tensor, rounding: Optional[str] = None):
+    """strhub/models/parseq/system.py:168-199 (`training_step`) with dropout off: one `encode`, one teacher-forced decode
+    per permutation, cross-entropy weighted by the number of non-<pad> targets; after the second permutation the <eos>
+    targets are dropped (:191-195).  `tgt` = tokenizer.encode(labels) [N, T+2]; `perms` = gen_tgt_perms(tgt) [K, T+2].
+    Returns (loss, per-permutation losses [K], per-permutation target counts [K])."""
+    memory = encode(sd, cfg, images, rounding)
+    tgt_in, tgt_out = tgt[:, :-1], tgt[:, 1:]
+    tgt_padding_mask = (tgt_in == cfg.pad_id) | (tgt_in == cfg.eos_id)
+    total, numel, per_perm, counts = 0.0, 0, [], []
+    n = int((tgt_out != cfg.pad_id).sum())
+    for i, perm in enumerate(perms):
+        _, query_mask = attn_masks_from_perm(perm)
+        out = decode(sd, cfg, tgt_in, memory, None, tgt_padding_mask, tgt_query_mask=query_mask, rounding=rounding)
+        logits = head(sd, out, rounding).flatten(end_dim=1)
+        ce = F.cross_entropy(logits.float(), tgt_out.flatten(), ignore_index=cfg.pad_id)
+        total = total + n * ce
+        numel += n
+        per_perm.append(ce.detach())
+        counts.append(n)
+        if i == 1:
+            tgt_out = torch.where(tgt_out == cfg.eos_id, cfg.pad_id, tgt_out)
+            n = int((tgt_out != cfg.pad_id).sum())
+    return total / numel, torch.stack(per_perm), torch.tensor(counts)

@@ -5,13 +5,20 @@ Mirrors `strhub/models/parseq/system.py:33-88` (constructor arguments, `.model`,
 `.tokenizer`, `.charset_adapter`, `.bos_id/.eos_id/.pad_id` :185-192).  The reference builds on
 `pytorch_lightning.LightningModule`; this is a plain `nn.Module` that provides the attributes those scripts use
 (`.hparams`, `.device`, `.eval()`, `.to()`), because Lightning is framework glue outside the hot path.
-Training (`training_step`, permutation sampling, optimiser) is out of scope.
+
+Row N3 (training step) is built as far as its forward half: the permutation sampler and the
+attention-mask construction (`system.py:90-166`, host logic, bit-identical to the reference under the same numpy / torch
+seeds) and the K-permutation loss of `training_step` (`system.py:168-199`) evaluated on the device with dropout off.
+The loss carries no autograd graph: backward kernels and the optimiser are not built.
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
+from itertools import permutations
 from typing import Any, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn as nn
 from torch import Tensor
@@ -99,6 +106,89 @@ def eval_step(system, batch, validation: bool):
     return dict(output=BatchResult(total, correct, ned, confidence, label_length, loss, loss_numel))
 
 
+# Of the 24 orderings of four characters (lexicographic index), the twelve the reference keeps when mirrored pairs are
+# requested, so that no kept ordering is the reverse of another (system.py:110-111; a fact of the algorithm, restated).
+_POOL4_MIRRORED = (0, 3, 4, 6, 9, 10, 12, 16, 17, 18, 19, 21)
+
+
+def sample_char_orders(num_chars: int, max_gen_perms: int, perm_forward: bool, perm_mirrored: bool,
+                       rng: np.random.Generator) -> Tensor:
+    """The character orderings of `gen_tgt_perms` before <bos> / <eos> are attached (system.py:96-132): [K', num_chars]
+    int64 on the CPU.  Draws from `rng` (pool branch, < 5 characters) or from torch's default CPU generator
+    (`torch.randperm`, >= 5 characters) in the reference's order, so equal seeds give equal orderings."""
+    forward = [torch.arange(num_chars)] if perm_forward else []
+    limit = math.factorial(num_chars) // (2 if perm_mirrored else 1)
+    want = min(max_gen_perms, limit) - len(forward)
+    if num_chars < 5:
+        keep = _POOL4_MIRRORED if (num_chars == 4 and perm_mirrored) else range(limit)
+        every = list(permutations(range(num_chars)))
+        pool = torch.tensor([every[i] for i in keep][1 if perm_forward else 0:], dtype=torch.long).reshape(-1, num_chars)
+        # (with perm_forward off the reference fails here — it stacks an empty list, system.py:122; this draws from the pool)
+        drawn = [pool[rng.choice(len(pool), size=want, replace=False)]] if len(pool) else []
+        return torch.cat(([torch.stack(forward)] if forward else []) + drawn)
+    return torch.stack(forward + [torch.randperm(num_chars) for _ in range(want)])
+
+
+def gen_tgt_perms(tgt: Tensor, max_gen_perms: int, perm_forward: bool, perm_mirrored: bool, rng: np.random.Generator) -> Tensor:
+    """PARSeq.gen_tgt_perms (system.py:90-150): position orderings [K, T + 2] shared by the whole batch — column 0 is <bos>,
+    the last column <eos>; row 1 (when present) is the right-to-left ordering with <eos> generated first."""
+    num_chars = tgt.shape[1] - 2
+    if num_chars == 1:
+        return torch.arange(3).unsqueeze(0)
+    orders = sample_char_orders(num_chars, max_gen_perms, perm_forward, perm_mirrored, rng)
+    if perm_mirrored:
+        orders = torch.stack([orders, orders.flip(-1)], dim=1).reshape(-1, num_chars)      # pairs next to each other
+    k = len(orders)
+    perms = torch.cat([orders.new_zeros(k, 1), orders + 1, orders.new_full((k, 1), num_chars + 1)], dim=1)
+    if k > 1:
+        perms[1, 1:] = torch.arange(num_chars + 1, 0, -1)
+    return perms
+
+
+def generate_attn_masks(perm: Tensor):
+    """PARSeq.generate_attn_masks (system.py:152-166): bool (content_mask, query_mask), True = masked.  Position q sees
+    position k only if k precedes q in `perm`; the query mask also hides q itself and drops the <bos> query row, both drop
+    the <eos> key column.  Computed from each position's rank in `perm`."""
+    sz = perm.shape[0]
+    rank = torch.empty(sz, dtype=torch.long, device=perm.device)
+    rank[perm] = torch.arange(sz, device=perm.device)
+    after = rank.unsqueeze(0) > rank.unsqueeze(1)
+    hidden = after | torch.eye(sz, dtype=torch.bool, device=perm.device)
+    return after[:-1, :-1].contiguous(), hidden[1:, :-1].contiguous()
+
+
+def permutation_loss(system, images: Tensor, labels, perms: Optional[Tensor] = None):
+    """Forward half of PARSeq.training_step (system.py:168-199) with dropout off: one `encode`, one teacher-forced decode
+    per permutation (the depth-1 decoder only reads the query mask), the cross-entropy of each weighted by its count of
+    non-<pad> targets; <eos> targets are dropped after the first two permutations (:191-195).  Everything after the mask
+    construction runs on the device (`parseq_decode_logits`, `parseq_cross_entropy`); no host synchronisation.
+    Returns (loss, per-permutation losses [K], per-permutation target counts [K], perms)."""
+    from . import _native
+    dev = system.device
+    tgt = system.tokenizer.encode(labels, dev)
+    if perms is None:
+        perms = system.gen_tgt_perms(tgt)
+    tgt_in, tgt_out = tgt[:, :-1], tgt[:, 1:]
+    L = tgt_in.shape[1]
+    masks = torch.stack([generate_attn_masks(p)[1] for p in perms.cpu()]).to(torch.uint8).to(dev)       # one upload
+    padding = ((tgt_in == system.pad_id) | (tgt_in == system.eos_id))
+    system.model.encode(images)                      # leaves the cross-attention K / V of these images on the device
+    targets = [tgt_out.to(torch.int32).contiguous().view(-1),
+               torch.where(tgt_out == system.eos_id, system.pad_id, tgt_out).to(torch.int32).contiguous().view(-1)]
+    K = len(perms)
+    losses = torch.empty(K, dtype=torch.float32, device=dev)
+    counts = torch.empty(K, dtype=torch.int32, device=dev)
+    ws = torch.empty(tgt_out.numel(), dtype=torch.float32, device=dev)
+    for i in range(K):
+        logits = system.model.decode_logits(tgt_in, 0, L, padding, masks[i])
+        flat = logits.view(-1, logits.shape[-1])
+        _native.check(_native.lib().parseq_cross_entropy(_native.ptr(flat), _native.ptr(targets[min(i // 2, 1)]), flat.shape[0],
+                                                         flat.shape[1], system.pad_id, _native.ptr(losses[i:]),
+                                                         _native.ptr(counts[i:]), _native.ptr(ws), _native.stream_ptr()))
+    weights = counts.float()
+    return (losses * weights).sum() / weights.sum(), losses, counts, perms
+
+
 class PARSeq(nn.Module):
 
     def __init__(self, charset_train: str, charset_test: str, max_label_length: int, batch_size: int, lr: float,
@@ -123,6 +213,10 @@ class PARSeq(nn.Module):
         self.model = Model(len(self.tokenizer), max_label_length, img_size, patch_size, embed_dim, enc_num_heads,
                            enc_mlp_ratio, enc_depth, dec_num_heads, dec_mlp_ratio, dec_depth, decode_ar, refine_iters,
                            dropout, precision=precision)
+        # permutation sampling state (system.py:81-85)
+        self.rng = np.random.default_rng()
+        self.max_gen_perms = perm_num // 2 if perm_mirrored else perm_num
+        self.perm_forward, self.perm_mirrored = perm_forward, perm_mirrored
 
     @property
     def device(self) -> torch.device:
@@ -146,6 +240,19 @@ class PARSeq(nn.Module):
 
     def forward_logits_loss(self, images: Tensor, labels):
         return forward_logits_loss(self, images, labels)
+
+    # ---- row N3, forward half (system.py:90-199) ------------------------------------------------------------------
+    def gen_tgt_perms(self, tgt: Tensor) -> Tensor:
+        """Orderings are drawn on the host (a few hundred bytes per step) whatever device `tgt` lives on."""
+        return gen_tgt_perms(tgt, self.max_gen_perms, self.perm_forward, self.perm_mirrored, self.rng)
+
+    def generate_attn_masks(self, perm: Tensor):
+        return generate_attn_masks(perm)
+
+    def training_step(self, batch, batch_idx):
+        """The loss of system.py:168-199 for one batch, dropout off, WITHOUT an autograd graph (backward is not built)."""
+        images, labels = batch
+        return permutation_loss(self, images, labels)[0]
 
     def validation_step(self, batch, batch_idx):
         return self._eval_step(batch, True)

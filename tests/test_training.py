@@ -1,0 +1,184 @@
+"""Row N3 (training step), forward half.
+
+CPU: the permutation sampler and mask construction of parseq_amd/system.py (host logic) and the oracle's `training_loss`
+against golden vectors minted by executing the reference's own `strhub/models/parseq/system.py` (oracle/make_golden_train.py),
+plus the oracle's autograd gradients against the reference's — the gate the backward kernels will be held to.
+GPU: the device evaluation of the K-permutation loss (`parseq_decode_logits` + `parseq_cross_entropy` per permutation)
+against the oracle on the same crops, labels and permutations."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle import parseq_oracle as O
+from oracle.synth import CONFIGS, synth_images, synth_state_dict
+from parseq_amd.system import gen_tgt_perms, generate_attn_masks
+from parseq_amd.tokenizer import Tokenizer
+
+CHARSET_94 = ("0123456789abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ"
+              "!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~")
+
+
+@pytest.fixture(scope='module')
+def perm_golden():
+    with open(os.path.join(GOLDEN_DIR, 'perms.json')) as f:
+        return json.load(f)
+
+
+def _sample(case):
+    rng = np.random.default_rng(case['np_seed'])
+    torch.manual_seed(case['torch_seed'])
+    max_gen = case['perm_num'] // 2 if case['perm_mirrored'] else case['perm_num']
+    return gen_tgt_perms(torch.zeros(3, case['num_chars'] + 2, dtype=torch.long), max_gen, case['perm_forward'],
+                         case['perm_mirrored'], rng)
+
+
+def test_permutation_sampler_matches_reference(perm_golden):
+    """Every label length 1..25 x six (perm_num, perm_forward, perm_mirrored) settings, same numpy / torch seeds: identical
+    orderings (pool branch below five characters, torch.randperm above, the one-character special case)."""
+    if perm_golden['torch'] != torch.__version__ or perm_golden['numpy'] != np.__version__:
+        pytest.skip('seeded streams are only comparable under the torch / numpy builds the goldens were minted with')
+    assert len(perm_golden['perms']) == 147
+    for case in perm_golden['perms']:
+        assert _sample(case).tolist() == case['perms'], case
+
+
+@pytest.mark.parametrize('setting', [(6, True, True), (6, False, True), (5, True, False), (1, True, False), (24, True, True)])
+def test_permutation_sampler_properties(setting):
+    """Seed-independent facts of system.py:90-150: every row is an ordering of 0..T+1 that starts at <bos>; the count is
+    min(perm_num, T! [/ 2 * 2]); mirrored pairs are reverses of each other; row 1 is right-to-left with <eos> first; below
+    five characters no ordering repeats."""
+    perm_num, fwd, mir = setting
+    rng = np.random.default_rng(5)
+    for T in range(1, 26):
+        p = gen_tgt_perms(torch.zeros(2, T + 2), perm_num // 2 if mir else perm_num, fwd, mir, rng)
+        if T == 1:
+            assert p.tolist() == [[0, 1, 2]]
+            continue
+        full = math.factorial(T)
+        assert len(p) == (2 * min(perm_num // 2, full // 2) if mir else min(perm_num, full))
+        assert (p.sort(dim=1).values == torch.arange(T + 2)).all() and (p[:, 0] == 0).all()
+        if fwd:
+            assert p[0].tolist() == list(range(T + 2))
+        if len(p) > 1:
+            assert p[1].tolist() == [0] + list(range(T + 1, 0, -1))
+        rest = torch.cat([p[:1], p[2:]])
+        assert (rest[:, -1] == T + 1).all()                        # everywhere else <eos> is generated last
+        if mir:
+            chars = p[:, 1:-1]
+            assert torch.equal(chars[2::2].flip(-1), chars[3::2])  # (pair 0 is forward / the rewritten row 1)
+        if T < 5:
+            assert len({tuple(r) for r in p.tolist()}) == len(p)
+
+
+def test_attention_masks_match_reference(perm_golden):
+    for case in perm_golden['masks']:
+        perm = torch.tensor(case['perm'])
+        for fn in (generate_attn_masks, O.attn_masks_from_perm):     # host logic and the oracle's restatement
+            cm, qm = fn(perm)
+            assert cm.dtype == qm.dtype == torch.bool
+            assert cm.int().tolist() == case['content_mask'] and qm.int().tolist() == case['query_mask']
+    # forward ordering: the query mask is the strict-causal mask shifted by one (query i sees <bos> .. token i-1 ... i.e. keys < i+1)
+    _, qm = generate_attn_masks(torch.arange(8))
+    assert torch.equal(qm, torch.triu(torch.ones(7, 7, dtype=torch.bool), diagonal=1))
+
+
+@pytest.fixture(scope='module')
+def train_golden(golden):
+    return golden('parseq_train')
+
+
+def test_oracle_training_loss_matches_reference(train_golden):
+    """One training step of the reference (dropout off) on the synthetic PARSeq-S: the oracle's loss equals the reference's
+    to fp32 round-off, the per-permutation target counts follow the <eos>-dropping rule, and autograd through the oracle
+    reproduces the reference's gradient for every one of the 175 parameters."""
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = {k: v.requires_grad_(True) for k, v in synth_state_dict(cfg, 0).items()}
+    tok = Tokenizer(CHARSET_94)
+    tgt = tok.encode(meta['labels'])
+    assert torch.equal(g['images'], synth_images(len(meta['labels']), cfg, seed=meta['image_seed']))
+    perms = g['perms'].long()
+    assert perms.tolist() == meta['perms'] and perms.shape == (6, 27)
+    loss, per_perm, counts = O.training_loss(sd, cfg, g['images'], tgt, perms)
+    assert abs(float(loss.detach()) - meta['loss']) <= 2e-6 * meta['loss']
+    chars = sum(len(s) for s in meta['labels'])
+    assert counts.tolist() == [chars + 8] * 2 + [chars] * 4
+    loss.backward()
+    assert len(meta['grads']) == 175
+    for k, want in meta['grads'].items():
+        grad = sd[k].grad
+        assert (grad is None) == want['none'], k
+        got = float(grad.double().norm()) if grad is not None else 0.0
+        assert abs(got - want['norm']) <= 1e-4 * max(want['norm'], 1e-4), (k, got, want['norm'])
+    for k, want in g.items():
+        if k.startswith('grad.'):
+            torch.testing.assert_close(sd[k[5:]].grad, want, rtol=0, atol=1e-6 * max(1.0, float(want.abs().max()) * 100))
+
+
+def test_training_loss_reduction_rule():
+    """system.py:184-196 on hand-made numbers: the loss is the target-count-weighted mean of the per-permutation means, with
+    the counts of permutations 2.. excluding <eos>."""
+    cfg = CONFIGS['parseq-tiny']
+    sd = synth_state_dict(cfg, 3)
+    tok = Tokenizer(CHARSET_94)
+    tgt = tok.encode(['abc', 'defgh', 'i'])
+    perms = gen_tgt_perms(tgt, 3, True, True, np.random.default_rng(0))
+    with torch.inference_mode():
+        loss, per_perm, counts = O.training_loss(sd, cfg, synth_images(3, cfg, 9), tgt, perms)
+    assert counts.tolist() == [12, 12, 9, 9, 9, 9]
+    want = float((per_perm.double() * counts).sum() / counts.sum())
+    assert abs(float(loss) - want) <= 1e-6 * want
+
+
+# ---- device ---------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision,tol', [('fp32', 1e-4), ('bf16', 2e-2)])
+def test_permutation_loss_on_device(train_golden, precision, tol):
+    """The device evaluation (one encode, six masked teacher-forced decodes, six cross-entropies, no host sync) against the
+    reference's loss for the same crops / labels / permutations, and per permutation against the oracle."""
+    from gpu_util import DEV, make_model
+    from parseq_amd.system import permutation_loss
+    g, meta = train_golden
+    m = make_model('parseq', precision)
+    perms = g['perms'].long()
+    loss, per_perm, counts, _ = permutation_loss(m, g['images'].to(DEV), meta['labels'], perms)
+    torch.cuda.synchronize()
+    assert not loss.requires_grad
+    cfg = CONFIGS['parseq']
+    with torch.inference_mode():
+        _, want_pp, want_counts = O.training_loss(synth_state_dict(cfg, 0), cfg, g['images'], m.tokenizer.encode(meta['labels']), perms)
+    assert counts.cpu().tolist() == want_counts.tolist()
+    assert (per_perm.cpu() - want_pp).abs().max() <= tol * float(want_pp.max())
+    assert abs(float(loss) - meta['loss']) <= tol * meta['loss']
+
+
+@pytest.mark.gpu
+def test_training_step_draws_permutations_and_is_repeatable(train_golden):
+    """`training_step` = sampler + loss: with the sampler state rewound the same loss comes back bit for bit; short labels
+    (pool branch) and one-character labels (single ordering) go through the same path."""
+    from gpu_util import DEV, make_model
+    g, meta = train_golden
+    m = make_model('parseq', 'bf16')
+    images = g['images'].to(DEV)
+    out = []
+    for _ in range(2):
+        m.rng = np.random.default_rng(3)
+        torch.manual_seed(4)
+        out.append(float(m.training_step((images, meta['labels']), 0)))
+    assert out[0] == out[1] and math.isfinite(out[0]) and 3.0 < out[0] < 8.0
+    for labels in (['ab', 'c', 'abcd', 'xyz', 'q', 'rs', 'tuv', 'w'], ['a', 'b', 'c', 'd', 'e', 'f', 'g', 'h']):
+        m.rng = np.random.default_rng(3)
+        tgt = m.tokenizer.encode(labels)
+        perms = m.gen_tgt_perms(tgt)
+        m.rng = np.random.default_rng(3)
+        got = float(m.training_step((images, labels), 0))
+        cfg = CONFIGS['parseq']
+        with torch.inference_mode():
+            want = float(O.training_loss(synth_state_dict(cfg, 0), cfg, g['images'], tgt, perms)[0])
+        assert abs(got - want) <= 2e-2 * want, (labels, got, want)
