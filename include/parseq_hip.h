@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 2
+#define PARSEQ_ABI_VERSION 3
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -188,6 +188,37 @@ int parseq_postprocess(const float* logits, int batch, int L, int C, int eos_id,
  * loss_out / numel_out: device scalars; workspace: device, `rows` floats.  Deterministic (fixed summation order). */
 int parseq_cross_entropy(const float* logits, const int32_t* targets, int rows, int C, int ignore_index, float* loss_out,
                          int32_t* numel_out, float* workspace, void* stream);
+
+/* ---- "next" row N3: training step, decoder side (strhub/models/parseq/system.py:168-199 + loss.backward()) ---------- */
+
+/* Offset (in floats) of parameter `index` inside a gradient buffer, and the buffer's length: gradients are laid out like
+ * the model's fp32 master weights, every tensor starting at a multiple of 8 floats.  -1 for a bad index. */
+int64_t parseq_model_param_offset(const parseq_model* m, int index);
+int64_t parseq_model_grad_elems(const parseq_model* m);
+
+/* Loss of the K-permutation training objective (system.py:168-199, dropout off) for a batch whose encoder output is
+ * `memory`, and its gradients — what `loss.backward()` leaves in `.grad` of every decoder-side parameter (decoder.*,
+ * head.*, text_embed.*, pos_queries; system.py:183-196 through model.py:86-103, modules.py:55-125) and the gradient
+ * w.r.t. `memory` that the encoder backward starts from.  fp32 throughout, computed from the model's master weights;
+ * deterministic.
+ *   memory            device fp32 [batch, tokens, embed_dim]             (parseq_encode output)
+ *   tokens            device int32 [batch, ctx_len]   tgt[:, :-1] of tokenizer.encode(labels)            (system.py:176)
+ *   targets           device int32 [2][batch * ctx_len]: tgt[:, 1:] flattened, and the same with <eos> replaced by <pad>
+ *                     (used from the third permutation on, system.py:191-195)
+ *   key_padding_mask  device uint8 [batch, ctx_len]   (tgt_in == pad) | (tgt_in == eos)                   (system.py:179)
+ *   query_masks       device uint8 [num_perms][ctx_len][ctx_len]   generate_attn_masks(perm)[1]           (system.py:152-166)
+ *   total_targets     sum over the permutations of their count of non-<pad> targets (the loss denominator, :189,196)
+ *   loss_out          device fp32 [1 + num_perms]: the loss, then each permutation's mean cross-entropy
+ *   grads             device fp32 [parseq_model_grad_elems]: ACCUMULATED into (zero it for a fresh step); encoder slots untouched
+ *   dmemory           device fp32 [batch, tokens, embed_dim]: written
+ *   workspace         device, parseq_train_decoder_workspace_bytes(...) bytes; after the call it holds the intermediates of
+ *                     the last permutation (parseq_train_decoder_workspace_offset names them; used by the parity tests) */
+size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, int batch, int ctx_len, int num_perms);
+int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, int batch, int ctx_len, int num_perms, const char* name);
+int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* tokens, const int32_t* targets,
+                         const uint8_t* key_padding_mask, const uint8_t* query_masks, int batch, int ctx_len, int num_perms,
+                         int total_targets, float* loss_out, float* grads, float* dmemory, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
 

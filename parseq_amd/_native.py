@@ -16,7 +16,7 @@ from . import build as _build
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8 = 0, 1, 2
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING = 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class ParseqConfig(C.Structure):
@@ -63,6 +63,12 @@ SIGNATURES = {
     'parseq_vitstr_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'parseq_decode_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    'parseq_model_param_offset': (C.c_int64, [C.c_void_p, C.c_int]),
+    'parseq_model_grad_elems': (C.c_int64, [C.c_void_p]),
+    'parseq_train_decoder_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    'parseq_train_decoder_workspace_offset': (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]),
+    'parseq_train_decoder': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'parseq_op_layernorm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_void_p]),
     'parseq_op_linear': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -25,6 +25,7 @@
 #include "encoder_mlp.h"
 #include "gemm.h"
 #include "rowops.h"
+#include "train_ops.h"
 
 using namespace pq;
 
@@ -996,6 +997,213 @@ extern "C" int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int b
                                     void* stream) {
     if (!hidden_out) return fail(PARSEQ_E_INVALID, "null hidden_out");
     return decode_entry(p, tokens, batch, ctx_len, q_start, q_len, query_mask, key_padding_mask, logits_out, hidden_out, stream);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// training step, decoder side: loss of system.py:168-199 and its gradients, fp32
+// -------------------------------------------------------------------------------------------------------------------
+static int sgemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
+                 long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate) {
+    if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
+    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0};
+    hipLaunchKernelGGL(sgemm_kernel, dim3((N + SG_BN - 1) / SG_BN, (M + SG_BM - 1) / SG_BM), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int colsum(hipStream_t s, const float* A, long lda, int M, int N, float* out, bool accumulate) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, A, lda, M, N, out, accumulate ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// y[M, N] = x[M, K] W[N, K]^T + bias + R[m % rper]
+static int lin_fwd(hipStream_t s, const float* x, const float* W, const float* bias, const float* R, int rper, float* y, int M, int N, int K) {
+    return sgemm(s, x, K, 1, W, 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false);
+}
+// dW[N, K] += dy[M, N]^T x[M, K];  db[N] += column sums of dy;  dx[M, K] = dy W   (dx may be null)
+static int lin_bwd(hipStream_t s, const float* x, const float* W, const float* dy, float* dW, float* db, float* dx, int M, int N, int K) {
+    CHK(sgemm(s, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true));
+    CHK(colsum(s, dy, N, M, N, db, true));
+    if (dx) CHK(sgemm(s, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false));
+    return 0;
+}
+// dx = add + LayerNorm backward; dgamma += column sums of dy * xhat; dbeta += column sums of dy.  `tmp` is [rows, E] scratch.
+static int ln_bwd(hipStream_t s, const float* x, const float* gamma, const float* dy, const float* add, float* dx, float* dgamma, float* dbeta,
+                  float* tmp, int rows, int E, float eps) {
+    if (E > 768) return fail(PARSEQ_E_INVALID, "layernorm backward: E=%d > 768", E);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, dy, add, dx, tmp, rows, E, eps);
+    HIPCHK(hipGetLastError());
+    CHK(colsum(s, tmp, E, rows, E, dgamma, true));
+    return colsum(s, dy, E, rows, E, dbeta, true);
+}
+static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backward) {
+    const size_t lds = train_attn_lds_floats(a.Lq, a.Lk, backward) * sizeof(float);
+    if (lds > 150 * 1024) return fail(PARSEQ_E_INVALID, "training attention: %d x %d does not fit in LDS", a.Lq, a.Lk);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_done = true;
+    }
+    if (backward) hipLaunchKernelGGL(train_attn_kernel<true>, dim3(B * a.H), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(train_attn_kernel<false>, dim3(B * a.H), dim3(256), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+struct TrainDecoderLayout {          // offsets in floats into the caller's workspace
+    size_t content, cn, kvc, qn, qsa, kvm, sa_o, t1, n1, q2, ca_o, t2, n2, hpre, hact, t3, out, logits;
+    size_t d_a, d_b, d_c, d_h, tmp, d_kvc, d_kvm, d_qsa, d_pq, d_qb, row_loss, losses, counts, total;
+};
+static TrainDecoderLayout train_decoder_layout(const parseq_model* m, int B, int L, int K) {
+    const size_t E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, M = (size_t)B * L, MS = (size_t)B * S;
+    TrainDecoderLayout o;
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t at = off; off += (n + 63) / 64 * 64; return at; };
+    o.content = take(M * E); o.cn = take(M * E); o.kvc = take(M * 2 * E); o.qn = take(L * E); o.qsa = take(L * E); o.kvm = take(MS * 2 * E);
+    o.sa_o = take(M * E); o.t1 = take(M * E); o.n1 = take(M * E); o.q2 = take(M * E); o.ca_o = take(M * E); o.t2 = take(M * E); o.n2 = take(M * E);
+    o.hpre = take(M * F); o.hact = take(M * F); o.t3 = take(M * E); o.out = take(M * E); o.logits = take(M * C);
+    o.d_a = take(M * E); o.d_b = take(M * E); o.d_c = take(M * E); o.d_h = take(M * F); o.tmp = take(M * E);
+    o.d_kvc = take(M * 2 * E); o.d_kvm = take(MS * 2 * E); o.d_qsa = take(L * E); o.d_pq = take(L * E); o.d_qb = take(M * E);
+    o.row_loss = take(M); o.losses = take(K + 1); o.counts = take(K + 1);
+    o.total = off;
+    return o;
+}
+
+extern "C" int64_t parseq_model_param_offset(const parseq_model* m, int index) {
+    if (!m || index < 0 || index >= (int)m->params.size()) return -1;
+    return (int64_t)m->params[index].offset;
+}
+extern "C" int64_t parseq_model_grad_elems(const parseq_model* m) { return m ? (int64_t)m->master_elems : 0; }
+
+// Where a named intermediate of the LAST permutation (or an accumulator) lives in the workspace, in floats; -1 if unknown.  For tests.
+extern "C" int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, int batch, int ctx_len, int num_perms, const char* name) {
+    if (!m || !name || batch <= 0 || ctx_len <= 0 || num_perms <= 0) return -1;
+    const TrainDecoderLayout o = train_decoder_layout(m, batch, ctx_len, num_perms);
+    const std::pair<const char*, size_t> table[] = {
+        {"content", o.content}, {"cn", o.cn}, {"kvc", o.kvc}, {"qn", o.qn}, {"qsa", o.qsa}, {"kvm", o.kvm}, {"sa_o", o.sa_o}, {"t1", o.t1}, {"n1", o.n1},
+        {"q2", o.q2}, {"ca_o", o.ca_o}, {"t2", o.t2}, {"n2", o.n2}, {"hpre", o.hpre}, {"hact", o.hact}, {"t3", o.t3}, {"out", o.out},
+        {"dlogits", o.logits}, {"d_kvc", o.d_kvc}, {"d_kvm", o.d_kvm}, {"d_qsa", o.d_qsa}, {"d_pq", o.d_pq}};
+    for (const auto& e : table) if (!strcmp(e.first, name)) return (int64_t)e.second;
+    return -1;
+}
+
+extern "C" size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, int batch, int ctx_len, int num_perms) {
+    if (!m || batch <= 0 || ctx_len <= 0 || num_perms <= 0) return 0;
+    return train_decoder_layout(m, batch, ctx_len, num_perms).total * sizeof(float);
+}
+
+extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* tokens, const int32_t* targets, const uint8_t* key_padding_mask,
+                                    const uint8_t* query_masks, int batch, int ctx_len, int num_perms, int total_targets, float* loss_out,
+                                    float* grads, float* dmemory, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !memory || !tokens || !targets || !key_padding_mask || !query_masks || !loss_out || !grads || !dmemory || !workspace)
+        return fail(PARSEQ_E_INVALID, "null argument");
+    if (m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
+    for (const ParamSpec& ps : m->params) if (!ps.set) return fail(PARSEQ_E_STATE, "parameter %s was never set", ps.key.c_str());
+    const int B = batch, L = ctx_len, K = num_perms;
+    if (B <= 0 || L < 2 || L > m->cfg.max_label_length + 1 || K <= 0 || total_targets <= 0)
+        return fail(PARSEQ_E_INVALID, "bad shape: batch %d, ctx_len %d (2..%d), %d permutations, %d targets", B, L, m->cfg.max_label_length + 1, K, total_targets);
+    const TrainDecoderLayout o = train_decoder_layout(m, B, L, K);
+    if (workspace_bytes < o.total * sizeof(float)) return fail(PARSEQ_E_INVALID, "workspace: %zu bytes given, %zu needed", workspace_bytes, o.total * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, H = m->cfg.dec_heads, M = B * L, MS = B * S;
+    const float eps = m->cfg.dec_ln_eps, scale = 1.0f / sqrtf((float)TA_HD), sqrtE = sqrtf((float)E);
+    float* w = reinterpret_cast<float*>(workspace);
+    const std::string p = "decoder.layers.0.";
+    auto P = [&](const std::string& key) { return m->p(key); };
+    auto G = [&](const std::string& key) { return grads + m->params[m->index.at(key)].offset; };
+    const float* pq = P("pos_queries");
+    const float* sa_w = P(p + "self_attn.in_proj_weight"); const float* sa_b = P(p + "self_attn.in_proj_bias");
+    const float* ca_w = P(p + "cross_attn.in_proj_weight"); const float* ca_b = P(p + "cross_attn.in_proj_bias");
+    float* content = w + o.content; float* cn = w + o.cn; float* kvc = w + o.kvc; float* qn = w + o.qn; float* qsa = w + o.qsa; float* kvm = w + o.kvm;
+    float* sa_o = w + o.sa_o; float* t1 = w + o.t1; float* n1 = w + o.n1; float* q2 = w + o.q2; float* ca_o = w + o.ca_o; float* t2 = w + o.t2;
+    float* n2 = w + o.n2; float* hpre = w + o.hpre; float* hact = w + o.hact; float* t3 = w + o.t3; float* out = w + o.out; float* logits = w + o.logits;
+    float* d_a = w + o.d_a; float* d_b = w + o.d_b; float* d_c = w + o.d_c; float* d_h = w + o.d_h; float* tmp = w + o.tmp;
+    float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_qsa = w + o.d_qsa; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
+    float* row_loss = w + o.row_loss; float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
+    const size_t elems = (size_t)M * F;
+
+    // ---- shared by all permutations: content stream, its K / V, the (batch-independent) self-attention queries, memory K / V
+    hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content);
+    HIPCHK(hipGetLastError());
+    CHK((run_layernorm<float>(s, content, P(p + "norm_c.weight"), P(p + "norm_c.bias"), cn, nullptr, M, E, eps)));
+    CHK(lin_fwd(s, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, M, 2 * E, E));
+    CHK((run_layernorm<float>(s, pq, P(p + "norm_q.weight"), P(p + "norm_q.bias"), qn, nullptr, L, E, eps)));
+    CHK(lin_fwd(s, qn, sa_w, sa_b, nullptr, 0, qsa, L, E, E));
+    CHK(lin_fwd(s, memory, ca_w + (size_t)E * E, ca_b + E, nullptr, 0, kvm, MS, 2 * E, E));
+    HIPCHK(hipMemsetAsync(d_kvc, 0, (size_t)M * 2 * E * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(d_kvm, 0, (size_t)MS * 2 * E * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(d_qsa, 0, (size_t)L * E * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(d_pq, 0, (size_t)L * E * sizeof(float), s));
+
+    TrainAttnArgs sa{};      // self-attention of the query stream over the content stream (modules.py:70-72)
+    sa.q = qsa; sa.q_bstride = 0; sa.ldq = E; sa.k = kvc; sa.v = kvc + E; sa.ldkv = 2 * E; sa.kmask = key_padding_mask; sa.ldkm = L;
+    sa.o = sa_o; sa.ldo = E; sa.d_o = d_b; sa.dq = d_qb; sa.lddq = E; sa.dk = d_kvc; sa.dv = d_kvc + E; sa.lddkv = 2 * E;
+    sa.Lq = L; sa.Lk = L; sa.H = H; sa.scale = scale;
+    TrainAttnArgs ca{};      // cross-attention over the encoder memory (modules.py:74-75)
+    ca.q = q2; ca.q_bstride = (long)L * E; ca.ldq = E; ca.k = kvm; ca.v = kvm + E; ca.ldkv = 2 * E; ca.o = ca_o; ca.ldo = E; ca.d_o = d_c;
+    ca.dq = d_a; ca.lddq = E; ca.dk = d_kvm; ca.dv = d_kvm + E; ca.lddkv = 2 * E; ca.Lq = L; ca.Lk = S; ca.H = H; ca.scale = scale;
+
+    for (int i = 0; i < K; ++i) {
+        const int32_t* tgt = targets + (size_t)(i < 2 ? 0 : 1) * M;      // <eos> targets are dropped after two permutations (system.py:191-195)
+        // ---- forward (modules.py:55-79, 110-125; model.py:63) ------------------------------------------------------
+        sa.qmask = query_masks + (size_t)i * L * L;
+        CHK(train_attn(s, sa, B, false));
+        CHK(lin_fwd(s, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), pq, L, t1, M, E, E));
+        CHK((run_layernorm<float>(s, t1, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, nullptr, M, E, eps)));
+        CHK(lin_fwd(s, n1, ca_w, ca_b, nullptr, 0, q2, M, E, E));
+        CHK(train_attn(s, ca, B, false));
+        CHK(lin_fwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), t1, M, t2, M, E, E));
+        CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, M, E, eps)));
+        CHK(lin_fwd(s, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, hact, elems);
+        HIPCHK(hipGetLastError());
+        CHK(lin_fwd(s, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), t2, M, t3, M, E, F));
+        CHK((run_layernorm<float>(s, t3, P("decoder.norm.weight"), P("decoder.norm.bias"), out, nullptr, M, E, eps)));
+        CHK(lin_fwd(s, out, P("head.weight"), P("head.bias"), nullptr, 0, logits, M, C, E));
+        hipLaunchKernelGGL(ce_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, row_loss);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, tgt, M, m->cfg.pad_id, losses + i, counts + i);
+        HIPCHK(hipGetLastError());
+        // ---- backward ----------------------------------------------------------------------------------------------
+        hipLaunchKernelGGL(ce_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, 1.0f / (float)total_targets);
+        HIPCHK(hipGetLastError());
+        CHK(lin_bwd(s, out, P("head.weight"), logits, G("head.weight"), G("head.bias"), d_a, M, C, E));                                    // d_a = d out
+        CHK(ln_bwd(s, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), tmp, M, E, eps));  // d_b = d t3
+        CHK(lin_bwd(s, hact, P(p + "linear2.weight"), d_b, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                 // d_h = d hact
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, elems);                // d_h = d hpre
+        HIPCHK(hipGetLastError());
+        CHK(lin_bwd(s, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, M, F, E));                   // d_a = d n2
+        CHK(ln_bwd(s, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
+        CHK(lin_bwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), d_b, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
+                    d_c, M, E, E));                                                                                                        // d_c = d ca_o
+        CHK(train_attn(s, ca, B, true));                                                                                                   // d_a = d q2; d_kvm +=
+        CHK(lin_bwd(s, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, M, E, E));                // d_c = d n1
+        CHK(ln_bwd(s, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, M, E, eps));              // d_a = d t1
+        CHK(lin_bwd(s, sa_o, P(p + "self_attn.out_proj.weight"), d_a, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
+                    d_b, M, E, E));                                                                                                        // d_b = d sa_o
+        CHK(colsum(s, d_a, (long)L * E, B, L * E, d_pq, true));                               // the query stream's residual input: pos_queries[l]
+        CHK(train_attn(s, sa, B, true));                                                      // d_qb = d q (per image); d_kvc +=
+        CHK(colsum(s, d_qb, (long)L * E, B, L * E, d_qsa, true));
+    }
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, losses, counts, K, losses + K);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(loss_out, losses + K, sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(loss_out + 1, losses, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, s));
+
+    // ---- the shared prefix, once --------------------------------------------------------------------------------------
+    CHK(lin_bwd(s, qn, sa_w, d_qsa, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_a, L, E, E));                   // d_a[:L] = d qn
+    CHK(ln_bwd(s, pq, P(p + "norm_q.weight"), d_a, d_pq, d_pq, G(p + "norm_q.weight"), G(p + "norm_q.bias"), tmp, L, E, eps));
+    CHK(lin_bwd(s, cn, sa_w + (size_t)E * E, d_kvc, G(p + "self_attn.in_proj_weight") + (size_t)E * E, G(p + "self_attn.in_proj_bias") + E,
+                d_a, M, 2 * E, E));                                                                                                       // d_a = d cn
+    CHK(ln_bwd(s, content, P(p + "norm_c.weight"), d_a, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), tmp, M, E, eps));     // d_b = d content
+    if (L > 1) CHK(colsum(s, d_b + E, (long)L * E, B, (L - 1) * E, d_pq, true));             // content row j carries pos_queries[j - 1]
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens), dim3(256), 0, s, d_b, tokens, L, B, L, E, sqrtE, G("text_embed.embedding.weight"));
+    HIPCHK(hipGetLastError());
+    CHK(lin_bwd(s, memory, ca_w + (size_t)E * E, d_kvm, G(p + "cross_attn.in_proj_weight") + (size_t)E * E, G(p + "cross_attn.in_proj_bias") + E,
+                dmemory, MS, 2 * E, E));
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)(((size_t)L * E + 255) / 256)), dim3(256), 0, s, G("pos_queries"), d_pq, G("pos_queries"), (size_t)L * E);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // -------------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,356 @@
+// Row N3 (training step), first correct version: fp32 kernels for the backward of the K-permutation loss, decoder side.
+//
+// These are deliberately plain — one generic strided GEMM on the VALU, wave-per-row LayerNorm / cross-entropy backward,
+// one workgroup per (image, head) attention forward / backward with everything in LDS — because this round's bar for the
+// row is gradient parity with the reference (tests/golden/parseq_train.*), not speed: every kernel below has a one-line CPU
+// counterpart in oracle/decoder_backward.py, which is itself checked against autograd.  The MFMA versions (bf16 operands,
+// TN / NN tile loaders, fused LayerNorm-backward epilogues) replace them once the whole step is parity-green.
+//
+// All tensors are fp32, row-major.  Kernels that accumulate say so; everything is deterministic (no atomics).
+#pragma once
+#include "common.h"
+
+namespace pq {
+
+// -------------------------------------------------------------------------------------------------------------------
+// C[m][n] (+)= alpha * sum_k A(m, k) * B(k, n) + bias[n] + R[m % rper][n]
+// A(m, k) = A[m * sam + k * sak], B(k, n) = B[k * sbk + n * sbn]: one kernel covers X W^T (forward, dX) and dY^T X (dW).
+// -------------------------------------------------------------------------------------------------------------------
+struct SgemmArgs {
+    const float* A; long sam, sak;
+    const float* B; long sbk, sbn;
+    const float* bias;                   // [N] or nullptr
+    const float* R; long ldr; int rper;  // residual rows (row m reads R[(m % rper) * ldr + n]) or nullptr
+    float* C; long ldc;
+    int M, N, K;
+    float alpha;
+    int accumulate;                      // C += ... instead of C = ...
+};
+
+constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16;
+
+__global__ __launch_bounds__(256)
+void sgemm_kernel(const SgemmArgs a) {
+    __shared__ float As[SG_BK][SG_BM + 4];
+    __shared__ float Bs[SG_BK][SG_BN + 4];
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.y * SG_BM, n0 = blockIdx.x * SG_BN;
+    const int tm = (tid >> 4) * 4, tn = (tid & 15) * 4;
+    const bool a_kfast = a.sak == 1, b_nfast = a.sbn == 1;      // walk the contiguous axis with consecutive threads
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < a.K; k0 += SG_BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int am = a_kfast ? idx / SG_BK : idx % SG_BM, ak = a_kfast ? idx % SG_BK : idx / SG_BM;
+            const int gm = m0 + am, gk = k0 + ak;
+            As[ak][am] = (gm < a.M && gk < a.K) ? a.A[(size_t)gm * a.sam + (size_t)gk * a.sak] : 0.f;
+            const int bn = b_nfast ? idx % SG_BN : idx / SG_BK, bk = b_nfast ? idx / SG_BN : idx % SG_BK;
+            const int gn = n0 + bn, gk2 = k0 + bk;
+            Bs[bk][bn] = (gn < a.N && gk2 < a.K) ? a.B[(size_t)gk2 * a.sbk + (size_t)gn * a.sbn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < SG_BK; ++kk) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[kk][tm + i]; bv[i] = Bs[kk][tn + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + tm + i;
+        if (gm >= a.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tn + j;
+            if (gn >= a.N) continue;
+            float v = a.alpha * acc[i][j];
+            if (a.bias) v += a.bias[gn];
+            if (a.R) v += a.R[(size_t)(gm % a.rper) * a.ldr + gn];
+            float* c = a.C + (size_t)gm * a.ldc + gn;
+            *c = a.accumulate ? *c + v : v;
+        }
+    }
+}
+
+// out[n] (+)= sum_m A[m * lda + n]: bias gradients, LayerNorm affine gradients, sums over the batch ([B, L * E] views).
+// 16 row groups x 64 columns per workgroup, rows added in a fixed order.
+__global__ __launch_bounds__(1024)
+void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* __restrict__ out, int accumulate) {
+    __shared__ float part[16][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (n < N)
+        for (int m = rg; m < M; m += 16) s += A[(size_t)m * lda + n];
+    part[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += part[i][c];
+        out[n] = accumulate ? out[n] + t : t;
+    }
+}
+
+// LayerNorm backward, one wave per row, statistics recomputed from x (E <= 768):
+//   dx_out = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
+//   dyxhat = dy * xhat        (column sums of it are the weight gradient; column sums of dy the bias gradient)
+__global__ __launch_bounds__(256)
+void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ add,
+                   float* __restrict__ dx_out, float* __restrict__ dyxhat, int rows, int E, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const size_t base = (size_t)r * E;
+    float xv[12], gv[12], dv[12];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = lane + 64 * i;
+        xv[i] = c < E ? x[base + c] : 0.f;
+        s += xv[i];
+    }
+    const float inv = 1.0f / (float)E;
+    const float mean = wave_sum(s) * inv;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < E ? xv[i] - mean : 0.f;
+        ss += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = lane + 64 * i;
+        xv[i] = c < E ? (xv[i] - mean) * rstd : 0.f;          // xhat
+        dv[i] = c < E ? dy[base + c] : 0.f;
+        gv[i] = c < E ? dv[i] * w[c] : 0.f;
+        s1 += gv[i];
+        s2 += gv[i] * xv[i];
+    }
+    const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = lane + 64 * i;
+        if (c < E) {
+            float d = rstd * (gv[i] - m1 - xv[i] * m2);
+            if (add) d += add[base + c];
+            dx_out[base + c] = d;
+            dyxhat[base + c] = dv[i] * xv[i];
+        }
+    }
+}
+
+// exact-erf GELU and its derivative (F.gelu default; modules.py:43,77)
+__global__ __launch_bounds__(256)
+void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) act[i] = gelu_erf(pre[i]);
+}
+__global__ __launch_bounds__(256)
+void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dact, float* __restrict__ dpre, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = pre[i];
+    const float cdf = 0.5f * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    const float pdf = __expf(-0.5f * v * v) * 0.39894228040143267794f;
+    dpre[i] = dact[i] * fmaf(v, pdf, cdf);
+}
+
+// y = a + b (elementwise)
+__global__ __launch_bounds__(256)
+void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = a[i] + b[i];
+}
+
+// Content stream of the teacher-forced decode (model.py:95-98): row (b, j) = sqrt(E) * emb[tok[b][j]] + (j ? pos_queries[j-1] : 0)
+__global__ __launch_bounds__(256)
+void train_content_kernel(const float* __restrict__ emb, const float* __restrict__ posq, const int* __restrict__ tok, int ldt, int L, int E,
+                          float scale, float* __restrict__ out) {
+    const int row = blockIdx.x, b = row / L, j = row % L;
+    const float* e = emb + (size_t)tok[b * ldt + j] * E;
+    for (int c = threadIdx.x; c < E; c += 256)
+        out[(size_t)row * E + c] = scale * e[c] + (j ? posq[(size_t)(j - 1) * E + c] : 0.f);
+}
+
+// d emb[v] += scale * sum over the rows whose token is v, rows visited in order (deterministic; one workgroup per token id)
+__global__ __launch_bounds__(256)
+void embed_bwd_kernel(const float* __restrict__ dcontent, const int* __restrict__ tok, int ldt, int B, int L, int E, float scale,
+                      float* __restrict__ demb) {
+    const int v = blockIdx.x;
+    float acc[3] = {0.f, 0.f, 0.f};                              // E <= 768
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < L; ++j) {
+            if (tok[b * ldt + j] != v) continue;                  // uniform across the workgroup
+            const float* row = dcontent + ((size_t)b * L + j) * E;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int c = threadIdx.x + 256 * i;
+                if (c < E) acc[i] += row[c];
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = threadIdx.x + 256 * i;
+        if (c < E) demb[(size_t)v * E + c] += scale * acc[i];
+    }
+}
+
+// d(total loss) / d logits, in place: kept rows (softmax - onehot) * inv_total, ignored rows 0.  One wave per row.
+__global__ __launch_bounds__(256)
+void ce_bwd_kernel(float* __restrict__ logits, const int* __restrict__ targets, int rows, int C, int ignore_index, float inv_total) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* row = logits + (size_t)r * C;
+    const int tgt = targets[r];
+    if (tgt == ignore_index) {
+        for (int c = lane; c < C; c += 64) row[c] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int c = lane; c < C; c += 64) sum += expf(row[c] - mx);
+    sum = wave_sum(sum);
+    const float k = inv_total / sum;
+    for (int c = lane; c < C; c += 64) row[c] = expf(row[c] - mx) * k - (c == tgt ? inv_total : 0.f);
+}
+
+// loss = sum_k n_k * loss_k / sum_k n_k   (system.py:189-196)
+__global__ void loss_combine_kernel(const float* __restrict__ losses, const int* __restrict__ counts, int K, float* __restrict__ out) {
+    if (threadIdx.x || blockIdx.x) return;
+    float num = 0.f; int den = 0;
+    for (int k = 0; k < K; ++k) { num += losses[k] * (float)counts[k]; den += counts[k]; }
+    *out = num / (float)den;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Soft-max attention of the decoder (head width 32), one workgroup per (image b, head h), all operands in LDS.
+//   q row (b, l): q + b * q_bstride + l * ldq + 32 h        (q_bstride = 0: the queries are shared by the batch)
+//   k / v row (b, j): k|v + (b * Lk + j) * ldkv + 32 h
+//   key j of query l is masked when qmask[l * Lk + j] or kmask[b * ldkm + j] (either pointer may be null)
+// Every query must keep at least one key (true on this path: <bos> is never masked).
+// -------------------------------------------------------------------------------------------------------------------
+struct TrainAttnArgs {
+    const float* q; long q_bstride; int ldq;
+    const float* k; const float* v; int ldkv;
+    const unsigned char* qmask; const unsigned char* kmask; int ldkm;
+    float* o; int ldo;                                           // forward output, row (b, l): o + (b * Lq + l) * ldo + 32 h
+    const float* d_o;                                            // backward: gradient of o (same layout as o)
+    float* dq; int lddq;                                         // backward: stored, row (b, l) even when q is shared
+    float* dk; float* dv; int lddkv;                             // backward: ACCUMULATED, layout of k / v
+    int Lq, Lk, H;
+    float scale;
+};
+
+constexpr int TA_HD = 32, TA_PAD = 33;
+
+__host__ __device__ inline size_t train_attn_lds_floats(int Lq, int Lk, bool backward) {
+    return (size_t)2 * Lk * TA_PAD + (size_t)(backward ? 2 : 1) * Lq * TA_PAD + (size_t)(backward ? 2 : 1) * Lq * (Lk + 1);
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256)
+void train_attn_kernel(const TrainAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+    const int Lq = a.Lq, Lk = a.Lk, ldp = Lk + 1;
+    float* Ks = ta_smem;                          // [Lk][33]
+    float* Vs = Ks + (size_t)Lk * TA_PAD;         // [Lk][33]
+    float* Qs = Vs + (size_t)Lk * TA_PAD;         // [Lq][33]
+    float* P = Qs + (size_t)Lq * TA_PAD;          // [Lq][Lk + 1]
+    float* dOs = P + (size_t)Lq * ldp;            // [Lq][33]       (backward only)
+    float* dS = dOs + (size_t)Lq * TA_PAD;        // [Lq][Lk + 1]   (backward only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+
+    for (int idx = tid; idx < Lk * TA_HD; idx += 256) {
+        const int j = idx >> 5, d = idx & 31;
+        const size_t g = ((size_t)b * Lk + j) * a.ldkv + h * TA_HD + d;
+        Ks[j * TA_PAD + d] = a.k[g];
+        Vs[j * TA_PAD + d] = a.v[g];
+    }
+    for (int idx = tid; idx < Lq * TA_HD; idx += 256) {
+        const int l = idx >> 5, d = idx & 31;
+        Qs[l * TA_PAD + d] = a.q[(size_t)b * a.q_bstride + (size_t)l * a.ldq + h * TA_HD + d];
+        if (BACKWARD) dOs[l * TA_PAD + d] = a.d_o[((size_t)b * Lq + l) * a.ldo + h * TA_HD + d];
+    }
+    __syncthreads();
+    // scores (and, backward, dP = dO V^T)
+    for (int idx = tid; idx < Lq * Lk; idx += 256) {
+        const int l = idx / Lk, j = idx % Lk;
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int d = 0; d < TA_HD; ++d) {
+            s = fmaf(Qs[l * TA_PAD + d], Ks[j * TA_PAD + d], s);
+            if (BACKWARD) dp = fmaf(dOs[l * TA_PAD + d], Vs[j * TA_PAD + d], dp);
+        }
+        const bool masked = (a.qmask && a.qmask[(size_t)l * Lk + j]) || (a.kmask && a.kmask[(size_t)b * a.ldkm + j]);
+        P[l * ldp + j] = masked ? -INFINITY : s * a.scale;
+        if (BACKWARD) dS[l * ldp + j] = dp;
+    }
+    __syncthreads();
+    // soft-max over the keys, one wave per query row (and, backward, dS = P * (dP - sum_j dP P) * scale)
+    for (int l = wave; l < Lq; l += 4) {
+        float mx = -INFINITY;
+        for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, P[l * ldp + j]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < Lk; j += 64) { const float e = expf(P[l * ldp + j] - mx); P[l * ldp + j] = e; sum += e; }
+        const float inv = 1.0f / wave_sum(sum);
+        float dot = 0.f;
+        for (int j = lane; j < Lk; j += 64) {
+            const float p = P[l * ldp + j] * inv;
+            P[l * ldp + j] = p;
+            if (BACKWARD) dot += dS[l * ldp + j] * p;
+        }
+        if (BACKWARD) {
+            dot = wave_sum(dot);
+            for (int j = lane; j < Lk; j += 64) dS[l * ldp + j] = P[l * ldp + j] * (dS[l * ldp + j] - dot) * a.scale;
+        }
+    }
+    __syncthreads();
+    if (!BACKWARD) {
+        for (int idx = tid; idx < Lq * TA_HD; idx += 256) {
+            const int l = idx >> 5, d = idx & 31;
+            float o = 0.f;
+            for (int j = 0; j < Lk; ++j) o = fmaf(P[l * ldp + j], Vs[j * TA_PAD + d], o);
+            a.o[((size_t)b * Lq + l) * a.ldo + h * TA_HD + d] = o;
+        }
+    } else {
+        for (int idx = tid; idx < Lq * TA_HD; idx += 256) {
+            const int l = idx >> 5, d = idx & 31;
+            float g = 0.f;
+            for (int j = 0; j < Lk; ++j) g = fmaf(dS[l * ldp + j], Ks[j * TA_PAD + d], g);
+            a.dq[((size_t)b * Lq + l) * a.lddq + h * TA_HD + d] = g;
+        }
+        for (int idx = tid; idx < Lk * TA_HD; idx += 256) {
+            const int j = idx >> 5, d = idx & 31;
+            float gk = 0.f, gv = 0.f;
+            for (int l = 0; l < Lq; ++l) {
+                gk = fmaf(dS[l * ldp + j], Qs[l * TA_PAD + d], gk);
+                gv = fmaf(P[l * ldp + j], dOs[l * TA_PAD + d], gv);
+            }
+            const size_t g = ((size_t)b * Lk + j) * a.lddkv + h * TA_HD + d;
+            a.dk[g] += gk;
+            a.dv[g] += gv;
+        }
+    }
+}
+
+}  // namespace pq

@@ -135,6 +135,42 @@ def test_training_loss_reduction_rule():
     assert abs(float(loss) - want) <= 1e-6 * want
 
 
+def test_hand_derived_decoder_backward_matches_reference(train_golden):
+    """oracle/decoder_backward.py — the chain rule spelled out in the order the device launches its kernels — against the
+    reference's `loss.backward()` for every decoder-side parameter, and against autograd for the gradient w.r.t. memory."""
+    from oracle import decoder_backward as DB
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    tgt = Tokenizer(CHARSET_94).encode(meta['labels'])
+    perms = g['perms'].long()
+    with torch.no_grad():
+        memory = O.encode(sd, cfg, g['images'])
+        loss, per_perm, grads, dmem = DB.loss_and_grads(sd, cfg, memory, tgt, perms, O.attn_masks_from_perm)
+    assert abs(float(loss) - meta['loss']) <= 2e-6 * meta['loss']
+    assert set(grads) == {k for k in meta['grads'] if not k.startswith('encoder.')} and len(grads) == 26
+    for k, got in grads.items():
+        want = meta['grads'][k]
+        assert abs(float(got.double().norm()) - want['norm']) <= 1e-4 * max(want['norm'], 1e-6), k
+        if 'grad.' + k in g:
+            assert (got - g['grad.' + k]).abs().max() <= 1e-5 * float(g['grad.' + k].abs().max()) + 1e-8, k
+    # d loss / d memory: autograd through the oracle's decoder with memory as the leaf
+    mem = memory.clone().requires_grad_(True)
+    sd_mem = dict(sd)
+    tgt_in, tgt_out = tgt[:, :-1], tgt[:, 1:]
+    pad = (tgt_in == cfg.pad_id) | (tgt_in == cfg.eos_id)
+    total, numel, n = 0.0, 0, int((tgt_out != cfg.pad_id).sum())
+    for i, perm in enumerate(perms):
+        out = O.decode(sd_mem, cfg, tgt_in, mem, None, pad, tgt_query_mask=O.attn_masks_from_perm(perm)[1])
+        ce = torch.nn.functional.cross_entropy(O.head(sd_mem, out).flatten(end_dim=1), tgt_out.flatten(), ignore_index=cfg.pad_id)
+        total, numel = total + n * ce, numel + n
+        if i == 1:
+            tgt_out = torch.where(tgt_out == cfg.eos_id, cfg.pad_id, tgt_out)
+            n = int((tgt_out != cfg.pad_id).sum())
+    (total / numel).backward()
+    assert (mem.grad - dmem).abs().max() <= 1e-5 * float(mem.grad.abs().max())
+
+
 # ---- device ---------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
@@ -182,3 +218,50 @@ def test_training_step_draws_permutations_and_is_repeatable(train_golden):
         with torch.inference_mode():
             want = float(O.training_loss(synth_state_dict(cfg, 0), cfg, g['images'], tgt, perms)[0])
         assert abs(got - want) <= 2e-2 * want, (labels, got, want)
+
+
+@pytest.mark.gpu
+def test_decoder_backward_matches_reference_gradients(train_golden):
+    """`parseq_train_decoder`: loss + gradient of every decoder-side parameter against the REFERENCE's `loss.backward()`
+    (tests/golden/parseq_train.*), the gradient w.r.t. the encoder output and every intermediate of the last permutation
+    against the hand-derived CPU backward (oracle/decoder_backward.py, itself checked against autograd)."""
+    from gpu_util import DEV, make_model
+    from oracle import decoder_backward as DB
+    from parseq_amd.train import decoder_backward
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    m = make_model('parseq', 'fp32')
+    perms = g['perms'].long()
+    res = decoder_backward(m, g['images'].to(DEV), meta['labels'], perms)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        memory = O.encode(sd, cfg, g['images'])
+        trace = {}
+        want_loss, want_pp, want_grads, want_dmem = DB.loss_and_grads(sd, cfg, memory, m.tokenizer.encode(meta['labels']), perms,
+                                                                      O.attn_masks_from_perm, trace)
+    report = []
+    for name, want in trace.items():          # forward intermediates first: the first line that is off names the kernel
+        got = res.intermediate(name, want.numel()).cpu().view(want.shape)
+        err = float((got - want).abs().max())
+        report.append(f'{name}: max|d| {err:.3e} of {float(want.abs().max()):.3e}')
+    print('\n'.join(report))
+    assert abs(float(res.loss) - meta['loss']) <= 1e-4 * meta['loss'], report
+    assert (res.perm_losses.cpu() - want_pp).abs().max() <= 1e-4 * float(want_pp.max())
+    bad = []
+    for key, want in meta['grads'].items():
+        got = res.grads[key].cpu()
+        if key.startswith('encoder.'):
+            assert not got.any()             # the encoder backward is not built: its slots stay untouched
+            continue
+        ref = want_grads[key]
+        err = float((got - ref).abs().max())
+        tol = 1e-4 * max(float(ref.abs().max()), 1e-6) + 1e-7
+        norm = float(got.double().norm())
+        if err > tol or abs(norm - want['norm']) > 1e-3 * max(want['norm'], 1e-6):
+            bad.append((key, err, tol, norm, want['norm']))
+        if 'grad.' + key in g:               # the reference's own tensor
+            assert (got - g['grad.' + key]).abs().max() <= tol, key
+    assert not bad, (bad, report)
+    err = float((res.dmemory.cpu() - want_dmem).abs().max())
+    assert err <= 1e-4 * float(want_dmem.abs().max()), (err, report)
