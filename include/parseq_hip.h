@@ -220,6 +220,17 @@ int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* to
                          int total_targets, float* loss_out, float* grads, float* dmemory, void* workspace,
                          size_t workspace_bytes, void* stream);
 
+/* Encoder half of the training step (timm VisionTransformer blocks, strhub/models/parseq/modules.py:128-165): a forward in
+ * fp32 from the master weights that keeps in `workspace` what the backward needs (per block: the residual stream before
+ * it, qkv, the attention output, the stream after the attention residual, the fc1 pre-activation), and the backward from
+ * `dmemory` (parseq_train_decoder) to the gradient of every encoder.* parameter, ACCUMULATED into `grads`.
+ * images: device fp32 [batch, 3, H, W], normalised as the reference's transform leaves them. */
+size_t parseq_train_encoder_workspace_bytes(const parseq_model* m, int batch);
+int parseq_train_encoder_forward(parseq_model* m, const float* images, int batch, float* memory_out, void* workspace,
+                                 size_t workspace_bytes, void* stream);
+int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int batch, float* grads, void* workspace,
+                                  size_t workspace_bytes, void* stream);
+
 /* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
 
 /* y = LayerNorm(x) over the last dim `E` (192 | 384 | 768); x fp32 [rows, E]; y in out_dtype. */

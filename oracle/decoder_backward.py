@@ -26,15 +26,15 @@ EPS = 1e-5
 HD = 32          # decoder head width (embed_dim / dec_num_heads, configs/model/parseq.yaml:11-12)
 
 
-def ln(x, w, b):
+def ln(x, w, b, eps=EPS):
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return (x - mu) * torch.rsqrt(var + EPS) * w + b
+    return (x - mu) * torch.rsqrt(var + eps) * w + b
 
 
-def ln_bwd(x, w, dy):
+def ln_bwd(x, w, dy, eps=EPS):
     mu = x.mean(-1, keepdim=True)
-    rstd = torch.rsqrt(((x - mu) ** 2).mean(-1, keepdim=True) + EPS)
+    rstd = torch.rsqrt(((x - mu) ** 2).mean(-1, keepdim=True) + eps)
     xhat = (x - mu) * rstd
     g = dy * w
     dx = rstd * (g - g.mean(-1, keepdim=True) - xhat * (g * xhat).mean(-1, keepdim=True))
@@ -42,8 +42,8 @@ def ln_bwd(x, w, dy):
     return dx, flat(dy * xhat).sum(0), flat(dy).sum(0)
 
 
-def split_heads(x, B, L):            # [B * L, E] -> [B, H, L, d]
-    return x.view(B, L, -1, HD).transpose(1, 2)
+def split_heads(x, B, L, hd=HD):     # [B * L, E] -> [B, H, L, d]
+    return x.reshape(B, L, -1, hd).transpose(1, 2)
 
 
 def merge_heads(x):                  # [B, H, L, d] -> [B * L, E]
@@ -52,7 +52,7 @@ def merge_heads(x):                  # [B, H, L, d] -> [B * L, E]
 
 
 def attn_probs(q, k, mask):
-    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(HD))
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
     if mask is not None:
         s = s.masked_fill(mask.unsqueeze(1), float('-inf'))
     return torch.softmax(s, dim=-1)
@@ -66,7 +66,7 @@ def attn_bwd(q, k, v, mask, do):
     p = attn_probs(q, k, mask)
     dv = p.transpose(-1, -2) @ do
     dp = do @ v.transpose(-1, -2)
-    ds = p * (dp - (dp * p).sum(-1, keepdim=True)) * (1.0 / math.sqrt(HD))
+    ds = p * (dp - (dp * p).sum(-1, keepdim=True)) * (1.0 / math.sqrt(q.shape[-1]))
     return ds @ k, ds.transpose(-1, -2) @ q, dv          # dq (per batch even when q is shared), dk, dv
 
 

@@ -1035,19 +1035,26 @@ static int ln_bwd(hipStream_t s, const float* x, const float* gamma, const float
     CHK(colsum(s, tmp, E, rows, E, dgamma, true));
     return colsum(s, dy, E, rows, E, dbeta, true);
 }
-static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backward) {
-    const size_t lds = train_attn_lds_floats(a.Lq, a.Lk, backward) * sizeof(float);
-    if (lds > 150 * 1024) return fail(PARSEQ_E_INVALID, "training attention: %d x %d does not fit in LDS", a.Lq, a.Lk);
-    static bool attr_done = false;
+template <int HD>
+static int train_attn_hd(hipStream_t s, const TrainAttnArgs& a, int B, bool backward) {
+    const size_t lds = train_attn_lds_floats(a.Lq, a.Lk, HD, backward) * sizeof(float);
+    if (lds > 150 * 1024 || (size_t)a.Lk * HD > (size_t)TA_NACC * 256)
+        return fail(PARSEQ_E_INVALID, "training attention: %d keys of width %d do not fit (LDS %zu bytes)", a.Lk, HD, lds);
+    static bool attr_done = false;      // one flag per head width
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<false, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<true, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_done = true;
     }
-    if (backward) hipLaunchKernelGGL(train_attn_kernel<true>, dim3(B * a.H), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(train_attn_kernel<false>, dim3(B * a.H), dim3(256), lds, s, a);
+    if (backward) hipLaunchKernelGGL((train_attn_kernel<true, HD>), dim3(B * a.H), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((train_attn_kernel<false, HD>), dim3(B * a.H), dim3(256), lds, s, a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backward, int hd) {
+    if (hd == 32) return train_attn_hd<32>(s, a, B, backward);
+    if (hd == 64) return train_attn_hd<64>(s, a, B, backward);
+    return fail(PARSEQ_E_INVALID, "training attention: head width %d not in {32, 64}", hd);
 }
 
 struct TrainDecoderLayout {          // offsets in floats into the caller's workspace
@@ -1106,7 +1113,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     if (workspace_bytes < o.total * sizeof(float)) return fail(PARSEQ_E_INVALID, "workspace: %zu bytes given, %zu needed", workspace_bytes, o.total * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     const int E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, H = m->cfg.dec_heads, M = B * L, MS = B * S;
-    const float eps = m->cfg.dec_ln_eps, scale = 1.0f / sqrtf((float)TA_HD), sqrtE = sqrtf((float)E);
+    const float eps = m->cfg.dec_ln_eps, scale = 1.0f / sqrtf(32.0f), sqrtE = sqrtf((float)E);
     float* w = reinterpret_cast<float*>(workspace);
     const std::string p = "decoder.layers.0.";
     auto P = [&](const std::string& key) { return m->p(key); };
@@ -1138,20 +1145,20 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     TrainAttnArgs sa{};      // self-attention of the query stream over the content stream (modules.py:70-72)
     sa.q = qsa; sa.q_bstride = 0; sa.ldq = E; sa.k = kvc; sa.v = kvc + E; sa.ldkv = 2 * E; sa.kmask = key_padding_mask; sa.ldkm = L;
     sa.o = sa_o; sa.ldo = E; sa.d_o = d_b; sa.dq = d_qb; sa.lddq = E; sa.dk = d_kvc; sa.dv = d_kvc + E; sa.lddkv = 2 * E;
-    sa.Lq = L; sa.Lk = L; sa.H = H; sa.scale = scale;
+    sa.Lq = L; sa.Lk = L; sa.H = H; sa.scale = scale; sa.kv_accumulate = 1;
     TrainAttnArgs ca{};      // cross-attention over the encoder memory (modules.py:74-75)
     ca.q = q2; ca.q_bstride = (long)L * E; ca.ldq = E; ca.k = kvm; ca.v = kvm + E; ca.ldkv = 2 * E; ca.o = ca_o; ca.ldo = E; ca.d_o = d_c;
-    ca.dq = d_a; ca.lddq = E; ca.dk = d_kvm; ca.dv = d_kvm + E; ca.lddkv = 2 * E; ca.Lq = L; ca.Lk = S; ca.H = H; ca.scale = scale;
+    ca.dq = d_a; ca.lddq = E; ca.dk = d_kvm; ca.dv = d_kvm + E; ca.lddkv = 2 * E; ca.Lq = L; ca.Lk = S; ca.H = H; ca.scale = scale; ca.kv_accumulate = 1;
 
     for (int i = 0; i < K; ++i) {
         const int32_t* tgt = targets + (size_t)(i < 2 ? 0 : 1) * M;      // <eos> targets are dropped after two permutations (system.py:191-195)
         // ---- forward (modules.py:55-79, 110-125; model.py:63) ------------------------------------------------------
         sa.qmask = query_masks + (size_t)i * L * L;
-        CHK(train_attn(s, sa, B, false));
+        CHK(train_attn(s, sa, B, false, 32));
         CHK(lin_fwd(s, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), pq, L, t1, M, E, E));
         CHK((run_layernorm<float>(s, t1, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, nullptr, M, E, eps)));
         CHK(lin_fwd(s, n1, ca_w, ca_b, nullptr, 0, q2, M, E, E));
-        CHK(train_attn(s, ca, B, false));
+        CHK(train_attn(s, ca, B, false, 32));
         CHK(lin_fwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), t1, M, t2, M, E, E));
         CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, M, E, eps)));
         CHK(lin_fwd(s, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
@@ -1176,13 +1183,13 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         CHK(ln_bwd(s, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
         CHK(lin_bwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), d_b, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
                     d_c, M, E, E));                                                                                                        // d_c = d ca_o
-        CHK(train_attn(s, ca, B, true));                                                                                                   // d_a = d q2; d_kvm +=
+        CHK(train_attn(s, ca, B, true, 32));                                                                                                   // d_a = d q2; d_kvm +=
         CHK(lin_bwd(s, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, M, E, E));                // d_c = d n1
         CHK(ln_bwd(s, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, M, E, eps));              // d_a = d t1
         CHK(lin_bwd(s, sa_o, P(p + "self_attn.out_proj.weight"), d_a, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
                     d_b, M, E, E));                                                                                                        // d_b = d sa_o
         CHK(colsum(s, d_a, (long)L * E, B, L * E, d_pq, true));                               // the query stream's residual input: pos_queries[l]
-        CHK(train_attn(s, sa, B, true));                                                      // d_qb = d q (per image); d_kvc +=
+        CHK(train_attn(s, sa, B, true, 32));                                                      // d_qb = d q (per image); d_kvc +=
         CHK(colsum(s, d_qb, (long)L * E, B, L * E, d_qsa, true));
     }
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, losses, counts, K, losses + K);
@@ -1204,6 +1211,122 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)(((size_t)L * E + 255) / 256)), dim3(256), 0, s, G("pos_queries"), d_pq, G("pos_queries"), (size_t)L * E);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+// ---- training step, encoder side: forward that keeps what the backward needs, and the backward ------------------------------
+struct TrainEncoderLayout {          // offsets in floats
+    size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, total;
+    size_t x(int i) const { return layer0 + i * layer_stride; }
+    size_t qkv, ao, x_mid, hpre;     // offsets inside one layer's record (x at 0)
+};
+static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
+    const size_t E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, MS = (size_t)B * m->tokens, PK = m->patch_k;
+    TrainEncoderLayout o;
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t at = off; off += (n + 63) / 64 * 64; return at; };
+    o.patches = take(MS * PK);
+    o.layer0 = off;
+    take(MS * E); o.qkv = off - o.layer0; take(MS * 3 * E); o.ao = off - o.layer0; take(MS * E); o.x_mid = off - o.layer0; take(MS * E);
+    o.hpre = off - o.layer0; take(MS * F);
+    o.layer_stride = off - o.layer0;
+    off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
+    o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
+    o.dqkv = take(MS * 3 * E); o.tmp = take(MS * E);
+    o.total = off;
+    return o;
+}
+
+extern "C" size_t parseq_train_encoder_workspace_bytes(const parseq_model* m, int batch) {
+    if (!m || batch <= 0) return 0;
+    return train_encoder_layout(m, batch).total * sizeof(float);
+}
+
+static int train_encoder_check(const parseq_model* m, int batch, const void* workspace, size_t workspace_bytes) {
+    if (!m || !workspace) return fail(PARSEQ_E_INVALID, "null argument");
+    if (m->vitstr) return fail(PARSEQ_E_INVALID, "the training step is built for PARSeq only");
+    if (batch <= 0) return fail(PARSEQ_E_INVALID, "batch %d", batch);
+    for (const ParamSpec& ps : m->params) if (!ps.set) return fail(PARSEQ_E_STATE, "parameter %s was never set", ps.key.c_str());
+    const size_t need = train_encoder_layout(m, batch).total * sizeof(float);
+    if (workspace_bytes < need) return fail(PARSEQ_E_INVALID, "workspace: %zu bytes given, %zu needed", workspace_bytes, need);
+    return 0;
+}
+
+static TrainAttnArgs enc_attn_args(const parseq_model* m, float* qkv, float* ao, const float* d_ao, float* dqkv) {
+    const int E = m->cfg.embed_dim, S = m->tokens;
+    TrainAttnArgs a{};
+    a.q = qkv; a.q_bstride = (long)S * 3 * E; a.ldq = 3 * E; a.k = qkv + E; a.v = qkv + 2 * E; a.ldkv = 3 * E;
+    a.o = ao; a.ldo = E; a.d_o = d_ao; a.dq = dqkv; a.lddq = 3 * E; a.dk = dqkv ? dqkv + E : nullptr; a.dv = dqkv ? dqkv + 2 * E : nullptr;
+    a.lddkv = 3 * E; a.kv_accumulate = 0; a.Lq = S; a.Lk = S; a.H = m->cfg.enc_heads; a.scale = 1.0f / sqrtf((float)ATT_HD);
+    return a;
+}
+
+extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images, int batch, float* memory_out, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    if (!images || !memory_out) return fail(PARSEQ_E_INVALID, "null argument");
+    CHK(train_encoder_check(m, batch, workspace, workspace_bytes));
+    const TrainEncoderLayout o = train_encoder_layout(m, batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, S = m->tokens, MS = batch * S, PK = m->patch_k;
+    const float eps = m->cfg.enc_ln_eps;
+    float* w = reinterpret_cast<float*>(workspace);
+    auto P = [&](const std::string& key) { return m->p(m->enc + key); };
+    hipLaunchKernelGGL(patches_kernel, dim3(MS), dim3(256), 0, s, images, m->cfg.img_h, m->cfg.img_w, m->cfg.patch_h, m->cfg.patch_w, w + o.patches);
+    HIPCHK(hipGetLastError());
+    CHK(lin_fwd(s, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
+    const size_t elems = (size_t)MS * F;
+    for (int i = 0; i < m->cfg.enc_depth; ++i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
+        float* x_out = i + 1 < m->cfg.enc_depth ? w + o.x(i + 1) : w + o.x_last;
+        CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), w + o.n, nullptr, MS, E, eps)));
+        CHK(lin_fwd(s, w + o.n, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
+        CHK(train_attn(s, enc_attn_args(m, qkv, ao, nullptr, nullptr), batch, false, ATT_HD));
+        CHK(lin_fwd(s, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
+        CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), w + o.n, nullptr, MS, E, eps)));
+        CHK(lin_fwd(s, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E));
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, w + o.hact, elems);
+        HIPCHK(hipGetLastError());
+        CHK(lin_fwd(s, w + o.hact, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
+    }
+    return run_layernorm<float>(s, w + o.x_last, P("norm.weight"), P("norm.bias"), memory_out, nullptr, MS, E, eps);
+}
+
+extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int batch, float* grads, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+    if (!dmemory || !grads) return fail(PARSEQ_E_INVALID, "null argument");
+    CHK(train_encoder_check(m, batch, workspace, workspace_bytes));
+    const TrainEncoderLayout o = train_encoder_layout(m, batch);
+    hipStream_t s = (hipStream_t)stream;
+    const int E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, S = m->tokens, MS = batch * S, PK = m->patch_k;
+    const float eps = m->cfg.enc_ln_eps;
+    float* w = reinterpret_cast<float*>(workspace);
+    auto P = [&](const std::string& key) { return m->p(m->enc + key); };
+    auto G = [&](const std::string& key) { return grads + m->params[m->index.at(m->enc + key)].offset; };
+    float* n = w + o.n; float* hact = w + o.hact; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
+    float* tmp = w + o.tmp;
+    const size_t elems = (size_t)MS * F;
+    CHK(ln_bwd(s, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps));
+    for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
+        const std::string p = "blocks." + std::to_string(i) + ".";
+        float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
+        // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, hact, elems);
+        HIPCHK(hipGetLastError());
+        CHK(lin_bwd(s, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F));
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, elems);
+        HIPCHK(hipGetLastError());
+        CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n, nullptr, MS, E, eps)));
+        CHK(lin_bwd(s, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));
+        CHK(ln_bwd(s, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps));   // d_x = d x_mid
+        // x_mid = x + proj(attention(qkv(norm1(x))))
+        CHK(lin_bwd(s, ao, P(p + "attn.proj.weight"), d_x, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, MS, E, E));        // d_a = d ao
+        CHK(train_attn(s, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
+        CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), n, nullptr, MS, E, eps)));
+        CHK(lin_bwd(s, n, P(p + "attn.qkv.weight"), dqkv, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, MS, 3 * E, E));
+        CHK(ln_bwd(s, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps));          // d_x = d x
+    }
+    CHK(colsum(s, d_x, (long)S * E, batch, S * E, G("pos_embed"), true));
+    return lin_bwd(s, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

@@ -241,115 +241,151 @@ __global__ void loss_combine_kernel(const float* __restrict__ losses, const int*
 }
 
 // -------------------------------------------------------------------------------------------------------------------
-// Soft-max attention of the decoder (head width 32), one workgroup per (image b, head h), all operands in LDS.
-//   q row (b, l): q + b * q_bstride + l * ldq + 32 h        (q_bstride = 0: the queries are shared by the batch)
-//   k / v row (b, j): k|v + (b * Lk + j) * ldkv + 32 h
+// Soft-max attention (decoder: head width 32, encoder: 64), one workgroup per (image b, head h), operands in LDS, the
+// queries walked in blocks of 32 rows (the key / value gradients of a head stay in registers across the blocks).
+//   q row (b, l): q + b * q_bstride + l * ldq + HD h        (q_bstride = 0: the queries are shared by the batch)
+//   k / v row (b, j): k|v + (b * Lk + j) * ldkv + HD h
 //   key j of query l is masked when qmask[l * Lk + j] or kmask[b * ldkm + j] (either pointer may be null)
-// Every query must keep at least one key (true on this path: <bos> is never masked).
+// Every query must keep at least one key (true on this path: <bos> is never masked).  Lk * HD <= 8192.
 // -------------------------------------------------------------------------------------------------------------------
 struct TrainAttnArgs {
     const float* q; long q_bstride; int ldq;
     const float* k; const float* v; int ldkv;
     const unsigned char* qmask; const unsigned char* kmask; int ldkm;
-    float* o; int ldo;                                           // forward output, row (b, l): o + (b * Lq + l) * ldo + 32 h
+    float* o; int ldo;                                           // forward output, row (b, l): o + (b * Lq + l) * ldo + HD h
     const float* d_o;                                            // backward: gradient of o (same layout as o)
     float* dq; int lddq;                                         // backward: stored, row (b, l) even when q is shared
-    float* dk; float* dv; int lddkv;                             // backward: ACCUMULATED, layout of k / v
+    float* dk; float* dv; int lddkv;                             // backward: layout of k / v; accumulated into if kv_accumulate
+    int kv_accumulate;
     int Lq, Lk, H;
     float scale;
 };
 
-constexpr int TA_HD = 32, TA_PAD = 33;
+constexpr int TA_QB = 32, TA_NACC = 32;
 
-__host__ __device__ inline size_t train_attn_lds_floats(int Lq, int Lk, bool backward) {
-    return (size_t)2 * Lk * TA_PAD + (size_t)(backward ? 2 : 1) * Lq * TA_PAD + (size_t)(backward ? 2 : 1) * Lq * (Lk + 1);
+__host__ __device__ inline size_t train_attn_lds_floats(int Lq, int Lk, int hd, bool backward) {
+    const int nq = Lq < TA_QB ? Lq : TA_QB;
+    return (size_t)2 * Lk * (hd + 1) + (size_t)(backward ? 2 : 1) * nq * (hd + 1) + (size_t)(backward ? 2 : 1) * nq * (Lk + 1);
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, int HD>
 __global__ __launch_bounds__(256)
 void train_attn_kernel(const TrainAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+    constexpr int PAD = HD + 1;
     const int Lq = a.Lq, Lk = a.Lk, ldp = Lk + 1;
-    float* Ks = ta_smem;                          // [Lk][33]
-    float* Vs = Ks + (size_t)Lk * TA_PAD;         // [Lk][33]
-    float* Qs = Vs + (size_t)Lk * TA_PAD;         // [Lq][33]
-    float* P = Qs + (size_t)Lq * TA_PAD;          // [Lq][Lk + 1]
-    float* dOs = P + (size_t)Lq * ldp;            // [Lq][33]       (backward only)
-    float* dS = dOs + (size_t)Lq * TA_PAD;        // [Lq][Lk + 1]   (backward only)
+    const int nqmax = Lq < TA_QB ? Lq : TA_QB;
+    float* Ks = ta_smem;                          // [Lk][PAD]
+    float* Vs = Ks + (size_t)Lk * PAD;            // [Lk][PAD]
+    float* Qs = Vs + (size_t)Lk * PAD;            // [nq][PAD]
+    float* P = Qs + (size_t)nqmax * PAD;          // [nq][Lk + 1]
+    float* dOs = P + (size_t)nqmax * ldp;         // [nq][PAD]      (backward only)
+    float* dS = dOs + (size_t)nqmax * PAD;        // [nq][Lk + 1]   (backward only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
 
-    for (int idx = tid; idx < Lk * TA_HD; idx += 256) {
-        const int j = idx >> 5, d = idx & 31;
-        const size_t g = ((size_t)b * Lk + j) * a.ldkv + h * TA_HD + d;
-        Ks[j * TA_PAD + d] = a.k[g];
-        Vs[j * TA_PAD + d] = a.v[g];
+    for (int idx = tid; idx < Lk * HD; idx += 256) {
+        const int j = idx / HD, d = idx % HD;
+        const size_t g = ((size_t)b * Lk + j) * a.ldkv + h * HD + d;
+        Ks[j * PAD + d] = a.k[g];
+        Vs[j * PAD + d] = a.v[g];
     }
-    for (int idx = tid; idx < Lq * TA_HD; idx += 256) {
-        const int l = idx >> 5, d = idx & 31;
-        Qs[l * TA_PAD + d] = a.q[(size_t)b * a.q_bstride + (size_t)l * a.ldq + h * TA_HD + d];
-        if (BACKWARD) dOs[l * TA_PAD + d] = a.d_o[((size_t)b * Lq + l) * a.ldo + h * TA_HD + d];
-    }
-    __syncthreads();
-    // scores (and, backward, dP = dO V^T)
-    for (int idx = tid; idx < Lq * Lk; idx += 256) {
-        const int l = idx / Lk, j = idx % Lk;
-        float s = 0.f, dp = 0.f;
+    float gk[TA_NACC], gv[TA_NACC];
 #pragma unroll
-        for (int d = 0; d < TA_HD; ++d) {
-            s = fmaf(Qs[l * TA_PAD + d], Ks[j * TA_PAD + d], s);
-            if (BACKWARD) dp = fmaf(dOs[l * TA_PAD + d], Vs[j * TA_PAD + d], dp);
+    for (int i = 0; i < TA_NACC; ++i) { gk[i] = 0.f; gv[i] = 0.f; }
+
+    for (int q0 = 0; q0 < Lq; q0 += TA_QB) {
+        const int nq = (Lq - q0) < TA_QB ? (Lq - q0) : TA_QB;
+        __syncthreads();                          // the previous block's readers are done with Qs / P / dOs / dS
+        for (int idx = tid; idx < nq * HD; idx += 256) {
+            const int l = idx / HD, d = idx % HD;
+            Qs[l * PAD + d] = a.q[(size_t)b * a.q_bstride + (size_t)(q0 + l) * a.ldq + h * HD + d];
+            if (BACKWARD) dOs[l * PAD + d] = a.d_o[((size_t)b * Lq + q0 + l) * a.ldo + h * HD + d];
         }
-        const bool masked = (a.qmask && a.qmask[(size_t)l * Lk + j]) || (a.kmask && a.kmask[(size_t)b * a.ldkm + j]);
-        P[l * ldp + j] = masked ? -INFINITY : s * a.scale;
-        if (BACKWARD) dS[l * ldp + j] = dp;
-    }
-    __syncthreads();
-    // soft-max over the keys, one wave per query row (and, backward, dS = P * (dP - sum_j dP P) * scale)
-    for (int l = wave; l < Lq; l += 4) {
-        float mx = -INFINITY;
-        for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, P[l * ldp + j]);
-        mx = wave_max(mx);
-        float sum = 0.f;
-        for (int j = lane; j < Lk; j += 64) { const float e = expf(P[l * ldp + j] - mx); P[l * ldp + j] = e; sum += e; }
-        const float inv = 1.0f / wave_sum(sum);
-        float dot = 0.f;
-        for (int j = lane; j < Lk; j += 64) {
-            const float p = P[l * ldp + j] * inv;
-            P[l * ldp + j] = p;
-            if (BACKWARD) dot += dS[l * ldp + j] * p;
-        }
-        if (BACKWARD) {
-            dot = wave_sum(dot);
-            for (int j = lane; j < Lk; j += 64) dS[l * ldp + j] = P[l * ldp + j] * (dS[l * ldp + j] - dot) * a.scale;
-        }
-    }
-    __syncthreads();
-    if (!BACKWARD) {
-        for (int idx = tid; idx < Lq * TA_HD; idx += 256) {
-            const int l = idx >> 5, d = idx & 31;
-            float o = 0.f;
-            for (int j = 0; j < Lk; ++j) o = fmaf(P[l * ldp + j], Vs[j * TA_PAD + d], o);
-            a.o[((size_t)b * Lq + l) * a.ldo + h * TA_HD + d] = o;
-        }
-    } else {
-        for (int idx = tid; idx < Lq * TA_HD; idx += 256) {
-            const int l = idx >> 5, d = idx & 31;
-            float g = 0.f;
-            for (int j = 0; j < Lk; ++j) g = fmaf(dS[l * ldp + j], Ks[j * TA_PAD + d], g);
-            a.dq[((size_t)b * Lq + l) * a.lddq + h * TA_HD + d] = g;
-        }
-        for (int idx = tid; idx < Lk * TA_HD; idx += 256) {
-            const int j = idx >> 5, d = idx & 31;
-            float gk = 0.f, gv = 0.f;
-            for (int l = 0; l < Lq; ++l) {
-                gk = fmaf(dS[l * ldp + j], Qs[l * TA_PAD + d], gk);
-                gv = fmaf(P[l * ldp + j], dOs[l * TA_PAD + d], gv);
+        __syncthreads();
+        // scores (and, backward, dP = dO V^T)
+        for (int idx = tid; idx < nq * Lk; idx += 256) {
+            const int l = idx / Lk, j = idx % Lk;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) {
+                s = fmaf(Qs[l * PAD + d], Ks[j * PAD + d], s);
+                if (BACKWARD) dp = fmaf(dOs[l * PAD + d], Vs[j * PAD + d], dp);
             }
-            const size_t g = ((size_t)b * Lk + j) * a.lddkv + h * TA_HD + d;
-            a.dk[g] += gk;
-            a.dv[g] += gv;
+            const bool masked = (a.qmask && a.qmask[(size_t)(q0 + l) * Lk + j]) || (a.kmask && a.kmask[(size_t)b * a.ldkm + j]);
+            P[l * ldp + j] = masked ? -INFINITY : s * a.scale;
+            if (BACKWARD) dS[l * ldp + j] = dp;
         }
+        __syncthreads();
+        // soft-max over the keys, one wave per query row (and, backward, dS = P * (dP - sum_j dP P) * scale)
+        for (int l = wave; l < nq; l += 4) {
+            float mx = -INFINITY;
+            for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, P[l * ldp + j]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int j = lane; j < Lk; j += 64) { const float e = expf(P[l * ldp + j] - mx); P[l * ldp + j] = e; sum += e; }
+            const float inv = 1.0f / wave_sum(sum);
+            float dot = 0.f;
+            for (int j = lane; j < Lk; j += 64) {
+                const float p = P[l * ldp + j] * inv;
+                P[l * ldp + j] = p;
+                if (BACKWARD) dot += dS[l * ldp + j] * p;
+            }
+            if (BACKWARD) {
+                dot = wave_sum(dot);
+                for (int j = lane; j < Lk; j += 64) dS[l * ldp + j] = P[l * ldp + j] * (dS[l * ldp + j] - dot) * a.scale;
+            }
+        }
+        __syncthreads();
+        if (!BACKWARD) {
+            for (int idx = tid; idx < nq * HD; idx += 256) {
+                const int l = idx / HD, d = idx % HD;
+                float o = 0.f;
+                for (int j = 0; j < Lk; ++j) o = fmaf(P[l * ldp + j], Vs[j * PAD + d], o);
+                a.o[((size_t)b * Lq + q0 + l) * a.ldo + h * HD + d] = o;
+            }
+        } else {
+            for (int idx = tid; idx < nq * HD; idx += 256) {
+                const int l = idx / HD, d = idx % HD;
+                float g = 0.f;
+                for (int j = 0; j < Lk; ++j) g = fmaf(dS[l * ldp + j], Ks[j * PAD + d], g);
+                a.dq[((size_t)b * Lq + q0 + l) * a.lddq + h * HD + d] = g;
+            }
+#pragma unroll
+            for (int i = 0; i < TA_NACC; ++i) {
+                const int idx = tid + 256 * i;
+                if (idx < Lk * HD) {
+                    const int j = idx / HD, d = idx % HD;
+                    for (int l = 0; l < nq; ++l) {
+                        gk[i] = fmaf(dS[l * ldp + j], Qs[l * PAD + d], gk[i]);
+                        gv[i] = fmaf(P[l * ldp + j], dOs[l * PAD + d], gv[i]);
+                    }
+                }
+            }
+        }
+    }
+    if (BACKWARD) {
+#pragma unroll
+        for (int i = 0; i < TA_NACC; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < Lk * HD) {
+                const int j = idx / HD, d = idx % HD;
+                const size_t g = ((size_t)b * Lk + j) * a.lddkv + h * HD + d;
+                a.dk[g] = a.kv_accumulate ? a.dk[g] + gk[i] : gk[i];
+                a.dv[g] = a.kv_accumulate ? a.dv[g] + gv[i] : gv[i];
+            }
+        }
+    }
+}
+
+// im2col of the patch embedding: row (b, gy, gx), column (c, ky, kx) = img[b][c][gy * ph + ky][gx * pw + kx]   (fp32)
+__global__ __launch_bounds__(256)
+void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw, float* __restrict__ out) {
+    const int gw = W / pw, gh = H / ph, pk = 3 * ph * pw;
+    const int row = blockIdx.x, b = row / (gh * gw), gy = (row / gw) % gh, gx = row % gw;
+    for (int col = threadIdx.x; col < pk; col += 256) {
+        const int c = col / (ph * pw), ky = (col / pw) % ph, kx = col % pw;
+        out[(size_t)row * pk + col] = img[(((size_t)b * 3 + c) * H + gy * ph + ky) * W + gx * pw + kx];
     }
 }
 

@@ -1,9 +1,10 @@
 """Row N3, backward: what `loss.backward()` leaves behind after `PARSeq.training_step` (strhub/models/parseq/system.py:168-199).
 
-Built so far: the decoder side — the gradient of the K-permutation loss w.r.t. every `decoder.*`, `head.*`, `text_embed.*`
-parameter and `pos_queries`, and w.r.t. the encoder output (`memory`), computed by `parseq_train_decoder` in fp32 from the
-model's master weights (dropout off).  The encoder backward, which starts from `dmemory`, is not built yet, so the `encoder.*`
-slots of the gradient buffer stay zero; optimiser and gradient all-reduce likewise.
+`loss_and_grads` = the whole step's forward and backward in fp32 from the model's master weights, dropout off:
+`parseq_train_encoder_forward` (keeps the activations the backward needs) -> `parseq_train_decoder` (loss, gradient of every
+`decoder.*` / `head.*` / `text_embed.*` parameter and `pos_queries`, and d loss / d memory) -> `parseq_train_encoder_backward`
+(gradient of every `encoder.*` parameter).  `decoder_backward` is the middle stage alone, on any `memory`.
+Not built: dropout, optimiser, gradient all-reduce.
 """
 from __future__ import annotations
 
@@ -27,6 +28,7 @@ class DecoderBackward:
     dmemory: Tensor                 # [B, tokens, E]
     perms: Tensor
     workspace: Tensor               # raw workspace (floats); `intermediate(name)` reads it
+    memory: Optional[Tensor] = None # the training forward's encoder output (loss_and_grads only)
     _shape: tuple = ()
     _model: Optional[object] = None
 
@@ -84,4 +86,27 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
                                            _native.ptr(masks), B, L, K, total, _native.ptr(loss), _native.ptr(flat), _native.ptr(dmemory),
                                            _native.ptr(workspace), ws_bytes, _native.stream_ptr()))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    return DecoderBackward(loss[0], loss[1:], param_views(native, flat, shapes), flat, dmemory, perms, workspace, (B, L, K), native)
+    return DecoderBackward(loss=loss[0], perm_losses=loss[1:], grads=param_views(native, flat, shapes), flat=flat, dmemory=dmemory, perms=perms,
+                           workspace=workspace, _shape=(B, L, K), _model=native)
+
+
+def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = None) -> DecoderBackward:
+    """Loss and the gradient of EVERY parameter for one batch — the state `loss.backward()` leaves after the reference's
+    `training_step` (system.py:168-199), dropout off.  `images`: fp32 [B, 3, H, W] on the device, normalised."""
+    lib = _native.lib()
+    model = system.model
+    images = model._check_images(images)
+    if images.dtype != torch.float32:
+        images = ((images.float() / 255.0) - 0.5) / 0.5 if images.dtype == torch.uint8 else images.float()
+    native = model._sync_native().model
+    B = images.shape[0]
+    ws_bytes = lib.parseq_train_encoder_workspace_bytes(native, B)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=images.device)
+    memory = torch.empty(B, model.encoder.pos_embed.shape[1], model._cfg['embed_dim'], dtype=torch.float32, device=images.device)
+    _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), B, _native.ptr(memory), _native.ptr(ws), ws_bytes,
+                                                   _native.stream_ptr()))
+    res = decoder_backward(system, images, labels, perms, memory=memory)
+    _native.check(lib.parseq_train_encoder_backward(native, _native.ptr(res.dmemory), B, _native.ptr(res.flat), _native.ptr(ws), ws_bytes,
+                                                    _native.stream_ptr()))
+    res.memory = memory
+    return res

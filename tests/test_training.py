@@ -252,7 +252,7 @@ def test_decoder_backward_matches_reference_gradients(train_golden):
     for key, want in meta['grads'].items():
         got = res.grads[key].cpu()
         if key.startswith('encoder.'):
-            assert not got.any()             # the encoder backward is not built: its slots stay untouched
+            assert not got.any()             # the decoder stage leaves the encoder's slots untouched
             continue
         ref = want_grads[key]
         err = float((got - ref).abs().max())
@@ -265,3 +265,38 @@ def test_decoder_backward_matches_reference_gradients(train_golden):
     assert not bad, (bad, report)
     err = float((res.dmemory.cpu() - want_dmem).abs().max())
     assert err <= 1e-4 * float(want_dmem.abs().max()), (err, report)
+
+
+@pytest.mark.gpu
+def test_full_step_gradients_match_reference(train_golden):
+    """Encoder forward (fp32, activations kept) -> decoder forward / backward -> encoder backward: the loss and the gradient of
+    all 175 parameters against the reference's `training_step` + `loss.backward()` (tests/golden/parseq_train.*; every tensor
+    by norm, fifteen whole), and every tensor against the hand-derived CPU backward."""
+    from gpu_util import DEV, make_model
+    from oracle import decoder_backward as DB, encoder_backward as EB
+    from parseq_amd.train import loss_and_grads
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    m = make_model('parseq', 'bf16')                       # the step computes in fp32 whatever the inference precision is
+    perms = g['perms'].long()
+    res = loss_and_grads(m, g['images'].to(DEV), meta['labels'], perms)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        memory, saved = EB.forward(sd, cfg, g['images'])
+        _, _, want, dmem = DB.loss_and_grads(sd, cfg, memory, m.tokenizer.encode(meta['labels']), perms, O.attn_masks_from_perm)
+        want.update(EB.backward(sd, cfg, saved, dmem))
+    assert (res.memory.cpu() - memory).abs().max() <= 1e-4
+    assert abs(float(res.loss) - meta['loss']) <= 1e-4 * meta['loss']
+    assert set(res.grads) == set(meta['grads']) and len(res.grads) == 175
+    bad = []
+    for key, ref in meta['grads'].items():
+        got = res.grads[key].cpu()
+        err = float((got - want[key]).abs().max())
+        tol = 2e-4 * max(float(want[key].abs().max()), 1e-6) + 1e-7
+        norm = float(got.double().norm())
+        if err > tol or abs(norm - ref['norm']) > 1e-3 * max(ref['norm'], 1e-6):
+            bad.append((key, err, tol, norm, ref['norm']))
+        if 'grad.' + key in g:
+            assert (got - g['grad.' + key]).abs().max() <= tol, key
+    assert not bad, bad
