@@ -231,6 +231,22 @@ int parseq_train_encoder_forward(parseq_model* m, const float* images, int batch
 int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int batch, float* grads, void* workspace,
                                   size_t workspace_bytes, void* stream);
 
+/* Optimiser half of the training step (strhub/models/base.py:98-107: timm create_optimizer_v2('adamw') = torch.optim.AdamW;
+ * configs/main.yaml:39 gradient_clip_val = torch.nn.utils.clip_grad_norm_), over the flat buffers:
+ *   parseq_grad_norm   norm_out[0] = L2 norm of grads[0..n)  (workspace: 1024 floats); deterministic
+ *   parseq_adamw_step  one AdamW update of the model's fp32 master weights IN PLACE from `grads`; exp_avg / exp_avg_sq are the
+ *                      caller-owned moment buffers [parseq_model_grad_elems] (zero before step 1); `step` counts from 1;
+ *                      decay_flags: host int32 [num_params], non-zero = weight decay applies to that tensor (NULL = none);
+ *                      grad_norm: device scalar from parseq_grad_norm or NULL — when given the gradient is scaled by
+ *                      min(1, max_norm / (norm + 1e-6)) on the fly (no host round trip).  Plans built on the model must be
+ *                      refreshed (parseq_plan_refresh) before the next inference call.
+ *   parseq_model_get_param  copies one parameter of the master weights out (device fp32), the inverse of parseq_model_set_param */
+int parseq_grad_norm(const float* grads, int64_t n, float* norm_out, float* workspace, void* stream);
+int parseq_adamw_step(parseq_model* m, const float* grads, float* exp_avg, float* exp_avg_sq, const int32_t* decay_flags, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm, float max_norm,
+                      void* stream);
+int parseq_model_get_param(const parseq_model* m, const char* key, float* device_ptr, int64_t numel, void* stream);
+
 /* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
 
 /* y = LayerNorm(x) over the last dim `E` (192 | 384 | 768); x fp32 [rows, E]; y in out_dtype. */

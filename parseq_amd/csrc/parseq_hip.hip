@@ -1329,6 +1329,53 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     return lin_bwd(s, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK);
 }
 
+// ---- training step, optimiser ---------------------------------------------------------------------------------------------
+extern "C" int parseq_grad_norm(const float* grads, int64_t n, float* norm_out, float* workspace, void* stream) {
+    if (!grads || !norm_out || !workspace || n <= 0) return fail(PARSEQ_E_INVALID, "null / empty argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, grads, (size_t)n, workspace);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, workspace, norm_out);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int parseq_adamw_step(parseq_model* m, const float* grads, float* exp_avg, float* exp_avg_sq, const int32_t* decay_flags, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm, float max_norm,
+                                 void* stream) {
+    if (!m || !grads || !exp_avg || !exp_avg_sq) return fail(PARSEQ_E_INVALID, "null argument");
+    if (step < 1) return fail(PARSEQ_E_INVALID, "step %d: steps count from 1", step);
+    for (const ParamSpec& ps : m->params) if (!ps.set) return fail(PARSEQ_E_STATE, "parameter %s was never set", ps.key.c_str());
+    hipStream_t s = (hipStream_t)stream;
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+    // runs of consecutive tensors with the same weight-decay flag are one launch (with weight_decay == 0, the reference's
+    // configuration, the whole buffer is)
+    const int np = (int)m->params.size();
+    int i = 0;
+    while (i < np) {
+        const bool decay = decay_flags && weight_decay != 0.f && decay_flags[i];
+        int j = i + 1;
+        while (j < np && (decay_flags && weight_decay != 0.f && decay_flags[j]) == decay) ++j;
+        const size_t lo = m->params[i].offset, hi = j < np ? m->params[j].offset : m->master_elems;
+        hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((hi - lo + 255) / 256)), dim3(256), 0, s, m->master + lo, grads + lo, exp_avg + lo,
+                           exp_avg_sq + lo, hi - lo, lr, beta1, beta2, eps, decay ? weight_decay : 0.f, bc1, bc2_sqrt, grad_norm, max_norm);
+        HIPCHK(hipGetLastError());
+        i = j;
+    }
+    m->version++;
+    return 0;
+}
+
+extern "C" int parseq_model_get_param(const parseq_model* m, const char* key, float* device_ptr, int64_t numel, void* stream) {
+    if (!m || !key || !device_ptr) return fail(PARSEQ_E_INVALID, "null argument");
+    auto it = m->index.find(key);
+    if (it == m->index.end()) return fail(PARSEQ_E_INVALID, "unknown parameter key '%s'", key);
+    const ParamSpec& ps = m->params[it->second];
+    if (ps.numel != numel) return fail(PARSEQ_E_INVALID, "parameter %s: numel %lld, expected %lld", key, (long long)numel, (long long)ps.numel);
+    HIPCHK(hipMemcpyAsync(device_ptr, m->master + ps.offset, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
 // -------------------------------------------------------------------------------------------------------------------
 // input resize
 // -------------------------------------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
-// Row N3 (training step), first correct version: fp32 kernels for the backward of the K-permutation loss, decoder side.
+// Row N3 (training step), first correct version: fp32 kernels for the forward / backward of the K-permutation loss (decoder and
+// encoder) and the optimiser step.
 //
 // These are deliberately plain — one generic strided GEMM on the VALU, wave-per-row LayerNorm / cross-entropy backward,
 // one workgroup per (image, head) attention forward / backward with everything in LDS — because this round's bar for the
@@ -387,6 +388,59 @@ void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw,
         const int c = col / (ph * pw), ky = (col / pw) % ph, kx = col % pw;
         out[(size_t)row * pk + col] = img[(((size_t)b * 3 + c) * H + gy * ph + ky) * W + gx * pw + kx];
     }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// optimiser step over the flat parameter / gradient buffers (timm create_optimizer_v2('adamw') = torch.optim.AdamW;
+// gradient clipping = torch.nn.utils.clip_grad_norm_, what Lightning's gradient_clip_val applies; configs/main.yaml:39)
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int SUMSQ_BLOCKS = 1024;
+
+// partial[block] = sum of g[i]^2 over the block's grid-stride slice (fixed order: deterministic)
+__global__ __launch_bounds__(256)
+void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)SUMSQ_BLOCKS * 256) s = fmaf(g[i], g[i], s);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256)
+void sumsq_final_kernel(const float* __restrict__ partial, float* __restrict__ norm_out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < SUMSQ_BLOCKS; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *norm_out = sqrtf(red[0]);
+}
+
+// torch.optim.AdamW (single-tensor path), with the clip coefficient min(1, max_norm / (norm + 1e-6)) applied to the gradient
+// on the fly when `norm` is given:   p *= 1 - lr wd;  m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g^2;
+//                                    p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256)
+void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt, const float* __restrict__ norm, float max_norm) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float coef = 1.f;
+    if (norm) coef = fminf(max_norm / (*norm + 1e-6f), 1.0f);
+    const float grad = g[i] * coef;
+    float param = p[i] * (1.0f - lr * weight_decay);
+    const float mi = m[i] + (grad - m[i]) * (1.0f - beta1);
+    const float vi = v[i] * beta2 + (1.0f - beta2) * grad * grad;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    param -= (lr / bc1) * (mi / denom);
+    p[i] = param; m[i] = mi; v[i] = vi;
 }
 
 }  // namespace pq

@@ -269,6 +269,19 @@ class _NativeBacked(nn.Module):
         st.signature = sig
         return st
 
+    def _adopt_native_weights(self):
+        """After an optimiser step on the device (`parseq_adamw_step` updates the library's fp32 master weights in place): copy
+        them back into this module's parameter tensors — through raw pointers, so their autograd versions, and with them the
+        signature, do not change and nothing is uploaded again — and re-pack the plans' bf16 copies / decoder tables."""
+        st: _NativeState = self._native_state
+        lib, stream = _native.lib(), _native.stream_ptr()
+        for key, t in self.state_dict().items():
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f'parameter {key}: training needs contiguous fp32 parameters')
+            _native.check(lib.parseq_model_get_param(st.model, key.encode(), _native.ptr(t), t.numel(), stream))
+        for plan, _ in st.plans.values():
+            _native.check(lib.parseq_plan_refresh(plan, stream))
+
     def _plan(self, batch: int, slot: int = 0):
         if self.precision not in _PRECISIONS:
             raise RuntimeError(f"precision must be one of {sorted(_PRECISIONS)}, got '{self.precision}'")

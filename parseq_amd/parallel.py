@@ -68,3 +68,24 @@ def data_parallel_forward(model, images: Tensor, max_length: Optional[int] = Non
     lo, hi = shard_bounds(images.shape[0], world, rank)
     local = model(images[lo:hi], max_length)
     return all_gather_logits(local, group)
+
+
+def average_gradients(flat: Tensor, group=None, bucket_elems: int = 6 * 1024 * 1024) -> Tensor:
+    """Data-parallel gradient synchronisation of the training step (row N3): the mean over ranks of the flat gradient buffer,
+    in place — what DDP's reducer leaves in `.grad` (the reference trains with Lightning's DDP strategy, train.py:88-96).
+
+    The buffer already IS one contiguous bucket list (the library lays all 175 gradients out back to back), so there is no
+    per-tensor flattening: it is all-reduced in slices of `bucket_elems` floats (24 MB by default — on an 8-GPU xGMI ring each
+    link moves 2 * 7/8 of that per bucket, ~0.3 ms at 153 GB/s, and four buckets cover PARSeq-S), issued back to back on the
+    collective stream so a later bucket's reduce-scatter overlaps the earlier one's all-gather."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    works = []
+    for lo in range(0, flat.numel(), bucket_elems):
+        works.append(dist.all_reduce(flat[lo:lo + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    flat.mul_(1.0 / world)
+    return flat

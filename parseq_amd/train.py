@@ -110,3 +110,78 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
                                                     _native.stream_ptr()))
     res.memory = memory
     return res
+
+
+def one_cycle_lr(step_num: int, total_steps: int, max_lr: float, pct_start: float, div_factor: float = 25.0,
+                 final_div_factor: float = 1e4) -> float:
+    """Learning rate of torch.optim.lr_scheduler.OneCycleLR(max_lr, total_steps, pct_start, cycle_momentum=False) — what
+    strhub/models/base.py:103-106 configures — after `step_num` scheduler steps (cosine annealing, two phases)."""
+    import math
+    initial, floor = max_lr / div_factor, max_lr / div_factor / final_div_factor
+    end1, end2 = float(pct_start * total_steps) - 1.0, float(total_steps) - 1.0
+    if step_num > end2:
+        raise ValueError(f'step {step_num} beyond the {total_steps} steps of the cycle')
+    anneal = lambda a, b, pct: b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+    if step_num <= end1:
+        return anneal(initial, max_lr, step_num / end1)
+    return anneal(max_lr, floor, (step_num - end1) / (end2 - end1))
+
+
+class TrainStep:
+    """The per-batch work of `Trainer.fit` on the reference's configuration (base.py:98-110, configs/main.yaml:33-41): forward and
+    backward of `training_step`, gradient averaging across ranks (what DDP does), gradient-norm clipping, one AdamW update under
+    the OneCycle schedule — all on the device, no host synchronisation inside a step.  Epoch loops, checkpoints, logging and
+    SWA are the framework's business and stay outside."""
+
+    def __init__(self, system, total_steps: int, lr: Optional[float] = None, weight_decay: Optional[float] = None,
+                 warmup_pct: Optional[float] = None, clip_val: float = 20.0, betas=(0.9, 0.999), eps: float = 1e-8,
+                 num_devices: int = 1, accumulate_grad_batches: int = 1, process_group=None):
+        import math
+        self.system = system
+        self.total_steps = total_steps
+        # base.py:98-101: linear scaling with the batch size, sqrt scaling with the number of devices
+        scale = accumulate_grad_batches * math.sqrt(num_devices) * system.batch_size / 256.0
+        self.max_lr = scale * (system.lr if lr is None else lr)
+        self.weight_decay = system.weight_decay if weight_decay is None else weight_decay
+        self.pct_start = system.warmup_pct if warmup_pct is None else warmup_pct
+        self.clip_val, self.betas, self.eps = clip_val, betas, eps
+        self.process_group = process_group
+        self.step_count = 0
+        lib = _native.lib()
+        model = system.model
+        native = model._sync_native().model
+        n = lib.parseq_model_grad_elems(native)
+        dev = system.device
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._norm_ws = torch.empty(1024, dtype=torch.float32, device=dev)
+        # timm param_groups_weight_decay: 1-D tensors and biases are not decayed
+        flags = [int(p.ndim > 1 and not k.endswith('.bias')) for k, p in model.state_dict().items()]
+        self._decay_flags = (C.c_int32 * len(flags))(*flags)
+
+    @property
+    def lr(self) -> float:
+        return one_cycle_lr(self.step_count, self.total_steps, self.max_lr, self.pct_start)
+
+    def __call__(self, images: Tensor, labels, perms: Optional[Tensor] = None) -> Tensor:
+        lib = _native.lib()
+        system, model = self.system, self.system.model
+        res = loss_and_grads(system, images, labels, perms)
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            from .parallel import average_gradients
+            average_gradients(res.flat, self.process_group)
+        native = model._sync_native().model
+        stream = _native.stream_ptr()
+        norm = None
+        if self.clip_val:
+            _native.check(lib.parseq_grad_norm(_native.ptr(res.flat), res.flat.numel(), _native.ptr(self._norm), _native.ptr(self._norm_ws), stream))
+            norm = self._norm
+        lr = self.lr
+        self.step_count += 1
+        _native.check(lib.parseq_adamw_step(native, _native.ptr(res.flat), _native.ptr(self.exp_avg), _native.ptr(self.exp_avg_sq),
+                                            self._decay_flags, lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                            self.step_count, _native.ptr(norm), float(self.clip_val or 0.0), stream))
+        model._adopt_native_weights()
+        self.last = res
+        return res.loss

@@ -79,3 +79,33 @@ def test_two_rank_gloo_sharded_forward(n_images):
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == [0, 1]
     assert all(r[1] and r[2] and r[3] for r in results), results
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from parseq_amd.parallel import average_gradients
+        n = 1000 + 37                                        # not a multiple of the bucket size: the last bucket is ragged
+        mine = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        out = average_gradients(mine, bucket_elems=256)
+        want = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        q.put((rank, out.data_ptr() == mine.data_ptr() and torch.allclose(out, want, rtol=1e-6, atol=0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_average():
+    """Row N3's data-parallel step: the flat gradient buffer is averaged across ranks in place, bucket by bucket."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1] and all(r[1] for r in results)

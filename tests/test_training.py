@@ -171,6 +171,22 @@ def test_hand_derived_decoder_backward_matches_reference(train_golden):
     assert (mem.grad - dmem).abs().max() <= 1e-5 * float(mem.grad.abs().max())
 
 
+@pytest.mark.parametrize('total,pct', [(100, 0.075), (1000, 0.3), (37, 0.075), (20, 0.5)])
+def test_one_cycle_schedule_matches_torch(total, pct):
+    """The schedule of base.py:103-106 (OneCycleLR, cycle_momentum=False) restated as a pure function of the step count."""
+    from parseq_amd.train import one_cycle_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=1e-3)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, 2.5e-3, total, pct_start=pct, cycle_momentum=False)
+    for step in range(total):
+        assert abs(one_cycle_lr(step, total, 2.5e-3, pct) - opt.param_groups[0]['lr']) <= 1e-9 * 2.5e-3 + 1e-15, step
+        opt.step()
+        if step + 1 < total:
+            sched.step()
+    with pytest.raises(ValueError):
+        one_cycle_lr(total, total, 2.5e-3, pct)
+
+
 # ---- device ---------------------------------------------------------------------------------------------------------------
 
 @pytest.mark.gpu
@@ -300,3 +316,69 @@ def test_full_step_gradients_match_reference(train_golden):
         if 'grad.' + key in g:
             assert (got - g['grad.' + key]).abs().max() <= tol, key
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_three_optimiser_steps_follow_torch_adamw(train_golden):
+    """TrainStep (forward, backward, gradient-norm clipping, AdamW under the OneCycle schedule, all on the device) against the
+    same three steps on the CPU: autograd through the oracle, torch.nn.utils.clip_grad_norm_, torch.optim.AdamW + OneCycleLR.
+    Clipping is made active (max norm 5 < the 11.1 of the first gradient).  Afterwards the module's own tensors and the
+    inference plans carry the updated weights."""
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import TrainStep
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    perms = g['perms'].long()
+    images = g['images']
+    step = TrainStep(m, total_steps=40, clip_val=5.0, weight_decay=0.01)
+    lrs, got_losses = [], []
+    for _ in range(3):
+        lrs.append(step.lr)
+        got_losses.append(float(step(images.to(DEV), meta['labels'], perms)))
+    torch.cuda.synchronize()
+    # CPU reference
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth_state_dict(cfg, 0).items()}
+    decay = [v for k, v in sd.items() if v.ndim > 1 and not k.endswith('.bias')]
+    rest = [v for k, v in sd.items() if not (v.ndim > 1 and not k.endswith('.bias'))]
+    opt = torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': rest, 'weight_decay': 0.0}], lr=step.max_lr)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, step.max_lr, 40, pct_start=m.warmup_pct, cycle_momentum=False)
+    tgt = m.tokenizer.encode(meta['labels'])
+    want_losses = []
+    for i in range(3):
+        assert abs(opt.param_groups[0]['lr'] - lrs[i]) <= 1e-9 * step.max_lr
+        opt.zero_grad()
+        loss = O.training_loss(sd, cfg, images, tgt, perms)[0]
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(sd.values()), 5.0)
+        if i == 0:
+            first_grads = {k: v.grad.clone() for k, v in sd.items()}
+        opt.step()
+        sched.step()
+        want_losses.append(float(loss.detach()))
+    assert all(abs(a - b) <= 2e-4 * b for a, b in zip(got_losses, want_losses)), (got_losses, want_losses)
+    assert got_losses[2] < got_losses[0]
+    # Parameters: Adam divides by sqrt(v), so where the true gradient is zero up to round-off (the key bias of every attention:
+    # soft-max is invariant to it) the update is +-lr times noise on both sides; compare where the first gradient is above that
+    # floor, and bound the rest by Adam's own step bound.
+    start = synth_state_dict(cfg, 0)
+    lr_sum = sum(lrs)
+    bad = []
+    for key, t in m.model.state_dict().items():
+        d_got, d_want = t.cpu() - start[key], sd[key].detach() - start[key]
+        err = (d_got - d_want).abs()
+        real = first_grads[key].abs() > 1e-6
+        if real.any():
+            if float(err[real].max()) > 0.1 * lr_sum or float(err[real].mean()) > 2e-3 * lr_sum:
+                bad.append((key, 'real', float(err[real].max()), float(err[real].mean())))
+        if float(d_got.abs().max()) > 1.05 * lr_sum + 0.02 * float(start[key].abs().max()) * lr_sum:
+            bad.append((key, 'bound', float(d_got.abs().max())))
+        if float(d_want.abs().max()) > 0 and float(d_got.abs().max()) == 0:
+            bad.append((key, 'unchanged'))
+    assert not bad, (bad, lr_sum)
+    # the inference path now runs on the updated weights (plans were re-packed): fp32-mode logits against the oracle with them
+    m.precision = 'fp32'
+    with torch.inference_mode():
+        got = m(images.to(DEV), 25).float().cpu()
+        want = O.forward({k: v.detach() for k, v in sd.items()}, cfg, images, 25, decode_ar=True, refine_iters=1)
+    assert (got - want).abs().max() <= 2e-3, float((got - want).abs().max())
