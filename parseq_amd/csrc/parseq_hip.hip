@@ -1002,16 +1002,53 @@ extern "C" int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int b
 // -------------------------------------------------------------------------------------------------------------------
 // training step, decoder side: loss of system.py:168-199 and its gradients, fp32
 // -------------------------------------------------------------------------------------------------------------------
+// Scratch shared by the split-K partials of the MFMA GEMM and the partial column sums; part of the caller's workspace.
+constexpr size_t TRAIN_SCRATCH_FLOATS = (size_t)16 << 20;
+struct TrainScratch { float* p; };
+static thread_local TrainScratch g_train_scratch{nullptr};
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 static int sgemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
                  long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate) {
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
     SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0};
+    // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
+    const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
+    const bool b_ok = aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0));
+    if (M % MG_BM == 0 && N % MG_BN == 0 && K % MG_BK == 0 && a_ok && b_ok && g_train_scratch.p) {
+        const int tiles = (M / MG_BM) * (N / MG_BN);
+        int splits = 1;
+        if (tiles < 256) {
+            splits = std::min((512 + tiles - 1) / tiles, K / (4 * MG_BK));
+            splits = (int)std::min<size_t>((size_t)std::max(splits, 1), TRAIN_SCRATCH_FLOATS / ((size_t)M * N));
+            splits = std::max(splits, 1);
+        }
+        const int k_chunk = ((K + splits - 1) / splits + MG_BK - 1) / MG_BK * MG_BK;
+        splits = (K + k_chunk - 1) / k_chunk;
+        hipLaunchKernelGGL(mfma_sgemm_kernel, dim3(N / MG_BN, M / MG_BM, splits), dim3(256), 0, s, a, k_chunk, g_train_scratch.p);
+        HIPCHK(hipGetLastError());
+        if (splits > 1) {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, a, g_train_scratch.p, splits);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     hipLaunchKernelGGL(sgemm_kernel, dim3((N + SG_BN - 1) / SG_BN, (M + SG_BM - 1) / SG_BM), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return 0;
 }
 static int colsum(hipStream_t s, const float* A, long lda, int M, int N, float* out, bool accumulate) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, A, lda, M, N, out, accumulate ? 1 : 0);
+    constexpr int CHUNKS = 64;
+    if (M >= 2048 && g_train_scratch.p && (size_t)CHUNKS * N <= TRAIN_SCRATCH_FLOATS) {
+        const int rows_per = (M + CHUNKS - 1) / CHUNKS;
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, CHUNKS), dim3(1024), 0, s, A, lda, M, N, g_train_scratch.p, 0, rows_per);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, g_train_scratch.p, (long)N, CHUNKS, N, out, accumulate ? 1 : 0, CHUNKS);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, A, lda, M, N, out, accumulate ? 1 : 0, M);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1059,7 +1096,7 @@ static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backwar
 
 struct TrainDecoderLayout {          // offsets in floats into the caller's workspace
     size_t content, cn, kvc, qn, qsa, kvm, sa_o, t1, n1, q2, ca_o, t2, n2, hpre, hact, t3, out, logits;
-    size_t d_a, d_b, d_c, d_h, tmp, d_kvc, d_kvm, d_qsa, d_pq, d_qb, row_loss, losses, counts, total;
+    size_t d_a, d_b, d_c, d_h, tmp, d_kvc, d_kvm, d_qsa, d_pq, d_qb, row_loss, losses, counts, scratch, total;
 };
 static TrainDecoderLayout train_decoder_layout(const parseq_model* m, int B, int L, int K) {
     const size_t E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, M = (size_t)B * L, MS = (size_t)B * S;
@@ -1071,7 +1108,7 @@ static TrainDecoderLayout train_decoder_layout(const parseq_model* m, int B, int
     o.hpre = take(M * F); o.hact = take(M * F); o.t3 = take(M * E); o.out = take(M * E); o.logits = take(M * C);
     o.d_a = take(M * E); o.d_b = take(M * E); o.d_c = take(M * E); o.d_h = take(M * F); o.tmp = take(M * E);
     o.d_kvc = take(M * 2 * E); o.d_kvm = take(MS * 2 * E); o.d_qsa = take(L * E); o.d_pq = take(L * E); o.d_qb = take(M * E);
-    o.row_loss = take(M); o.losses = take(K + 1); o.counts = take(K + 1);
+    o.row_loss = take(M); o.losses = take(K + 1); o.counts = take(K + 1); o.scratch = take(TRAIN_SCRATCH_FLOATS);
     o.total = off;
     return o;
 }
@@ -1128,6 +1165,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_qsa = w + o.d_qsa; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
     float* row_loss = w + o.row_loss; float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
     const size_t elems = (size_t)M * F;
+    g_train_scratch.p = w + o.scratch;
 
     // ---- shared by all permutations: content stream, its K / V, the (batch-independent) self-attention queries, memory K / V
     hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content);
@@ -1215,7 +1253,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
 
 // ---- training step, encoder side: forward that keeps what the backward needs, and the backward ------------------------------
 struct TrainEncoderLayout {          // offsets in floats
-    size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, total;
+    size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, total;
     size_t x(int i) const { return layer0 + i * layer_stride; }
     size_t qkv, ao, x_mid, hpre;     // offsets inside one layer's record (x at 0)
 };
@@ -1231,7 +1269,7 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     o.layer_stride = off - o.layer0;
     off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
     o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
-    o.dqkv = take(MS * 3 * E); o.tmp = take(MS * E);
+    o.dqkv = take(MS * 3 * E); o.tmp = take(MS * E); o.scratch = take(TRAIN_SCRATCH_FLOATS);
     o.total = off;
     return o;
 }
@@ -1270,6 +1308,7 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     const float eps = m->cfg.enc_ln_eps;
     float* w = reinterpret_cast<float*>(workspace);
     auto P = [&](const std::string& key) { return m->p(m->enc + key); };
+    g_train_scratch.p = w + o.scratch;
     hipLaunchKernelGGL(patches_kernel, dim3(MS), dim3(256), 0, s, images, m->cfg.img_h, m->cfg.img_w, m->cfg.patch_h, m->cfg.patch_w, w + o.patches);
     HIPCHK(hipGetLastError());
     CHK(lin_fwd(s, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
@@ -1305,6 +1344,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* n = w + o.n; float* hact = w + o.hact; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
+    g_train_scratch.p = w + o.scratch;
     CHK(ln_bwd(s, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps));
     for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
         const std::string p = "blocks." + std::to_string(i) + ".";

@@ -84,23 +84,123 @@ void sgemm_kernel(const SgemmArgs a) {
     }
 }
 
+// The same contraction on the matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate) for the shapes that
+// carry the step's FLOPs: M % 128 == 0, N % 128 == 0, K % 16 == 0, 16-byte aligned rows.  128 x 128 block tile, four waves of
+// 64 x 64, 16 of K per LDS stage, operands parked k-major in LDS (As[k][m], Bs[k][n]) so that a lane's MFMA operand is one
+// ds_read_b32 and either memory orientation of A / B (k- or m/n-contiguous) is loaded with 16-byte accesses.
+// blockIdx.z splits K (the dW contractions run over batch * tokens rows but have few output tiles): split z handles
+// [z * k_chunk, +k_chunk) and, when gridDim.z > 1, writes its tile to partial[z][M][N]; splitk_reduce_kernel folds them in a
+// fixed order (deterministic).  bias / residual / accumulate are applied by whichever kernel writes C.
+constexpr int MG_BM = 128, MG_BN = 128, MG_BK = 16, MG_LD = 128 + 16;
+
+__device__ __forceinline__ void mg_load_tile(const float* __restrict__ base, long s_outer, long s_k, int outer0, int k0, bool k_fast,
+                                            float (*tile)[MG_LD], int tid) {
+    // tile[k][o] = base[(outer0 + o) * s_outer + (k0 + k) * s_k]   for o < 128, k < 16; one of s_outer / s_k is 1
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (k_fast) {
+            const int o = tid & 127, k4 = (tid >> 7) + 2 * it;             // 4 consecutive k of one row
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(outer0 + o) * s_outer + k0 + 4 * k4);
+            tile[4 * k4 + 0][o] = v.x; tile[4 * k4 + 1][o] = v.y; tile[4 * k4 + 2][o] = v.z; tile[4 * k4 + 3][o] = v.w;
+        } else {
+            const int o4 = tid & 31, k = (tid >> 5) + 8 * it;              // 4 consecutive rows of one k
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)(k0 + k) * s_k + outer0 + 4 * o4);
+            *reinterpret_cast<float4*>(&tile[k][4 * o4]) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void mfma_sgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As[MG_BK][MG_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[MG_BK][MG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * MG_BM, n0 = blockIdx.x * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    for (int k0 = kbeg; k0 < kend; k0 += MG_BK) {
+        mg_load_tile(a.A, a.sam, a.sak, m0, k0, a_kfast, As, tid);
+        mg_load_tile(a.B, a.sbn, a.sbk, n0, k0, b_kfast, Bs, tid);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < MG_BK / 4; ++ks) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { av[i] = As[4 * ks + g][wm + 16 * i + r16]; bv[i] = Bs[4 * ks + g][wn + 16 * i + r16]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // lane holds D[row = 16 i + 4 g + r][col = 16 j + r16]
+    const bool direct = gridDim.z == 1;
+    float* out = direct ? a.C : partial + (size_t)blockIdx.z * a.M * a.N;
+    const long ldo = direct ? a.ldc : a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + wm + 16 * i + 4 * g + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + wn + 16 * j + r16;
+                float v = acc[i][j][r];
+                float* c = out + (size_t)gm * ldo + gn;
+                if (direct) {
+                    v *= a.alpha;
+                    if (a.bias) v += a.bias[gn];
+                    if (a.R) v += a.R[(size_t)(gm % a.rper) * a.ldr + gn];
+                    if (a.accumulate) v += *c;
+                }
+                *c = v;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256)
+void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, int splits) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)a.M * a.N;
+    if (idx >= total) return;
+    const int gm = (int)(idx / a.N), gn = (int)(idx % a.N);
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += partial[(size_t)z * total + idx];
+    v *= a.alpha;
+    if (a.bias) v += a.bias[gn];
+    if (a.R) v += a.R[(size_t)(gm % a.rper) * a.ldr + gn];
+    float* c = a.C + (size_t)gm * a.ldc + gn;
+    *c = a.accumulate ? *c + v : v;
+}
+
 // out[n] (+)= sum_m A[m * lda + n]: bias gradients, LayerNorm affine gradients, sums over the batch ([B, L * E] views).
-// 16 row groups x 64 columns per workgroup, rows added in a fixed order.
+// Many rows: two deterministic stages (row chunks -> partials, then this kernel again over the partials).
+// 16 row groups x 64 columns per workgroup, rows added in a fixed order.  blockIdx.y = row chunk of `rows_per` rows; with more
+// than one chunk the kernel writes out[chunk][n] (a partial, never accumulated into).
 __global__ __launch_bounds__(1024)
-void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* __restrict__ out, int accumulate) {
+void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* __restrict__ out, int accumulate, int rows_per) {
     __shared__ float part[16][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const int m_lo = blockIdx.y * rows_per, m_hi = min(M, m_lo + rows_per);
     float s = 0.f;
     if (n < N)
-        for (int m = rg; m < M; m += 16) s += A[(size_t)m * lda + n];
+        for (int m = m_lo + rg; m < m_hi; m += 16) s += A[(size_t)m * lda + n];
     part[rg][c] = s;
     __syncthreads();
     if (rg == 0 && n < N) {
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += part[i][c];
-        out[n] = accumulate ? out[n] + t : t;
+        float* o = out + (size_t)blockIdx.y * N + n;
+        *o = (accumulate && gridDim.y == 1) ? *o + t : t;
     }
 }
 

@@ -382,3 +382,38 @@ def test_three_optimiser_steps_follow_torch_adamw(train_golden):
         got = m(images.to(DEV), 25).float().cpu()
         want = O.forward({k: v.detach() for k, v in sd.items()}, cfg, images, 25, decode_ar=True, refine_iters=1)
     assert (got - want).abs().max() <= 2e-3, float((got - want).abs().max())
+
+
+@pytest.mark.gpu
+def test_batch_64_step_uses_the_matrix_core_gemms():
+    """64 crops x 26 positions = 1664 decoder rows and 8192 encoder rows: every Linear (forward, dX, dW with split-K) runs on the
+    MFMA fp32 GEMM and the column sums take their two-stage form.  All 175 gradients against the hand-derived CPU backward."""
+    from gpu_util import DEV, make_model
+    from oracle import decoder_backward as DB, encoder_backward as EB
+    from parseq_amd.train import loss_and_grads
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    m = make_model('parseq', 'bf16')
+    gen = torch.Generator().manual_seed(99)
+    images = synth_images(64, cfg, seed=77)
+    lengths = torch.randint(1, 26, (64,), generator=gen).tolist()
+    lengths[5] = 25
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+    m.rng = np.random.default_rng(8)
+    torch.manual_seed(9)
+    res = loss_and_grads(m, images.to(DEV), labels)
+    torch.cuda.synchronize()
+    assert res.perms.shape == (6, 27)
+    with torch.no_grad():
+        memory, saved = EB.forward(sd, cfg, images)
+        want_loss, _, want, dmem = DB.loss_and_grads(sd, cfg, memory, m.tokenizer.encode(labels), res.perms, O.attn_masks_from_perm)
+        want.update(EB.backward(sd, cfg, saved, dmem))
+    assert abs(float(res.loss) - float(want_loss)) <= 1e-4 * float(want_loss)
+    bad = []
+    for key, ref in want.items():
+        got = res.grads[key].cpu()
+        err = float((got - ref).abs().max())
+        tol = 3e-4 * max(float(ref.abs().max()), 1e-6) + 1e-7
+        if err > tol:
+            bad.append((key, err, tol))
+    assert not bad, bad
