@@ -208,6 +208,12 @@ int64_t parseq_model_grad_elems(const parseq_model* m);
  *   key_padding_mask  device uint8 [batch, ctx_len]   (tgt_in == pad) | (tgt_in == eos)                   (system.py:179)
  *   query_masks       device uint8 [num_perms][ctx_len][ctx_len]   generate_attn_masks(perm)[1]           (system.py:152-166)
  *   total_targets     sum over the permutations of their count of non-<pad> targets (the loss denominator, :189,196)
+ *   dropout_p, seed   dropout probability of the decoder (configs/model/parseq.yaml:21; 0 = off, the evaluation-mode step the
+ *                     parity tests use) and the 64-bit seed of this step's masks.  Eight sites per permutation pass, as in
+ *                     the reference (model.py:99-102 embeddings and queries, dropped afresh in every pass; modules.py:33-43,
+ *                     70-79 both attentions' probabilities, both projections, the MLP's hidden layer and output).  Masks
+ *                     come from a counter-based generator (train_ops.h:drop_factor), not torch's Philox stream: with the
+ *                     same masks the gradients are exact (tests), against the reference's run they agree in distribution.
  *   loss_out          device fp32 [1 + num_perms]: the loss, then each permutation's mean cross-entropy
  *   grads             device fp32 [parseq_model_grad_elems]: ACCUMULATED into (zero it for a fresh step); encoder slots untouched
  *   dmemory           device fp32 [batch, tokens, embed_dim]: written
@@ -217,8 +223,8 @@ size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, int batch, in
 int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, int batch, int ctx_len, int num_perms, const char* name);
 int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* tokens, const int32_t* targets,
                          const uint8_t* key_padding_mask, const uint8_t* query_masks, int batch, int ctx_len, int num_perms,
-                         int total_targets, float* loss_out, float* grads, float* dmemory, void* workspace,
-                         size_t workspace_bytes, void* stream);
+                         int total_targets, float dropout_p, uint64_t seed, float* loss_out, float* grads, float* dmemory,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* Encoder half of the training step (timm VisionTransformer blocks, strhub/models/parseq/modules.py:128-165): a forward in
  * fp32 from the master weights that keeps in `workspace` what the backward needs (per block: the residual stream before

@@ -68,7 +68,7 @@ SIGNATURES = {
     'parseq_train_decoder_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'parseq_train_decoder_workspace_offset': (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]),
     'parseq_train_decoder': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                       C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                       C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'parseq_train_encoder_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'parseq_train_encoder_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'parseq_train_encoder_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

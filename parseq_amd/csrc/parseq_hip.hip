@@ -1095,19 +1095,20 @@ static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backwar
 }
 
 struct TrainDecoderLayout {          // offsets in floats into the caller's workspace
-    size_t content, cn, kvc, qn, qsa, kvm, sa_o, t1, n1, q2, ca_o, t2, n2, hpre, hact, t3, out, logits;
-    size_t d_a, d_b, d_c, d_h, tmp, d_kvc, d_kvm, d_qsa, d_pq, d_qb, row_loss, losses, counts, scratch, total;
+    size_t content0, content, cn, kvc, qd, qn, qsa, kvm, sa_o, t1, n1, q2, ca_o, t2, n2, hpre, hact, t3, out, logits;
+    size_t d_a, d_b, d_c, d_h, pm, tmp, d_kvc, d_kvm, d_content, d_pq, d_qb, row_loss, losses, counts, scratch, total;
 };
 static TrainDecoderLayout train_decoder_layout(const parseq_model* m, int B, int L, int K) {
     const size_t E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, M = (size_t)B * L, MS = (size_t)B * S;
     TrainDecoderLayout o;
     size_t off = 0;
     auto take = [&](size_t n) { const size_t at = off; off += (n + 63) / 64 * 64; return at; };
-    o.content = take(M * E); o.cn = take(M * E); o.kvc = take(M * 2 * E); o.qn = take(L * E); o.qsa = take(L * E); o.kvm = take(MS * 2 * E);
+    o.content0 = take(M * E); o.content = take(M * E); o.cn = take(M * E); o.kvc = take(M * 2 * E); o.qd = take(M * E); o.qn = take(M * E);
+    o.qsa = take(M * E); o.kvm = take(MS * 2 * E);
     o.sa_o = take(M * E); o.t1 = take(M * E); o.n1 = take(M * E); o.q2 = take(M * E); o.ca_o = take(M * E); o.t2 = take(M * E); o.n2 = take(M * E);
     o.hpre = take(M * F); o.hact = take(M * F); o.t3 = take(M * E); o.out = take(M * E); o.logits = take(M * C);
-    o.d_a = take(M * E); o.d_b = take(M * E); o.d_c = take(M * E); o.d_h = take(M * F); o.tmp = take(M * E);
-    o.d_kvc = take(M * 2 * E); o.d_kvm = take(MS * 2 * E); o.d_qsa = take(L * E); o.d_pq = take(L * E); o.d_qb = take(M * E);
+    o.d_a = take(M * E); o.d_b = take(M * E); o.d_c = take(M * E); o.d_h = take(M * F); o.pm = take(M * E); o.tmp = take(M * E);
+    o.d_kvc = take(M * 2 * E); o.d_kvm = take(MS * 2 * E); o.d_content = take(M * E); o.d_pq = take(L * E); o.d_qb = take(M * E);
     o.row_loss = take(M); o.losses = take(K + 1); o.counts = take(K + 1); o.scratch = take(TRAIN_SCRATCH_FLOATS);
     o.total = off;
     return o;
@@ -1124,9 +1125,9 @@ extern "C" int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, 
     if (!m || !name || batch <= 0 || ctx_len <= 0 || num_perms <= 0) return -1;
     const TrainDecoderLayout o = train_decoder_layout(m, batch, ctx_len, num_perms);
     const std::pair<const char*, size_t> table[] = {
-        {"content", o.content}, {"cn", o.cn}, {"kvc", o.kvc}, {"qn", o.qn}, {"qsa", o.qsa}, {"kvm", o.kvm}, {"sa_o", o.sa_o}, {"t1", o.t1}, {"n1", o.n1},
-        {"q2", o.q2}, {"ca_o", o.ca_o}, {"t2", o.t2}, {"n2", o.n2}, {"hpre", o.hpre}, {"hact", o.hact}, {"t3", o.t3}, {"out", o.out},
-        {"dlogits", o.logits}, {"d_kvc", o.d_kvc}, {"d_kvm", o.d_kvm}, {"d_qsa", o.d_qsa}, {"d_pq", o.d_pq}};
+        {"content", o.content}, {"cn", o.cn}, {"kvc", o.kvc}, {"qd", o.qd}, {"qn", o.qn}, {"qsa", o.qsa}, {"kvm", o.kvm}, {"sa_o", o.sa_o}, {"t1", o.t1},
+        {"n1", o.n1}, {"q2", o.q2}, {"ca_o", o.ca_o}, {"t2", o.t2}, {"n2", o.n2}, {"hpre", o.hpre}, {"hact", o.hact}, {"t3", o.t3}, {"out", o.out},
+        {"dlogits", o.logits}, {"d_kvc", o.d_kvc}, {"d_kvm", o.d_kvm}, {"d_content", o.d_content}, {"d_pq", o.d_pq}};
     for (const auto& e : table) if (!strcmp(e.first, name)) return (int64_t)e.second;
     return -1;
 }
@@ -1136,9 +1137,16 @@ extern "C" size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, in
     return train_decoder_layout(m, batch, ctx_len, num_perms).total * sizeof(float);
 }
 
+// y = R + dropout(x) over n elements (R may be null, x == y allowed); with dropout off a plain add / copy
+static int dropout_add(hipStream_t s, const float* x, const float* R, float* y, size_t n, const DropSpec& d, unsigned site) {
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, R, y, n, d, site);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* tokens, const int32_t* targets, const uint8_t* key_padding_mask,
-                                    const uint8_t* query_masks, int batch, int ctx_len, int num_perms, int total_targets, float* loss_out,
-                                    float* grads, float* dmemory, void* workspace, size_t workspace_bytes, void* stream) {
+                                    const uint8_t* query_masks, int batch, int ctx_len, int num_perms, int total_targets, float dropout_p,
+                                    uint64_t seed, float* loss_out, float* grads, float* dmemory, void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !memory || !tokens || !targets || !key_padding_mask || !query_masks || !loss_out || !grads || !dmemory || !workspace)
         return fail(PARSEQ_E_INVALID, "null argument");
     if (m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
@@ -1146,11 +1154,14 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     const int B = batch, L = ctx_len, K = num_perms;
     if (B <= 0 || L < 2 || L > m->cfg.max_label_length + 1 || K <= 0 || total_targets <= 0)
         return fail(PARSEQ_E_INVALID, "bad shape: batch %d, ctx_len %d (2..%d), %d permutations, %d targets", B, L, m->cfg.max_label_length + 1, K, total_targets);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(PARSEQ_E_INVALID, "dropout_p %g outside [0, 1)", dropout_p);
     const TrainDecoderLayout o = train_decoder_layout(m, B, L, K);
     if (workspace_bytes < o.total * sizeof(float)) return fail(PARSEQ_E_INVALID, "workspace: %zu bytes given, %zu needed", workspace_bytes, o.total * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     const int E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, H = m->cfg.dec_heads, M = B * L, MS = B * S;
     const float eps = m->cfg.dec_ln_eps, scale = 1.0f / sqrtf(32.0f), sqrtE = sqrtf((float)E);
+    DropSpec drop{(unsigned)(seed & 0xFFFFFFFFull), (unsigned)(seed >> 32), 0u, 1.0f};
+    if (dropout_p > 0.f) { drop.thresh = (unsigned)((double)dropout_p * 4294967296.0); drop.scale = 1.0f / (1.0f - dropout_p); }
     float* w = reinterpret_cast<float*>(workspace);
     const std::string p = "decoder.layers.0.";
     auto P = [&](const std::string& key) { return m->p(key); };
@@ -1158,91 +1169,108 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     const float* pq = P("pos_queries");
     const float* sa_w = P(p + "self_attn.in_proj_weight"); const float* sa_b = P(p + "self_attn.in_proj_bias");
     const float* ca_w = P(p + "cross_attn.in_proj_weight"); const float* ca_b = P(p + "cross_attn.in_proj_bias");
-    float* content = w + o.content; float* cn = w + o.cn; float* kvc = w + o.kvc; float* qn = w + o.qn; float* qsa = w + o.qsa; float* kvm = w + o.kvm;
+    float* content0 = w + o.content0; float* content = w + o.content; float* cn = w + o.cn; float* kvc = w + o.kvc; float* qd = w + o.qd;
+    float* qn = w + o.qn; float* qsa = w + o.qsa; float* kvm = w + o.kvm;
     float* sa_o = w + o.sa_o; float* t1 = w + o.t1; float* n1 = w + o.n1; float* q2 = w + o.q2; float* ca_o = w + o.ca_o; float* t2 = w + o.t2;
     float* n2 = w + o.n2; float* hpre = w + o.hpre; float* hact = w + o.hact; float* t3 = w + o.t3; float* out = w + o.out; float* logits = w + o.logits;
-    float* d_a = w + o.d_a; float* d_b = w + o.d_b; float* d_c = w + o.d_c; float* d_h = w + o.d_h; float* tmp = w + o.tmp;
-    float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_qsa = w + o.d_qsa; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
+    float* d_a = w + o.d_a; float* d_b = w + o.d_b; float* d_c = w + o.d_c; float* d_h = w + o.d_h; float* pm = w + o.pm; float* tmp = w + o.tmp;
+    float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_content = w + o.d_content; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
     float* row_loss = w + o.row_loss; float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
-    const size_t elems = (size_t)M * F;
+    const size_t ME = (size_t)M * E, MF = (size_t)M * F;
     g_train_scratch.p = w + o.scratch;
 
-    // ---- shared by all permutations: content stream, its K / V, the (batch-independent) self-attention queries, memory K / V
-    hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content);
+    // ---- shared by all permutations: the content rows before dropout, and the memory's K / V (model.py:95-98, modules.py:74) ----
+    hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content0);
     HIPCHK(hipGetLastError());
-    CHK((run_layernorm<float>(s, content, P(p + "norm_c.weight"), P(p + "norm_c.bias"), cn, nullptr, M, E, eps)));
-    CHK(lin_fwd(s, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, M, 2 * E, E));
-    CHK((run_layernorm<float>(s, pq, P(p + "norm_q.weight"), P(p + "norm_q.bias"), qn, nullptr, L, E, eps)));
-    CHK(lin_fwd(s, qn, sa_w, sa_b, nullptr, 0, qsa, L, E, E));
     CHK(lin_fwd(s, memory, ca_w + (size_t)E * E, ca_b + E, nullptr, 0, kvm, MS, 2 * E, E));
-    HIPCHK(hipMemsetAsync(d_kvc, 0, (size_t)M * 2 * E * sizeof(float), s));
     HIPCHK(hipMemsetAsync(d_kvm, 0, (size_t)MS * 2 * E * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(d_qsa, 0, (size_t)L * E * sizeof(float), s));
+    HIPCHK(hipMemsetAsync(d_content, 0, ME * sizeof(float), s));
     HIPCHK(hipMemsetAsync(d_pq, 0, (size_t)L * E * sizeof(float), s));
 
     TrainAttnArgs sa{};      // self-attention of the query stream over the content stream (modules.py:70-72)
-    sa.q = qsa; sa.q_bstride = 0; sa.ldq = E; sa.k = kvc; sa.v = kvc + E; sa.ldkv = 2 * E; sa.kmask = key_padding_mask; sa.ldkm = L;
+    sa.q = qsa; sa.q_bstride = (long)L * E; sa.ldq = E; sa.k = kvc; sa.v = kvc + E; sa.ldkv = 2 * E; sa.kmask = key_padding_mask; sa.ldkm = L;
     sa.o = sa_o; sa.ldo = E; sa.d_o = d_b; sa.dq = d_qb; sa.lddq = E; sa.dk = d_kvc; sa.dv = d_kvc + E; sa.lddkv = 2 * E;
-    sa.Lq = L; sa.Lk = L; sa.H = H; sa.scale = scale; sa.kv_accumulate = 1;
+    sa.Lq = L; sa.Lk = L; sa.H = H; sa.scale = scale; sa.kv_accumulate = 0; sa.drop = drop;
     TrainAttnArgs ca{};      // cross-attention over the encoder memory (modules.py:74-75)
     ca.q = q2; ca.q_bstride = (long)L * E; ca.ldq = E; ca.k = kvm; ca.v = kvm + E; ca.ldkv = 2 * E; ca.o = ca_o; ca.ldo = E; ca.d_o = d_c;
     ca.dq = d_a; ca.lddq = E; ca.dk = d_kvm; ca.dv = d_kvm + E; ca.lddkv = 2 * E; ca.Lq = L; ca.Lk = S; ca.H = H; ca.scale = scale; ca.kv_accumulate = 1;
+    ca.drop = drop;
+    enum { S_CONTENT, S_QUERY, S_SA_PROB, S_SA_OUT, S_CA_PROB, S_CA_OUT, S_FF_HIDDEN, S_FF_OUT };      // dropout sites of one pass
 
     for (int i = 0; i < K; ++i) {
         const int32_t* tgt = targets + (size_t)(i < 2 ? 0 : 1) * M;      // <eos> targets are dropped after two permutations (system.py:191-195)
-        // ---- forward (modules.py:55-79, 110-125; model.py:63) ------------------------------------------------------
-        sa.qmask = query_masks + (size_t)i * L * L;
+        auto site = [&](int k) { return (unsigned)(8 * i + k); };
+        // ---- forward: model.decode (model.py:86-103) — the embeddings and the queries are dropped afresh in every pass -----------
+        CHK(dropout_add(s, content0, nullptr, content, ME, drop, site(S_CONTENT)));
+        CHK((run_layernorm<float>(s, content, P(p + "norm_c.weight"), P(p + "norm_c.bias"), cn, nullptr, M, E, eps)));
+        CHK(lin_fwd(s, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, M, 2 * E, E));
+        hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)((ME + 255) / 256)), dim3(256), 0, s, pq, L, E, qd, ME, drop, site(S_QUERY));
+        HIPCHK(hipGetLastError());
+        CHK((run_layernorm<float>(s, qd, P(p + "norm_q.weight"), P(p + "norm_q.bias"), qn, nullptr, M, E, eps)));
+        CHK(lin_fwd(s, qn, sa_w, sa_b, nullptr, 0, qsa, M, E, E));
+        // ---- DecoderLayer.forward_stream (modules.py:55-79), Decoder.norm (:124), head (model.py:63) -----------------------------
+        sa.qmask = query_masks + (size_t)i * L * L; sa.drop_site = site(S_SA_PROB);
         CHK(train_attn(s, sa, B, false, 32));
-        CHK(lin_fwd(s, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), pq, L, t1, M, E, E));
+        CHK(lin_fwd(s, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
+        CHK(dropout_add(s, pm, qd, t1, ME, drop, site(S_SA_OUT)));
         CHK((run_layernorm<float>(s, t1, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, nullptr, M, E, eps)));
         CHK(lin_fwd(s, n1, ca_w, ca_b, nullptr, 0, q2, M, E, E));
+        ca.drop_site = site(S_CA_PROB);
         CHK(train_attn(s, ca, B, false, 32));
-        CHK(lin_fwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), t1, M, t2, M, E, E));
+        CHK(lin_fwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
+        CHK(dropout_add(s, pm, t1, t2, ME, drop, site(S_CA_OUT)));
         CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, M, E, eps)));
         CHK(lin_fwd(s, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, hact, elems);
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((MF + 255) / 256)), dim3(256), 0, s, hpre, hact, MF);
         HIPCHK(hipGetLastError());
-        CHK(lin_fwd(s, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), t2, M, t3, M, E, F));
+        if (drop.thresh) CHK(dropout_add(s, hact, nullptr, hact, MF, drop, site(S_FF_HIDDEN)));
+        CHK(lin_fwd(s, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, M, E, F));
+        CHK(dropout_add(s, pm, t2, t3, ME, drop, site(S_FF_OUT)));
         CHK((run_layernorm<float>(s, t3, P("decoder.norm.weight"), P("decoder.norm.bias"), out, nullptr, M, E, eps)));
         CHK(lin_fwd(s, out, P("head.weight"), P("head.bias"), nullptr, 0, logits, M, C, E));
         hipLaunchKernelGGL(ce_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, row_loss);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, tgt, M, m->cfg.pad_id, losses + i, counts + i);
         HIPCHK(hipGetLastError());
-        // ---- backward ----------------------------------------------------------------------------------------------
+        // ---- backward ------------------------------------------------------------------------------------------------------------
         hipLaunchKernelGGL(ce_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, 1.0f / (float)total_targets);
         HIPCHK(hipGetLastError());
         CHK(lin_bwd(s, out, P("head.weight"), logits, G("head.weight"), G("head.bias"), d_a, M, C, E));                                    // d_a = d out
         CHK(ln_bwd(s, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), tmp, M, E, eps));  // d_b = d t3
-        CHK(lin_bwd(s, hact, P(p + "linear2.weight"), d_b, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                 // d_h = d hact
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, elems);                // d_h = d hpre
+        CHK(dropout_add(s, d_b, nullptr, pm, ME, drop, site(S_FF_OUT)));
+        CHK(lin_bwd(s, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                  // d_h = d hact
+        if (drop.thresh) CHK(dropout_add(s, d_h, nullptr, d_h, MF, drop, site(S_FF_HIDDEN)));
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((MF + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, MF);                      // d_h = d hpre
         HIPCHK(hipGetLastError());
         CHK(lin_bwd(s, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, M, F, E));                   // d_a = d n2
         CHK(ln_bwd(s, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
-        CHK(lin_bwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), d_b, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
+        CHK(dropout_add(s, d_b, nullptr, pm, ME, drop, site(S_CA_OUT)));
+        CHK(lin_bwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), pm, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
                     d_c, M, E, E));                                                                                                        // d_c = d ca_o
-        CHK(train_attn(s, ca, B, true, 32));                                                                                                   // d_a = d q2; d_kvm +=
+        CHK(train_attn(s, ca, B, true, 32));                                                                                               // d_a = d q2; d_kvm +=
         CHK(lin_bwd(s, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, M, E, E));                // d_c = d n1
         CHK(ln_bwd(s, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, M, E, eps));              // d_a = d t1
-        CHK(lin_bwd(s, sa_o, P(p + "self_attn.out_proj.weight"), d_a, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
+        CHK(dropout_add(s, d_a, nullptr, pm, ME, drop, site(S_SA_OUT)));
+        CHK(lin_bwd(s, sa_o, P(p + "self_attn.out_proj.weight"), pm, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
                     d_b, M, E, E));                                                                                                        // d_b = d sa_o
-        CHK(colsum(s, d_a, (long)L * E, B, L * E, d_pq, true));                               // the query stream's residual input: pos_queries[l]
-        CHK(train_attn(s, sa, B, true, 32));                                                      // d_qb = d q (per image); d_kvc +=
-        CHK(colsum(s, d_qb, (long)L * E, B, L * E, d_qsa, true));
+        CHK(train_attn(s, sa, B, true, 32));                                                                                               // d_qb = d q; d_kvc =
+        CHK(lin_bwd(s, qn, sa_w, d_qb, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_c, M, E, E));                 // d_c = d qn
+        CHK(ln_bwd(s, qd, P(p + "norm_q.weight"), d_c, d_a, d_b, G(p + "norm_q.weight"), G(p + "norm_q.bias"), tmp, M, E, eps));           // d_b = d qd
+        CHK(dropout_add(s, d_b, nullptr, d_b, ME, drop, site(S_QUERY)));
+        CHK(colsum(s, d_b, (long)L * E, B, L * E, d_pq, true));                                // every image's query rows are pos_queries[l]
+        CHK(lin_bwd(s, cn, sa_w + (size_t)E * E, d_kvc, G(p + "self_attn.in_proj_weight") + (size_t)E * E, G(p + "self_attn.in_proj_bias") + E,
+                    d_c, M, 2 * E, E));                                                                                                    // d_c = d cn
+        CHK(ln_bwd(s, content, P(p + "norm_c.weight"), d_c, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), tmp, M, E, eps));  // d_b = d content
+        CHK(dropout_add(s, d_b, d_content, d_content, ME, drop, site(S_CONTENT)));             // d_content += through this pass's mask
     }
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, losses, counts, K, losses + K);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(loss_out, losses + K, sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(loss_out + 1, losses, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, s));
 
-    // ---- the shared prefix, once --------------------------------------------------------------------------------------
-    CHK(lin_bwd(s, qn, sa_w, d_qsa, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_a, L, E, E));                   // d_a[:L] = d qn
-    CHK(ln_bwd(s, pq, P(p + "norm_q.weight"), d_a, d_pq, d_pq, G(p + "norm_q.weight"), G(p + "norm_q.bias"), tmp, L, E, eps));
-    CHK(lin_bwd(s, cn, sa_w + (size_t)E * E, d_kvc, G(p + "self_attn.in_proj_weight") + (size_t)E * E, G(p + "self_attn.in_proj_bias") + E,
-                d_a, M, 2 * E, E));                                                                                                       // d_a = d cn
-    CHK(ln_bwd(s, content, P(p + "norm_c.weight"), d_a, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), tmp, M, E, eps));     // d_b = d content
-    if (L > 1) CHK(colsum(s, d_b + E, (long)L * E, B, (L - 1) * E, d_pq, true));             // content row j carries pos_queries[j - 1]
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens), dim3(256), 0, s, d_b, tokens, L, B, L, E, sqrtE, G("text_embed.embedding.weight"));
+    // ---- what every permutation shares, once ---------------------------------------------------------------------------------------
+    if (L > 1) CHK(colsum(s, d_content + E, (long)L * E, B, (L - 1) * E, d_pq, true));       // content row j carries pos_queries[j - 1]
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens), dim3(256), 0, s, d_content, tokens, L, B, L, E, sqrtE, G("text_embed.embedding.weight"));
     HIPCHK(hipGetLastError());
     CHK(lin_bwd(s, memory, ca_w + (size_t)E * E, d_kvm, G(p + "cross_attn.in_proj_weight") + (size_t)E * E, G(p + "cross_attn.in_proj_bias") + E,
                 dmemory, MS, 2 * E, E));

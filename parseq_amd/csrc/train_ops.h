@@ -342,6 +342,48 @@ __global__ void loss_combine_kernel(const float* __restrict__ losses, const int*
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// Dropout (configs/model/parseq.yaml:21, p = 0.1: model.py:99-102 on the embeddings and the queries, modules.py:33-43,70-79
+// inside both attentions, after both attention projections, inside and after the MLP).  A mask is never stored: element `idx`
+// of site `site` is kept iff hash(seed, site, idx) >= p * 2^32, a counter-based generator (two rounds of a 32-bit integer
+// mixer) that the backward kernels re-evaluate and that oracle/decoder_backward.py restates bit for bit.  The stream differs
+// from torch's Philox, so training parity with the reference under dropout is statistical; given the same masks it is exact.
+// -------------------------------------------------------------------------------------------------------------------
+struct DropSpec {
+    unsigned seed_lo, seed_hi;
+    unsigned thresh;             // keep iff hash >= thresh; 0 = dropout off
+    float scale;                 // 1 / (1 - p)
+};
+
+__host__ __device__ __forceinline__ unsigned drop_mix(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// multiplier of element idx of site: 0 (dropped) or 1 / (1 - p)
+__host__ __device__ __forceinline__ float drop_factor(const DropSpec& d, unsigned site, unsigned long long idx) {
+    if (d.thresh == 0u) return 1.0f;
+    unsigned h = drop_mix((unsigned)idx ^ d.seed_lo);
+    h = drop_mix(h + (unsigned)(idx >> 32) * 0x9e3779b9u + site * 0x85ebca6bu + d.seed_hi);
+    return h >= d.thresh ? d.scale : 0.0f;
+}
+
+// y[i] = (R ? R[i] : 0) + drop(x[i])      (x == y allowed)
+__global__ __launch_bounds__(256)
+void dropout_kernel(const float* x, const float* R, float* y, size_t n, DropSpec d, unsigned site) {      // x / R may alias y
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i] * drop_factor(d, site, i);
+    y[i] = R ? R[i] + v : v;
+}
+// y[m][e] = drop(table[m % L][e]), element index m * E + e: the decoder queries pos_queries[:, :L] expanded over the batch
+__global__ __launch_bounds__(256)
+void dropout_rows_kernel(const float* __restrict__ table, int L, int E, float* __restrict__ y, size_t n, DropSpec d, unsigned site) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t m = i / E, e = i % E;
+    y[i] = table[(m % L) * E + e] * drop_factor(d, site, i);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // Soft-max attention (decoder: head width 32, encoder: 64), one workgroup per (image b, head h), operands in LDS, the
 // queries walked in blocks of 32 rows (the key / value gradients of a head stay in registers across the blocks).
 //   q row (b, l): q + b * q_bstride + l * ldq + HD h        (q_bstride = 0: the queries are shared by the batch)
@@ -360,13 +402,14 @@ struct TrainAttnArgs {
     int kv_accumulate;
     int Lq, Lk, H;
     float scale;
+    DropSpec drop; unsigned drop_site;                           // dropout on the probabilities, element ((b H + h) Lq + l) Lk + j
 };
 
 constexpr int TA_QB = 32, TA_NACC = 32;
 
 __host__ __device__ inline size_t train_attn_lds_floats(int Lq, int Lk, int hd, bool backward) {
     const int nq = Lq < TA_QB ? Lq : TA_QB;
-    return (size_t)2 * Lk * (hd + 1) + (size_t)(backward ? 2 : 1) * nq * (hd + 1) + (size_t)(backward ? 2 : 1) * nq * (Lk + 1);
+    return (size_t)2 * Lk * (hd + 1) + (size_t)(backward ? 2 : 1) * nq * (hd + 1) + (size_t)(backward ? 3 : 1) * nq * (Lk + 1);
 }
 
 template <bool BACKWARD, int HD>
@@ -382,6 +425,7 @@ void train_attn_kernel(const TrainAttnArgs a) {
     float* P = Qs + (size_t)nqmax * PAD;          // [nq][Lk + 1]
     float* dOs = P + (size_t)nqmax * ldp;         // [nq][PAD]      (backward only)
     float* dS = dOs + (size_t)nqmax * PAD;        // [nq][Lk + 1]   (backward only)
+    float* PD = dS + (size_t)nqmax * ldp;         // [nq][Lk + 1]   (backward only) probabilities after dropout
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
 
@@ -426,11 +470,20 @@ void train_attn_kernel(const TrainAttnArgs a) {
             float sum = 0.f;
             for (int j = lane; j < Lk; j += 64) { const float e = expf(P[l * ldp + j] - mx); P[l * ldp + j] = e; sum += e; }
             const float inv = 1.0f / wave_sum(sum);
+            const unsigned long long row = ((unsigned long long)blockIdx.x * Lq + q0 + l) * Lk;
             float dot = 0.f;
             for (int j = lane; j < Lk; j += 64) {
                 const float p = P[l * ldp + j] * inv;
-                P[l * ldp + j] = p;
-                if (BACKWARD) dot += dS[l * ldp + j] * p;
+                const float f = drop_factor(a.drop, a.drop_site, row + j);
+                if (BACKWARD) {
+                    P[l * ldp + j] = p;                       // soft-max output
+                    PD[l * ldp + j] = p * f;                  // what multiplied V
+                    const float dp = dS[l * ldp + j] * f;     // gradient w.r.t. the soft-max output
+                    dS[l * ldp + j] = dp;
+                    dot += dp * p;
+                } else {
+                    P[l * ldp + j] = p * f;
+                }
             }
             if (BACKWARD) {
                 dot = wave_sum(dot);
@@ -459,7 +512,7 @@ void train_attn_kernel(const TrainAttnArgs a) {
                     const int j = idx / HD, d = idx % HD;
                     for (int l = 0; l < nq; ++l) {
                         gk[i] = fmaf(dS[l * ldp + j], Qs[l * PAD + d], gk[i]);
-                        gv[i] = fmaf(P[l * ldp + j], dOs[l * PAD + d], gv[i]);
+                        gv[i] = fmaf(PD[l * ldp + j], dOs[l * PAD + d], gv[i]);
                     }
                 }
             }

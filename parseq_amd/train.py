@@ -1,10 +1,11 @@
 """Row N3, backward: what `loss.backward()` leaves behind after `PARSeq.training_step` (strhub/models/parseq/system.py:168-199).
 
-`loss_and_grads` = the whole step's forward and backward in fp32 from the model's master weights, dropout off:
+`loss_and_grads` = the whole step's forward and backward in fp32 from the model's master weights (dropout: the decoder's
+eight sites per permutation pass when the system is in training mode; the encoder has none — timm's drop rates are 0):
 `parseq_train_encoder_forward` (keeps the activations the backward needs) -> `parseq_train_decoder` (loss, gradient of every
 `decoder.*` / `head.*` / `text_embed.*` parameter and `pos_queries`, and d loss / d memory) -> `parseq_train_encoder_backward`
 (gradient of every `encoder.*` parameter).  `decoder_backward` is the middle stage alone, on any `memory`.
-Not built: dropout, optimiser, gradient all-reduce.
+`TrainStep` adds gradient averaging across ranks, clipping and AdamW under the OneCycle schedule.
 """
 from __future__ import annotations
 
@@ -53,9 +54,12 @@ def param_views(native_model, flat: Tensor, shapes: Dict[str, Sequence[int]]) ->
     return out
 
 
-def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None) -> DecoderBackward:
+def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None,
+                     dropout: Optional[float] = None, seed: Optional[int] = None) -> DecoderBackward:
     """One training batch up to and including the decoder's backward.  `perms` defaults to a fresh draw from the system's
-    sampler (system.py:175); `memory` defaults to `system.model.encode(images)` in the system's precision."""
+    sampler (system.py:175); `memory` defaults to `system.model.encode(images)` in the system's precision; `dropout` defaults
+    to the model's rate in training mode (`system.train()`) and to 0 in evaluation mode; `seed` (the step's dropout masks)
+    defaults to a draw from the system's numpy generator."""
     lib = _native.lib()
     model = system.model
     dev = system.device
@@ -76,6 +80,10 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
     if memory is None:
         memory = model.encode(images)
     memory = memory.float().contiguous()
+    if dropout is None:
+        dropout = float(system.hparams.dropout) if system.training else 0.0
+    if seed is None:
+        seed = int(system.rng.integers(0, 2 ** 63)) if dropout > 0 else 0
     native = model._sync_native().model
     flat = torch.zeros(lib.parseq_model_grad_elems(native), dtype=torch.float32, device=dev)
     dmemory = torch.empty_like(memory)
@@ -83,14 +91,16 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
     workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
     loss = torch.empty(1 + K, dtype=torch.float32, device=dev)
     _native.check(lib.parseq_train_decoder(native, _native.ptr(memory), _native.ptr(tokens), _native.ptr(targets), _native.ptr(padding),
-                                           _native.ptr(masks), B, L, K, total, _native.ptr(loss), _native.ptr(flat), _native.ptr(dmemory),
+                                           _native.ptr(masks), B, L, K, total, float(dropout), int(seed), _native.ptr(loss), _native.ptr(flat),
+                                           _native.ptr(dmemory),
                                            _native.ptr(workspace), ws_bytes, _native.stream_ptr()))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     return DecoderBackward(loss=loss[0], perm_losses=loss[1:], grads=param_views(native, flat, shapes), flat=flat, dmemory=dmemory, perms=perms,
                            workspace=workspace, _shape=(B, L, K), _model=native)
 
 
-def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = None) -> DecoderBackward:
+def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = None, dropout: Optional[float] = None,
+                   seed: Optional[int] = None) -> DecoderBackward:
     """Loss and the gradient of EVERY parameter for one batch — the state `loss.backward()` leaves after the reference's
     `training_step` (system.py:168-199), dropout off.  `images`: fp32 [B, 3, H, W] on the device, normalised."""
     lib = _native.lib()
@@ -105,7 +115,7 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
     memory = torch.empty(B, model.encoder.pos_embed.shape[1], model._cfg['embed_dim'], dtype=torch.float32, device=images.device)
     _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), B, _native.ptr(memory), _native.ptr(ws), ws_bytes,
                                                    _native.stream_ptr()))
-    res = decoder_backward(system, images, labels, perms, memory=memory)
+    res = decoder_backward(system, images, labels, perms, memory=memory, dropout=dropout, seed=seed)
     _native.check(lib.parseq_train_encoder_backward(native, _native.ptr(res.dmemory), B, _native.ptr(res.flat), _native.ptr(ws), ws_bytes,
                                                     _native.stream_ptr()))
     res.memory = memory

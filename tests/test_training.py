@@ -171,6 +171,81 @@ def test_hand_derived_decoder_backward_matches_reference(train_golden):
     assert (mem.grad - dmem).abs().max() <= 1e-5 * float(mem.grad.abs().max())
 
 
+def _autograd_decoder_loss(sd, cfg, memory, tgt, perms, drop):
+    """The training loss with dropout masks from `drop`, written with plain differentiable torch ops (F.layer_norm, F.softmax,
+    F.gelu, F.embedding) — independent of the operator code in oracle/decoder_backward.py — for autograd to differentiate."""
+    import torch.nn.functional as F
+    from oracle import decoder_backward as DB
+    E, H = cfg.embed_dim, cfg.dec_num_heads
+    p = 'decoder.layers.0.'
+    B, L = tgt.shape[0], tgt.shape[1] - 1
+    S = memory.shape[1]
+    tgt_in, tgt_out = tgt[:, :-1], tgt[:, 1:]
+    pad = (tgt_in == cfg.pad_id) | (tgt_in == cfg.eos_id)
+    norm = lambda x, k: F.layer_norm(x, (E,), sd[k + '.weight'], sd[k + '.bias'], 1e-5)
+    heads = lambda x, n: x.view(B, n, H, 32).transpose(1, 2)
+
+    def mha(pre, q_in, kv_in, n_kv, mask, pf):
+        w, b = sd[pre + 'in_proj_weight'], sd[pre + 'in_proj_bias']
+        q, k, v = heads(F.linear(q_in, w[:E], b[:E]), L), heads(F.linear(kv_in, w[E:2 * E], b[E:2 * E]), n_kv), heads(F.linear(kv_in, w[2 * E:], b[2 * E:]), n_kv)
+        s_ = q @ k.transpose(-1, -2) / (32 ** 0.5)
+        if mask is not None:
+            s_ = s_.masked_fill(mask.unsqueeze(1), float('-inf'))
+        o = (F.softmax(s_, -1) * pf) @ v
+        return F.linear(o.transpose(1, 2).reshape(B, L, E), sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'])
+
+    pq = sd['pos_queries'][:, :L]
+    total, numel, n = 0.0, 0, int((tgt_out != cfg.pad_id).sum())
+    for i, perm in enumerate(perms):
+        f = lambda s_, shape: drop.factor(8 * i + s_, shape)
+        emb = (E ** 0.5) * F.embedding(tgt_in, sd['text_embed.embedding.weight'])
+        content = torch.cat([emb[:, :1], emb[:, 1:] + pq[:, :L - 1]], dim=1) * f(DB.S_CONTENT, (B, L, E))
+        x = pq.expand(B, -1, -1) * f(DB.S_QUERY, (B, L, E))
+        mask = O.attn_masks_from_perm(perm)[1].unsqueeze(0) | pad.unsqueeze(1)
+        x = x + mha(p + 'self_attn.', norm(x, p + 'norm_q'), norm(content, p + 'norm_c'), L, mask, f(DB.S_SA_PROB, (B, H, L, L))) * f(DB.S_SA_OUT, (B, L, E))
+        x = x + mha(p + 'cross_attn.', norm(x, p + 'norm1'), memory, S, None, f(DB.S_CA_PROB, (B, H, L, S))) * f(DB.S_CA_OUT, (B, L, E))
+        h = F.gelu(F.linear(norm(x, p + 'norm2'), sd[p + 'linear1.weight'], sd[p + 'linear1.bias'])) * f(DB.S_FF_HIDDEN, (B, L, 4 * E))
+        x = x + F.linear(h, sd[p + 'linear2.weight'], sd[p + 'linear2.bias']) * f(DB.S_FF_OUT, (B, L, E))
+        logits = F.linear(norm(x, 'decoder.norm'), sd['head.weight'], sd['head.bias'])
+        total = total + n * F.cross_entropy(logits.flatten(end_dim=1), tgt_out.flatten(), ignore_index=cfg.pad_id)
+        numel += n
+        if i == 1:
+            tgt_out = torch.where(tgt_out == cfg.eos_id, cfg.pad_id, tgt_out)
+            n = int((tgt_out != cfg.pad_id).sum())
+    return total / numel
+
+
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_hand_derived_backward_with_dropout_matches_autograd(train_golden, p_drop):
+    """The eight dropout sites of a permutation pass (model.py:99-102, modules.py:33-43,70-79) with masks from the counter-based
+    generator: hand-derived gradients == autograd through an independently written forward using the same masks."""
+    from oracle import decoder_backward as DB
+    g, meta = train_golden
+    cfg = CONFIGS['parseq-tiny']
+    sd = {k: v for k, v in synth_state_dict(cfg, 1).items() if not k.startswith('encoder.')}
+    tgt = Tokenizer(CHARSET_94).encode(meta['labels'][:5])
+    torch.manual_seed(5)
+    perms = gen_tgt_perms(tgt, 2, True, True, np.random.default_rng(1))
+    assert perms.shape == (4, tgt.shape[1])
+    memory = torch.randn(5, 128, cfg.embed_dim, generator=torch.Generator().manual_seed(3))
+    drop = DB.Dropout(p_drop, seed=0x1234567890ABCDEF)
+    if p_drop:
+        f = drop.factor(3, (200, 1000))
+        u = f.unique().tolist()
+        assert len(u) == 2 and u[0] == 0.0 and abs(u[1] - 1 / 0.9) < 1e-6 and abs(float((f == 0).float().mean()) - 0.1) < 4e-3
+        assert not torch.equal(f, drop.factor(4, (200, 1000)))                      # sites are independent streams
+    with torch.no_grad():
+        loss, _, grads, dmem = DB.loss_and_grads(sd, cfg, memory, tgt, perms, O.attn_masks_from_perm, dropout=drop)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    mem = memory.clone().requires_grad_(True)
+    want = _autograd_decoder_loss(leaves, cfg, mem, tgt, perms, drop)
+    want.backward()
+    assert abs(float(loss) - float(want.detach())) <= 1e-5 * float(want.detach())
+    for k, v in leaves.items():
+        assert (grads[k] - v.grad).abs().max() <= 2e-5 * float(v.grad.abs().max()) + 1e-8, k
+    assert (dmem - mem.grad).abs().max() <= 2e-5 * float(mem.grad.abs().max())
+
+
 @pytest.mark.parametrize('total,pct', [(100, 0.075), (1000, 0.3), (37, 0.075), (20, 0.5)])
 def test_one_cycle_schedule_matches_torch(total, pct):
     """The schedule of base.py:103-106 (OneCycleLR, cycle_momentum=False) restated as a pure function of the step count."""
@@ -237,10 +312,12 @@ def test_training_step_draws_permutations_and_is_repeatable(train_golden):
 
 
 @pytest.mark.gpu
-def test_decoder_backward_matches_reference_gradients(train_golden):
-    """`parseq_train_decoder`: loss + gradient of every decoder-side parameter against the REFERENCE's `loss.backward()`
-    (tests/golden/parseq_train.*), the gradient w.r.t. the encoder output and every intermediate of the last permutation
-    against the hand-derived CPU backward (oracle/decoder_backward.py, itself checked against autograd)."""
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_decoder_backward_matches_reference_gradients(train_golden, p_drop):
+    """`parseq_train_decoder`: loss, gradient of every decoder-side parameter, gradient w.r.t. the encoder output and every
+    intermediate of the last permutation against the hand-derived CPU backward (oracle/decoder_backward.py, itself checked
+    against autograd).  Dropout off: also against the REFERENCE's `loss.backward()` (tests/golden/parseq_train.*).  Dropout
+    0.1: the CPU side regenerates the very same masks (the counter-based generator restated), so the comparison stays exact."""
     from gpu_util import DEV, make_model
     from oracle import decoder_backward as DB
     from parseq_amd.train import decoder_backward
@@ -249,20 +326,27 @@ def test_decoder_backward_matches_reference_gradients(train_golden):
     sd = synth_state_dict(cfg, 0)
     m = make_model('parseq', 'fp32')
     perms = g['perms'].long()
-    res = decoder_backward(m, g['images'].to(DEV), meta['labels'], perms)
+    seed = 0x0123456789ABCDEF
+    res = decoder_backward(m, g['images'].to(DEV), meta['labels'], perms, dropout=p_drop, seed=seed)
     torch.cuda.synchronize()
     with torch.no_grad():
         memory = O.encode(sd, cfg, g['images'])
         trace = {}
         want_loss, want_pp, want_grads, want_dmem = DB.loss_and_grads(sd, cfg, memory, m.tokenizer.encode(meta['labels']), perms,
-                                                                      O.attn_masks_from_perm, trace)
+                                                                      O.attn_masks_from_perm, trace, DB.Dropout(p_drop, seed))
     report = []
     for name, want in trace.items():          # forward intermediates first: the first line that is off names the kernel
         got = res.intermediate(name, want.numel()).cpu().view(want.shape)
         err = float((got - want).abs().max())
         report.append(f'{name}: max|d| {err:.3e} of {float(want.abs().max()):.3e}')
     print('\n'.join(report))
-    assert abs(float(res.loss) - meta['loss']) <= 1e-4 * meta['loss'], report
+    if p_drop:
+        dropped = float((res.intermediate('hact', trace['hact'].numel()) == 0).float().mean())
+        assert abs(dropped - p_drop) < 5e-3, dropped
+        assert abs(float(want_loss) - meta['loss']) > 1e-3         # the masks do change the loss
+    else:
+        assert abs(float(res.loss) - meta['loss']) <= 1e-4 * meta['loss'], report
+    assert abs(float(res.loss) - float(want_loss)) <= 1e-4 * float(want_loss), report
     assert (res.perm_losses.cpu() - want_pp).abs().max() <= 1e-4 * float(want_pp.max())
     bad = []
     for key, want in meta['grads'].items():
@@ -274,9 +358,9 @@ def test_decoder_backward_matches_reference_gradients(train_golden):
         err = float((got - ref).abs().max())
         tol = 1e-4 * max(float(ref.abs().max()), 1e-6) + 1e-7
         norm = float(got.double().norm())
-        if err > tol or abs(norm - want['norm']) > 1e-3 * max(want['norm'], 1e-6):
+        if err > tol or (not p_drop and abs(norm - want['norm']) > 1e-3 * max(want['norm'], 1e-6)):
             bad.append((key, err, tol, norm, want['norm']))
-        if 'grad.' + key in g:               # the reference's own tensor
+        if not p_drop and 'grad.' + key in g:               # the reference's own tensor
             assert (got - g['grad.' + key]).abs().max() <= tol, key
     assert not bad, (bad, report)
     err = float((res.dmemory.cpu() - want_dmem).abs().max())

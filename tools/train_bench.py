@@ -82,7 +82,8 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'final_loss': round(float(loss), 4),
             'config': {'workload': f'{args.model} training step, batch={B}/GPU, labels of 1..25 characters (sequence length 26), 6 permutations, '
-                                   f'dropout off, fp32 first-correct-version kernels (BASELINE.json configs[4] asks for bf16)',
+                                   f'dropout {system.hparams.dropout if system.training else 0} (decoder, 8 sites per pass), fp32 first-correct-version kernels '
+                                   f'(BASELINE.json configs[4] asks for bf16)',
                        'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-reduce of the flat gradient buffer' if world > 1 else '')}}))
     if dist is not None:
         dist.destroy_process_group()
