@@ -6,10 +6,10 @@ Mirrors `strhub/models/parseq/system.py:33-88` (constructor arguments, `.model`,
 `pytorch_lightning.LightningModule`; this is a plain `nn.Module` that provides the attributes those scripts use
 (`.hparams`, `.device`, `.eval()`, `.to()`), because Lightning is framework glue outside the hot path.
 
-Row N3 (training step) is built as far as its forward half: the permutation sampler and the
-attention-mask construction (`system.py:90-166`, host logic, bit-identical to the reference under the same numpy / torch
-seeds) and the K-permutation loss of `training_step` (`system.py:168-199`) evaluated on the device with dropout off.
-The loss carries no autograd graph: backward kernels and the optimiser are not built.
+Row N3 (training step): the permutation sampler and the attention-mask construction
+(`system.py:90-166`, host logic, bit-identical to the reference under the same numpy / torch seeds) live here;
+`training_step` (`system.py:168-199`) returns a loss whose `backward()` fills `.grad` of every parameter — forward and
+backward run on the device (parseq_amd/train.py); `permutation_loss` is the forward-only evaluation with the inference kernels.
 """
 from __future__ import annotations
 
@@ -250,8 +250,13 @@ class PARSeq(nn.Module):
         return generate_attn_masks(perm)
 
     def training_step(self, batch, batch_idx):
-        """The loss of system.py:168-199 for one batch, dropout off, WITHOUT an autograd graph (backward is not built)."""
+        """system.py:168-199.  With autograd enabled: the loss as ONE autograd node whose backward deposits the gradient of every
+        parameter (forward and backward run fused on the device in fp32, parseq_amd/train.py; dropout as `self.training` says).
+        Under `torch.no_grad()`: the forward-only evaluation of the same loss with the inference kernels (`permutation_loss`)."""
         images, labels = batch
+        if torch.is_grad_enabled():
+            from .train import training_step_loss
+            return training_step_loss(self, images, labels)
         return permutation_loss(self, images, labels)[0]
 
     def validation_step(self, batch, batch_idx):

@@ -195,3 +195,28 @@ class TrainStep:
         model._adopt_native_weights()
         self.last = res
         return res.loss
+
+
+class _TrainingStepFunction(torch.autograd.Function):
+    """`training_step` as one autograd node: the forward launches the whole fused forward + backward on the device and keeps the
+    gradients; `loss.backward()` hands them to the parameters (scaled by the incoming gradient), so torch optimisers,
+    `clip_grad_norm_`, gradient accumulation and Lightning's automatic optimisation work unchanged on top."""
+
+    @staticmethod
+    def forward(ctx, system, images, labels, perms, *params):
+        res = loss_and_grads(system, images, labels, perms)
+        ctx.grads = [res.grads[k] for k, _ in system.model.named_parameters()]
+        return res.loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grads, ctx.grads = ctx.grads, None
+        return (None, None, None, None) + tuple(g * grad_out for g in grads)
+
+
+def training_step_loss(system, images: Tensor, labels, perms: Optional[Tensor] = None) -> Tensor:
+    """The loss of `PARSeq.training_step` (system.py:168-199) as a differentiable scalar w.r.t. every parameter of the model."""
+    names = [k for k, _ in system.model.named_parameters()]
+    if names != list(system.model.state_dict().keys()):
+        raise RuntimeError('parameters and state_dict disagree (buffers?): the gradient buffer is laid out by state_dict order')
+    return _TrainingStepFunction.apply(system, images, labels, perms, *system.model.parameters())

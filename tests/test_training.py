@@ -297,14 +297,29 @@ def test_training_step_draws_permutations_and_is_repeatable(train_golden):
     for _ in range(2):
         m.rng = np.random.default_rng(3)
         torch.manual_seed(4)
-        out.append(float(m.training_step((images, meta['labels']), 0)))
+        with torch.no_grad():
+            out.append(float(m.training_step((images, meta['labels']), 0)))
     assert out[0] == out[1] and math.isfinite(out[0]) and 3.0 < out[0] < 8.0
+    # with autograd on, training_step is one node whose backward fills .grad of every parameter (the reference's contract)
+    m.rng = np.random.default_rng(3)
+    torch.manual_seed(4)
+    m.model.zero_grad()
+    loss = m.training_step((images, meta['labels']), 0)
+    assert loss.requires_grad and abs(float(loss) - out[0]) <= 2e-2 * out[0]
+    (2.0 * loss).backward()
+    from parseq_amd.train import loss_and_grads
+    m.rng = np.random.default_rng(3)
+    torch.manual_seed(4)
+    ref = loss_and_grads(m, images, meta['labels'])
+    for key, prm in m.model.named_parameters():
+        assert prm.grad is not None and torch.equal(prm.grad, 2.0 * ref.grads[key]), key
     for labels in (['ab', 'c', 'abcd', 'xyz', 'q', 'rs', 'tuv', 'w'], ['a', 'b', 'c', 'd', 'e', 'f', 'g', 'h']):
         m.rng = np.random.default_rng(3)
         tgt = m.tokenizer.encode(labels)
         perms = m.gen_tgt_perms(tgt)
         m.rng = np.random.default_rng(3)
-        got = float(m.training_step((images, labels), 0))
+        with torch.no_grad():
+            got = float(m.training_step((images, labels), 0))
         cfg = CONFIGS['parseq']
         with torch.inference_mode():
             want = float(O.training_loss(synth_state_dict(cfg, 0), cfg, g['images'], tgt, perms)[0])
