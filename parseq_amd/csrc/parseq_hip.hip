@@ -1088,7 +1088,23 @@ static int train_attn_hd(hipStream_t s, const TrainAttnArgs& a, int B, bool back
     HIPCHK(hipGetLastError());
     return 0;
 }
+// encoder shape on the matrix cores (train_attn_mfma_kernel): head width 64, whole 32-row query blocks and 16-key tiles, no masks
+static int train_attn_mfma(hipStream_t s, const TrainAttnArgs& a, int B, bool backward) {
+    const size_t lds = ((size_t)2 * a.Lk * 65 + (size_t)(backward ? 2 : 1) * 32 * 65 + (size_t)(backward ? 2 : 1) * 32 * (a.Lk + 1)) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_done = true;
+    }
+    if (backward) hipLaunchKernelGGL((train_attn_mfma_kernel<true>), dim3(B * a.H), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((train_attn_mfma_kernel<false>), dim3(B * a.H), dim3(256), lds, s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backward, int hd) {
+    if (hd == 64 && a.Lq % 32 == 0 && a.Lk % 16 == 0 && a.Lk <= 128 && !a.qmask && !a.kmask && !a.drop.thresh && !getenv("PARSEQ_TRAIN_VALU_ATTN"))
+        return train_attn_mfma(s, a, B, backward);
     if (hd == 32) return train_attn_hd<32>(s, a, B, backward);
     if (hd == 64) return train_attn_hd<64>(s, a, B, backward);
     return fail(PARSEQ_E_INVALID, "training attention: head width %d not in {32, 64}", hd);

@@ -532,6 +532,149 @@ void train_attn_kernel(const TrainAttnArgs a) {
     }
 }
 
+// The encoder's attention (head width 64, no masks, no dropout, Lq % 32 == 0, Lk % 16 == 0, Lk <= 128) with its five products on
+// the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32): same LDS residency, query blocks and register-held dK / dV as above.
+// MFMA conventions as in mfma_sgemm_kernel: lane (r16 = lane & 15, g = lane >> 4) feeds A[row r16][k g] and B[k g][col r16] and
+// receives D[row 4 g + r][col r16], r = 0..3.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256)
+void train_attn_mfma_kernel(const TrainAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ta_smem[];
+    constexpr int HD = 64, PAD = HD + 1, QB = 32, MAXJT = 8;
+    const int Lq = a.Lq, Lk = a.Lk, ldp = Lk + 1, njt = Lk / 16;
+    float* Ks = ta_smem;                          // [Lk][PAD]
+    float* Vs = Ks + (size_t)Lk * PAD;            // [Lk][PAD]
+    float* Qs = Vs + (size_t)Lk * PAD;            // [QB][PAD]
+    float* P = Qs + (size_t)QB * PAD;             // [QB][Lk + 1]
+    float* dOs = P + (size_t)QB * ldp;            // [QB][PAD]      (backward only)
+    float* dS = dOs + (size_t)QB * PAD;           // [QB][Lk + 1]   (backward only)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+
+    for (int idx = tid; idx < Lk * HD; idx += 256) {
+        const int j = idx / HD, d = idx % HD;
+        const size_t gi = ((size_t)b * Lk + j) * a.ldkv + h * HD + d;
+        Ks[j * PAD + d] = a.k[gi];
+        Vs[j * PAD + d] = a.v[gi];
+    }
+    f32x4 gk[MAXJT], gv[MAXJT];                   // dK / dV tiles (key tile jt, head columns [16 wave, +16)) of this wave
+#pragma unroll
+    for (int i = 0; i < MAXJT; ++i) { gk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int q0 = 0; q0 < Lq; q0 += QB) {
+        __syncthreads();
+        for (int idx = tid; idx < QB * HD; idx += 256) {
+            const int l = idx / HD, d = idx % HD;
+            Qs[l * PAD + d] = a.q[(size_t)b * a.q_bstride + (size_t)(q0 + l) * a.ldq + h * HD + d];
+            if (BACKWARD) dOs[l * PAD + d] = a.d_o[((size_t)b * Lq + q0 + l) * a.ldo + h * HD + d];
+        }
+        __syncthreads();
+        // S = Q K^T (and dP = dO V^T): key tiles wave, wave + 4 for both 16-row halves of the query block
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int jt = wave + 4 * jj;
+            if (jt < njt) {
+                f32x4 sacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                f32x4 pacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+                for (int ks = 0; ks < HD / 4; ++ks) {
+                    const float kb = Ks[(16 * jt + r16) * PAD + 4 * ks + g];
+                    const float q0v = Qs[r16 * PAD + 4 * ks + g], q1v = Qs[(16 + r16) * PAD + 4 * ks + g];
+                    sacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(q0v, kb, sacc[0], 0, 0, 0);
+                    sacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(q1v, kb, sacc[1], 0, 0, 0);
+                    if (BACKWARD) {
+                        const float vb = Vs[(16 * jt + r16) * PAD + 4 * ks + g];
+                        const float o0 = dOs[r16 * PAD + 4 * ks + g], o1 = dOs[(16 + r16) * PAD + 4 * ks + g];
+                        pacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(o0, vb, pacc[0], 0, 0, 0);
+                        pacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(o1, vb, pacc[1], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int lt = 0; lt < 2; ++lt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int at = (16 * lt + 4 * g + r) * ldp + 16 * jt + r16;
+                        P[at] = sacc[lt][r] * a.scale;
+                        if (BACKWARD) dS[at] = pacc[lt][r];
+                    }
+            }
+        }
+        __syncthreads();
+        // soft-max over the keys, one wave per query row (and, backward, dS = P * (dP - sum_j dP P) * scale)
+        for (int l = wave; l < QB; l += 4) {
+            float mx = -INFINITY;
+            for (int j = lane; j < Lk; j += 64) mx = fmaxf(mx, P[l * ldp + j]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int j = lane; j < Lk; j += 64) { const float e = expf(P[l * ldp + j] - mx); P[l * ldp + j] = e; sum += e; }
+            const float inv = 1.0f / wave_sum(sum);
+            float dot = 0.f;
+            for (int j = lane; j < Lk; j += 64) {
+                const float p = P[l * ldp + j] * inv;
+                P[l * ldp + j] = p;
+                if (BACKWARD) dot += dS[l * ldp + j] * p;
+            }
+            if (BACKWARD) {
+                dot = wave_sum(dot);
+                for (int j = lane; j < Lk; j += 64) dS[l * ldp + j] = P[l * ldp + j] * (dS[l * ldp + j] - dot) * a.scale;
+            }
+        }
+        __syncthreads();
+        // O = P V (forward) / dQ = dS K (backward): head columns [16 wave, +16) for both halves of the query block
+        {
+            const float* L_ = BACKWARD ? dS : P;
+            const float* R_ = BACKWARD ? Ks : Vs;
+            f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+            for (int ks = 0; ks < Lk / 4; ++ks) {
+                const float rb = R_[(4 * ks + g) * PAD + 16 * wave + r16];
+                const float l0 = L_[r16 * ldp + 4 * ks + g], l1 = L_[(16 + r16) * ldp + 4 * ks + g];
+                oacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(l0, rb, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(l1, rb, oacc[1], 0, 0, 0);
+            }
+            float* dst = BACKWARD ? a.dq : a.o;
+            const int ldd = BACKWARD ? a.lddq : a.ldo;
+#pragma unroll
+            for (int lt = 0; lt < 2; ++lt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    dst[((size_t)b * Lq + q0 + 16 * lt + 4 * g + r) * ldd + h * HD + 16 * wave + r16] = oacc[lt][r];
+        }
+        if (BACKWARD) {
+            // dK += dS^T Q, dV += P^T dO over the 32 query rows of the block: every key tile, head columns [16 wave, +16)
+#pragma unroll
+            for (int ks = 0; ks < QB / 4; ++ks) {
+                const float qb = Qs[(4 * ks + g) * PAD + 16 * wave + r16];
+                const float ob = dOs[(4 * ks + g) * PAD + 16 * wave + r16];
+#pragma unroll
+                for (int jt = 0; jt < MAXJT; ++jt) {
+                    if (jt < njt) {
+                        const float sa = dS[(4 * ks + g) * ldp + 16 * jt + r16];
+                        const float pa = P[(4 * ks + g) * ldp + 16 * jt + r16];
+                        gk[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(sa, qb, gk[jt], 0, 0, 0);
+                        gv[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, ob, gv[jt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (BACKWARD) {
+#pragma unroll
+        for (int jt = 0; jt < MAXJT; ++jt) {
+            if (jt < njt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t gi = ((size_t)b * Lk + 16 * jt + 4 * g + r) * a.lddkv + h * HD + 16 * wave + r16;
+                    a.dk[gi] = a.kv_accumulate ? a.dk[gi] + gk[jt][r] : gk[jt][r];
+                    a.dv[gi] = a.kv_accumulate ? a.dv[gi] + gv[jt][r] : gv[jt][r];
+                }
+            }
+        }
+    }
+}
+
 // im2col of the patch embedding: row (b, gy, gx), column (c, ky, kx) = img[b][c][gy * ph + ky][gx * pw + kx]   (fp32)
 __global__ __launch_bounds__(256)
 void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw, float* __restrict__ out) {
