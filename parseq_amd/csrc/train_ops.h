@@ -644,7 +644,8 @@ void train_attn_mfma_kernel(const TrainAttnArgs a) {
         }
         if (BACKWARD) {
             // dK += dS^T Q, dV += P^T dO over the 32 query rows of the block: every key tile, head columns [16 wave, +16)
-#pragma unroll
+            // (ks is NOT unrolled: with all 64 (ks, jt) bodies in flight the scheduler hoists 128 LDS loads and spills 2000 VGPRs)
+#pragma unroll 1
             for (int ks = 0; ks < QB / 4; ++ks) {
                 const float qb = Qs[(4 * ks + g) * PAD + 16 * wave + r16];
                 const float ob = dOs[(4 * ks + g) * PAD + 16 * wave + r16];
