@@ -1004,19 +1004,22 @@ extern "C" int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int b
 // -------------------------------------------------------------------------------------------------------------------
 // Scratch shared by the split-K partials of the MFMA GEMM and the partial column sums; part of the caller's workspace.
 constexpr size_t TRAIN_SCRATCH_FLOATS = (size_t)16 << 20;
-struct TrainScratch { float* p; };
-static thread_local TrainScratch g_train_scratch{nullptr};
+struct TrainCtx {
+    hipStream_t s;
+    float* scratch;      // TRAIN_SCRATCH_FLOATS floats
+};
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static int sgemm(hipStream_t s, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
+static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
                  long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate) {
+    hipStream_t s = cx.s;
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
     SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0};
     // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
     const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
     const bool b_ok = aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0));
-    if (M % MG_BM == 0 && N % MG_BN == 0 && K % MG_BK == 0 && a_ok && b_ok && g_train_scratch.p) {
+    if (M % MG_BM == 0 && N % MG_BN == 0 && K % MG_BK == 0 && a_ok && b_ok && cx.scratch) {
         const int tiles = (M / MG_BM) * (N / MG_BN);
         int splits = 1;
         if (tiles < 256) {
@@ -1026,10 +1029,10 @@ static int sgemm(hipStream_t s, const float* A, long sam, long sak, const float*
         }
         const int k_chunk = ((K + splits - 1) / splits + MG_BK - 1) / MG_BK * MG_BK;
         splits = (K + k_chunk - 1) / k_chunk;
-        hipLaunchKernelGGL(mfma_sgemm_kernel, dim3(N / MG_BN, M / MG_BM, splits), dim3(256), 0, s, a, k_chunk, g_train_scratch.p);
+        hipLaunchKernelGGL(mfma_sgemm_kernel, dim3(N / MG_BN, M / MG_BM, splits), dim3(256), 0, s, a, k_chunk, cx.scratch);
         HIPCHK(hipGetLastError());
         if (splits > 1) {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, a, g_train_scratch.p, splits);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, a, cx.scratch, splits);
             HIPCHK(hipGetLastError());
         }
         return 0;
@@ -1038,13 +1041,14 @@ static int sgemm(hipStream_t s, const float* A, long sam, long sak, const float*
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int colsum(hipStream_t s, const float* A, long lda, int M, int N, float* out, bool accumulate) {
+static int colsum(const TrainCtx& cx, const float* A, long lda, int M, int N, float* out, bool accumulate) {
+    hipStream_t s = cx.s;
     constexpr int CHUNKS = 64;
-    if (M >= 2048 && g_train_scratch.p && (size_t)CHUNKS * N <= TRAIN_SCRATCH_FLOATS) {
+    if (M >= 2048 && cx.scratch && (size_t)CHUNKS * N <= TRAIN_SCRATCH_FLOATS) {
         const int rows_per = (M + CHUNKS - 1) / CHUNKS;
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, CHUNKS), dim3(1024), 0, s, A, lda, M, N, g_train_scratch.p, 0, rows_per);
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, CHUNKS), dim3(1024), 0, s, A, lda, M, N, cx.scratch, 0, rows_per);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, g_train_scratch.p, (long)N, CHUNKS, N, out, accumulate ? 1 : 0, CHUNKS);
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, cx.scratch, (long)N, CHUNKS, N, out, accumulate ? 1 : 0, CHUNKS);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -1053,27 +1057,29 @@ static int colsum(hipStream_t s, const float* A, long lda, int M, int N, float* 
     return 0;
 }
 // y[M, N] = x[M, K] W[N, K]^T + bias + R[m % rper]
-static int lin_fwd(hipStream_t s, const float* x, const float* W, const float* bias, const float* R, int rper, float* y, int M, int N, int K) {
-    return sgemm(s, x, K, 1, W, 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false);
+static int lin_fwd(const TrainCtx& cx, const float* x, const float* W, const float* bias, const float* R, int rper, float* y, int M, int N, int K) {
+    return sgemm(cx, x, K, 1, W, 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false);
 }
 // dW[N, K] += dy[M, N]^T x[M, K];  db[N] += column sums of dy;  dx[M, K] = dy W   (dx may be null)
-static int lin_bwd(hipStream_t s, const float* x, const float* W, const float* dy, float* dW, float* db, float* dx, int M, int N, int K) {
-    CHK(sgemm(s, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true));
-    CHK(colsum(s, dy, N, M, N, db, true));
-    if (dx) CHK(sgemm(s, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false));
+static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const float* dy, float* dW, float* db, float* dx, int M, int N, int K) {
+    CHK(sgemm(cx, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true));
+    CHK(colsum(cx, dy, N, M, N, db, true));
+    if (dx) CHK(sgemm(cx, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false));
     return 0;
 }
 // dx = add + LayerNorm backward; dgamma += column sums of dy * xhat; dbeta += column sums of dy.  `tmp` is [rows, E] scratch.
-static int ln_bwd(hipStream_t s, const float* x, const float* gamma, const float* dy, const float* add, float* dx, float* dgamma, float* dbeta,
+static int ln_bwd(const TrainCtx& cx, const float* x, const float* gamma, const float* dy, const float* add, float* dx, float* dgamma, float* dbeta,
                   float* tmp, int rows, int E, float eps) {
+    hipStream_t s = cx.s;
     if (E > 768) return fail(PARSEQ_E_INVALID, "layernorm backward: E=%d > 768", E);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, dy, add, dx, tmp, rows, E, eps);
     HIPCHK(hipGetLastError());
-    CHK(colsum(s, tmp, E, rows, E, dgamma, true));
-    return colsum(s, dy, E, rows, E, dbeta, true);
+    CHK(colsum(cx, tmp, E, rows, E, dgamma, true));
+    return colsum(cx, dy, E, rows, E, dbeta, true);
 }
 template <int HD>
-static int train_attn_hd(hipStream_t s, const TrainAttnArgs& a, int B, bool backward) {
+static int train_attn_hd(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
+    hipStream_t s = cx.s;
     const size_t lds = train_attn_lds_floats(a.Lq, a.Lk, HD, backward) * sizeof(float);
     if (lds > 150 * 1024 || (size_t)a.Lk * HD > (size_t)TA_NACC * 256)
         return fail(PARSEQ_E_INVALID, "training attention: %d keys of width %d do not fit (LDS %zu bytes)", a.Lk, HD, lds);
@@ -1089,7 +1095,8 @@ static int train_attn_hd(hipStream_t s, const TrainAttnArgs& a, int B, bool back
     return 0;
 }
 // encoder shape on the matrix cores (train_attn_mfma_kernel): head width 64, whole 32-row query blocks and 16-key tiles, no masks
-static int train_attn_mfma(hipStream_t s, const TrainAttnArgs& a, int B, bool backward) {
+static int train_attn_mfma(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
+    hipStream_t s = cx.s;
     const size_t lds = ((size_t)2 * a.Lk * 65 + (size_t)(backward ? 2 : 1) * 32 * 65 + (size_t)(backward ? 2 : 1) * 32 * (a.Lk + 1)) * sizeof(float);
     static bool attr_done = false;
     if (!attr_done) {
@@ -1102,11 +1109,11 @@ static int train_attn_mfma(hipStream_t s, const TrainAttnArgs& a, int B, bool ba
     HIPCHK(hipGetLastError());
     return 0;
 }
-static int train_attn(hipStream_t s, const TrainAttnArgs& a, int B, bool backward, int hd) {
+static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward, int hd) {
     if (hd == 64 && a.Lq % 32 == 0 && a.Lk % 16 == 0 && a.Lk <= 128 && !a.qmask && !a.kmask && !a.drop.thresh && !getenv("PARSEQ_TRAIN_VALU_ATTN"))
-        return train_attn_mfma(s, a, B, backward);
-    if (hd == 32) return train_attn_hd<32>(s, a, B, backward);
-    if (hd == 64) return train_attn_hd<64>(s, a, B, backward);
+        return train_attn_mfma(cx, a, B, backward);
+    if (hd == 32) return train_attn_hd<32>(cx, a, B, backward);
+    if (hd == 64) return train_attn_hd<64>(cx, a, B, backward);
     return fail(PARSEQ_E_INVALID, "training attention: head width %d not in {32, 64}", hd);
 }
 
@@ -1154,7 +1161,8 @@ extern "C" size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, in
 }
 
 // y = R + dropout(x) over n elements (R may be null, x == y allowed); with dropout off a plain add / copy
-static int dropout_add(hipStream_t s, const float* x, const float* R, float* y, size_t n, const DropSpec& d, unsigned site) {
+static int dropout_add(const TrainCtx& cx, const float* x, const float* R, float* y, size_t n, const DropSpec& d, unsigned site) {
+    hipStream_t s = cx.s;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, R, y, n, d, site);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1193,12 +1201,12 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_content = w + o.d_content; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
     float* row_loss = w + o.row_loss; float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
     const size_t ME = (size_t)M * E, MF = (size_t)M * F;
-    g_train_scratch.p = w + o.scratch;
+    const TrainCtx cx{s, w + o.scratch};
 
     // ---- shared by all permutations: the content rows before dropout, and the memory's K / V (model.py:95-98, modules.py:74) ----
     hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content0);
     HIPCHK(hipGetLastError());
-    CHK(lin_fwd(s, memory, ca_w + (size_t)E * E, ca_b + E, nullptr, 0, kvm, MS, 2 * E, E));
+    CHK(lin_fwd(cx, memory, ca_w + (size_t)E * E, ca_b + E, nullptr, 0, kvm, MS, 2 * E, E));
     HIPCHK(hipMemsetAsync(d_kvm, 0, (size_t)MS * 2 * E * sizeof(float), s));
     HIPCHK(hipMemsetAsync(d_content, 0, ME * sizeof(float), s));
     HIPCHK(hipMemsetAsync(d_pq, 0, (size_t)L * E * sizeof(float), s));
@@ -1217,33 +1225,33 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         const int32_t* tgt = targets + (size_t)(i < 2 ? 0 : 1) * M;      // <eos> targets are dropped after two permutations (system.py:191-195)
         auto site = [&](int k) { return (unsigned)(8 * i + k); };
         // ---- forward: model.decode (model.py:86-103) — the embeddings and the queries are dropped afresh in every pass -----------
-        CHK(dropout_add(s, content0, nullptr, content, ME, drop, site(S_CONTENT)));
+        CHK(dropout_add(cx, content0, nullptr, content, ME, drop, site(S_CONTENT)));
         CHK((run_layernorm<float>(s, content, P(p + "norm_c.weight"), P(p + "norm_c.bias"), cn, nullptr, M, E, eps)));
-        CHK(lin_fwd(s, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, M, 2 * E, E));
+        CHK(lin_fwd(cx, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, M, 2 * E, E));
         hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)((ME + 255) / 256)), dim3(256), 0, s, pq, L, E, qd, ME, drop, site(S_QUERY));
         HIPCHK(hipGetLastError());
         CHK((run_layernorm<float>(s, qd, P(p + "norm_q.weight"), P(p + "norm_q.bias"), qn, nullptr, M, E, eps)));
-        CHK(lin_fwd(s, qn, sa_w, sa_b, nullptr, 0, qsa, M, E, E));
+        CHK(lin_fwd(cx, qn, sa_w, sa_b, nullptr, 0, qsa, M, E, E));
         // ---- DecoderLayer.forward_stream (modules.py:55-79), Decoder.norm (:124), head (model.py:63) -----------------------------
         sa.qmask = query_masks + (size_t)i * L * L; sa.drop_site = site(S_SA_PROB);
-        CHK(train_attn(s, sa, B, false, 32));
-        CHK(lin_fwd(s, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
-        CHK(dropout_add(s, pm, qd, t1, ME, drop, site(S_SA_OUT)));
+        CHK(train_attn(cx, sa, B, false, 32));
+        CHK(lin_fwd(cx, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
+        CHK(dropout_add(cx, pm, qd, t1, ME, drop, site(S_SA_OUT)));
         CHK((run_layernorm<float>(s, t1, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, nullptr, M, E, eps)));
-        CHK(lin_fwd(s, n1, ca_w, ca_b, nullptr, 0, q2, M, E, E));
+        CHK(lin_fwd(cx, n1, ca_w, ca_b, nullptr, 0, q2, M, E, E));
         ca.drop_site = site(S_CA_PROB);
-        CHK(train_attn(s, ca, B, false, 32));
-        CHK(lin_fwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
-        CHK(dropout_add(s, pm, t1, t2, ME, drop, site(S_CA_OUT)));
+        CHK(train_attn(cx, ca, B, false, 32));
+        CHK(lin_fwd(cx, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
+        CHK(dropout_add(cx, pm, t1, t2, ME, drop, site(S_CA_OUT)));
         CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, M, E, eps)));
-        CHK(lin_fwd(s, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
+        CHK(lin_fwd(cx, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
         hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((MF + 255) / 256)), dim3(256), 0, s, hpre, hact, MF);
         HIPCHK(hipGetLastError());
-        if (drop.thresh) CHK(dropout_add(s, hact, nullptr, hact, MF, drop, site(S_FF_HIDDEN)));
-        CHK(lin_fwd(s, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, M, E, F));
-        CHK(dropout_add(s, pm, t2, t3, ME, drop, site(S_FF_OUT)));
+        if (drop.thresh) CHK(dropout_add(cx, hact, nullptr, hact, MF, drop, site(S_FF_HIDDEN)));
+        CHK(lin_fwd(cx, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, M, E, F));
+        CHK(dropout_add(cx, pm, t2, t3, ME, drop, site(S_FF_OUT)));
         CHK((run_layernorm<float>(s, t3, P("decoder.norm.weight"), P("decoder.norm.bias"), out, nullptr, M, E, eps)));
-        CHK(lin_fwd(s, out, P("head.weight"), P("head.bias"), nullptr, 0, logits, M, C, E));
+        CHK(lin_fwd(cx, out, P("head.weight"), P("head.bias"), nullptr, 0, logits, M, C, E));
         hipLaunchKernelGGL(ce_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, row_loss);
         HIPCHK(hipGetLastError());
         hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, tgt, M, m->cfg.pad_id, losses + i, counts + i);
@@ -1251,33 +1259,33 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         // ---- backward ------------------------------------------------------------------------------------------------------------
         hipLaunchKernelGGL(ce_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, 1.0f / (float)total_targets);
         HIPCHK(hipGetLastError());
-        CHK(lin_bwd(s, out, P("head.weight"), logits, G("head.weight"), G("head.bias"), d_a, M, C, E));                                    // d_a = d out
-        CHK(ln_bwd(s, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), tmp, M, E, eps));  // d_b = d t3
-        CHK(dropout_add(s, d_b, nullptr, pm, ME, drop, site(S_FF_OUT)));
-        CHK(lin_bwd(s, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                  // d_h = d hact
-        if (drop.thresh) CHK(dropout_add(s, d_h, nullptr, d_h, MF, drop, site(S_FF_HIDDEN)));
+        CHK(lin_bwd(cx, out, P("head.weight"), logits, G("head.weight"), G("head.bias"), d_a, M, C, E));                                    // d_a = d out
+        CHK(ln_bwd(cx, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), tmp, M, E, eps));  // d_b = d t3
+        CHK(dropout_add(cx, d_b, nullptr, pm, ME, drop, site(S_FF_OUT)));
+        CHK(lin_bwd(cx, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                  // d_h = d hact
+        if (drop.thresh) CHK(dropout_add(cx, d_h, nullptr, d_h, MF, drop, site(S_FF_HIDDEN)));
         hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((MF + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, MF);                      // d_h = d hpre
         HIPCHK(hipGetLastError());
-        CHK(lin_bwd(s, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, M, F, E));                   // d_a = d n2
-        CHK(ln_bwd(s, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
-        CHK(dropout_add(s, d_b, nullptr, pm, ME, drop, site(S_CA_OUT)));
-        CHK(lin_bwd(s, ca_o, P(p + "cross_attn.out_proj.weight"), pm, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
+        CHK(lin_bwd(cx, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, M, F, E));                   // d_a = d n2
+        CHK(ln_bwd(cx, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
+        CHK(dropout_add(cx, d_b, nullptr, pm, ME, drop, site(S_CA_OUT)));
+        CHK(lin_bwd(cx, ca_o, P(p + "cross_attn.out_proj.weight"), pm, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
                     d_c, M, E, E));                                                                                                        // d_c = d ca_o
-        CHK(train_attn(s, ca, B, true, 32));                                                                                               // d_a = d q2; d_kvm +=
-        CHK(lin_bwd(s, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, M, E, E));                // d_c = d n1
-        CHK(ln_bwd(s, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, M, E, eps));              // d_a = d t1
-        CHK(dropout_add(s, d_a, nullptr, pm, ME, drop, site(S_SA_OUT)));
-        CHK(lin_bwd(s, sa_o, P(p + "self_attn.out_proj.weight"), pm, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
+        CHK(train_attn(cx, ca, B, true, 32));                                                                                               // d_a = d q2; d_kvm +=
+        CHK(lin_bwd(cx, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, M, E, E));                // d_c = d n1
+        CHK(ln_bwd(cx, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, M, E, eps));              // d_a = d t1
+        CHK(dropout_add(cx, d_a, nullptr, pm, ME, drop, site(S_SA_OUT)));
+        CHK(lin_bwd(cx, sa_o, P(p + "self_attn.out_proj.weight"), pm, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
                     d_b, M, E, E));                                                                                                        // d_b = d sa_o
-        CHK(train_attn(s, sa, B, true, 32));                                                                                               // d_qb = d q; d_kvc =
-        CHK(lin_bwd(s, qn, sa_w, d_qb, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_c, M, E, E));                 // d_c = d qn
-        CHK(ln_bwd(s, qd, P(p + "norm_q.weight"), d_c, d_a, d_b, G(p + "norm_q.weight"), G(p + "norm_q.bias"), tmp, M, E, eps));           // d_b = d qd
-        CHK(dropout_add(s, d_b, nullptr, d_b, ME, drop, site(S_QUERY)));
-        CHK(colsum(s, d_b, (long)L * E, B, L * E, d_pq, true));                                // every image's query rows are pos_queries[l]
-        CHK(lin_bwd(s, cn, sa_w + (size_t)E * E, d_kvc, G(p + "self_attn.in_proj_weight") + (size_t)E * E, G(p + "self_attn.in_proj_bias") + E,
+        CHK(train_attn(cx, sa, B, true, 32));                                                                                               // d_qb = d q; d_kvc =
+        CHK(lin_bwd(cx, qn, sa_w, d_qb, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_c, M, E, E));                 // d_c = d qn
+        CHK(ln_bwd(cx, qd, P(p + "norm_q.weight"), d_c, d_a, d_b, G(p + "norm_q.weight"), G(p + "norm_q.bias"), tmp, M, E, eps));           // d_b = d qd
+        CHK(dropout_add(cx, d_b, nullptr, d_b, ME, drop, site(S_QUERY)));
+        CHK(colsum(cx, d_b, (long)L * E, B, L * E, d_pq, true));                                // every image's query rows are pos_queries[l]
+        CHK(lin_bwd(cx, cn, sa_w + (size_t)E * E, d_kvc, G(p + "self_attn.in_proj_weight") + (size_t)E * E, G(p + "self_attn.in_proj_bias") + E,
                     d_c, M, 2 * E, E));                                                                                                    // d_c = d cn
-        CHK(ln_bwd(s, content, P(p + "norm_c.weight"), d_c, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), tmp, M, E, eps));  // d_b = d content
-        CHK(dropout_add(s, d_b, d_content, d_content, ME, drop, site(S_CONTENT)));             // d_content += through this pass's mask
+        CHK(ln_bwd(cx, content, P(p + "norm_c.weight"), d_c, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), tmp, M, E, eps));  // d_b = d content
+        CHK(dropout_add(cx, d_b, d_content, d_content, ME, drop, site(S_CONTENT)));             // d_content += through this pass's mask
     }
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, losses, counts, K, losses + K);
     HIPCHK(hipGetLastError());
@@ -1285,10 +1293,10 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     HIPCHK(hipMemcpyAsync(loss_out + 1, losses, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice, s));
 
     // ---- what every permutation shares, once ---------------------------------------------------------------------------------------
-    if (L > 1) CHK(colsum(s, d_content + E, (long)L * E, B, (L - 1) * E, d_pq, true));       // content row j carries pos_queries[j - 1]
+    if (L > 1) CHK(colsum(cx, d_content + E, (long)L * E, B, (L - 1) * E, d_pq, true));       // content row j carries pos_queries[j - 1]
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens), dim3(256), 0, s, d_content, tokens, L, B, L, E, sqrtE, G("text_embed.embedding.weight"));
     HIPCHK(hipGetLastError());
-    CHK(lin_bwd(s, memory, ca_w + (size_t)E * E, d_kvm, G(p + "cross_attn.in_proj_weight") + (size_t)E * E, G(p + "cross_attn.in_proj_bias") + E,
+    CHK(lin_bwd(cx, memory, ca_w + (size_t)E * E, d_kvm, G(p + "cross_attn.in_proj_weight") + (size_t)E * E, G(p + "cross_attn.in_proj_bias") + E,
                 dmemory, MS, 2 * E, E));
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)(((size_t)L * E + 255) / 256)), dim3(256), 0, s, G("pos_queries"), d_pq, G("pos_queries"), (size_t)L * E);
     HIPCHK(hipGetLastError());
@@ -1352,24 +1360,24 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     const float eps = m->cfg.enc_ln_eps;
     float* w = reinterpret_cast<float*>(workspace);
     auto P = [&](const std::string& key) { return m->p(m->enc + key); };
-    g_train_scratch.p = w + o.scratch;
+    const TrainCtx cx{s, w + o.scratch};
     hipLaunchKernelGGL(patches_kernel, dim3(MS), dim3(256), 0, s, images, m->cfg.img_h, m->cfg.img_w, m->cfg.patch_h, m->cfg.patch_w, w + o.patches);
     HIPCHK(hipGetLastError());
-    CHK(lin_fwd(s, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
+    CHK(lin_fwd(cx, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
     const size_t elems = (size_t)MS * F;
     for (int i = 0; i < m->cfg.enc_depth; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         float* x_out = i + 1 < m->cfg.enc_depth ? w + o.x(i + 1) : w + o.x_last;
         CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), w + o.n, nullptr, MS, E, eps)));
-        CHK(lin_fwd(s, w + o.n, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
-        CHK(train_attn(s, enc_attn_args(m, qkv, ao, nullptr, nullptr), batch, false, ATT_HD));
-        CHK(lin_fwd(s, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
+        CHK(lin_fwd(cx, w + o.n, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
+        CHK(train_attn(cx, enc_attn_args(m, qkv, ao, nullptr, nullptr), batch, false, ATT_HD));
+        CHK(lin_fwd(cx, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), w + o.n, nullptr, MS, E, eps)));
-        CHK(lin_fwd(s, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E));
+        CHK(lin_fwd(cx, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E));
         hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, w + o.hact, elems);
         HIPCHK(hipGetLastError());
-        CHK(lin_fwd(s, w + o.hact, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
+        CHK(lin_fwd(cx, w + o.hact, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
     }
     return run_layernorm<float>(s, w + o.x_last, P("norm.weight"), P("norm.bias"), memory_out, nullptr, MS, E, eps);
 }
@@ -1388,29 +1396,29 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* n = w + o.n; float* hact = w + o.hact; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
-    g_train_scratch.p = w + o.scratch;
-    CHK(ln_bwd(s, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps));
+    const TrainCtx cx{s, w + o.scratch};
+    CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps));
     for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
         hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, hact, elems);
         HIPCHK(hipGetLastError());
-        CHK(lin_bwd(s, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F));
+        CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F));
         hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, elems);
         HIPCHK(hipGetLastError());
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n, nullptr, MS, E, eps)));
-        CHK(lin_bwd(s, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));
-        CHK(ln_bwd(s, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps));   // d_x = d x_mid
+        CHK(lin_bwd(cx, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));
+        CHK(ln_bwd(cx, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps));   // d_x = d x_mid
         // x_mid = x + proj(attention(qkv(norm1(x))))
-        CHK(lin_bwd(s, ao, P(p + "attn.proj.weight"), d_x, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, MS, E, E));        // d_a = d ao
-        CHK(train_attn(s, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
+        CHK(lin_bwd(cx, ao, P(p + "attn.proj.weight"), d_x, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, MS, E, E));        // d_a = d ao
+        CHK(train_attn(cx, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
         CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), n, nullptr, MS, E, eps)));
-        CHK(lin_bwd(s, n, P(p + "attn.qkv.weight"), dqkv, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, MS, 3 * E, E));
-        CHK(ln_bwd(s, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps));          // d_x = d x
+        CHK(lin_bwd(cx, n, P(p + "attn.qkv.weight"), dqkv, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, MS, 3 * E, E));
+        CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps));          // d_x = d x
     }
-    CHK(colsum(s, d_x, (long)S * E, batch, S * E, G("pos_embed"), true));
-    return lin_bwd(s, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK);
+    CHK(colsum(cx, d_x, (long)S * E, batch, S * E, G("pos_embed"), true));
+    return lin_bwd(cx, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK);
 }
 
 // ---- training step, optimiser ---------------------------------------------------------------------------------------------
