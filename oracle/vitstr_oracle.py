@@ -15,7 +15,6 @@ from __future__ import annotations
 from collections import OrderedDict
 from typing import Optional
 
-import torch
 from torch import Tensor
 
 from . import parseq_oracle as O

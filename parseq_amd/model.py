@@ -11,7 +11,6 @@ library through `parseq_amd._native`; on a CPU tensor or without the library the
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 from typing import Optional, Sequence
 

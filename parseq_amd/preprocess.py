@@ -7,7 +7,6 @@ batch of uint8 HWC images that already live in device memory; its uint8 [N, 3, H
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Sequence
 
 import torch
