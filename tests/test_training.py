@@ -171,6 +171,28 @@ def test_hand_derived_decoder_backward_matches_reference(train_golden):
     assert (mem.grad - dmem).abs().max() <= 1e-5 * float(mem.grad.abs().max())
 
 
+@pytest.mark.parametrize('name', ['parseq-tiny', 'parseq'])
+def test_hand_derived_encoder_backward_matches_autograd(name):
+    """oracle/encoder_backward.py (forward that keeps x / qkv / attention output / x_mid / fc1 pre-activation per block, backward
+    from d memory) against autograd through the oracle's own `encode`, for an arbitrary upstream gradient."""
+    from oracle import encoder_backward as EB
+    cfg = CONFIGS[name]
+    sd = synth_state_dict(cfg, 2)
+    images = synth_images(3, cfg, seed=5)
+    upstream = torch.randn(3, cfg.num_patches, cfg.embed_dim, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        memory, saved = EB.forward(sd, cfg, images)
+        grads = EB.backward(sd, cfg, saved, upstream)
+    leaves = {k: (v.clone().requires_grad_(True) if k.startswith('encoder.') else v) for k, v in sd.items()}
+    mem = O.encode(leaves, cfg, images)
+    assert (mem.detach() - memory).abs().max() <= 2e-5
+    (mem * upstream).sum().backward()
+    assert len(grads) == sum(k.startswith('encoder.') for k in sd)
+    for k, got in grads.items():
+        want = leaves[k].grad
+        assert (got - want).abs().max() <= 5e-5 * float(want.abs().max()) + 1e-7, k
+
+
 def _autograd_decoder_loss(sd, cfg, memory, tgt, perms, drop):
     """The training loss with dropout masks from `drop`, written with plain differentiable torch ops (F.layer_norm, F.softmax,
     F.gelu, F.embedding) — independent of the operator code in oracle/decoder_backward.py — for autograd to differentiate."""
