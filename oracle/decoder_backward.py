@@ -25,6 +25,31 @@ import torch.nn.functional as F
 EPS = 1e-5
 HD = 32          # decoder head width (embed_dim / dec_num_heads, configs/model/parseq.yaml:11-12)
 
+# Arithmetic of every matrix product below: None = exact fp32 (the device's first version, and the parity gate), 'bf16' = both
+# operands rounded to bfloat16, fp32 accumulate — what a matrix-core bf16 training step computes (BASELINE configs[4]); used to
+# size the gradient error that rounding alone introduces, i.e. the tolerance a bf16 device path can be held to.
+_ROUNDING = [None]
+
+
+class rounding:
+    """`with rounding('bf16'): ...` — switch the arithmetic of `mm` inside the block."""
+
+    def __init__(self, mode):
+        assert mode in (None, 'bf16')
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev, _ROUNDING[0] = _ROUNDING[0], self.mode
+
+    def __exit__(self, *exc):
+        _ROUNDING[0] = self.prev
+
+
+def mm(a, b):
+    if _ROUNDING[0] == 'bf16':
+        return a.to(torch.bfloat16).float() @ b.to(torch.bfloat16).float()
+    return a @ b
+
 
 def ln(x, w, b, eps=EPS):
     mu = x.mean(-1, keepdim=True)
@@ -89,7 +114,7 @@ S_CONTENT, S_QUERY, S_SA_PROB, S_SA_OUT, S_CA_PROB, S_CA_OUT, S_FF_HIDDEN, S_FF_
 
 
 def attn_probs(q, k, mask):
-    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
+    s = mm(q, k.transpose(-1, -2)) * (1.0 / math.sqrt(q.shape[-1]))
     if mask is not None:
         s = s.masked_fill(mask.unsqueeze(1), float('-inf'))
     return torch.softmax(s, dim=-1)
@@ -98,18 +123,18 @@ def attn_probs(q, k, mask):
 def attn(q, k, v, mask, pf=None):
     """`pf`: dropout multipliers of the probabilities [B, H, Lq, Lk] (modules.py:33-34: nn.MultiheadAttention(dropout=...))."""
     p = attn_probs(q, k, mask)
-    return (p if pf is None else p * pf) @ v
+    return mm(p if pf is None else p * pf, v)
 
 
 def attn_bwd(q, k, v, mask, do, pf=None):
     p = attn_probs(q, k, mask)
     pd = p if pf is None else p * pf
-    dv = pd.transpose(-1, -2) @ do
-    dp = do @ v.transpose(-1, -2)
+    dv = mm(pd.transpose(-1, -2), do)
+    dp = mm(do, v.transpose(-1, -2))
     if pf is not None:
         dp = dp * pf
     ds = p * (dp - (dp * p).sum(-1, keepdim=True)) * (1.0 / math.sqrt(q.shape[-1]))
-    return ds @ k, ds.transpose(-1, -2) @ q, dv          # dq (per batch even when q is shared), dk, dv
+    return mm(ds, k), mm(ds.transpose(-1, -2), q), dv          # dq (per batch even when q is shared), dk, dv
 
 
 def gelu_bwd(pre, dact):
@@ -140,9 +165,9 @@ def loss_and_grads(sd: dict, cfg, memory: torch.Tensor, tgt: torch.Tensor, perms
 
     def acc_linear(wkey, bkey, rows, x, dy):
         """dW[rows] += dy^T x ; db[rows] += colsum(dy) ; returns dx = dy W[rows]"""
-        grads[wkey][rows] += dy.t() @ x
+        grads[wkey][rows] += mm(dy.t(), x)
         grads[bkey][rows] += dy.sum(0)
-        return dy @ W(wkey)[rows]
+        return mm(dy, W(wkey)[rows])
 
     def acc_ln(key, x, dy):
         dx, dw, db = ln_bwd(x, W(key + '.weight'), dy)
@@ -157,7 +182,7 @@ def loss_and_grads(sd: dict, cfg, memory: torch.Tensor, tgt: torch.Tensor, perms
     sa_w, sa_b = W(p + 'self_attn.in_proj_weight'), W(p + 'self_attn.in_proj_bias')
     ca_w, ca_b = W(p + 'cross_attn.in_proj_weight'), W(p + 'cross_attn.in_proj_bias')
     mem2 = memory.detach().reshape(B * S, E)
-    kvm = mem2 @ ca_w[E:].t() + ca_b[E:]                                                  # [B * S, 2E]
+    kvm = mm(mem2, ca_w[E:].t()) + ca_b[E:]                                                  # [B * S, 2E]
     km, vm = split_heads(kvm[:, :E], B, S), split_heads(kvm[:, E:], B, S)
 
     n_first = int((tgt_out != cfg.pad_id).sum())
@@ -183,24 +208,24 @@ def loss_and_grads(sd: dict, cfg, memory: torch.Tensor, tgt: torch.Tensor, perms
         # forward (model.py:95-103, modules.py:55-98)
         content = content0 * f_content
         cn = ln(content, W(p + 'norm_c.weight'), W(p + 'norm_c.bias'))
-        kvc = cn @ sa_w[E:].t() + sa_b[E:]                                                # [M, 2E]
+        kvc = mm(cn, sa_w[E:].t()) + sa_b[E:]                                                # [M, 2E]
         kc, vc = split_heads(kvc[:, :E], B, L), split_heads(kvc[:, E:], B, L)
         qd = pq.repeat(B, 1) * f_query                                                    # the query stream's input, per image
         qn = ln(qd, W(p + 'norm_q.weight'), W(p + 'norm_q.bias'))
-        qsa = qn @ sa_w[:E].t() + sa_b[:E]
+        qsa = mm(qn, sa_w[:E].t()) + sa_b[:E]
         q_sa = split_heads(qsa, B, L)
         sa_o = merge_heads(attn(q_sa, kc, vc, sa_mask, f_sa))                             # [M, E]
-        t1 = qd + (sa_o @ W(p + 'self_attn.out_proj.weight').t() + W(p + 'self_attn.out_proj.bias')) * f_sa_out
+        t1 = qd + (mm(sa_o, W(p + 'self_attn.out_proj.weight').t()) + W(p + 'self_attn.out_proj.bias')) * f_sa_out
         n1 = ln(t1, W(p + 'norm1.weight'), W(p + 'norm1.bias'))
-        q2 = split_heads(n1 @ ca_w[:E].t() + ca_b[:E], B, L)
+        q2 = split_heads(mm(n1, ca_w[:E].t()) + ca_b[:E], B, L)
         ca_o = merge_heads(attn(q2, km, vm, None, f_ca))
-        t2 = t1 + (ca_o @ W(p + 'cross_attn.out_proj.weight').t() + W(p + 'cross_attn.out_proj.bias')) * f_ca_out
+        t2 = t1 + (mm(ca_o, W(p + 'cross_attn.out_proj.weight').t()) + W(p + 'cross_attn.out_proj.bias')) * f_ca_out
         n2 = ln(t2, W(p + 'norm2.weight'), W(p + 'norm2.bias'))
-        hpre = n2 @ W(p + 'linear1.weight').t() + W(p + 'linear1.bias')
+        hpre = mm(n2, W(p + 'linear1.weight').t()) + W(p + 'linear1.bias')
         hact = F.gelu(hpre) * f_hidden
-        t3 = t2 + (hact @ W(p + 'linear2.weight').t() + W(p + 'linear2.bias')) * f_ff_out
+        t3 = t2 + (mm(hact, W(p + 'linear2.weight').t()) + W(p + 'linear2.bias')) * f_ff_out
         out = ln(t3, W('decoder.norm.weight'), W('decoder.norm.bias'))
-        logits = out @ W('head.weight').t() + W('head.bias')
+        logits = mm(out, W('head.weight').t()) + W('head.bias')
         keep = targets != cfg.pad_id
         logp = torch.log_softmax(logits, -1)
         row_loss = -logp[keep, targets[keep]]

@@ -13,7 +13,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .decoder_backward import attn, attn_bwd, gelu_bwd, ln, ln_bwd, merge_heads, split_heads
+from .decoder_backward import attn, attn_bwd, gelu_bwd, ln, ln_bwd, merge_heads, mm, split_heads
 
 
 def patches_of(images: torch.Tensor, ph: int, pw: int) -> torch.Tensor:
@@ -32,18 +32,18 @@ def forward(sd: dict, cfg, images: torch.Tensor):
     W = lambda k: sd['encoder.' + k].detach()
     patches = patches_of(images, ph, pw)
     S = patches.shape[0] // B
-    x = patches @ W('patch_embed.proj.weight').reshape(E, -1).t() + W('patch_embed.proj.bias') + W('pos_embed')[0].repeat(B, 1)
+    x = mm(patches, W('patch_embed.proj.weight').reshape(E, -1).t()) + W('patch_embed.proj.bias') + W('pos_embed')[0].repeat(B, 1)
     saved = {'patches': patches, 'blocks': []}
     for i in range(cfg.enc_depth):
         p = f'blocks.{i}.'
         n1 = ln(x, W(p + 'norm1.weight'), W(p + 'norm1.bias'), eps)
-        qkv = n1 @ W(p + 'attn.qkv.weight').t() + W(p + 'attn.qkv.bias')
+        qkv = mm(n1, W(p + 'attn.qkv.weight').t()) + W(p + 'attn.qkv.bias')
         q, k, v = (split_heads(qkv[:, j * E:(j + 1) * E], B, S, hd) for j in range(3))
         ao = merge_heads(attn(q, k, v, None))
-        x_mid = x + ao @ W(p + 'attn.proj.weight').t() + W(p + 'attn.proj.bias')
+        x_mid = x + mm(ao, W(p + 'attn.proj.weight').t()) + W(p + 'attn.proj.bias')
         n2 = ln(x_mid, W(p + 'norm2.weight'), W(p + 'norm2.bias'), eps)
-        hpre = n2 @ W(p + 'mlp.fc1.weight').t() + W(p + 'mlp.fc1.bias')
-        x_out = x_mid + F.gelu(hpre) @ W(p + 'mlp.fc2.weight').t() + W(p + 'mlp.fc2.bias')
+        hpre = mm(n2, W(p + 'mlp.fc1.weight').t()) + W(p + 'mlp.fc1.bias')
+        x_out = x_mid + mm(F.gelu(hpre), W(p + 'mlp.fc2.weight').t()) + W(p + 'mlp.fc2.bias')
         saved['blocks'].append({'x': x, 'qkv': qkv, 'ao': ao, 'x_mid': x_mid, 'hpre': hpre})
         x = x_out
     saved['x_last'] = x
@@ -60,9 +60,9 @@ def backward(sd: dict, cfg, saved: dict, dmemory: torch.Tensor) -> dict:
     G = lambda k: grads['encoder.' + k]
 
     def lin_bwd(wkey, bkey, x, dy):
-        G(wkey).view(dy.shape[1], -1).add_(dy.t() @ x)
+        G(wkey).view(dy.shape[1], -1).add_(mm(dy.t(), x))
         G(bkey).add_(dy.sum(0))
-        return dy @ W(wkey).reshape(dy.shape[1], -1)
+        return mm(dy, W(wkey).reshape(dy.shape[1], -1))
 
     dx, dw, db = ln_bwd(saved['x_last'], W('norm.weight'), dmemory.reshape(B * S, E), eps)
     G('norm.weight').add_(dw); G('norm.bias').add_(db)

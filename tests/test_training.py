@@ -193,6 +193,40 @@ def test_hand_derived_encoder_backward_matches_autograd(name):
         assert (got - want).abs().max() <= 5e-5 * float(want.abs().max()) + 1e-7, k
 
 
+def test_bf16_operand_rounding_budget(train_golden):
+    """What rounding every matrix-product operand to bfloat16 (fp32 accumulate, everything else fp32) does to one training step
+    of PARSeq-S: the tolerance a bf16 device path (BASELINE configs[4]) can be held to against the fp32 gate.  Measured:
+    loss 4e-5 relative; per-tensor gradient error 0.8 % median, 2.8 % worst (L2, relative); cosine >= 0.9996."""
+    from oracle import decoder_backward as DB, encoder_backward as EB
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    tgt = Tokenizer(CHARSET_94).encode(meta['labels'])
+    perms = g['perms'].long()
+
+    def step():
+        with torch.no_grad():
+            memory, saved = EB.forward(sd, cfg, g['images'])
+            loss, _, grads, dmem = DB.loss_and_grads(sd, cfg, memory, tgt, perms, O.attn_masks_from_perm)
+            grads.update(EB.backward(sd, cfg, saved, dmem))
+        return float(loss), grads
+
+    exact_loss, exact = step()
+    with DB.rounding('bf16'):
+        bf_loss, bf = step()
+    assert DB._ROUNDING[0] is None
+    assert abs(exact_loss - meta['loss']) <= 2e-6 * meta['loss'] and 0 < abs(bf_loss - exact_loss) <= 5e-4 * exact_loss
+    rel, cos = [], []
+    for k, a in exact.items():
+        a, b = a.double().flatten(), bf[k].double().flatten()
+        if float(a.norm()) < 1e-7:
+            continue
+        rel.append(float((a - b).norm() / a.norm()))
+        cos.append(float(a @ b / (a.norm() * b.norm())))
+    rel.sort()
+    assert 1e-3 < rel[len(rel) // 2] < 2e-2 and rel[-1] < 6e-2 and min(cos) > 0.998
+
+
 def _autograd_decoder_loss(sd, cfg, memory, tgt, perms, drop):
     """The training loss with dropout masks from `drop`, written with plain differentiable torch ops (F.layer_norm, F.softmax,
     F.gelu, F.embedding) — independent of the operator code in oracle/decoder_backward.py — for autograd to differentiate."""
