@@ -54,6 +54,13 @@ def param_views(native_model, flat: Tensor, shapes: Dict[str, Sequence[int]]) ->
     return out
 
 
+def loss_denominator(labels, num_perms: int) -> int:
+    """Sum over the permutation passes of their count of non-<pad> targets (system.py:183-196), from the labels alone: every
+    label contributes its characters plus <eos> to the first two passes and its characters only to the later ones."""
+    chars = sum(len(s) for s in labels)
+    return (chars + len(labels)) * min(num_perms, 2) + chars * max(num_perms - 2, 0)
+
+
 def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None,
                      dropout: Optional[float] = None, seed: Optional[int] = None) -> DecoderBackward:
     """One training batch up to and including the decoder's backward.  `perms` defaults to a fresh draw from the system's
@@ -71,9 +78,7 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
     K = len(perms)
     late = torch.where(tgt_out == system.eos_id, system.pad_id, tgt_out)
     targets = torch.stack([tgt_out.reshape(-1), late.reshape(-1)]).to(torch.int32).contiguous()
-    # the loss denominator (system.py:189,196) from the labels, on the host: no device round trip
-    chars = sum(len(s) for s in labels)
-    total = (chars + len(labels)) * min(K, 2) + chars * max(K - 2, 0)
+    total = loss_denominator(labels, K)          # on the host: no device round trip
     masks = torch.stack([generate_attn_masks(p)[1] for p in perms.cpu()]).to(torch.uint8).to(dev).contiguous()
     padding = ((tgt_in == system.pad_id) | (tgt_in == system.eos_id)).to(torch.uint8).contiguous()
     tokens = tgt_in.to(torch.int32).contiguous()

@@ -193,6 +193,22 @@ def test_hand_derived_encoder_backward_matches_autograd(name):
         assert (got - want).abs().max() <= 5e-5 * float(want.abs().max()) + 1e-7, k
 
 
+def test_loss_denominator_matches_the_counted_targets():
+    """parseq_amd.train.loss_denominator (computed from the labels on the host, so the step needs no device read) against the
+    counts `training_step` derives from the encoded targets (system.py:183-196), for 1..8 permutation passes."""
+    from parseq_amd.train import loss_denominator
+    cfg = CONFIGS['parseq-tiny']
+    sd = synth_state_dict(cfg, 3)
+    tok = Tokenizer(CHARSET_94)
+    labels = ['a', 'bc', 'hello', 'W0rld#42', 'x' * 25, 'Zz']
+    tgt = tok.encode(labels)
+    for k in range(1, 9):
+        perms = torch.stack([torch.arange(tgt.shape[1])] * k)
+        with torch.inference_mode():
+            counts = O.training_loss(sd, cfg, synth_images(len(labels), cfg, 1), tgt, perms)[2]
+        assert int(counts.sum()) == loss_denominator(labels, k), k
+
+
 def test_bf16_operand_rounding_budget(train_golden):
     """What rounding every matrix-product operand to bfloat16 (fp32 accumulate, everything else fp32) does to one training step
     of PARSeq-S: the tolerance a bf16 device path (BASELINE configs[4]) can be held to against the fp32 gate.  Measured:
