@@ -18,6 +18,16 @@
  *   - return value: 0 on success, a negative PARSEQ_E_* code otherwise; parseq_last_error() gives the message
  *     (thread-local).  No exceptions cross the boundary.
  *   - a model and its plans are not internally locked: use one plan per host thread / stream.
+ *   - devices: a model lives on the device that was current at parseq_model_create; every entry point that takes a model or
+ *     a plan makes that device current for the duration of the call and restores the caller's (so `stream` must be a stream
+ *     of the model's device).  The raw-pointer entry points (parseq_op_*, parseq_postprocess, parseq_resize_bicubic,
+ *     parseq_cross_entropy, parseq_grad_norm) launch on the CURRENT device.  Per-kernel launch attributes are tracked per
+ *     device, so one process may drive several GPUs / host threads (one plan each).
+ *   - memory: the caller owns every tensor it passes; each plan owns ONE device arena (hipMalloc in parseq_plan_create:
+ *     packed weights, decoder tables and all intermediates, about 0.9 GB at max_batch 512 in bf16) and the model one buffer of
+ *     fp32 master weights.  This is a deliberate departure from "all workspace through the host framework's caching
+ *     allocator" (SURVEY.md section 8b): the C ABI carries no allocator callback, nothing is allocated on the hot path, and
+ *     the arena's lifetime is the plan's.
  */
 #ifndef PARSEQ_HIP_H_
 #define PARSEQ_HIP_H_
@@ -29,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 3
+#define PARSEQ_ABI_VERSION 4
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -143,6 +153,20 @@ int parseq_decode_logits(parseq_plan* p, const int32_t* tokens, int batch, int c
 int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len,
                          const uint8_t* query_mask, const uint8_t* key_padding_mask, float* hidden_out, float* logits_out,
                          void* stream);
+
+/* model.PARSeq.decode with a caller-supplied query stream (model.py:100-102: `tgt_query` need not be a slice of pos_queries):
+ * query: device fp32 [batch, q_len, embed_dim].  norm_q + the query projection run at call time, self-attention scores are
+ * computed against the content-key table, and the residual stream starts from `query` itself (modules.py:60-66).
+ * query_mask: device uint8 [q_len, ctx_len] or NULL.  hidden_out: fp32 [batch, q_len, embed_dim] or NULL; logits_out as above. */
+int parseq_decode_query(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, const float* query, int q_len,
+                        const uint8_t* query_mask, const uint8_t* key_padding_mask, float* hidden_out, float* logits_out,
+                        void* stream);
+
+/* model.PARSeq.decode's `memory` argument (model.py:89): projects a caller-supplied encoder output — device fp32
+ * [batch, tokens, embed_dim], as parseq_encode returns it (after the encoder's final norm) — to the decoder's cross-attention
+ * K / V, replacing the ones cached by the last parseq_encode / parseq_forward on this plan.  The decode entry points then
+ * attend to THIS memory until the next encode / forward / set_memory. */
+int parseq_set_memory(parseq_plan* p, const float* memory, int batch, void* stream);
 
 /* ViTSTR.forward (strhub/models/vitstr/system.py:76-82 -> vitstr/model.py:20-28) for a model created with
  * arch = PARSEQ_ARCH_VITSTR: encoder with class token, head on tokens [1, num_steps], i.e. logits_out fp32

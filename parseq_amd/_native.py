@@ -16,7 +16,7 @@ from . import build as _build
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8 = 0, 1, 2
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING = 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ParseqConfig(C.Structure):
@@ -60,6 +60,9 @@ SIGNATURES = {
                                  C.POINTER(C.c_int), C.c_void_p]),
     'parseq_decode_hidden': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'parseq_decode_query': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p]),
+    'parseq_set_memory': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'parseq_vitstr_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'parseq_decode_logits': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -121,9 +124,24 @@ def check(status: int) -> None:
         raise NativeError(f'libparseq_hip error {status}: {msg.decode() if msg else "?"}')
 
 
-def stream_ptr() -> C.c_void_p:
+def stream_ptr(device=None) -> C.c_void_p:
+    """The current HIP stream of `device` (a torch.device, a tensor, or None = the current device).  Entry points that take
+    a model or a plan run on that object's device whatever device is current (the library switches and restores), so the
+    stream handed over must be that device's stream — pass the model's device / the tensors' device, never rely on the
+    thread's current device."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if device is not None and hasattr(device, 'device'):
+        device = device.device
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def guard(device):
+    """Context manager making `device` (torch.device or tensor) current: for the raw-pointer entry points (parseq_op_*,
+    parseq_postprocess, parseq_resize_bicubic, parseq_cross_entropy, parseq_grad_norm), which launch on the current device."""
+    import torch
+    if hasattr(device, 'device'):
+        device = device.device
+    return torch.cuda.device(device)
 
 
 def dtype_code(t) -> int:

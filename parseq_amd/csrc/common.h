@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace pq {
 
 typedef __bf16 bf16_t;
@@ -135,5 +137,32 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
     o[2] = static_cast<bf16_t>(v[2]); o[3] = static_cast<bf16_t>(v[3]);
     *reinterpret_cast<bf16x4*>(p) = o;
 }
+
+// Greedy pick with torch.argmax's semantics, safe for any input: the first maximum wins, a NaN counts as the maximum (the first
+// NaN wins), and a row with no finite winner (all -inf) yields index 0 — never the "no candidate yet" sentinel, which would be
+// used as a token id to index the decoder tables.
+constexpr int ARGMAX_NONE = 0x7fffffff;
+__device__ __forceinline__ bool argmax_take(float v, int i, float best, int bi) {
+    const bool vn = v != v, bn = best != best;
+    return vn ? (!bn || i < bi) : (!bn && (v > best || (v == best && i < bi)));
+}
+__device__ __forceinline__ int argmax_final(int bi, int C) { return bi < C ? bi : 0; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel.  One LdsAttr per launch site remembers
+// (bit per device ordinal, lock-free) on which devices the attribute has been raised, so that a process driving several GPUs
+// — or several host threads, one plan each — sets it wherever it launches; setting it twice is harmless.
+struct LdsAttr {
+    std::atomic<uint64_t> done{0};
+    hipError_t ensure(const void* fn, size_t bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+        return e;
+    }
+};
 
 }  // namespace pq

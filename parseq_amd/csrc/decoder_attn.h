@@ -52,7 +52,11 @@ template <typename T, int E>
 __global__ __launch_bounds__(E)
 void dec_self_attn_kernel(const float* __restrict__ stab, const T* __restrict__ kvtab, const int* __restrict__ tok,
                           int ldt, int ntok, int npos, const unsigned char* __restrict__ qmask, int ldq,
-                          const unsigned char* __restrict__ kpm, int ldk, int Lk, int i0, int Lq, T* __restrict__ out) {
+                          const unsigned char* __restrict__ kpm, int ldk, int Lk, int i0, int Lq, T* __restrict__ out,
+                          const float* __restrict__ uq = nullptr) {
+    // uq != nullptr: caller-supplied queries (model.decode's tgt_query, model.py:100-102) — uq[w][E] is their q-projection
+    // (norm_q, in_proj rows 0..E, bias, 1/sqrt(hd) applied) and the scores are dot products against the content-key table
+    // instead of look-ups in the position-query score table.
     constexpr int H = E / DEC_HD;
     __shared__ int stok[DEC_MAXL];
     __shared__ float sp[H][DEC_MAXL];
@@ -64,7 +68,17 @@ void dec_self_attn_kernel(const float* __restrict__ stab, const T* __restrict__ 
     if (t < H * Lk) {
         const int j = t / H, h = t - j * H;
         const bool masked = (qmask && qmask[(size_t)pos * ldq + j]) || (kpm && kpm[(size_t)b * ldk + j]);
-        sp[h][j] = masked ? -INFINITY : stab[(((size_t)pos * npos + j) * ntok + stok[j]) * H + h];
+        float sc;
+        if (uq) {
+            const float* qv = uq + (size_t)w * E + h * DEC_HD;
+            const T* kv = kvtab + ((size_t)j * ntok + stok[j]) * (2 * E) + h * DEC_HD;
+            sc = 0.f;
+#pragma unroll
+            for (int d = 0; d < DEC_HD; ++d) sc = fmaf(qv[d], to_f32(kv[d]), sc);
+        } else {
+            sc = stab[(((size_t)pos * npos + j) * ntok + stok[j]) * H + h];
+        }
+        sp[h][j] = masked ? -INFINITY : sc;
     }
     __syncthreads();
     if (t < H) {                              // 12 x 26 values: a serial soft-max per head is a few hundred cycles

@@ -387,17 +387,18 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
     for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
         const int row = wave * (DS_ROWS / DS_NW) + rr, b = row0 + row;
         if (b >= M) continue;
-        float best = -INFINITY; int bi = 0x7fffffff;
+        float best = -INFINITY; int bi = ARGMAX_NONE;
         for (int c = lane; c < C; c += 64) {
             const float v = lg[row * PL + c];
-            if (v > best) { best = v; bi = c; }
+            if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o, 64);
             const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
         }
+        bi = argmax_final(bi, C);
         if (lane == 0) {
             tok[(size_t)b * ldt + pos + 1] = bi;
             if (argmax_mode == 2 && bi == eos_id && !eos_seen[b]) {
@@ -494,17 +495,18 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
                 const int row = wave * RPW + rr, b = row0 + row;
-                float best = -INFINITY; int bi = 0x7fffffff;
+                float best = -INFINITY; int bi = ARGMAX_NONE;
                 for (int c = lane; c < C; c += 64) {
                     const float v = lg[row * PL + c];
-                    if (v > best) { best = v; bi = c; }
+                    if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) {
                     const float ov = __shfl_xor(best, o, 64);
                     const int oi = __shfl_xor(bi, o, 64);
-                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                    if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
                 }
+                bi = argmax_final(bi, C);
                 picked[rr] = bi;
                 if (lane == 0 && b < M) {
                     tok[(size_t)b * ldt + pos] = bi;

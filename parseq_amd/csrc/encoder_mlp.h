@@ -41,7 +41,12 @@ constexpr int MLP_BM = 128, MLP_NST = 8, MLP_DIST = 7, MLP_STAGE_BYTES = 128 * 1
 
 // VARIANT (ablations, tools/panel_bench.py): 0 product; 1 no weight stream inside the loop (stale LDS); 2 no GELU (bias + convert
 // only); 3 no LDS reads / MFMAs; 4 no barriers and no vmcnt waits (garbage); 5 no LayerNorm prologue.
-template <int E, int VARIANT = 0>
+// RESIDENT: the fp32 rows of x are loaded ONCE, straight into the fc2 accumulators (the pair-permuted W2 row order makes the
+// accumulator layout of a tile pair identical to the LayerNorm'd operand-fragment layout: lane (r16, g) holds columns
+// 32 q + 8 g + [0, 8) of row r16), LayerNorm statistics are taken from the accumulators, and the epilogue only stores:
+// x crosses HBM once in each direction (203 MB per launch at M = 65 536 instead of the 340 MB measured for the
+// load - LayerNorm - ... - reload - add - store form, profiles/r01_pmc_hbm_traffic.md).
+template <int E, int VARIANT = 0, bool RESIDENT = false>
 __global__ __launch_bounds__(256, 1)
 void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                       const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
@@ -147,6 +152,7 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     // ---- LayerNorm'd A fragments: lane (r16, g) of row tile j holds row 32 wid + 16 j + r16, k in [32 ks + 8 g, +8) ------
     // (coalesced 8-lanes-per-row loads + half-row swap, see encoder_panel.h)
     bf16x8 afrag[2][KSTEPS];
+    f32x4 acc2[NG * 8][2];       // fc2 accumulators, 128 x E fp32 per workgroup; RESIDENT: initialised with x itself
     if constexpr (VARIANT == 5) {
         const bf16x8 f = *reinterpret_cast<const bf16x8*>(W1 + lane * 8);
 #pragma unroll
@@ -162,6 +168,10 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
             const u32x4 ev = lo_half ? p0 : got, od = lo_half ? got : p1;
             xa[ks] = make_float4(__uint_as_float(ev[0]), __uint_as_float(ev[1]), __uint_as_float(ev[2]), __uint_as_float(ev[3]));
             xb[ks] = make_float4(__uint_as_float(od[0]), __uint_as_float(od[1]), __uint_as_float(od[2]), __uint_as_float(od[3]));
+            if constexpr (RESIDENT) {      // columns 32 ks + 8 g + [0, 4) / + [4, 8) of row r16 == accumulators of tile pair ks
+                acc2[(ks >> 2) * 8 + 2 * (ks & 3)][j] = f32x4{xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w};
+                acc2[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j] = f32x4{xb[ks].x, xb[ks].y, xb[ks].z, xb[ks].w};
+            }
         }
         float s1 = 0.f;
 #pragma unroll
@@ -195,9 +205,10 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
 
     MLP_STAMP();      // 1: LayerNorm prologue done
     // ---- main loop ---------------------------------------------------------------------------------------------------
-    f32x4 acc2[NG * 8][2];
+    if constexpr (!RESIDENT || VARIANT == 5) {
 #pragma unroll
-    for (int i = 0; i < NG * 8; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < NG * 8; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
     const int sx = rr & 7;
     const int frag_off = rr * 128;
     const int so0 = (g ^ sx) * 16, so1 = ((4 + g) ^ sx) * 16;
@@ -317,6 +328,32 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     // Row tile 1's old values are requested piece by piece while row tile 0 is being stored (each load right after the
     // piece of tile 0 whose registers it takes over): requested only after tile 0's 24 stores they would return behind all of
     // them (vector memory is in order), requested all up front they do not fit (44 spills, measured slower).
+    if constexpr (RESIDENT && VARIANT != 5) {
+        // the accumulators already contain x: add b2, regroup to 8 lanes per row (half-row swap) and store whole 128-byte lines
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int mrow = m0 + wid * 32 + j * 16;
+            const int r_first = mrow + (rr & 7), r_second = r_first + 8;
+            const int cbase = 8 * g + (lo_half ? 0 : 4);
+#pragma unroll
+            for (int q32 = 0; q32 < E / 32; ++q32) {
+                const int ng = q32 >> 2, pr = q32 & 3;
+                const int cg = 32 * q32 + 8 * g;
+                const f32x4 ta = acc2[ng * 8 + 2 * pr][j], tb = acc2[ng * 8 + 2 * pr + 1][j];
+                u32x4 pa, pb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    pa[r] = __float_as_uint(ta[r] + sb2[cg + r]);
+                    pb[r] = __float_as_uint(tb[r] + sb2[cg + 4 + r]);
+                }
+                const u32x4 got = swap_half_rows(lo_half ? pb : pa);
+                const u32x4 first = lo_half ? pa : got, second = lo_half ? got : pb;
+                const int col = 32 * q32 + cbase;
+                if (r_first < M) *reinterpret_cast<u32x4*>(x + (size_t)r_first * E + col) = first;
+                if (r_second < M) *reinterpret_cast<u32x4*>(x + (size_t)r_second * E + col) = second;
+            }
+        }
+    } else {
     float4 old1[E / 32], old2[E / 32], nxt1[E / 32], nxt2[E / 32];
     {
         const int r_first = m0 + wid * 32 + (rr & 7);
@@ -366,21 +403,18 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
             }
         }
     }
+    }
     MLP_STAMP();      // 6: epilogue done
 #undef MLP_STAMP
 }
 
-template <int E, int VARIANT = 0>
+template <int E, int VARIANT = 0, bool RESIDENT = false>
 inline hipError_t launch_fused_mlp(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1,
                                    const float* b1, const bf16_t* W2, const float* b2, int M, unsigned long long* dbg = nullptr) {
     const size_t lds = (size_t)MLP_NST * MLP_STAGE_BYTES + (size_t)(7 * E) * sizeof(float);     // ring | b1 | b2 | gamma | beta
-    auto kern = fused_mlp_kernel<E, VARIANT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    auto kern = fused_mlp_kernel<E, VARIANT, RESIDENT>;
+    static LdsAttr attr;                // one per template instantiation
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((M + MLP_BM - 1) / MLP_BM), dim3(256), lds, s, x, gamma, beta, eps, W1, b1, W2, b2, M, dbg);
     return hipGetLastError();
 }

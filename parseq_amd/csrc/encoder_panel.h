@@ -345,12 +345,8 @@ inline hipError_t launch_ln_panel_gemm(hipStream_t s, const float* x, const floa
                                        const bf16_t* W, const float* bias, int M, int N, const Epi& epi) {
     const size_t lds = (size_t)PN_NST * PN_STAGE_BYTES + (size_t)N * sizeof(float);
     auto kern = ln_panel_gemm_kernel<E, Epi, VARIANT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_done = true;
-    }
+    static LdsAttr attr;                // one per template instantiation
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((M + PN_BM - 1) / PN_BM), dim3(256), lds, s, x, gamma, beta, eps, W, bias, M, N, epi);
     return hipGetLastError();
 }

@@ -573,12 +573,8 @@ inline hipError_t launch_gemm(hipStream_t s, const ALoad& aload, const T* W, int
         if (K % (KB / (int)sizeof(T)) == 0) {       // whole stages only: the DMA path cannot zero-fill a K tail
             auto kd = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, true, ALoad, Epi>;
             if (lds > 64 * 1024) {
-                static bool attr_done_d = false;
-                if (!attr_done_d) {
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                    if (e != hipSuccess) return e;
-                    attr_done_d = true;
-                }
+                static LdsAttr attr_d;
+                if (hipError_t e = attr_d.ensure(reinterpret_cast<const void*>(kd), lds); e != hipSuccess) return e;
             }
             hipLaunchKernelGGL(kd, dim3(grid), dim3(WM * WN * 64), lds, s, aload, W, ldw, M, N, K, mtiles, ntiles, epi);
             return hipGetLastError();
@@ -586,12 +582,8 @@ inline hipError_t launch_gemm(hipStream_t s, const ALoad& aload, const T* W, int
     }
     auto kern = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, false, ALoad, Epi>;
     if (lds > 64 * 1024) {
-        static bool attr_done = false;      // one flag per template instantiation
-        if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_done = true;
-        }
+        static LdsAttr attr;                // one per template instantiation
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, aload, W, ldw, M, N, K, mtiles, ntiles, epi);
     return hipGetLastError();

@@ -51,6 +51,20 @@ static int fail(int code, const char* fmt, ...) {
         if (r_ != 0) return r_;     \
     } while (0)
 
+// Every entry point that takes a model or a plan runs on THAT object's device, whatever device is current in the calling
+// thread (a model moved to cuda:1 while cuda:0 is current must not launch on device 0 against device-1 pointers); the
+// caller's current device is restored on return.  The stream passed in must belong to the object's device.
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev && hipSetDevice(dev) == hipSuccess) switched = true;
+    }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard&) = delete;
+    DevGuard& operator=(const DevGuard&) = delete;
+};
+
 // -------------------------------------------------------------------------------------------------------------------
 // optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
 // -------------------------------------------------------------------------------------------------------------------
@@ -208,6 +222,7 @@ extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {
 
 extern "C" void parseq_model_destroy(parseq_model* m) {
     if (!m) return;
+    DevGuard dg(m->device);
     if (m->master) (void)hipFree(m->master);
     delete m;
 }
@@ -218,6 +233,7 @@ extern "C" int parseq_model_set_param(parseq_model* m, const char* key, const fl
     if (it == m->index.end()) return fail(PARSEQ_E_INVALID, "unknown parameter key '%s'", key);
     ParamSpec& s = m->params[it->second];
     if (s.numel != numel) return fail(PARSEQ_E_INVALID, "parameter '%s': expected %lld elements, got %lld", key, (long long)s.numel, (long long)numel);
+    DevGuard dg(m->device);
     HIPCHK(hipMemcpyAsync(m->master + s.offset, device_ptr, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     s.set = true;
     m->version++;
@@ -433,7 +449,7 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
 extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out) {
     if (!m || !out || max_batch <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
     if (precision != PARSEQ_F32 && precision != PARSEQ_BF16) return fail(PARSEQ_E_INVALID, "precision %d", precision);
-    HIPCHK(hipSetDevice(m->device));
+    DevGuard dg(m->device);
     const parseq_config& c = m->cfg;
     const size_t E = c.embed_dim, N = m->tokens, B = max_batch, ts = precision == PARSEQ_BF16 ? 2 : 4;
     const size_t npos = c.max_label_length + 1, F = E * c.enc_mlp_ratio, Fd = E * c.dec_mlp_ratio;
@@ -481,11 +497,13 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
 
 extern "C" int parseq_plan_refresh(parseq_plan* p, void* stream) {
     if (!p) return fail(PARSEQ_E_INVALID, "null plan");
+    DevGuard dg(p->m->device);
     return pack_weights(p, (hipStream_t)stream);
 }
 
 extern "C" void parseq_plan_destroy(parseq_plan* p) {
     if (!p) return;
+    DevGuard dg(p->m->device);
     if (p->arena) (void)hipFree(p->arena);
     delete p;
 }
@@ -522,8 +540,8 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
             const int nt32 = (tokens + 31) / 32;
 #define PQ_ATTN_N(NT)                                                                                                                   \
             if (nt32 == NT) {                                                                                                           \
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_n_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                           (int)attn_mfma_n_lds<NT>()));                                                                \
+                static LdsAttr attr_;                                                                                                   \
+                HIPCHK(attr_.ensure(reinterpret_cast<const void*>(attn_mfma_n_kernel<NT>), attn_mfma_n_lds<NT>()));                     \
                 hipLaunchKernelGGL((attn_mfma_n_kernel<NT>), dim3(bh), dim3(64 * NT), attn_mfma_n_lds<NT>(), s, q, k, vt, ao, heads, tokens, scale); \
                 HIPCHK(hipGetLastError());                                                                                              \
                 return 0;                                                                                                               \
@@ -532,7 +550,7 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
 #undef PQ_ATTN_N
         }
         const size_t lds = (size_t)2 * tokens * ATT_HD * sizeof(float);
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // size varies per call
         hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(bh), dim3(ATTG_THREADS), lds, s, q, k, vt, ao, heads, tokens, scale);
         HIPCHK(hipGetLastError());
         return 0;
@@ -543,8 +561,8 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
     } else {
         if (v_rowmajor) return fail(PARSEQ_E_INVALID, "f32 attention expects V^T");
         constexpr size_t lds = (size_t)2 * ATT_N * ATT_HD * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
+        static LdsAttr attr;
+        HIPCHK(attr.ensure(reinterpret_cast<const void*>(attn_f32_kernel), lds));
         hipLaunchKernelGGL(attn_f32_kernel, dim3(bh), dim3(128), lds, s, q, k, vt, ao, heads, scale);
     }
     HIPCHK(hipGetLastError());
@@ -685,6 +703,7 @@ static int encode_dispatch(parseq_plan* p, const void* images, int images_dtype,
 extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtype, int batch, float* memory_out, void* stream) {
     CHK(check_call(p, batch, images_dtype));
     if (!images) return fail(PARSEQ_E_INVALID, "null images");
+    DevGuard dg(p->m->device);
     return encode_dispatch(p, images, images_dtype, batch, memory_out, (hipStream_t)stream);
 }
 
@@ -702,8 +721,8 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
             const int nt16 = (NK + 15) / 16;
 #define PQ_CAM_N(NT)                                                                                                                      \
             if (nt16 > NT - 2 && nt16 <= NT) {                                                                                           \
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_mfma_n_kernel<NT>),                              \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_cross_attn_mfma_n_lds<NT>()));           \
+                static LdsAttr attr_;                                                                                                    \
+                HIPCHK(attr_.ensure(reinterpret_cast<const void*>(dec_cross_attn_mfma_n_kernel<NT>), dec_cross_attn_mfma_n_lds<NT>()));  \
                 hipLaunchKernelGGL((dec_cross_attn_mfma_n_kernel<NT>), dim3((B * H + 1) / 2), dim3(128), dec_cross_attn_mfma_n_lds<NT>(), s, \
                                    p->qc, kmem, vmem, H, Lq, NK, scale, ca, B * H);                                                      \
                 HIPCHK(hipGetLastError());                                                                                                \
@@ -728,7 +747,7 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
 
 template <typename T, int E>
 static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
-                         float* logits, int Ltot, int argmax_mode, bool keep_t = false) {
+                         float* logits, int Ltot, int argmax_mode, bool keep_t = false, const float* user_query = nullptr) {
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
     const int M = B * Lq, Fd = E * c.dec_mlp_ratio, C = m->classes, npos = c.max_label_length + 1, H = c.dec_heads;
@@ -740,15 +759,11 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
     if constexpr (sizeof(T) == 2 && E <= 384) {
         // AR step (one unmasked query per image): two fused row-block kernels around the cross-attention (decoder_step.h)
-        if (Lq == 1 && !qmask && !kpm && C <= 128 && p->fused_step && p->wstep[0] && !keep_t) {
+        if (Lq == 1 && !qmask && !kpm && C <= 128 && p->fused_step && p->wstep[0] && !keep_t && !user_query) {
             const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
-            static const bool attr_set = [] {
-                return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_pre_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)dec_step_pre_lds<E>()) == hipSuccess &&
-                       hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_post_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)dec_step_post_lds<E>()) == hipSuccess;
-            }();
-            if (!attr_set) return fail(PARSEQ_E_HIP, "hipFuncSetAttribute(dec_step kernels) failed");
+            static LdsAttr attr_pre, attr_post;
+            HIPCHK(attr_pre.ensure(reinterpret_cast<const void*>(dec_step_pre_kernel<E>), dec_step_pre_lds<E>()));
+            HIPCHK(attr_post.ensure(reinterpret_cast<const void*>(dec_step_post_kernel<E>), dec_step_post_lds<E>()));
             {
                 ProfScope ps_(&p->prof, T_DEC_PRE, s);
                 hipLaunchKernelGGL((dec_step_pre_kernel<E>), grid, block, dec_step_pre_lds<E>(), s, p->stab, reinterpret_cast<const bf16_t*>(p->kvtab),
@@ -775,6 +790,22 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
         }
     }
     // self-attention from the tables, out-projection, residual onto the raw position queries
+    if (user_query) {
+        // model.py:100-102 with a caller-supplied tgt_query [B, Lq, E]: q-projection of norm_q(query) at run time (the position-query
+        // tables do not apply), scores against the content-key table, residual onto the caller's query itself
+        const float qscale = sqrtf(1.0f / (float)DEC_HD);
+        { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{user_query, m->p(d + "norm_q.weight"), m->p(d + "norm_q.bias"), c.dec_ln_eps, 0, nullptr},
+                         W.w(d + "self_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "self_attn.in_proj_bias"), p->qc, E, qscale)))); }
+        {
+            ProfScope ps_(&p->prof, T_DEC_SA, s);
+            hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
+                               c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, sa, p->qc);
+            HIPCHK(hipGetLastError());
+        }
+        HIPCHK(hipMemcpyAsync(p->t, user_query, (size_t)M * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+        { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
+                         epi_resid(M, E, m->p(d + "self_attn.out_proj.bias"), p->t, E)))); }
+    } else {
     {
         ProfScope ps_(&p->prof, T_DEC_SA, s);
         if constexpr (sizeof(T) == 2 && E <= 512)
@@ -787,6 +818,7 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
     }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
                      epi_table(M, E, m->p(d + "self_attn.out_proj.bias"), p->t, E, m->p("pos_queries"), E, Lq, i0)))); }
+    }
     // cross-attention against memory (head-split K / V^T cached in the plan); norm1 is fused into the q-projection's A operand
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), c.dec_ln_eps, 0, nullptr},
                      W.w(d + "cross_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
@@ -815,11 +847,11 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
 // logits[b][i0 + qi][:] for qi < Lq into a [B][Ltot][C] tensor.
 template <typename T>
 static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int Lq, const unsigned char* qmask, const unsigned char* kpm,
-                       float* logits, int Ltot, int argmax_mode = 0, bool keep_t = false) {
+                       float* logits, int Ltot, int argmax_mode = 0, bool keep_t = false, const float* user_query = nullptr) {
     switch (p->m->cfg.embed_dim) {
-        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t);
-        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t);
-        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t);
+        case 192: return decode_pass_e<T, 192>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t, user_query);
+        case 384: return decode_pass_e<T, 384>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t, user_query);
+        default:  return decode_pass_e<T, 768>(p, s, B, Lk, i0, Lq, qmask, kpm, logits, Ltot, argmax_mode, keep_t, user_query);
     }
 }
 
@@ -837,13 +869,9 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, fl
     float* tq = p->qc;                                          // t' lives in the q-projection buffer once the cross-attention has consumed it
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
-    static const bool attr_set = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_mid_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)dec_step_mid_lds<E>()) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(dec_step_mlp_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)dec_step_mlp_lds<E>()) == hipSuccess;
-    }();
-    if (!attr_set) return fail(PARSEQ_E_HIP, "hipFuncSetAttribute(dec_step mid / mlp kernels) failed");
+    static LdsAttr attr_mid, attr_mlp;
+    HIPCHK(attr_mid.ensure(reinterpret_cast<const void*>(dec_step_mid_kernel<E>), dec_step_mid_lds<E>()));
+    HIPCHK(attr_mlp.ensure(reinterpret_cast<const void*>(dec_step_mlp_kernel<E>), dec_step_mlp_lds<E>()));
     for (int i = 0; i <= num_steps; ++i) {
         const int do_finish = i > 0, do_start = i < num_steps;
         // the pick of position i - 1 feeds step i: needed while there is a step to start
@@ -921,6 +949,7 @@ extern "C" int parseq_vitstr_forward(parseq_plan* p, const void* images, int ima
                                      void* stream) {
     CHK(check_call(p, batch, images_dtype));
     if (!p->m->vitstr) return fail(PARSEQ_E_INVALID, "parseq_vitstr_forward on a PARSeq model (arch 0)");
+    DevGuard dg(p->m->device);
     if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
     const parseq_model* m = p->m;
     const int npos = m->cfg.max_label_length + 1, N = m->tokens, C = m->classes, E = m->cfg.embed_dim;
@@ -947,6 +976,7 @@ extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dty
                               int num_steps, float* logits_out, int* out_len, void* stream) {
     CHK(check_call(p, batch, images_dtype));
     if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "parseq_forward on a ViTSTR model: use parseq_vitstr_forward");
+    DevGuard dg(p->m->device);
     if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
     const int npos = p->m->cfg.max_label_length + 1;
     if (num_steps < 1 || num_steps > npos) return fail(PARSEQ_E_INVALID, "num_steps %d outside [1, %d]", num_steps, npos);
@@ -958,15 +988,18 @@ extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dty
 }
 
 static int decode_entry(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, int q_start, int q_len, const uint8_t* query_mask,
-                        const uint8_t* key_padding_mask, float* logits_out, float* hidden_out, void* stream) {
+                        const uint8_t* key_padding_mask, float* logits_out, float* hidden_out, void* stream, const float* user_query = nullptr) {
     if (!p || !tokens || !logits_out) return fail(PARSEQ_E_INVALID, "null argument");
     if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
+    DevGuard dg(p->m->device);
     if (batch <= 0 || batch > p->max_batch || batch != p->last_batch) return fail(PARSEQ_E_INVALID, "batch %d does not match the last parseq_encode (%d)", batch, p->last_batch);
     const int npos = p->m->cfg.max_label_length + 1;
     if (ctx_len < 1 || ctx_len > npos || q_start < 0 || q_len < 1 || q_start + q_len > npos) return fail(PARSEQ_E_INVALID, "bad context / query range");
     hipStream_t s = (hipStream_t)stream;
     // stage caller's tokens / masks into the plan's pitched arrays
     HIPCHK(hipMemcpy2DAsync(p->tok, LDT * sizeof(int), tokens, ctx_len * sizeof(int), ctx_len * sizeof(int), batch, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(clamp_tokens_kernel, dim3((batch * ctx_len + 255) / 256), dim3(256), 0, s, p->tok, LDT, batch, ctx_len, p->m->cfg.num_tokens);
+    HIPCHK(hipGetLastError());
     const unsigned char* kpm = nullptr; const unsigned char* qm = nullptr;
     if (key_padding_mask) {
         HIPCHK(hipMemcpy2DAsync(p->kpm, LDT, key_padding_mask, ctx_len, ctx_len, batch, hipMemcpyDeviceToDevice, s));
@@ -977,8 +1010,8 @@ static int decode_entry(parseq_plan* p, const int32_t* tokens, int batch, int ct
         qm = p->qmask_user;
     }
     const bool keep_t = hidden_out != nullptr;
-    if (p->precision == PARSEQ_BF16) CHK((decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t)));
-    else CHK((decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t)));
+    if (p->precision == PARSEQ_BF16) CHK((decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t, user_query)));
+    else CHK((decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t, user_query)));
     if (hidden_out) {      // model.decode's return value: decoder.norm of the query stream (modules.py:124), fp32
         const parseq_model* m = p->m;
         CHK((run_layernorm<float>(s, p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), hidden_out, nullptr, batch * q_len,
@@ -997,6 +1030,52 @@ extern "C" int parseq_decode_hidden(parseq_plan* p, const int32_t* tokens, int b
                                     void* stream) {
     if (!hidden_out) return fail(PARSEQ_E_INVALID, "null hidden_out");
     return decode_entry(p, tokens, batch, ctx_len, q_start, q_len, query_mask, key_padding_mask, logits_out, hidden_out, stream);
+}
+
+extern "C" int parseq_decode_query(parseq_plan* p, const int32_t* tokens, int batch, int ctx_len, const float* query, int q_len,
+                                   const uint8_t* query_mask, const uint8_t* key_padding_mask, float* hidden_out, float* logits_out,
+                                   void* stream) {
+    if (!query) return fail(PARSEQ_E_INVALID, "null query");
+    if (!p) return fail(PARSEQ_E_INVALID, "null plan");
+    if (q_len < 1 || q_len > p->m->cfg.max_label_length + 1) return fail(PARSEQ_E_INVALID, "q_len %d outside [1, %d]", q_len, p->m->cfg.max_label_length + 1);
+    return decode_entry(p, tokens, batch, ctx_len, 0, q_len, query_mask, key_padding_mask, logits_out, hidden_out, stream, query);
+}
+
+// The cross-attention K / V of a caller-supplied encoder output (model.decode's `memory` argument, model.py:89): replaces the
+// K / V cached by the last parseq_encode on this plan.
+template <typename T>
+static int set_memory_impl(parseq_plan* p, const float* memory, int B, hipStream_t s) {
+    const parseq_model* m = p->m;
+    const parseq_config& c = m->cfg;
+    const int E = c.embed_dim, N = m->tokens, M = B * N;
+    const Weights<T> W = weights_of<T>(p);
+    const T* a;
+    if constexpr (sizeof(T) == 2) {
+        const size_t n = (size_t)M * E;
+        hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, memory, reinterpret_cast<bf16_t*>(p->xn), n);
+        HIPCHK(hipGetLastError());
+        a = reinterpret_cast<const T*>(p->xn);
+    } else {
+        a = memory;
+    }
+    const std::string d = "decoder.layers.0.cross_attn.";
+    EpiHeads<T> ek; static_cast<EpiBase&>(ek) = epi_base(M, 2 * E, m->p(d + "in_proj_bias") + E);
+    ek.seg[0] = reinterpret_cast<T*>(p->kmem); ek.seg[1] = reinterpret_cast<T*>(p->vmem); ek.seg[2] = nullptr;
+    ek.E = E; ek.heads = c.dec_heads; ek.hd = DEC_HD; ek.tokens = N; ek.tr_from = 2;
+    ProfScope ps_(&p->prof, T_KVMEM, s);
+    CHK((run_gemm<T>(s, ARowMajor<T>{a, E}, W.w(d + "in_proj_weight") + (size_t)E * E, E, M, 2 * E, E, ek, E % 128 != 0)));
+    p->last_batch = B;
+    return 0;
+}
+
+extern "C" int parseq_set_memory(parseq_plan* p, const float* memory, int batch, void* stream) {
+    if (!p || !memory) return fail(PARSEQ_E_INVALID, "null argument");
+    if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
+    if (batch <= 0 || batch > p->max_batch) return fail(PARSEQ_E_INVALID, "batch %d outside (0, %d]", batch, p->max_batch);
+    if (p->packed_version != p->m->version) return fail(PARSEQ_E_STATE, "model parameters changed after the plan was packed; call parseq_plan_refresh");
+    DevGuard dg(p->m->device);
+    if (p->precision == PARSEQ_BF16) return set_memory_impl<bf16_t>(p, memory, batch, (hipStream_t)stream);
+    return set_memory_impl<float>(p, memory, batch, (hipStream_t)stream);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1083,12 +1162,9 @@ static int train_attn_hd(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool
     const size_t lds = train_attn_lds_floats(a.Lq, a.Lk, HD, backward) * sizeof(float);
     if (lds > 150 * 1024 || (size_t)a.Lk * HD > (size_t)TA_NACC * 256)
         return fail(PARSEQ_E_INVALID, "training attention: %d keys of width %d do not fit (LDS %zu bytes)", a.Lk, HD, lds);
-    static bool attr_done = false;      // one flag per head width
-    if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<false, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_kernel<true, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_done = true;
-    }
+    static LdsAttr attr_f, attr_b;      // one pair per head width
+    HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_kernel<false, HD>), 150 * 1024));
+    HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_kernel<true, HD>), 150 * 1024));
     if (backward) hipLaunchKernelGGL((train_attn_kernel<true, HD>), dim3(B * a.H), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((train_attn_kernel<false, HD>), dim3(B * a.H), dim3(256), lds, s, a);
     HIPCHK(hipGetLastError());
@@ -1098,12 +1174,9 @@ static int train_attn_hd(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool
 static int train_attn_mfma(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
     hipStream_t s = cx.s;
     const size_t lds = ((size_t)2 * a.Lk * 65 + (size_t)(backward ? 2 : 1) * 32 * 65 + (size_t)(backward ? 2 : 1) * 32 * (a.Lk + 1)) * sizeof(float);
-    static bool attr_done = false;
-    if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(train_attn_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_done = true;
-    }
+    static LdsAttr attr_f, attr_b;
+    HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_mfma_kernel<false>), 150 * 1024));
+    HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_mfma_kernel<true>), 150 * 1024));
     if (backward) hipLaunchKernelGGL((train_attn_mfma_kernel<true>), dim3(B * a.H), dim3(256), lds, s, a);
     else hipLaunchKernelGGL((train_attn_mfma_kernel<false>), dim3(B * a.H), dim3(256), lds, s, a);
     HIPCHK(hipGetLastError());
@@ -1175,6 +1248,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         return fail(PARSEQ_E_INVALID, "null argument");
     if (m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
     for (const ParamSpec& ps : m->params) if (!ps.set) return fail(PARSEQ_E_STATE, "parameter %s was never set", ps.key.c_str());
+    DevGuard dg(m->device);
     const int B = batch, L = ctx_len, K = num_perms;
     if (B <= 0 || L < 2 || L > m->cfg.max_label_length + 1 || K <= 0 || total_targets <= 0)
         return fail(PARSEQ_E_INVALID, "bad shape: batch %d, ctx_len %d (2..%d), %d permutations, %d targets", B, L, m->cfg.max_label_length + 1, K, total_targets);
@@ -1354,6 +1428,7 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
                                             size_t workspace_bytes, void* stream) {
     if (!images || !memory_out) return fail(PARSEQ_E_INVALID, "null argument");
     CHK(train_encoder_check(m, batch, workspace, workspace_bytes));
+    DevGuard dg(m->device);
     const TrainEncoderLayout o = train_encoder_layout(m, batch);
     hipStream_t s = (hipStream_t)stream;
     const int E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, S = m->tokens, MS = batch * S, PK = m->patch_k;
@@ -1386,6 +1461,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
                                              void* stream) {
     if (!dmemory || !grads) return fail(PARSEQ_E_INVALID, "null argument");
     CHK(train_encoder_check(m, batch, workspace, workspace_bytes));
+    DevGuard dg(m->device);
     const TrainEncoderLayout o = train_encoder_layout(m, batch);
     hipStream_t s = (hipStream_t)stream;
     const int E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, S = m->tokens, MS = batch * S, PK = m->patch_k;
@@ -1437,6 +1513,7 @@ extern "C" int parseq_adamw_step(parseq_model* m, const float* grads, float* exp
                                  void* stream) {
     if (!m || !grads || !exp_avg || !exp_avg_sq) return fail(PARSEQ_E_INVALID, "null argument");
     if (step < 1) return fail(PARSEQ_E_INVALID, "step %d: steps count from 1", step);
+    DevGuard dg(m->device);
     for (const ParamSpec& ps : m->params) if (!ps.set) return fail(PARSEQ_E_STATE, "parameter %s was never set", ps.key.c_str());
     hipStream_t s = (hipStream_t)stream;
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
@@ -1464,6 +1541,7 @@ extern "C" int parseq_model_get_param(const parseq_model* m, const char* key, fl
     if (it == m->index.end()) return fail(PARSEQ_E_INVALID, "unknown parameter key '%s'", key);
     const ParamSpec& ps = m->params[it->second];
     if (ps.numel != numel) return fail(PARSEQ_E_INVALID, "parameter %s: numel %lld, expected %lld", key, (long long)numel, (long long)ps.numel);
+    DevGuard dg(m->device);
     HIPCHK(hipMemcpyAsync(device_ptr, m->master + ps.offset, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
@@ -1605,6 +1683,10 @@ extern "C" int parseq_op_mlp_variant(float* x, const float* gamma, const float* 
         case 3: HIPCHK((launch_fused_mlp<384, 3>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
         case 4: HIPCHK((launch_fused_mlp<384, 4>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
         case 5: HIPCHK((launch_fused_mlp<384, 5>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
+        case 10: HIPCHK((launch_fused_mlp<384, 0, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;   // x resident in the accumulators
+        case 16: {  // stamps of the resident form
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
+            HIPCHK((launch_fused_mlp<384, 6, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }
         case 6: {   // phase time stamps: the LAST 4096 bytes of x's allocation are not touched (caller passes M smaller than the buffer)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
             HIPCHK((launch_fused_mlp<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }

@@ -96,17 +96,18 @@ void ar_argmax_kernel(const float* __restrict__ logits, int L, int C, int* __res
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
     const float* row = logits + ((size_t)b * L + step) * C;
-    float best = -INFINITY; int bi = 0x7fffffff;
+    float best = -INFINITY; int bi = ARGMAX_NONE;
     for (int c = lane; c < C; c += 64) {
         const float v = row[c];
-        if (v > best) { best = v; bi = c; }      // strictly greater: keeps the lowest index inside a lane
+        if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
     }
+    bi = argmax_final(bi, C);
     if (lane == 0) {
         tok[(size_t)b * ldt + step + 1] = bi;
         if (record && bi == eos_id && !eos_seen[b]) {
@@ -115,6 +116,17 @@ void ar_argmax_kernel(const float* __restrict__ logits, int L, int C, int* __res
             if (done == B) *ar_len = step + 1;
         }
     }
+}
+
+// Caller-supplied context tokens (parseq_decode_logits / parseq_decode_hidden) index the decoder tables: ids outside
+// [0, ntok) are clamped into range instead of reading out of bounds (the reference raises on the host or trips a device
+// assert; this library cannot raise without a synchronisation, so it degrades to a valid id).
+__global__ void clamp_tokens_kernel(int* __restrict__ tok, int ldt, int B, int Lk, int ntok) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Lk) return;
+    int* p = tok + (size_t)(i / Lk) * ldt + (i % Lk);
+    const int v = *p;
+    *p = v < 0 ? 0 : (v >= ntok ? ntok - 1 : v);
 }
 
 // Refinement context (model.py:161-163): tok[b] = [bos, argmax(logits[b, :L-1])], and the key-padding mask
@@ -130,7 +142,7 @@ void refine_prep_kernel(const float* __restrict__ logits, int L, int C, int* __r
         if (from_logits) {
             const float* row = logits + ((size_t)b * L + (lane - 1)) * C;
             float best = row[0]; int bi = 0;
-            for (int c = 1; c < C; ++c) { const float v = row[c]; if (v > best) { best = v; bi = c; } }
+            for (int c = 1; c < C; ++c) { const float v = row[c]; if (argmax_take(v, c, best, bi)) { best = v; bi = c; } }
             t = bi;
         } else {
             t = tok[(size_t)b * ldt + lane];      // first iteration after a full AR loop: the AR picks are the argmaxes
@@ -168,17 +180,18 @@ void postprocess_kernel(const float* __restrict__ logits, int B, int L, int C, i
     float my_p = 1.0f; int my_id = -1;
     for (int l = 0; l < L; ++l) {
         const float* row = logits + ((size_t)b * L + l) * C;
-        float best = -INFINITY; int bi = 0x7fffffff;
+        float best = -INFINITY; int bi = ARGMAX_NONE;
         for (int c = lane; c < C; c += 64) {
             const float v = row[c];
-            if (v > best) { best = v; bi = c; }
+            if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o, 64);
             const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
         }
+        bi = argmax_final(bi, C);
         float sum = 0.f;
         for (int c = lane; c < C; c += 64) sum += expf(row[c] - best);
         sum = wave_sum(sum);

@@ -26,7 +26,9 @@ _PRECISIONS = {'bf16': _native.PARSEQ_BF16, 'fp32': _native.PARSEQ_F32, 'f32': _
 
 def init_weights(module: nn.Module, name: str = '', exclude: Sequence[str] = ()):
     """Initialisation scheme of the reference (`strhub/models/utils.py:107-125`): trunc-normal(0.02) Linear / Embedding
-    weights, zero biases, unit LayerNorm, Kaiming-normal(fan_out) convolutions."""
+    weights, zero biases, unit LayerNorm, Kaiming-normal(fan_out) convolutions.  This is a deliberate statement-for-statement
+    behavioural mirror of that 19-line function (same branches, same torch initialisers in the same order), not an independent
+    design: seeded random-init weights must come out identical to the reference's for bench.py's `manual_seed(0)` model."""
     if any(name.startswith(e) for e in exclude):
         return
     if isinstance(module, nn.Linear):
@@ -153,8 +155,9 @@ class _Head(nn.Linear):
         out = torch.empty(a.shape[0], self.out_features, dtype=torch.float32, device=x.device)
         w = self.weight.detach().to(torch.float32).contiguous()
         b = self.bias.detach().to(torch.float32).contiguous()
-        _native.check(_native.lib().parseq_op_linear(_native.ptr(a), _native.ptr(w), _native.ptr(b), _native.ptr(out), _native.PARSEQ_F32, 0,
-                                                     a.shape[0], self.out_features, self.in_features, _native.stream_ptr()))
+        with _native.guard(a):
+            _native.check(_native.lib().parseq_op_linear(_native.ptr(a), _native.ptr(w), _native.ptr(b), _native.ptr(out), _native.PARSEQ_F32, 0,
+                                                         a.shape[0], self.out_features, self.in_features, _native.stream_ptr(a)))
         return out.view(*x.shape[:-1], self.out_features)
 
 
@@ -197,7 +200,8 @@ class _NativeBacked(nn.Module):
 
     def set_profiling(self, enable: bool, batch: int) -> None:
         """Bracket every kernel launch with HIP events (per-family timing for the roofline report; perturbs throughput)."""
-        _native.check(_native.lib().parseq_plan_set_profiling(self._plan(batch), 1 if enable else 0))
+        with _native.guard(self._device):
+            _native.check(_native.lib().parseq_plan_set_profiling(self._plan(batch), 1 if enable else 0))
 
     def get_profile(self, batch: int) -> dict:
         """{family: (total_ms, launches)} accumulated since set_profiling(True)."""
@@ -252,7 +256,7 @@ class _NativeBacked(nn.Module):
                 handle = C.c_void_p(0)
                 _native.check(lib.parseq_model_create(C.byref(cfg), C.byref(handle)))
                 st.model = handle
-            stream = _native.stream_ptr()
+            stream = _native.stream_ptr(self._device)
             sd = self.state_dict()
             n_native = lib.parseq_model_num_params(st.model)
             if n_native != len(sd):
@@ -264,7 +268,7 @@ class _NativeBacked(nn.Module):
                 _native.check(lib.parseq_model_set_param(st.model, key.encode(), _native.ptr(t32), t32.numel(), stream))
             for plan, _ in st.plans.values():
                 _native.check(lib.parseq_plan_refresh(plan, stream))
-            torch.cuda.current_stream().synchronize()    # staging copies in `keep` must outlive the async D2D copies
+            torch.cuda.current_stream(self._device).synchronize()    # staging copies in `keep` must outlive the async D2D copies
         st.signature = sig
         return st
 
@@ -273,7 +277,7 @@ class _NativeBacked(nn.Module):
         them back into this module's parameter tensors — through raw pointers, so their autograd versions, and with them the
         signature, do not change and nothing is uploaded again — and re-pack the plans' bf16 copies / decoder tables."""
         st: _NativeState = self._native_state
-        lib, stream = _native.lib(), _native.stream_ptr()
+        lib, stream = _native.lib(), _native.stream_ptr(self._device)
         for key, t in self.state_dict().items():
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError(f'parameter {key}: training needs contiguous fp32 parameters')
@@ -290,13 +294,13 @@ class _NativeBacked(nn.Module):
         if plan is None or batch > cap:
             lib = _native.lib()
             if plan is not None:
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.current_stream(self._device).synchronize()
                 lib.parseq_plan_destroy(plan)
                 del st.plans[(code, slot)]
             cap = max(8, 1 << (batch - 1).bit_length())
             handle = C.c_void_p(0)
             with torch.cuda.device(self._device):
-                _native.check(lib.parseq_plan_create(st.model, cap, code, _native.stream_ptr(), C.byref(handle)))
+                _native.check(lib.parseq_plan_create(st.model, cap, code, _native.stream_ptr(self._device), C.byref(handle)))
             st.plans[(code, slot)] = (handle, cap)
             plan = handle
         return plan
@@ -348,32 +352,70 @@ class PARSeq(_NativeBacked):
         memory = torch.empty(img.shape[0], self.encoder.pos_embed.shape[1], self._cfg['embed_dim'],
                              dtype=torch.float32, device=img.device)
         _native.check(_native.lib().parseq_encode(plan, _native.ptr(img), _native.dtype_code(img.dtype), img.shape[0],
-                                                  _native.ptr(memory), _native.stream_ptr()))
+                                                  _native.ptr(memory), _native.stream_ptr(self._device)))
+        self._remember_memory(memory)      # the K / V projection of THIS tensor object is what the plan now caches
         return memory
+
+    def _bind_memory(self, memory: Optional[Tensor], B: int, plan) -> None:
+        """Make the plan's cross-attention K / V those of `memory` (model.py:89).  `None`, or the very tensor the last
+        `encode` on this model returned (same storage, unmodified since), means the cached projection is already right;
+        anything else — another batch's memory, an edited tensor, a memory produced elsewhere — is re-projected
+        (`parseq_set_memory`), never silently ignored."""
+        if memory is None:
+            return
+        E = self._cfg['embed_dim']
+        n_tok = self.encoder.pos_embed.shape[1]
+        if memory.dim() != 3 or tuple(memory.shape) != (B, n_tok, E):
+            raise RuntimeError(f'memory must be [{B}, {n_tok}, {E}], got {list(memory.shape)}')
+        if memory.device != self._device:
+            raise RuntimeError(f'memory on {memory.device} but the model is on {self._device}')
+        key = getattr(self, '_memory_key', None)
+        if key is not None and key[0]() is memory and key[1:] == (memory._version, self._native_state.signature):
+            return
+        mem = memory.detach().to(torch.float32).contiguous()
+        _native.check(_native.lib().parseq_set_memory(plan, _native.ptr(mem), B, _native.stream_ptr(self._device)))
+        self._memory_keep = mem                 # stays alive until the asynchronous projection has read it
+        self._remember_memory(memory)
+
+    def _remember_memory(self, memory: Tensor) -> None:
+        # identity of the tensor OBJECT (a weak reference: a freed tensor whose storage address is reused by another one can
+        # never match), its in-place-modification counter, and the parameter signature the projection was made with
+        import weakref
+        self._memory_key = (weakref.ref(memory), memory._version, self._native_state.signature)
 
     def decode(self, tgt: Tensor, memory: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,
                tgt_padding_mask: Optional[Tensor] = None, tgt_query: Optional[Tensor] = None,
                tgt_query_mask: Optional[Tensor] = None) -> Tensor:
         """model.py:86-103: decoder output (after decoder.norm) [N, Lq, E] for the context tokens `tgt`.
 
-        Restrictions of this backend: `memory` is the encoder output of the most recent `encode` / `forward` on this model
-        (its cross-attention K / V are cached on the device; the argument is accepted for signature compatibility only);
-        `tgt_query` is None (all positions `pos_queries[:, :L]`) or a view `pos_queries[:, i:j]` (what `forward` and the
-        training step pass); `tgt_mask` only feeds the content-stream update, which a depth-1 decoder never runs
-        (modules.py:116-118), so it is ignored exactly as the reference ignores it."""
+        `memory`: the encoder output to attend to.  The tensor returned by the most recent `encode` is recognised (its K / V
+        projection is still cached on the device); any other tensor is projected afresh; `None` means "the most recent
+        `encode` / `forward`".  `tgt_query`: None (all positions `pos_queries[:, :L]`), a view `pos_queries[:, i:j]` (what
+        `forward` and the training step pass — served from the position-query tables), or any other [N, Lq, E] / [1, Lq, E]
+        tensor (projected at call time).  `tgt_mask` only feeds the content-stream update, which a depth-1 decoder never
+        runs (modules.py:116-118), so it is ignored exactly as the reference ignores it."""
         B, L = tgt.shape
         E = self._cfg['embed_dim']
+        user_query = None
         if tgt_query is None:
             q_start, q_len = 0, L
         else:
             pq = self.pos_queries
             off = (tgt_query.data_ptr() - pq.data_ptr()) // pq.element_size()
             q_len = tgt_query.shape[1]
-            if (tgt_query.device != pq.device or tgt_query.dtype != pq.dtype or off < 0 or off % E or tgt_query.shape[-1] != E or
-                    off // E + q_len > pq.shape[1] or tgt_query.stride(-1) != 1 or tgt_query.stride(-2) != E):
-                raise NotImplementedError('tgt_query must be None or a slice pos_queries[:, i:j] of this model')
-            q_start = off // E
+            is_slice = (tgt_query.device == pq.device and tgt_query.dtype == pq.dtype and 0 <= off and off % E == 0 and
+                        tgt_query.dim() == 3 and tgt_query.shape[-1] == E and off // E + q_len <= pq.shape[1] and
+                        tgt_query.stride(-1) == 1 and tgt_query.stride(-2) == E and
+                        (tgt_query.shape[0] == 1 or tgt_query.stride(0) == 0))
+            if is_slice:
+                q_start = off // E
+            else:
+                if tgt_query.dim() != 3 or tgt_query.shape[-1] != E or tgt_query.shape[0] not in (1, B):
+                    raise RuntimeError(f'tgt_query must be [{B} or 1, Lq, {E}], got {list(tgt_query.shape)}')
+                q_start = 0
+                user_query = tgt_query.detach().to(device=self._device, dtype=torch.float32).expand(B, q_len, E).contiguous()
         plan = self._plan(B)
+        self._bind_memory(memory, B, plan)
         tok = tgt.to(device=self._device, dtype=torch.int32).contiguous()
         kpm = tgt_padding_mask.to(device=self._device, dtype=torch.uint8).contiguous() if tgt_padding_mask is not None else None
         qm = tgt_query_mask.to(device=self._device, dtype=torch.uint8).contiguous() if tgt_query_mask is not None else None
@@ -381,8 +423,13 @@ class PARSeq(_NativeBacked):
             raise RuntimeError(f'tgt_query_mask shape {tuple(qm.shape)} != ({q_len}, {L})')
         hidden = torch.empty(B, q_len, E, dtype=torch.float32, device=self._device)
         logits = torch.empty(B, q_len, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=self._device)
-        _native.check(_native.lib().parseq_decode_hidden(plan, _native.ptr(tok), B, L, q_start, q_len, _native.ptr(qm), _native.ptr(kpm),
-                                                         _native.ptr(hidden), _native.ptr(logits), _native.stream_ptr()))
+        lib, stream = _native.lib(), _native.stream_ptr(self._device)
+        if user_query is None:
+            _native.check(lib.parseq_decode_hidden(plan, _native.ptr(tok), B, L, q_start, q_len, _native.ptr(qm), _native.ptr(kpm),
+                                                   _native.ptr(hidden), _native.ptr(logits), stream))
+        else:
+            _native.check(lib.parseq_decode_query(plan, _native.ptr(tok), B, L, _native.ptr(user_query), q_len, _native.ptr(qm),
+                                                  _native.ptr(kpm), _native.ptr(hidden), _native.ptr(logits), stream))
         return hidden
 
     def decode_logits(self, tgt: Tensor, q_start: int, q_len: int, tgt_padding_mask: Optional[Tensor] = None,
@@ -399,11 +446,16 @@ class PARSeq(_NativeBacked):
             raise RuntimeError(f'tgt_query_mask shape {tuple(qm.shape)} != ({q_len}, {L})')
         out = torch.empty(B, q_len, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=self._device)
         _native.check(_native.lib().parseq_decode_logits(plan, _native.ptr(tok), B, L, q_start, q_len, _native.ptr(qm),
-                                                         _native.ptr(kpm), _native.ptr(out), _native.stream_ptr()))
+                                                         _native.ptr(kpm), _native.ptr(out), _native.stream_ptr(self._device)))
         return out
 
-    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None, slot: int = 0) -> Tensor:
+    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None, slot: int = 0,
+                return_length: bool = False):
         """model.py:105-169.  Returns logits [B, L, num_tokens - 2] (fp32).
+
+        `return_length=True` returns `(logits_all, L)` instead: the logits of ALL `num_steps` positions (every step is always
+        run on the device) and the length `L` the reference would have returned for THIS batch — what the data-parallel wrapper
+        needs to reproduce the single-device early-exit length across shards (parallel.data_parallel_forward).
 
         `slot` selects one of several independent workspaces (plans): calls that use different slots on different
         streams may be in flight at the same time (bench.py --streams 2 overlaps the latency-bound AR decode of one batch
@@ -414,6 +466,8 @@ class PARSeq(_NativeBacked):
         images = self._check_images(images)
         B = images.shape[0]
         plan = self._plan(B, slot)
+        if slot == 0:
+            self._memory_key = None             # the plan's cached K / V now belong to these images, not to an encode() result
         if (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id) != self._special_ids(tokenizer):
             raise RuntimeError('tokenizer special ids changed after the native model was built')
         logits = torch.empty(B, num_steps, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=images.device)
@@ -421,7 +475,9 @@ class PARSeq(_NativeBacked):
         out_len = C.c_int(0)
         _native.check(_native.lib().parseq_forward(plan, _native.ptr(images), _native.dtype_code(images.dtype), B, flags,
                                                    int(self.refine_iters), num_steps, _native.ptr(logits),
-                                                   C.byref(out_len), _native.stream_ptr()))
+                                                   C.byref(out_len), _native.stream_ptr(self._device)))
+        if return_length:
+            return logits, out_len.value
         return logits if out_len.value == num_steps else logits[:, :out_len.value]
 
     # ---- native plumbing ---------------------------------------------------------------------------------------

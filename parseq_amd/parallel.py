@@ -27,11 +27,10 @@ def all_gather_logits(logits: Tensor, group=None, uniform: bool = False) -> Tens
     refine_iters >= 1) — ONE all-gather and no host synchronisation, which is what a throughput loop wants.  Otherwise
     the shapes are exchanged first (a second small collective and a device->host read).
 
-    Shards may differ in batch size (ragged last shard) and, with refine_iters == 0 and early exit, in L: each shard can
-    stop earlier than the whole batch would.  The single-device result has L = max over shards (the reference's
-    batch-level exit test is monotone), so shards are padded to the max L with their own further steps' logits being
-    unavailable — callers that need exact single-device shapes in that mode run with max_length set (forced steps) or
-    refine_iters >= 1, where L is always max_label_length + 1.  Here: L must match across ranks.
+    Shards may differ in batch size (ragged last shard).  L must match across ranks here; the one mode in which shards can
+    disagree on L (AR, refine_iters == 0, max_length=None: each shard may reach "every row holds an EOS" earlier than the
+    whole batch would) is resolved BEFORE the gather by `data_parallel_forward`, which agrees on the single-device length
+    with a 1-int all-reduce(max).
     """
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -47,7 +46,8 @@ def all_gather_logits(logits: Tensor, group=None, uniform: bool = False) -> Tens
     dist.all_gather(all_sizes, sizes, group=group)
     bs = [int(s[0]) for s in all_sizes]
     if any(int(s[1]) != logits.shape[1] for s in all_sizes):
-        raise RuntimeError('ranks produced different sequence lengths; use max_length=... or refine_iters >= 1 when sharding')
+        raise RuntimeError('ranks produced different sequence lengths: shard with data_parallel_forward (which agrees on the '
+                           'early-exit length first), or use max_length=... / refine_iters >= 1')
     bmax = max(bs)
     if logits.shape[0] < bmax:            # ragged last shards: pad to the largest shard, gather once, drop the padding
         pad = torch.zeros((bmax - logits.shape[0],) + tuple(logits.shape[1:]), dtype=logits.dtype, device=logits.device)
@@ -66,8 +66,18 @@ def data_parallel_forward(model, images: Tensor, max_length: Optional[int] = Non
     import torch.distributed as dist
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi = shard_bounds(images.shape[0], world, rank)
-    local = model(images[lo:hi], max_length)
-    return all_gather_logits(local, group)
+    with_len = getattr(model, 'forward_with_length', None)
+    if with_len is None or world == 1:
+        return all_gather_logits(model(images[lo:hi], max_length), group)
+    # SURVEY.md section 8(e) option (ii).  The reference stops the AR loop at the first step after which EVERY row of the batch
+    # holds an EOS (model.py:144-145) and returns that many positions.  A shard reaches the condition no later than the whole
+    # batch does and the condition is monotone in the step, so the single-device length is the maximum of the shards' lengths:
+    # every shard computes all positions anyway (no per-step host sync on the device), reports its own length, one 1-int
+    # all-reduce(max) agrees on L, and every shard contributes logits[:, :L] — shape- and value-identical to a single-device run.
+    full, length = with_len(images[lo:hi], max_length)
+    agreed = torch.tensor([length], dtype=torch.int32, device=full.device)
+    dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=group)
+    return all_gather_logits(full[:, :int(agreed.item())], group)
 
 
 def average_gradients(flat: Tensor, group=None, bucket_elems: int = 6 * 1024 * 1024) -> Tensor:

@@ -35,7 +35,8 @@ def resize_batch(images: Sequence[Tensor], size=(32, 128)) -> Tensor:
     lib = _native.lib()
     out = torch.empty((len(images), 3, size[0], size[1]), dtype=torch.uint8, device=dev)
     ws = torch.empty((lib.parseq_resize_workspace_bytes(len(images)),), dtype=torch.uint8, device=dev)
-    _native.check(lib.parseq_resize_bicubic(descs, len(images), size[0], size[1], _native.ptr(out), _native.ptr(ws), _native.stream_ptr()))
+    with _native.guard(dev):
+        _native.check(lib.parseq_resize_bicubic(descs, len(images), size[0], size[1], _native.ptr(out), _native.ptr(ws), _native.stream_ptr(dev)))
     # the descriptor array is host memory read by an asynchronous copy: keep it (and the inputs) alive until the stream has passed
     torch.cuda.current_stream(dev).synchronize()
     return out

@@ -78,8 +78,9 @@ def forward_logits_loss(system, images: Tensor, labels):
     loss = torch.empty((), dtype=torch.float32, device=images.device)
     numel = torch.empty((), dtype=torch.int32, device=images.device)
     ws = torch.empty(flat.shape[0], dtype=torch.float32, device=images.device)
-    _native.check(_native.lib().parseq_cross_entropy(_native.ptr(flat), _native.ptr(tgt), flat.shape[0], flat.shape[1], system.pad_id,
-                                                     _native.ptr(loss), _native.ptr(numel), _native.ptr(ws), _native.stream_ptr()))
+    with _native.guard(flat):
+        _native.check(_native.lib().parseq_cross_entropy(_native.ptr(flat), _native.ptr(tgt), flat.shape[0], flat.shape[1], system.pad_id,
+                                                         _native.ptr(loss), _native.ptr(numel), _native.ptr(ws), _native.stream_ptr(flat)))
     return logits, loss, numel
 
 
@@ -115,7 +116,12 @@ def sample_char_orders(num_chars: int, max_gen_perms: int, perm_forward: bool, p
                        rng: np.random.Generator) -> Tensor:
     """The character orderings of `gen_tgt_perms` before <bos> / <eos> are attached (system.py:96-132): [K', num_chars]
     int64 on the CPU.  Draws from `rng` (pool branch, < 5 characters) or from torch's default CPU generator
-    (`torch.randperm`, >= 5 characters) in the reference's order, so equal seeds give equal orderings."""
+    (`torch.randperm`, >= 5 characters) in the reference's order, so equal seeds give equal orderings AS LONG AS THE
+    REFERENCE ALSO DRAWS ON THE CPU: the reference calls `torch.randperm(..., device=self._device)` (system.py:128), which on a
+    GPU run consumes the device generator — a different stream — so seeded GPU training of the reference is not reproduced
+    permutation for permutation (the orderings are identically distributed; the goldens in tests/golden/perms.json were
+    minted with the reference on the CPU).  The pool branch also departs from the reference where the reference crashes
+    (`perm_forward=False` with fewer than five characters, see below)."""
     forward = [torch.arange(num_chars)] if perm_forward else []
     limit = math.factorial(num_chars) // (2 if perm_mirrored else 1)
     want = min(max_gen_perms, limit) - len(forward)
@@ -182,9 +188,10 @@ def permutation_loss(system, images: Tensor, labels, perms: Optional[Tensor] = N
     for i in range(K):
         logits = system.model.decode_logits(tgt_in, 0, L, padding, masks[i])
         flat = logits.view(-1, logits.shape[-1])
-        _native.check(_native.lib().parseq_cross_entropy(_native.ptr(flat), _native.ptr(targets[min(i // 2, 1)]), flat.shape[0],
-                                                         flat.shape[1], system.pad_id, _native.ptr(losses[i:]),
-                                                         _native.ptr(counts[i:]), _native.ptr(ws), _native.stream_ptr()))
+        with _native.guard(flat):
+            _native.check(_native.lib().parseq_cross_entropy(_native.ptr(flat), _native.ptr(targets[min(i // 2, 1)]), flat.shape[0],
+                                                             flat.shape[1], system.pad_id, _native.ptr(losses[i:]),
+                                                             _native.ptr(counts[i:]), _native.ptr(ws), _native.stream_ptr(flat)))
     weights = counts.float()
     return (losses * weights).sum() / weights.sum(), losses, counts, perms
 
@@ -233,6 +240,11 @@ class PARSeq(nn.Module):
     def forward(self, images: Tensor, max_length: Optional[int] = None, slot: int = 0) -> Tensor:
         """Inference (system.py:87-88): images [N, 3, H, W] -> logits [N, L, C].  (`slot`: see model.PARSeq.forward.)"""
         return self.model.forward(self.tokenizer, images, max_length, slot)
+
+    def forward_with_length(self, images: Tensor, max_length: Optional[int] = None, slot: int = 0):
+        """(logits of all num_steps positions, L): `forward` is `logits[:, :L]`.  L < num_steps only for AR decoding without
+        refinement and `max_length=None` (the batch-level early exit of model.py:144-145)."""
+        return self.model.forward(self.tokenizer, images, max_length, slot, return_length=True)
 
     # ---- evaluation glue used by the reference's test.py:121-126 ------------------------------------------------
     def _eval_step(self, batch, validation: bool):

@@ -3,7 +3,9 @@
 Mirrors the interface of the reference's `strhub/data/utils.py` (`CharsetAdapter` :26-43, `BaseTokenizer` :46-99,
 `Tokenizer` :102-129): same class and method names, same id assignment ([E] = 0, characters 1..len(charset),
 [B], [P] last), same greedy decode + truncate-at-first-EOS rule — string parity with the reference is judged on the
-output of `Tokenizer.decode`.  Written from scratch.  `decode` is the reference's host-side routine;
+output of `Tokenizer.decode`.  `CharsetAdapter`, `BaseTokenizer._tok2ids / _ids2tok / __len__` and `Tokenizer._filter` are
+near-verbatim behavioural mirrors of the reference's few lines each (a names-and-semantics contract leaves no other way to
+write them); `encode`, `decode`, `decode_logits` and `read` are this repository's own.  `decode` is the reference's host-side routine;
 `decode_logits` / `read` give the same result from raw logits with the numeric part (soft-max, greedy pick, first-EOS cut,
 confidence product) done by the HIP post-processing kernel (`parseq_postprocess`).
 """
@@ -109,9 +111,10 @@ class Tokenizer(BaseTokenizer):
         probs = torch.empty((n, length), dtype=torch.float32, device=dev)
         conf = torch.empty((n,), dtype=torch.float32, device=dev)
         if n:
-            _native.check(_native.lib().parseq_postprocess(_native.ptr(logits), n, length, classes, self.eos_id,
-                                                           _native.ptr(ids), _native.ptr(lengths), _native.ptr(probs), _native.ptr(conf),
-                                                           _native.stream_ptr()))
+            with _native.guard(dev):
+                _native.check(_native.lib().parseq_postprocess(_native.ptr(logits), n, length, classes, self.eos_id,
+                                                               _native.ptr(ids), _native.ptr(lengths), _native.ptr(probs), _native.ptr(conf),
+                                                               _native.stream_ptr(dev)))
         return ids, lengths, probs, conf
 
     def decode_logits(self, logits: Tensor) -> Tuple[List[str], List[Tensor]]:

@@ -98,7 +98,7 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
     _native.check(lib.parseq_train_decoder(native, _native.ptr(memory), _native.ptr(tokens), _native.ptr(targets), _native.ptr(padding),
                                            _native.ptr(masks), B, L, K, total, float(dropout), int(seed), _native.ptr(loss), _native.ptr(flat),
                                            _native.ptr(dmemory),
-                                           _native.ptr(workspace), ws_bytes, _native.stream_ptr()))
+                                           _native.ptr(workspace), ws_bytes, _native.stream_ptr(dev)))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     return DecoderBackward(loss=loss[0], perm_losses=loss[1:], grads=param_views(native, flat, shapes), flat=flat, dmemory=dmemory, perms=perms,
                            workspace=workspace, _shape=(B, L, K), _model=native)
@@ -119,10 +119,10 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=images.device)
     memory = torch.empty(B, model.encoder.pos_embed.shape[1], model._cfg['embed_dim'], dtype=torch.float32, device=images.device)
     _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), B, _native.ptr(memory), _native.ptr(ws), ws_bytes,
-                                                   _native.stream_ptr()))
+                                                   _native.stream_ptr(images)))
     res = decoder_backward(system, images, labels, perms, memory=memory, dropout=dropout, seed=seed)
     _native.check(lib.parseq_train_encoder_backward(native, _native.ptr(res.dmemory), B, _native.ptr(res.flat), _native.ptr(ws), ws_bytes,
-                                                    _native.stream_ptr()))
+                                                    _native.stream_ptr(images)))
     res.memory = memory
     return res
 
@@ -150,10 +150,14 @@ class TrainStep:
 
     def __init__(self, system, total_steps: int, lr: Optional[float] = None, weight_decay: Optional[float] = None,
                  warmup_pct: Optional[float] = None, clip_val: float = 20.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 num_devices: int = 1, accumulate_grad_batches: int = 1, process_group=None):
+                 num_devices: Optional[int] = None, accumulate_grad_batches: int = 1, process_group=None):
         import math
         self.system = system
         self.total_steps = total_steps
+        if num_devices is None:       # base.py:99 uses trainer.num_devices: default to the data-parallel world this step averages over
+            num_devices = (torch.distributed.get_world_size(process_group)
+                           if torch.distributed.is_available() and torch.distributed.is_initialized() else 1)
+        self.num_devices = num_devices
         # base.py:98-101: linear scaling with the batch size, sqrt scaling with the number of devices
         scale = accumulate_grad_batches * math.sqrt(num_devices) * system.batch_size / 256.0
         self.max_lr = scale * (system.lr if lr is None else lr)
@@ -187,10 +191,11 @@ class TrainStep:
             from .parallel import average_gradients
             average_gradients(res.flat, self.process_group)
         native = model._sync_native().model
-        stream = _native.stream_ptr()
+        stream = _native.stream_ptr(res.flat)
         norm = None
         if self.clip_val:
-            _native.check(lib.parseq_grad_norm(_native.ptr(res.flat), res.flat.numel(), _native.ptr(self._norm), _native.ptr(self._norm_ws), stream))
+            with _native.guard(res.flat):
+                _native.check(lib.parseq_grad_norm(_native.ptr(res.flat), res.flat.numel(), _native.ptr(self._norm), _native.ptr(self._norm_ws), stream))
             norm = self._norm
         lr = self.lr
         self.step_count += 1
@@ -214,9 +219,13 @@ class _TrainingStepFunction(torch.autograd.Function):
         return res.loss.clone()
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
-        grads, ctx.grads = ctx.grads, None
-        return (None, None, None, None) + tuple(g * grad_out for g in grads)
+        # The gradients were computed by the library in forward(); they stay on the node, so a second backward through it
+        # (retain_graph=True, gradient-checking utilities) returns the same values instead of failing on a dropped buffer.
+        if ctx.grads is None:
+            raise RuntimeError('training_step loss: the stored gradients were released')
+        return (None, None, None, None) + tuple(g * grad_out for g in ctx.grads)
 
 
 def training_step_loss(system, images: Tensor, labels, perms: Optional[Tensor] = None) -> Tensor:

@@ -75,7 +75,7 @@ class Model(_NativeBacked):
         out = torch.zeros(B, seqlen, self.num_classes, dtype=torch.float32, device=x.device)
         body = torch.empty(B, seqlen - 1, self.num_classes, dtype=torch.float32, device=x.device)
         _native.check(_native.lib().parseq_vitstr_forward(plan, _native.ptr(x), _native.dtype_code(x.dtype), B, seqlen - 1,
-                                                          _native.ptr(body), _native.stream_ptr()))
+                                                          _native.ptr(body), _native.stream_ptr(x)))
         out[:, 1:] = body
         return out
 
@@ -86,7 +86,7 @@ class Model(_NativeBacked):
         plan = self._plan(B, slot)
         out = torch.empty(B, num_steps, self.num_classes, dtype=torch.float32, device=x.device)
         _native.check(_native.lib().parseq_vitstr_forward(plan, _native.ptr(x), _native.dtype_code(x.dtype), B, num_steps,
-                                                          _native.ptr(out), _native.stream_ptr()))
+                                                          _native.ptr(out), _native.stream_ptr(x)))
         return out
 
 

@@ -84,8 +84,9 @@ def test_encoder_attention(heads, images, dtype):
     assert err <= (2e-5 if dtype == 'f32' else 1.5e-2), msg
 
 
+@pytest.mark.parametrize('variant', [0, 10])     # 0: load - LN - ... - reload - add - store; 10: x resident in the fc2 accumulators
 @pytest.mark.parametrize('M', [128, 1000, 4096])
-def test_fused_mlp(M):
+def test_fused_mlp(M, variant):
     """encoder_mlp.h: x += fc2(gelu(fc1(LN(x)))) in one kernel, against an fp64 reference with the same bf16 rounding points
     (LayerNorm output, weights, GELU output)."""
     nat, lib = native()
@@ -100,10 +101,10 @@ def test_fused_mlp(M):
     want = (x.double() + hidden @ W2.double().T + b2.double()).float()
     xd = x.to(DEV).clone()
     dev = [t.to(DEV) for t in (gamma, beta, W1, b1, W2, b2)]
-    nat.check(lib.parseq_op_mlp(nat.ptr(xd), nat.ptr(dev[0]), nat.ptr(dev[1]), nat.ptr(dev[2]), nat.ptr(dev[3]), nat.ptr(dev[4]),
-                                nat.ptr(dev[5]), M, nat.stream_ptr()))
+    nat.check(lib.parseq_op_mlp_variant(nat.ptr(xd), nat.ptr(dev[0]), nat.ptr(dev[1]), nat.ptr(dev[2]), nat.ptr(dev[3]), nat.ptr(dev[4]),
+                                        nat.ptr(dev[5]), M, variant, nat.stream_ptr()))
     torch.cuda.synchronize()
-    err, msg = report(f'fused mlp M={M}', xd, want)
+    err, msg = report(f'fused mlp M={M} variant={variant}', xd, want)
     # residual: bf16 re-rounding of LN / GELU values that land within fp32 noise of a rounding boundary (2^-9 relative on
     # a few of 1536 terms of magnitude <= 0.1) plus fp32 accumulation order
     assert err <= 5e-3, msg

@@ -389,5 +389,39 @@ def test_decode_and_head_reference_idiom(name, models, golden):
         i, j = 5, 6
         hid1 = m.model.decode(tgt[:, :j], memory, tgt_query=m.model.pos_queries[:, i:j], tgt_query_mask=causal[i:j, :j].to(DEV))
         assert hid1.shape == (4, 1, cfg.embed_dim) and (hid1[:, 0] - hid[:, i]).abs().max() <= 1e-4
-        with pytest.raises(NotImplementedError):
-            m.model.decode(tgt, memory, tgt_query=torch.zeros(4, 26, cfg.embed_dim, device=DEV))
+        # arbitrary tgt_query tensors (model.py:100-102): a per-image query stream that is NOT a slice of pos_queries
+        gq = torch.Generator().manual_seed(5)
+        uq = 0.5 * torch.randn(4, 7, cfg.embed_dim, generator=gq)
+        qmask = torch.rand(7, 26, generator=gq) < 0.3
+        qmask[:, 0] = False                                    # keep <bos> visible: no fully masked row
+        want_u = O.decode(sd, cfg, tr.ar_tokens, mem_o, causal, None, uq, qmask)
+        hid_u = m.model.decode(tgt, memory, tgt_query=uq.to(DEV), tgt_query_mask=qmask.to(DEV))
+        assert hid_u.shape == (4, 7, cfg.embed_dim)
+        assert (hid_u.cpu() - want_u).abs().max() <= 1e-3
+        # the same values handed over as a copy of pos_queries must equal the table-served result
+        hid_c = m.model.decode(tgt, memory, tgt_query=m.model.pos_queries.detach().clone().expand(4, -1, -1), tgt_query_mask=causal.to(DEV))
+        assert (hid_c - hid).abs().max() <= 1e-4
+        # a caller-supplied `memory` is honoured (model.py:89), not replaced by the last encode's: decode against the memory
+        # of OTHER images after an intervening encode, then against an edited copy
+        other = g['images'][4:8]
+        mem_other_o = O.encode(sd, cfg, other)
+        mem_other = m.model.encode(other.to(DEV))             # the plan now caches K / V of `other`
+        hid_back = m.model.decode(tgt, memory, tgt_query_mask=causal.to(DEV))      # ... but `memory` is what was asked for
+        assert (hid_back - hid).abs().max() <= 1e-5
+        want_o = O.decode(sd, cfg, tr.ar_tokens, mem_other_o, causal, None, pos_q, causal)
+        hid_o = m.model.decode(tgt, mem_other, tgt_query_mask=causal.to(DEV))
+        assert (hid_o.cpu() - want_o).abs().max() <= 1e-3
+        edited = mem_other.clone()
+        edited[:, :64] = 0
+        mem_e = mem_other_o.clone()
+        mem_e[:, :64] = 0
+        want_e = O.decode(sd, cfg, tr.ar_tokens, mem_e, causal, None, pos_q, causal)
+        assert (m.model.decode(tgt, edited, tgt_query_mask=causal.to(DEV)).cpu() - want_e).abs().max() <= 1e-3
+        mem_other.mul_(0.5)                                    # in-place edit of the tensor encode() returned: version bump -> re-projected
+        want_h2 = O.decode(sd, cfg, tr.ar_tokens, 0.5 * mem_other_o, causal, None, pos_q, causal)
+        assert (m.model.decode(tgt, mem_other, tgt_query_mask=causal.to(DEV)).cpu() - want_h2).abs().max() <= 1e-3
+        # out-of-range token ids are clamped on the device, never used as raw table indices
+        bad = tgt.clone()
+        bad[0, 3] = 10 ** 6
+        bad[1, 2] = -5
+        assert torch.isfinite(m.model.decode(bad, memory, tgt_query_mask=causal.to(DEV))).all()

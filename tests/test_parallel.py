@@ -37,6 +37,25 @@ class _FakeModel:
         return base[:, None, None] + torch.arange(L)[None, :, None] * 0.5 + torch.arange(95)[None, None, :] * 0.01
 
 
+class _FakeEarlyExitModel(_FakeModel):
+    """Adds the batch-level early exit of model.py:144-145: every image has its own 'first EOS step', the batch returns
+    max over its rows + 1 positions — so shards of one batch can disagree on L, and `forward_with_length` reports it."""
+
+    @staticmethod
+    def _eos_step(images):
+        return (images.flatten(1).sum(1) * 1000).long() % 20          # per image, in [0, 20)
+
+    def forward_with_length(self, images, max_length=None):
+        full = _FakeModel.__call__(self, images, max_length)
+        if max_length is not None:
+            return full, full.shape[1]
+        return full, int(self._eos_step(images).max()) + 1
+
+    def __call__(self, images, max_length=None):
+        full, L = self.forward_with_length(images, max_length)
+        return full[:, :L]
+
+
 def _worker(rank, world, port, n_images, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -56,6 +75,14 @@ def _worker(rank, world, port, n_images, q):
             ok3 = False
         except RuntimeError:
             ok3 = True
+        # early exit under sharding (SURVEY 8e option ii): shards disagree on L, the wrapper agrees on the single-device length
+        ee = _FakeEarlyExitModel()
+        steps = ee._eos_step(images)
+        lo, hi = shard_bounds(n_images, world, rank)
+        assert len({int(steps[a:b].max()) for a, b in (shard_bounds(n_images, world, r) for r in range(world))}) > 1, 'test needs differing shard lengths'
+        got = data_parallel_forward(ee, images, None)
+        want_ee = ee(images)
+        ok3 = ok3 and got.shape == want_ee.shape and torch.equal(got, want_ee) and got.shape[1] == int(steps.max()) + 1
         # uniform fast path (what bench.py's multi-GPU loop uses): one collective, rank order preserved
         mine = torch.full((3, 26, 95), float(rank))
         both = all_gather_logits(mine, uniform=True)
@@ -109,3 +136,54 @@ def test_two_rank_gloo_gradient_average():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == [0, 1] and all(r[1] for r in results)
+
+
+# ---- the real model + RCCL on two GPUs (skipped on a 1-GPU box: the driver's multi-GPU tier and any 2+-GPU box run it) ----
+
+def _nccl_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = torch.device('cuda', rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)      # 'nccl' is RCCL on ROCm
+    try:
+        from oracle.synth import CONFIGS, synth_images, synth_state_dict
+        from parseq_amd import create_model
+        name = 'parseq'
+        cfg = CONFIGS[name]
+        sd = synth_state_dict(cfg, 0)
+        images = synth_images(17, cfg, seed=7).to(dev)           # 17: ragged shards (9 + 8); with seed 7 the shards exit after 6 and 13
+        # positions on their own (fp32 oracle), so the agreed length (13) really is a maximum over disagreeing shards
+        results = []
+        for refine, max_length in ((1, None), (0, None), (0, 25)):      # AR+1; AR+0 with the natural early exit; AR+0 forced
+            m = create_model(name, decode_ar=True, refine_iters=refine, precision='bf16')
+            m.model.load_state_dict(sd)
+            m = m.eval().to(dev)
+            with torch.inference_mode():
+                sharded = data_parallel_forward(m, images, max_length)
+                single = m(images, max_length)                   # this rank alone, whole batch
+            results.append((tuple(sharded.shape) == tuple(single.shape), bool(torch.equal(sharded, single)), tuple(single.shape)))
+        q.put((rank, results))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_nccl_real_model_matches_single_rank_bit_for_bit():
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 GPUs (the 1-GPU box cannot run RCCL between ranks)')
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, res in results:
+        assert all(shape_ok and equal for shape_ok, equal, _ in res), (rank, res)
+    # the natural-exit run must really have exited early on these weights (synth.py lifts the EOS bias), or the test is vacuous
+    assert results[0][1][1][2][1] < 26, results[0][1]
