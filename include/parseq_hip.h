@@ -67,6 +67,12 @@ enum { PARSEQ_ARCH_PARSEQ = 0, PARSEQ_ARCH_VITSTR = 1 };
 enum {
     PARSEQ_F32 = 0,    /* exact mode: f32 storage, v_mfma_f32_16x16x4_f32; parity target |dlogit| <= 1e-3 vs CPU fp32 */
     PARSEQ_BF16 = 1,   /* throughput mode: bf16 GEMM/attention operands, fp32 accumulate / residual / LayerNorm / softmax */
+    PARSEQ_BF16X3 = 3, /* precision only (plans, parseq_op_linear / parseq_op_encoder_attention): exact-tolerance mode at matrix-core
+                        * speed.  Storage is f32 exactly as in PARSEQ_F32 (images are passed as PARSEQ_F32 / _BF16 / _U8), but every
+                        * GEMM / attention operand is split into a bf16 pair hi = bf16(v), lo = bf16(v - hi) and every product is
+                        * evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_*_bf16 with fp32 accumulation: ~2^-17 relative error per
+                        * product (bf16: 2^-9), 3 bf16 MFMAs per product instead of the f32 MFMA's 16x cost.  Meets the north
+                        * star's |dlogit| <= 1e-3 with argmax-identical decodes (tests/test_hip_parity.py) */
     PARSEQ_U8 = 2      /* images_dtype only: raw 0..255 pixels, [batch, 3, H, W]; the patch-embed
                         * operand loader applies the reference transform's ToTensor + Normalize(0.5, 0.5)
                         * (strhub/data/module.py:78-81): ((v / 255) - 0.5) / 0.5 in f32, bit-identical to feeding the
@@ -108,7 +114,7 @@ int parseq_model_param_info(const parseq_model* m, int index, const char** key, 
 /* ---- plan: per-(max_batch, precision) workspace, packed weights and batch-independent decoder tables ------------ */
 
 /* All device memory the hot path needs is allocated here, never inside parseq_forward / parseq_encode.
- * Requires every parameter to have been set.  (Re)packs weights for `precision`; call parseq_plan_refresh after
+ * Requires every parameter to have been set.  precision: PARSEQ_F32, PARSEQ_BF16 or PARSEQ_BF16X3.  (Re)packs weights for `precision`; call parseq_plan_refresh after
  * parameters change. */
 int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out);
 int parseq_plan_refresh(parseq_plan* p, void* stream);
@@ -286,6 +292,9 @@ int parseq_op_layernorm(const float* x, const float* w, const float* b, void* y,
  * C in `dtype` with exact-erf GELU applied (act = 1).  K must be a multiple of 8. */
 int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                      void* stream);
+/* dtype = PARSEQ_BF16X3: A is f32 [M, K], K a multiple of 32; W must be the block-planar hi / lo copy of the f32 weight that
+ * parseq_op_split_pack(src f32 [numel], dst [numel * 4 bytes]) produces (numel a multiple of 32); C as for PARSEQ_F32. */
+int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream);
 /* Same as parseq_op_linear with an explicit tile configuration (tools/gemm_bench.py sweeps these; ids in parseq_hip.hip). */
 int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                          int cfg, void* stream);
@@ -301,7 +310,7 @@ int parseq_op_mlp(float* x, const float* gamma, const float* beta, const void* W
 int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                           const float* b2, int M, int variant, void* stream);
 /* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;
- * out [bh / heads * 128, heads * 64] in `dtype`. */
+ * out [bh / heads * 128, heads * 64] in `dtype`.  dtype = PARSEQ_BF16X3: f32 tensors, split-bf16 products. */
 int parseq_op_encoder_attention(const void* q, const void* k, const void* vt, void* out, int dtype, int bh, int heads,
                                 void* stream);
 

@@ -13,7 +13,7 @@ from typing import Optional
 
 from . import build as _build
 
-PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8 = 0, 1, 2
+PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8, PARSEQ_BF16X3 = 0, 1, 2, 3
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING = 1, 2
 ABI_VERSION = 4
@@ -83,6 +83,7 @@ SIGNATURES = {
                                       C.c_float, C.c_void_p]),
     'parseq_op_linear': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_void_p]),
+    'parseq_op_split_pack': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'parseq_op_linear_cfg': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p]),
     'parseq_op_ln_linear_gelu': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -142,6 +142,134 @@ void attn_mfma_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k
         }
 }
 
+// attn_mfma_kernel for precision bf16x3 (gemm.h SPLIT): q, k [B][H][128][64] and V^T [B][H][64][128] arrive as f32, every
+// MFMA operand is carried as a bf16 pair (hi, lo = value - hi) and every product is three MFMAs (lo*hi + hi*lo + hi*hi) with
+// fp32 accumulation; scores, soft-max and the output stay f32.  Same structure and the same in-register P operand trick.
+constexpr size_t attn_split_lds() { return (size_t)2 * (ATT_N * ATT_KROWB + ATT_HD * ATT_VROWB); }
+
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        hi[i] = static_cast<bf16_t>(v[i]);
+        lo[i] = static_cast<bf16_t>(v[i] - static_cast<float>(hi[i]));
+    }
+}
+
+__global__ __launch_bounds__(256)
+void attn_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vt,
+                       float* __restrict__ ao, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
+    unsigned char* Kh = smem_split;                       // [128][ATT_KROWB] hi plane
+    unsigned char* Kl = Kh + ATT_N * ATT_KROWB;           // lo plane
+    unsigned char* Vh = Kl + ATT_N * ATT_KROWB;           // [64][ATT_VROWB] V^T hi
+    unsigned char* Vl = Vh + ATT_HD * ATT_VROWB;
+
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t base = (size_t)bh * ATT_N * ATT_HD;
+    const int E = heads * ATT_HD;
+    {
+        const float4* kg = reinterpret_cast<const float4*>(k + base);
+        const float4* vg = reinterpret_cast<const float4*>(vt + base);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int c = it * 256 + tid;                  // 4 consecutive floats
+            const float4 kv = kg[c], vv = vg[c];
+            union { uint2 u; bf16_t e[4]; } khi, klo, vhi, vlo;
+            const float kf[4] = {kv.x, kv.y, kv.z, kv.w}, vf[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                khi.e[i] = static_cast<bf16_t>(kf[i]); klo.e[i] = static_cast<bf16_t>(kf[i] - static_cast<float>(khi.e[i]));
+                vhi.e[i] = static_cast<bf16_t>(vf[i]); vlo.e[i] = static_cast<bf16_t>(vf[i] - static_cast<float>(vhi.e[i]));
+            }
+            const int kofs = (c >> 4) * ATT_KROWB + (c & 15) * 8;        // K row = token, 16 chunks of 4 d per row
+            *reinterpret_cast<uint2*>(Kh + kofs) = khi.u;
+            *reinterpret_cast<uint2*>(Kl + kofs) = klo.u;
+            const int vofs = (c >> 5) * ATT_VROWB + (c & 31) * 8;        // V^T row = d, 32 chunks of 4 tokens per row
+            *reinterpret_cast<uint2*>(Vh + vofs) = vhi.u;
+            *reinterpret_cast<uint2*>(Vl + vofs) = vlo.u;
+        }
+    }
+    const int qi = lane & 31, hi = lane >> 5;
+    const int q0 = wid * 32;
+    bf16x8 qh[4], ql[4];
+    {
+        const float* qrow = q + base + (size_t)(q0 + qi) * ATT_HD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + ks * 16), c4 = *reinterpret_cast<const float4*>(qrow + ks * 16 + 4);
+            const float v8[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+            split8(v8, qh[ks], ql[ks]);
+        }
+    }
+    __syncthreads();
+
+    f32x16 st[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        st[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int kb = (t * 32 + qi) * ATT_KROWB + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 kfh = *reinterpret_cast<const bf16x8*>(Kh + kb + ks * 32);
+            const bf16x8 kfl = *reinterpret_cast<const bf16x8*>(Kl + kb + ks * 32);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfl, qh[ks], st[t], 0, 0, 0);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, ql[ks], st[t], 0, 0, 0);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfh, qh[ks], st[t], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[t][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c = scale * 1.44269504088896340736f;
+    const float mc = mx * c;
+    float sum = 0.f;
+    bf16x8 ph[4][2], pl[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float p = exp2f(st[t][m2 * 8 + j] * c - mc);
+                sum += p;
+                ph[t][m2][j] = static_cast<bf16_t>(p);
+                pl[t][m2][j] = static_cast<bf16_t>(p - static_cast<float>(ph[t][m2][j]));
+            }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        ot[nt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int vb = (nt * 32 + qi) * ATT_VROWB + hi * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const int p0 = vb + (t * 32 + m2 * 16) * 2;
+                union { bf16x8 v; uint2 u[2]; } vfh, vfl;
+                vfh.u[0] = *reinterpret_cast<const uint2*>(Vh + p0); vfh.u[1] = *reinterpret_cast<const uint2*>(Vh + p0 + 16);
+                vfl.u[0] = *reinterpret_cast<const uint2*>(Vl + p0); vfl.u[1] = *reinterpret_cast<const uint2*>(Vl + p0 + 16);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfl.v, ph[t][m2], ot[nt], 0, 0, 0);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh.v, pl[t][m2], ot[nt], 0, 0, 0);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfh.v, ph[t][m2], ot[nt], 0, 0, 0);
+            }
+    }
+    float* orow = ao + ((size_t)b * ATT_N + q0 + qi) * E + h * ATT_HD + 4 * hi;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+            *reinterpret_cast<float4*>(orow + nt * 32 + rg * 8) = make_float4(ot[nt][rg * 4 + 0] * inv, ot[nt][rg * 4 + 1] * inv,
+                                                                              ot[nt][rg * 4 + 2] * inv, ot[nt][rg * 4 + 3] * inv);
+}
+
 // attn_mfma_kernel for any token count N <= 32 * NT32 (129 tokens for ViTSTR, 196 for
 // parseq-patch16-224): NT32 waves per workgroup, wave w owns queries 32 w .. 32 w + 31; K and V^T are zero-padded to
 // 32 * NT32 keys in LDS and the padded keys are excluded from the soft-max.  q, k, v: [B][H][N][64] (row-major V).

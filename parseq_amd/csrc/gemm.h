@@ -13,6 +13,15 @@
 // m -> vector stores along a row of a row-major output; "m4" form (A first) leaves 4 consecutive m for one n ->
 // vector stores into a transposed output (the V^T the encoder attention kernel wants).
 //
+// SPLIT (precision bf16x3, T = float): every operand value v is carried as a PAIR of bf16, hi = bf16(v) and lo = bf16(v - hi)
+// (16 mantissa bits between them), and a product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation: ~2^-17 relative error per product instead of bf16's 2^-9, at 3/16 of the exact-f32 MFMA's cycles per
+// product.  Layout "block-planar": 32 consecutive elements of a row occupy 128 bytes — 64 bytes of hi then 64 bytes of lo —
+// so a row of K elements is still K * 4 bytes and all tile / stage address arithmetic is shared with f32.  Weights are stored
+// that way once (split_pack_kernel); activations arrive as plain f32 and are split by the A-loader's staging pass (once per
+// tile load, not once per MFMA).  A fragment of the 32-deep k-group is then 16 bytes of the hi plane and 16 bytes of the lo
+// plane at the same offset: the main loop is three MFMAs per tile pair and no conversion.
+//
 // Workgroup id -> tile mapping is XCD-aware: ids that land on the same XCD (id % 8, observed dispatch) walk the n-tiles
 // of the same m-tile back to back, so an A row-panel is fetched into one XCD's L2 once instead of up to 8 times.
 #pragma once
@@ -303,7 +312,19 @@ struct EpiNull : EpiBase {
 // ---------------------------------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, bool DIRECT, typename ALoad, typename Epi>
+// one f32 chunk (4 values) -> 8 bytes of the hi plane + 8 bytes of the lo plane
+__device__ __forceinline__ void split4(const u32x4& v, uint2& hi, uint2& lo) {
+    union { uint2 u; bf16_t e[4]; } h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float f = __uint_as_float(v[i]);
+        h.e[i] = static_cast<bf16_t>(f);                                   // round to nearest even
+        l.e[i] = static_cast<bf16_t>(f - static_cast<float>(h.e[i]));      // exact residual, rounded once
+    }
+    hi = h.u; lo = l.u;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, bool DIRECT, typename ALoad, typename Epi, bool SPLIT = false>
 __global__ __launch_bounds__(WM * WN * 64)
 void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, int N, int K, int mtiles, int ntiles,
                  const Epi epi) {
@@ -317,6 +338,7 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
     constexpr int A_IT = BM * CPR / NT, W_IT = BN * CPR / NT;
     static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/thread mismatch");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
+    static_assert(!SPLIT || (sizeof(T) == 4 && !DIRECT && KB % 128 == 0), "split-bf16 products: f32 storage, register-staged loop, whole 32-element blocks");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                                  // [NBUF][BM][ROWB]
@@ -449,9 +471,17 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
     {                                                                                                                  \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                          \
             const int c_ = it * NT + tid, k_ = (k0) + a_col[it];                                                       \
-            const u32x4 v_ = aload.finish(ra[it], a_row[it], k_ < K ? k_ : klast);                                     \
-            *reinterpret_cast<u32x4*>(As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + (c_ % CPR) * 16) =                     \
-                (a_ok[it] && k_ < K) ? v_ : zero;                                                                      \
+            const u32x4 v0_ = aload.finish(ra[it], a_row[it], k_ < K ? k_ : klast);                                    \
+            const u32x4 v_ = (a_ok[it] && k_ < K) ? v0_ : zero;                                                        \
+            if constexpr (SPLIT) {      /* chunk q of the stage row: block q / 8, hi at 8 (q % 8), lo 64 bytes further */ \
+                uint2 hi_, lo_;                                                                                        \
+                split4(v_, hi_, lo_);                                                                                  \
+                unsigned char* d_ = As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + ((c_ % CPR) >> 3) * 128 + ((c_ % CPR) & 7) * 8; \
+                *reinterpret_cast<uint2*>(d_) = hi_;                                                                   \
+                *reinterpret_cast<uint2*>(d_ + 64) = lo_;                                                              \
+            } else {                                                                                                   \
+                *reinterpret_cast<u32x4*>(As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + (c_ % CPR) * 16) = v_;             \
+            }                                                                                                          \
         }                                                                                                              \
         _Pragma("unroll") for (int it = 0; it < W_IT; ++it) {                                                          \
             const int c_ = it * NT + tid, k_ = (k0) + w_col[it];                                                       \
@@ -474,6 +504,30 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
         const unsigned char* Wb = Ws + cur * BN * GEMM_ROWB + w_off;
         const unsigned char* Pb = tr ? Ab : Wb;
         const unsigned char* Qb = tr ? Wb : Ab;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int kb = 0; kb < KB / 128; ++kb) {          // one 32-element block: hi plane at +0, lo plane at +64
+                Frag<bf16_t> ph[TM], pl[TM], qh[TN], ql[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ph[i].v = *reinterpret_cast<const bf16x8*>(Pb + i * 16 * GEMM_ROWB + kb * 128);
+                    pl[i].v = *reinterpret_cast<const bf16x8*>(Pb + i * 16 * GEMM_ROWB + kb * 128 + 64);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    qh[j].v = *reinterpret_cast<const bf16x8*>(Qb + j * 16 * GEMM_ROWB + kb * 128);
+                    ql[j].v = *reinterpret_cast<const bf16x8*>(Qb + j * 16 * GEMM_ROWB + kb * 128 + 64);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        mma16(acc[i][j], pl[i], qh[j]);          // small terms first
+                        mma16(acc[i][j], ph[i], ql[j]);
+                        mma16(acc[i][j], ph[i], qh[j]);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < KB / 64; ++kk) {
             Frag<T> fp[TM], fq[TN];
@@ -485,6 +539,7 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16(acc[i][j], fp[i], fq[j]);
+        }
         }
         if (kt + 1 < nk) {
             if constexpr (NBUF == 1) __syncthreads();        // every wave has finished reading the single stage
@@ -563,12 +618,12 @@ constexpr size_t gemm_lds_bytes() {
     return pipe > stage ? pipe : stage;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, typename ALoad, typename Epi>
+template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, typename ALoad, typename Epi, bool SPLIT = false>
 inline hipError_t launch_gemm(hipStream_t s, const ALoad& aload, const T* W, int ldw, int M, int N, int K, const Epi& epi) {
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
     constexpr size_t lds = gemm_lds_bytes<BM, BN, KB, NBUF, ALoad::kStatsFloats, (int)sizeof(typename Epi::S)>();
-    constexpr bool can_direct = ALoad::kDirect && KB == 128 && NBUF == 2 && (BM % (8 * WM * WN) == 0) && (BN % (8 * WM * WN) == 0);
+    constexpr bool can_direct = !SPLIT && ALoad::kDirect && KB == 128 && NBUF == 2 && (BM % (8 * WM * WN) == 0) && (BN % (8 * WM * WN) == 0);
     if constexpr (can_direct) {
         if (K % (KB / (int)sizeof(T)) == 0) {       // whole stages only: the DMA path cannot zero-fill a K tail
             auto kd = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, true, ALoad, Epi>;
@@ -580,7 +635,7 @@ inline hipError_t launch_gemm(hipStream_t s, const ALoad& aload, const T* W, int
             return hipGetLastError();
         }
     }
-    auto kern = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, false, ALoad, Epi>;
+    auto kern = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, false, ALoad, Epi, SPLIT>;
     if (lds > 64 * 1024) {
         static LdsAttr attr;                // one per template instantiation
         if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;

@@ -65,6 +65,16 @@ struct DevGuard {
     DevGuard& operator=(const DevGuard&) = delete;
 };
 
+// precision bf16x3: the storage type of every activation is float (all kernels of the exact-f32 path are shared), but the
+// GEMMs and the 128-token encoder attention evaluate their products on bf16 pairs (gemm.h SPLIT, attn_split_kernel) and the
+// weights are read from the plan's block-planar hi / lo copy.  The mode of the call in progress on this host thread:
+static thread_local bool g_split = false;
+struct SplitScope {
+    bool prev;
+    explicit SplitScope(bool on) : prev(g_split) { g_split = on; }
+    ~SplitScope() { g_split = prev; }
+};
+
 // -------------------------------------------------------------------------------------------------------------------
 // optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
 // -------------------------------------------------------------------------------------------------------------------
@@ -140,7 +150,8 @@ static void add_param(parseq_model* m, const std::string& key, int64_t numel) {
     ParamSpec s{key, numel, m->master_elems, false};
     m->index[key] = (int)m->params.size();
     m->params.push_back(s);
-    m->master_elems += (size_t)((numel + 7) / 8 * 8);   // keeps every tensor 16-byte aligned in bf16 too
+    m->master_elems += (size_t)((numel + 31) / 32 * 32);   // every tensor starts on a 32-element boundary: 16-byte aligned in bf16,
+                                                             // and whole 32-element blocks of the bf16x3 hi / lo layout (gemm.h)
 }
 
 static int check_arch() {
@@ -262,6 +273,20 @@ __global__ void cvt_f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __
     }
 }
 
+// bf16x3 weights (gemm.h SPLIT): flat block-planar copy of the fp32 master — elements [32 b, 32 b + 32) -> bytes [128 b, 128 b + 64)
+// hi = bf16(v), bytes [128 b + 64, 128 b + 128) lo = bf16(v - hi).  Every tensor starts on a 32-element boundary and every GEMM
+// weight row is a multiple of 32 long, so blocks never straddle rows and element offsets into the copy equal those into the master.
+__global__ void split_pack_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;       // 4 consecutive elements
+    if (i >= n) return;
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    uint2 hi, lo;
+    split4(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, hi, lo);
+    unsigned char* d = dst + (i >> 5) * 128 + (i & 31) * 2;
+    *reinterpret_cast<uint2*>(d) = hi;
+    *reinterpret_cast<uint2*>(d + 64) = lo;
+}
+
 __global__ void cloze_mask_kernel(unsigned char* __restrict__ mask, int n, int ld) {
     // model.py:117,157: causal triu(1) with triu(2) cleared -> query i may not see key i + 1 only
     const int i = blockIdx.x, j = threadIdx.x;
@@ -331,7 +356,7 @@ template <typename T> struct Weights {
 
 template <typename T>
 static Weights<T> weights_of(const parseq_plan* p) {
-    if constexpr (sizeof(T) == 4) return Weights<T>{p->m, reinterpret_cast<const T*>(p->m->master)};
+    if constexpr (sizeof(T) == 4) return Weights<T>{p->m, reinterpret_cast<const T*>(p->precision == PARSEQ_BF16X3 ? p->wpack : (void*)p->m->master)};
     else return Weights<T>{p->m, reinterpret_cast<const T*>(p->wpack)};
 }
 
@@ -351,6 +376,14 @@ static int run_layernorm(hipStream_t s, const float* x, const float* w, const fl
 // GEMM dispatch: big tiles for the encoder's M = batch * 128 rows, small tiles for the decoder's M = batch (* 26).
 template <typename T, typename ALoad, typename Epi>
 static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, int N, int K, const Epi& epi, bool force_small = false) {
+    if constexpr (sizeof(T) == 4) {
+        if (g_split) {      // bf16x3: W is the block-planar hi / lo copy, products are three bf16 MFMAs (gemm.h SPLIT)
+            if (K % 32) return fail(PARSEQ_E_INVALID, "bf16x3 GEMM: K=%d is not a multiple of 32", K);
+            if (M >= 4096 && !force_small) HIPCHK((launch_gemm<T, 128, 128, 2, 2, 128, 2, ALoad, Epi, true>(s, a, W, ldw, M, N, K, epi)));
+            else HIPCHK((launch_gemm<T, 64, 64, 2, 2, 768, 1, ALoad, Epi, true>(s, a, W, ldw, M, N, K, epi)));
+            return 0;
+        }
+    }
     if (M >= 4096 && !force_small) HIPCHK((launch_gemm<T, 128, 128, 2, 2, 128, 2>(s, a, W, ldw, M, N, K, epi)));
     else HIPCHK((launch_gemm<T, 64, 64, 2, 2, 768, 1>(s, a, W, ldw, M, N, K, epi)));
     return 0;
@@ -437,6 +470,12 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
             }
         }
     } else {
+        if (p->precision == PARSEQ_BF16X3) {
+            const size_t n = m->master_elems;
+            hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<unsigned char*>(p->wpack), n);
+            HIPCHK(hipGetLastError());
+        }
+        SplitScope ss(p->precision == PARSEQ_BF16X3);
         if (!m->vitstr) CHK(build_tables<float>(p, s));
     }
     const int npos = m->cfg.max_label_length + 1;
@@ -448,7 +487,7 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
 
 extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out) {
     if (!m || !out || max_batch <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
-    if (precision != PARSEQ_F32 && precision != PARSEQ_BF16) return fail(PARSEQ_E_INVALID, "precision %d", precision);
+    if (precision != PARSEQ_F32 && precision != PARSEQ_BF16 && precision != PARSEQ_BF16X3) return fail(PARSEQ_E_INVALID, "precision %d", precision);
     DevGuard dg(m->device);
     const parseq_config& c = m->cfg;
     const size_t E = c.embed_dim, N = m->tokens, B = max_batch, ts = precision == PARSEQ_BF16 ? 2 : 4;
@@ -458,7 +497,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->m = m; p->max_batch = max_batch; p->precision = precision;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount; }
     size_t off = 0;
-    const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : 0);
+    const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : (precision == PARSEQ_BF16X3 ? m->master_elems * 4 : 0));
     const bool step_ok = !m->vitstr && precision == PARSEQ_BF16 && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
     const size_t step_elems[6] = {frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(Fd, E),
                                   frag_pack_elems(E, Fd), frag_pack_elems(m->classes, E)};
@@ -558,6 +597,11 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
     if constexpr (sizeof(T) == 2) {
         if (v_rowmajor) hipLaunchKernelGGL(attn_mfma_kernel<true>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
         else hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
+    } else if (g_split) {
+        if (v_rowmajor) return fail(PARSEQ_E_INVALID, "bf16x3 attention expects V^T");
+        static LdsAttr attr;
+        HIPCHK(attr.ensure(reinterpret_cast<const void*>(attn_split_kernel), attn_split_lds()));
+        hipLaunchKernelGGL(attn_split_kernel, dim3(bh), dim3(256), attn_split_lds(), s, q, k, vt, ao, heads, scale);
     } else {
         if (v_rowmajor) return fail(PARSEQ_E_INVALID, "f32 attention expects V^T");
         constexpr size_t lds = (size_t)2 * ATT_N * ATT_HD * sizeof(float);
@@ -704,6 +748,7 @@ extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtyp
     CHK(check_call(p, batch, images_dtype));
     if (!images) return fail(PARSEQ_E_INVALID, "null images");
     DevGuard dg(p->m->device);
+    SplitScope ss(p->precision == PARSEQ_BF16X3);
     return encode_dispatch(p, images, images_dtype, batch, memory_out, (hipStream_t)stream);
 }
 
@@ -950,6 +995,7 @@ extern "C" int parseq_vitstr_forward(parseq_plan* p, const void* images, int ima
     CHK(check_call(p, batch, images_dtype));
     if (!p->m->vitstr) return fail(PARSEQ_E_INVALID, "parseq_vitstr_forward on a PARSeq model (arch 0)");
     DevGuard dg(p->m->device);
+    SplitScope ss(p->precision == PARSEQ_BF16X3);
     if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
     const parseq_model* m = p->m;
     const int npos = m->cfg.max_label_length + 1, N = m->tokens, C = m->classes, E = m->cfg.embed_dim;
@@ -977,6 +1023,7 @@ extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dty
     CHK(check_call(p, batch, images_dtype));
     if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "parseq_forward on a ViTSTR model: use parseq_vitstr_forward");
     DevGuard dg(p->m->device);
+    SplitScope ss(p->precision == PARSEQ_BF16X3);
     if (!images || !logits_out) return fail(PARSEQ_E_INVALID, "null images / logits_out");
     const int npos = p->m->cfg.max_label_length + 1;
     if (num_steps < 1 || num_steps > npos) return fail(PARSEQ_E_INVALID, "num_steps %d outside [1, %d]", num_steps, npos);
@@ -992,6 +1039,7 @@ static int decode_entry(parseq_plan* p, const int32_t* tokens, int batch, int ct
     if (!p || !tokens || !logits_out) return fail(PARSEQ_E_INVALID, "null argument");
     if (p->m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
     DevGuard dg(p->m->device);
+    SplitScope ss(p->precision == PARSEQ_BF16X3);
     if (batch <= 0 || batch > p->max_batch || batch != p->last_batch) return fail(PARSEQ_E_INVALID, "batch %d does not match the last parseq_encode (%d)", batch, p->last_batch);
     const int npos = p->m->cfg.max_label_length + 1;
     if (ctx_len < 1 || ctx_len > npos || q_start < 0 || q_len < 1 || q_start + q_len > npos) return fail(PARSEQ_E_INVALID, "bad context / query range");
@@ -1074,6 +1122,7 @@ extern "C" int parseq_set_memory(parseq_plan* p, const float* memory, int batch,
     if (batch <= 0 || batch > p->max_batch) return fail(PARSEQ_E_INVALID, "batch %d outside (0, %d]", batch, p->max_batch);
     if (p->packed_version != p->m->version) return fail(PARSEQ_E_STATE, "model parameters changed after the plan was packed; call parseq_plan_refresh");
     DevGuard dg(p->m->device);
+    SplitScope ss(p->precision == PARSEQ_BF16X3);
     if (p->precision == PARSEQ_BF16) return set_memory_impl<bf16_t>(p, memory, batch, (hipStream_t)stream);
     return set_memory_impl<float>(p, memory, batch, (hipStream_t)stream);
 }
@@ -1627,7 +1676,16 @@ extern "C" int parseq_op_linear(const void* A, const void* W, const float* bias,
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || (K % 8)) return fail(PARSEQ_E_INVALID, "bad argument (K must be a multiple of 8)");
     if (act && (N % 4)) return fail(PARSEQ_E_INVALID, "act=1 needs N %% 4 == 0");
     if (dtype == PARSEQ_BF16) return op_linear_impl<bf16_t>((const bf16_t*)A, (const bf16_t*)W, bias, C, act, M, N, K, (hipStream_t)stream);
+    SplitScope ss(dtype == PARSEQ_BF16X3);          // A: f32; W: the block-planar hi / lo copy made by parseq_op_split_pack
     return op_linear_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, (hipStream_t)stream);
+}
+
+extern "C" int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream) {
+    CHK(check_arch());
+    if (!src || !dst || numel <= 0 || (numel % 32)) return fail(PARSEQ_E_INVALID, "bad argument (numel must be a multiple of 32)");
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((numel / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (unsigned char*)dst, (size_t)numel);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 // Tile-configuration sweep hook for tools/gemm_bench.py (not used by the product path, which picks via run_gemm).
@@ -1717,5 +1775,6 @@ extern "C" int parseq_op_encoder_attention(const void* q, const void* k, const v
     CHK(check_arch());
     if (!q || !k || !vt || !out || bh <= 0 || heads <= 0 || bh % heads) return fail(PARSEQ_E_INVALID, "bad argument");
     if (dtype == PARSEQ_BF16) return run_enc_attention<bf16_t>((hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vt, (bf16_t*)out, bh, heads);
+    SplitScope ss(dtype == PARSEQ_BF16X3);
     return run_enc_attention<float>((hipStream_t)stream, (const float*)q, (const float*)k, (const float*)vt, (float*)out, bh, heads);
 }

@@ -21,7 +21,7 @@ from torch import Tensor
 from . import _native
 from .tokenizer import Tokenizer
 
-_PRECISIONS = {'bf16': _native.PARSEQ_BF16, 'fp32': _native.PARSEQ_F32, 'f32': _native.PARSEQ_F32}
+_PRECISIONS = {'bf16': _native.PARSEQ_BF16, 'fp32': _native.PARSEQ_F32, 'f32': _native.PARSEQ_F32, 'bf16x3': _native.PARSEQ_BF16X3}
 
 
 def init_weights(module: nn.Module, name: str = '', exclude: Sequence[str] = ()):

@@ -38,6 +38,28 @@ LINEAR_SHAPES = [(4096, 1152, 384), (4096, 384, 1536), (8192, 384, 384), (512, 3
                  (512, 1536, 384), (300, 768, 192), (4096, 384, 96), (130, 200, 96), (1, 95, 192)]
 
 
+@pytest.mark.parametrize('M,N,K', [s for s in LINEAR_SHAPES if s[2] % 32 == 0])
+def test_linear_bf16x3(M, N, K):
+    """gemm.h SPLIT: f32 operands carried as bf16 hi / lo pairs, three MFMAs per product.  Against fp64 on UNROUNDED f32
+    operands: the error is the dropped lo*lo term and the second rounding, ~2^-17 relative per product."""
+    nat, lib = native()
+    A = _gen(M, K, seed=4)
+    W = _gen(N, K, seed=5) / K ** 0.5
+    bias = 0.1 * _gen(N, seed=6)
+    want = A.double() @ W.double().T + bias.double()
+    Ad, Wd, bd = A.to(DEV), W.to(DEV).contiguous(), bias.to(DEV)
+    Wp = torch.empty(N * K, dtype=torch.float32, device=DEV)              # same bytes, block-planar hi / lo
+    nat.check(lib.parseq_op_split_pack(nat.ptr(Wd), nat.ptr(Wp), N * K, nat.stream_ptr()))
+    out = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+    nat.check(lib.parseq_op_linear(nat.ptr(Ad), nat.ptr(Wp), nat.ptr(bd), nat.ptr(out), nat.PARSEQ_BF16X3, 0, M, N, K, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    err, msg = report(f'linear bf16x3 {M}x{N}x{K}', out, want.float())
+    assert err <= 5e-5, msg        # |sum| <= ~4, K <= 1536 random-sign terms of relative error 2^-17: ~1e-5 expected
+    # and it must really be better than one bf16 product (guards against a path that silently drops the lo terms)
+    one = (A.bfloat16().double() @ W.bfloat16().double().T + bias.double()).float()
+    assert (one - want.float()).abs().max() > 20 * err
+
+
 @pytest.mark.parametrize('M,N,K', LINEAR_SHAPES)
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_linear(M, N, K, dtype):
@@ -64,11 +86,11 @@ def test_linear(M, N, K, dtype):
 
 
 @pytest.mark.parametrize('heads,images', [(6, 3), (3, 2)])
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'bf16x3'])
 def test_encoder_attention(heads, images, dtype):
     nat, lib = native()
-    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
-    code = nat.PARSEQ_F32 if dtype == 'f32' else nat.PARSEQ_BF16
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    code = {'f32': nat.PARSEQ_F32, 'bf16': nat.PARSEQ_BF16, 'bf16x3': nat.PARSEQ_BF16X3}[dtype]
     bh = heads * images
     q = _gen(bh, 128, 64, seed=7, scale=1.5).to(tdt)
     k = _gen(bh, 128, 64, seed=8, scale=1.5).to(tdt)
@@ -81,7 +103,8 @@ def test_encoder_attention(heads, images, dtype):
     torch.cuda.synchronize()
     err, msg = report(f'enc attention {dtype} heads={heads}', out, want.float())
     # f32: exp/accumulation rounding.  bf16: probabilities and the output are rounded to bf16 (2^-9 relative each)
-    assert err <= (2e-5 if dtype == 'f32' else 1.5e-2), msg
+    # bf16x3: f32 tensors, operands as bf16 pairs -> ~2^-17 relative per product
+    assert err <= {'f32': 2e-5, 'bf16': 1.5e-2, 'bf16x3': 3e-5}[dtype], msg
 
 
 @pytest.mark.parametrize('variant', [0, 10])     # 0: load - LN - ... - reload - add - store; 10: x resident in the fc2 accumulators

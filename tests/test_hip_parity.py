@@ -33,7 +33,7 @@ def name(request):
 
 @pytest.fixture(scope='module')
 def models(name):
-    return {p: make_model(name, p) for p in ('fp32', 'bf16')}
+    return {p: make_model(name, p) for p in ('fp32', 'bf16', 'bf16x3')}
 
 
 def _run(m, images, mode):
@@ -45,11 +45,13 @@ def _run(m, images, mode):
     return out.float().cpu()
 
 
-def test_encoder_memory_fp32(name, models, golden):
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_encoder_memory_fp32(name, models, golden, precision):
     g, _ = golden(name)
-    mem = models['fp32'].model.encode(g['images'].to(DEV)).cpu()
-    err, msg = report(f'{name} memory fp32 vs reference', mem, g['memory'])
-    assert err <= 2e-4, msg       # 12 layers of fp32 reassociation on O(1) activations
+    mem = models[precision].model.encode(g['images'].to(DEV)).cpu()
+    err, msg = report(f'{name} memory {precision} vs reference', mem, g['memory'])
+    # fp32: 12 layers of fp32 reassociation on O(1) activations.  bf16x3: operands carry 16 mantissa bits (2^-17 per product)
+    assert err <= (2e-4 if precision == 'fp32' else 5e-4), msg
 
 
 def test_encoder_memory_bf16_vs_rounding_oracle(name, models, golden):
@@ -63,14 +65,15 @@ def test_encoder_memory_bf16_vs_rounding_oracle(name, models, golden):
     assert err <= 3e-2, msg       # same rounding points; residual = fp32 reassociation amplified through bf16 re-rounding
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])     # the two modes that meet the north star's 1e-3 (bf16x3: at matrix-core speed)
 @pytest.mark.parametrize('mode', list(MODES))
-def test_forward_fp32_matches_reference(name, models, golden, mode):
+def test_forward_fp32_matches_reference(name, models, golden, mode, precision):
     g, meta = golden(name)
-    m = models['fp32']
+    m = models[precision]
     got = _run(m, g['images'].to(DEV), mode)
     ref = g[f'logits.{mode}']
     assert list(got.shape) == list(ref.shape) == meta['modes'][mode]['shape']
-    err, msg = report(f'{name} {mode} fp32 logits vs reference', got, ref)
+    err, msg = report(f'{name} {mode} {precision} logits vs reference', got, ref)
     assert err <= 1e-3, msg
     assert torch.equal(got.argmax(-1), ref.argmax(-1))
     strings, _ = m.tokenizer.decode(got.softmax(-1))
@@ -425,3 +428,57 @@ def test_decode_and_head_reference_idiom(name, models, golden):
         bad[0, 3] = 10 ** 6
         bad[1, 2] = -5
         assert torch.isfinite(m.model.decode(bad, memory, tgt_query_mask=causal.to(DEV))).all()
+
+
+# ---- BASELINE.json configurations on DISTINCT data (configs[1]: 512 crops AR+1; configs[3]: 1024 crops AR+2) -----------------
+# 512 / 1024 different seeded crops end to end.  The exact-tolerance modes are held to the north star's bar against the CPU
+# oracle on every crop (|dlogit| <= 1e-3, argmax identical); the bf16 mode to its stated bars against the rounding-aware oracle,
+# with the string-agreement fraction ASSERTED against a floor (95.7 % measured on 4096 crops for AR+1).
+def _oracle_batched(sd, cfg, images, refine_iters, rounding=None, chunk=64):
+    outs = []
+    with torch.inference_mode():
+        for i in range(0, images.shape[0], chunk):
+            outs.append(O.forward(sd, cfg, images[i:i + chunk], 25, decode_ar=True, refine_iters=refine_iters, rounding=rounding))
+    return torch.cat(outs)
+
+
+@pytest.mark.parametrize('batch,refine', [(512, 1), (1024, 2)])
+def test_baseline_configs_distinct_crops(batch, refine):
+    name = 'parseq'
+    cfg, sd = CONFIGS[name], synth_state_dict(CONFIGS[name], 0)
+    images = synth_images(batch, cfg, seed=20250924 + batch)
+    assert images.flatten(1).unique(dim=0).shape[0] == batch              # really distinct crops
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    want = _oracle_batched(sd, cfg, images, refine)
+    top2 = want.topk(2, -1).values
+    margin = top2[..., 0] - top2[..., 1]
+    for precision in ('fp32', 'bf16x3'):
+        m = make_model(name, precision, refine_iters=refine)
+        with torch.inference_mode():
+            got = m(images.to(DEV), 25).float().cpu()
+        err, msg = report(f'{name} {precision} batch {batch} AR+{refine} distinct crops vs CPU oracle', got, want)
+        assert got.shape == want.shape == (batch, 26, 95)
+        assert err <= 1e-3, msg
+        # argmax: identical wherever the oracle's own decision is not a tie inside fp32 round-off of the two paths
+        agree = got.argmax(-1) == want.argmax(-1)
+        assert bool(agree[margin > 2e-3].all()) and agree.float().mean() > 0.9999, f'{precision}: argmax agreement {agree.float().mean():.6f}'
+        s_got, _ = m.tokenizer.decode(got.softmax(-1))
+        s_want, _ = m.tokenizer.decode(want.softmax(-1))
+        same = sum(a == b for a, b in zip(s_got, s_want)) / batch
+        print(f'[{precision} batch {batch}] strings identical to the oracle: {same:.4f}')
+        assert same >= 0.998, f'{precision}: only {same:.4f} of the strings equal the oracle'
+        del m
+    # bf16: same rounding points as the rounding-aware oracle
+    want16 = _oracle_batched(sd, cfg, images, refine, rounding='bf16')
+    m = make_model(name, 'bf16', refine_iters=refine)
+    with torch.inference_mode():
+        got = m(images.to(DEV), 25).float().cpu()
+    err, msg = report(f'{name} bf16 batch {batch} AR+{refine} distinct crops vs rounding-aware oracle', got, want16)
+    gap, gmsg = report(f'{name} bf16 batch {batch} AR+{refine} distinct crops vs exact fp32 oracle', got, want)
+    assert err <= 3e-2, msg
+    assert gap <= 6e-2, gmsg
+    s_got, _ = m.tokenizer.decode(got.softmax(-1))
+    s_want, _ = m.tokenizer.decode(want.softmax(-1))
+    same = sum(a == b for a, b in zip(s_got, s_want)) / batch
+    print(f'[bf16 batch {batch}] strings identical to the fp32 oracle: {same:.4f}')
+    assert same >= 0.90, f'bf16: only {same:.4f} of the strings equal the fp32 oracle (floor 0.90; 0.957 measured on 4096 crops)'
