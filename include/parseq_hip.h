@@ -306,7 +306,14 @@ int parseq_op_ln_linear_gelu(const float* x, const float* gamma, const float* be
  * W1 bf16 [1536, 384], b1 fp32 [1536], W2 bf16 [384, 1536], b2 fp32 [384]  (timm Block: x + mlp(norm2(x))). */
 int parseq_op_mlp(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                   const float* b2, int M, void* stream);
-/* Ablation variants of parseq_op_mlp for tools/panel_bench.py (variant 0 = the product kernel). */
+/* In place x[M, 384] (fp32) += proj(attention(qkv(LayerNorm(x; gamma, beta, eps 1e-6)))) through the fused attention-branch kernel
+ * (timm Block: x + attn(norm1(x)), 6 heads of 64, one image = 128 consecutive rows per workgroup; M a multiple of 128):
+ * Wqkv bf16 [1152, 384] (q | k | v rows, head-major), bqkv fp32 [1152], Wproj bf16 [384, 384], bproj fp32 [384].
+ * variant 0 = the product kernel; 6 = phase time stamps (tools/panel_bench.py). */
+int parseq_op_attn_fused(float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv, const void* Wproj,
+                         const float* bproj, int M, int variant, void* stream);
+/* Ablation variants of parseq_op_mlp for tools/panel_bench.py (variant 0 = the product kernel; 10 = x resident in the fc2
+ * accumulators, the form the encoder uses). */
 int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                           const float* b2, int M, int variant, void* stream);
 /* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;

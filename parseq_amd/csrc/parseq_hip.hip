@@ -23,6 +23,7 @@
 #include "encoder_attn.h"
 #include "encoder_panel.h"
 #include "encoder_mlp.h"
+#include "encoder_attn_fused.h"
 #include "gemm.h"
 #include "rowops.h"
 #include "train_ops.h"
@@ -78,9 +79,9 @@ struct SplitScope {
 // -------------------------------------------------------------------------------------------------------------------
 // optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
 // -------------------------------------------------------------------------------------------------------------------
-enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_DEC_PRE, T_DEC_POST, T_COUNT };
+enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_ATTNF, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_DEC_PRE, T_DEC_POST, T_COUNT };
 static const char* const kProfNames[T_COUNT] = {"enc.patch_embed_gemm", "enc.layernorm", "enc.qkv_gemm", "enc.attention", "enc.proj_gemm",
-                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "enc.mlp_fused", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
+                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "enc.mlp_fused", "enc.attn_fused", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
                                                 "dec.cross_attention", "dec.layernorm", "dec.misc", "dec.step_pre", "dec.step_post"};
 struct Profiler {
     bool enabled = false;
@@ -339,6 +340,8 @@ struct parseq_plan {
     int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
     int num_cus = 256;             // compute units of the device (tail-round avoidance of the one- and two-workgroup-per-CU kernels)
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
+    bool fused_attn = getenv("PARSEQ_NO_FUSED_ATTN") == nullptr;   // diagnostics: qkv panel GEMM + attention + proj GEMM instead of encoder_attn_fused.h
+    bool mlp_resident = getenv("PARSEQ_MLP_RELOAD") == nullptr;    // diagnostics: the fused MLP's first form (x re-read by the epilogue)
     Profiler prof;
 };
 constexpr int LDT = 32;            // row pitch of token / mask arrays
@@ -655,9 +658,19 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         const int tiles = (M + 127) / 128, slots = per_cu * p->num_cus, rem = tiles % slots;
         return (tiles > slots && rem > 0 && rem <= slots / 16) ? (tiles - rem) * 128 : M;
     };
+    // encoder_attn_fused.h: LayerNorm + qkv + attention + proj + residual in one kernel, one image (128 tokens) per workgroup
+    const bool fused_attn = kBf16 && E == 384 && N == ATT_N && p->fused_attn;
+    const int Ma = fused_attn ? main_rows(1) : 0;
     const int Mq = panel_qkv ? main_rows(2) : M, Mm = fused_mlp ? main_rows(1) : M;
     for (int i = 0; i < c.enc_depth; ++i) {
         const std::string b = pe + "blocks." + std::to_string(i) + ".";
+        if (fused_attn && Ma == M) {
+            if constexpr (kBf16) {
+                ProfScope ps_(&p->prof, T_ATTNF, s);
+                HIPCHK((launch_fused_attn<384>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"),
+                                               m->p(b + "attn.qkv.bias"), W.w(b + "attn.proj.weight"), m->p(b + "attn.proj.bias"), M)));
+            }
+        } else {
         if (panel_qkv) {
             if constexpr (kBf16) {
                 PanelHeads ph; ph.seg[0] = q; ph.seg[1] = k; ph.seg[2] = vt; ph.E = E; ph.heads = H; ph.hd = ATT_HD; ph.tokens = N;
@@ -681,9 +694,14 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         }
         { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv || N != ATT_N, N))); }
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
+        }
         if (fused_mlp) {
             if constexpr (kBf16) {
                 ProfScope ps_(&p->prof, T_MLP, s);
+                if (p->mlp_resident)
+                    HIPCHK((launch_fused_mlp<384, 0, true>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
+                                                           m->p(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), m->p(b + "mlp.fc2.bias"), Mm)));
+                else
                 HIPCHK((launch_fused_mlp<384>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
                                               m->p(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), m->p(b + "mlp.fc2.bias"), Mm)));
                 if (Mm < M) {        // tail rows through the per-op kernels (same rounding points)
@@ -1748,6 +1766,21 @@ extern "C" int parseq_op_mlp_variant(float* x, const float* gamma, const float* 
         case 6: {   // phase time stamps: the LAST 4096 bytes of x's allocation are not touched (caller passes M smaller than the buffer)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
             HIPCHK((launch_fused_mlp<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }
+        default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
+    }
+    return 0;
+}
+
+extern "C" int parseq_op_attn_fused(float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv, const void* Wproj,
+                                    const float* bproj, int M, int variant, void* stream) {
+    CHK(check_arch());
+    if (!x || !gamma || !beta || !Wqkv || !bqkv || !Wproj || !bproj || M <= 0 || (M % 128)) return fail(PARSEQ_E_INVALID, "bad argument (M must be a multiple of 128: whole images)");
+    hipStream_t s = (hipStream_t)stream;
+    switch (variant) {
+        case 0: HIPCHK((launch_fused_attn<384, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M))); break;
+        case 6: {   // phase time stamps behind the matrix (see parseq_op_mlp_variant)
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
+            HIPCHK((launch_fused_attn<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M, dbg))); break; }
         default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
     }
     return 0;

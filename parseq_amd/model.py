@@ -370,7 +370,7 @@ class PARSeq(_NativeBacked):
         if memory.device != self._device:
             raise RuntimeError(f'memory on {memory.device} but the model is on {self._device}')
         key = getattr(self, '_memory_key', None)
-        if key is not None and key[0]() is memory and key[1:] == (memory._version, self._native_state.signature):
+        if key is not None and key[0]() is memory and key[1] is not None and key[1:] == (self._version_of(memory), self._native_state.signature):
             return
         mem = memory.detach().to(torch.float32).contiguous()
         _native.check(_native.lib().parseq_set_memory(plan, _native.ptr(mem), B, _native.stream_ptr(self._device)))
@@ -381,7 +381,13 @@ class PARSeq(_NativeBacked):
         # identity of the tensor OBJECT (a weak reference: a freed tensor whose storage address is reused by another one can
         # never match), its in-place-modification counter, and the parameter signature the projection was made with
         import weakref
-        self._memory_key = (weakref.ref(memory), memory._version, self._native_state.signature)
+        self._memory_key = (weakref.ref(memory), self._version_of(memory), self._native_state.signature)
+
+    @staticmethod
+    def _version_of(t: Tensor):
+        """In-place-modification counter, or None for tensors that do not keep one (created under torch.inference_mode): an
+        in-place edit of such a tensor cannot be noticed, so it is never taken as "the cached memory" — it is re-projected."""
+        return None if t.is_inference() else t._version
 
     def decode(self, tgt: Tensor, memory: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,
                tgt_padding_mask: Optional[Tensor] = None, tgt_query: Optional[Tensor] = None,

@@ -91,8 +91,76 @@ def mlp_stamps():
             print(f'block {"0" if blk == 0 else "300"} wave {w}: ' + ', '.join(f'{n} {(b - v[0]) / 2400.0:.1f}us' for n, b in zip(names, v)) + '   (s_memtime ticks / 2.4 GHz)')
 
 
+def mlp_ab(variants=(0, 10), rounds=6, reps=10):
+    """Interleaved A/B of fused-MLP variants in one process (cdna_hip_programming.md rule 24): median and min per variant."""
+    lib = nat.lib()
+    M, E, F = 65536, 384, 1536
+    x = torch.randn(M, E, device='cuda')
+    gamma, beta = torch.rand(E, device='cuda') + 0.5, torch.randn(E, device='cuda') * 0.1
+    W1 = (torch.randn(F, E, device='cuda') / E ** 0.5).bfloat16(); W2 = (torch.randn(E, F, device='cuda') / F ** 0.5).bfloat16()
+    b1, b2 = torch.randn(F, device='cuda') * 0.1, torch.randn(E, device='cuda') * 0.1
+    times = {v: [] for v in variants}
+    for r in range(rounds + 1):
+        for v in variants:
+            x.normal_()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                nat.check(lib.parseq_op_mlp_variant(nat.ptr(x), nat.ptr(gamma), nat.ptr(beta), nat.ptr(W1), nat.ptr(b1), nat.ptr(W2), nat.ptr(b2), M, v, nat.stream_ptr()))
+            e1.record()
+            torch.cuda.synchronize()
+            if r:                                             # round 0 is warm-up
+                times[v].append(1e3 * e0.elapsed_time(e1) / reps)
+    for v in variants:
+        t = sorted(times[v])
+        print(f'fused MLP variant {v:2d}: median {t[len(t) // 2]:7.1f} us  min {t[0]:7.1f} us  max {t[-1]:7.1f} us   '
+              f'{4.0 * M * E * F / t[len(t) // 2] / 1e6:7.1f} TFLOP/s at the median')
+
+
+def attn_fused():
+    """Fused attention-branch kernel at batch 512 (M = 65536): time per launch and the phase stamps of two workgroups."""
+    lib = nat.lib()
+    M, E = 65536, 384
+    xbuf = torch.randn(M * E + 1024, device='cuda')
+    gamma, beta = torch.rand(E, device='cuda') + 0.5, torch.randn(E, device='cuda') * 0.1
+    Wqkv = (torch.randn(3 * E, E, device='cuda') / E ** 0.5).bfloat16(); Wproj = (torch.randn(E, E, device='cuda') / E ** 0.5).bfloat16()
+    bqkv, bproj = torch.randn(3 * E, device='cuda') * 0.1, torch.randn(E, device='cuda') * 0.1
+    def run(v):
+        nat.check(lib.parseq_op_attn_fused(nat.ptr(xbuf), nat.ptr(gamma), nat.ptr(beta), nat.ptr(Wqkv), nat.ptr(bqkv), nat.ptr(Wproj), nat.ptr(bproj), M, v, nat.stream_ptr()))
+    times = []
+    for r in range(6):
+        xbuf.normal_()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run(0)
+        e1.record()
+        torch.cuda.synchronize()
+        if r:
+            times.append(1e3 * e0.elapsed_time(e1) / 10)
+    t = sorted(times)
+    fl = 2.0 * M * 4 * E * E + 4.0 * (M // 128) * 6 * 128 * 128 * 64
+    print(f'fused attention branch: median {t[len(t) // 2]:7.1f} us  min {t[0]:7.1f} us  max {t[-1]:7.1f} us   {fl / t[len(t) // 2] / 1e6:7.1f} TFLOP/s at the median')
+    xbuf.normal_()
+    for _ in range(3):
+        run(6)
+    torch.cuda.synchronize()
+    st = xbuf[M * E:].view(torch.int64).cpu().view(-1)[:8 * 64].view(2, 4, 64)
+    names = ['start', 'LN done', 'head 1', 'last head', 'loop done', 'epilogue done']
+    for blk in range(2):
+        for w in range(4):
+            v = st[blk, w, :len(names)].tolist()
+            print(f'block {"0" if blk == 0 else "300"} wave {w}: ' + ', '.join(f'{n} {(b - v[0]) / 2400.0:.1f}us' for n, b in zip(names, v)) + '   (s_memtime ticks / 2.4 GHz)')
+
+
 if __name__ == '__main__':
-    if 'stamps' in sys.argv:
+    if 'attn' in sys.argv:
+        attn_fused()
+    elif 'ab' in sys.argv:
+        mlp_ab()
+    elif 'stamps' in sys.argv:
         mlp_stamps()
     elif 'mlp' in sys.argv:
         mlp()
