@@ -88,9 +88,9 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
     n = min(64, images.shape[0])
     x = images[:n]
     exact_prec = args.exact_precision
+    exact = make_model(exact_prec)              # outside inference_mode: parameters must be ordinary (version-counted) tensors
     with torch.inference_mode():
         got = model(x, max_length).float()
-        exact = make_model(exact_prec)
         ref = exact(x.float(), max_length).float()
         tok = model.tokenizer
         s_got, _ = tok.decode_logits(got)
@@ -100,6 +100,22 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
                'max_abs_vs_fp32': round(float((got[:, :L] - ref[:, :L]).abs().max()), 6),
                'argmax_agree': round(float((got[:, :L].argmax(-1) == ref[:, :L].argmax(-1)).float().mean()), 6),
                'strings_agree': round(sum(a == b for a, b in zip(s_got, s_ref)) / n, 6)}
+        # the same comparison without decision feedback (NAR pass: one decoder pass from <bos>, nothing is fed back): pure arithmetic
+        # difference of the two precisions on the timed weights — on random-init weights the AR numbers above are dominated by
+        # near-tie decisions flipping and every later position then seeing a different context
+        ar_a, ar_b = model.model.decode_ar, exact.model.decode_ar
+        ri_a, ri_b = model.model.refine_iters, exact.model.refine_iters
+        try:
+            model.model.decode_ar = exact.model.decode_ar = False
+            model.model.refine_iters = exact.model.refine_iters = 0
+            g0, r0 = model(x, max_length).float(), exact(x.float(), max_length).float()
+            out['nar_max_abs_vs_fp32'] = round(float((g0 - r0).abs().max()), 6)
+            out['nar_argmax_agree'] = round(float((g0.argmax(-1) == r0.argmax(-1)).float().mean()), 6)
+            top2 = r0.topk(2, -1).values
+            out['nar_median_top2_margin'] = round(float((top2[..., 0] - top2[..., 1]).median()), 6)
+        finally:
+            model.model.decode_ar, exact.model.decode_ar = ar_a, ar_b
+            model.model.refine_iters, exact.model.refine_iters = ri_a, ri_b
         if oracle_logits is not None:
             want = oracle_logits
             Lo = min(want.shape[1], ref.shape[1])

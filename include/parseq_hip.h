@@ -292,6 +292,11 @@ int parseq_op_layernorm(const float* x, const float* w, const float* b, void* y,
  * C in `dtype` with exact-erf GELU applied (act = 1).  K must be a multiple of 8. */
 int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                      void* stream);
+/* C[M, N] (fp32) = LayerNorm(x[M, 384]; gamma, beta, eps) W^T + bias with the LayerNorm fused into the A-operand loader of the tile
+ * GEMM (the decoder's q-projection / linear1 / head form).  dtype PARSEQ_F32 (W fp32 [N, 384]) or PARSEQ_BF16X3 (W from
+ * parseq_op_split_pack). */
+int parseq_op_ln_linear(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, float* C, int dtype,
+                        int M, int N, float eps, void* stream);
 /* dtype = PARSEQ_BF16X3: A is f32 [M, K], K a multiple of 32; W must be the block-planar hi / lo copy of the f32 weight that
  * parseq_op_split_pack(src f32 [numel], dst [numel * 4 bytes]) produces (numel a multiple of 32); C as for PARSEQ_F32. */
 int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream);
@@ -312,6 +317,12 @@ int parseq_op_mlp(float* x, const float* gamma, const float* beta, const void* W
  * variant 0 = the product kernel; 6 = phase time stamps (tools/panel_bench.py). */
 int parseq_op_attn_fused(float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv, const void* Wproj,
                          const float* bproj, int M, int variant, void* stream);
+/* `depth` encoder blocks in one launch (encoder_blocks.h): in place on x[M, 384] (fp32), M a multiple of 128 (one image = 128
+ * consecutive rows per workgroup).  block_ptrs: HOST array of depth * 12 DEVICE pointers, per block in this order: norm1 weight,
+ * norm1 bias (fp32 [384]), Wqkv bf16 [1152, 384], bqkv fp32 [1152], Wproj bf16 [384, 384], bproj fp32 [384], norm2 weight, norm2
+ * bias, W1 bf16 [1536, 384], b1 fp32 [1536], W2 bf16 [384, 1536], b2 fp32 [384].  table_ws: device scratch of depth * 48 bytes.
+ * Test hook (the product path builds the table once per plan); uploads the table synchronously. */
+int parseq_op_enc_blocks(float* x, const void* const* block_ptrs, int depth, int M, void* table_ws, void* stream);
 /* Ablation variants of parseq_op_mlp for tools/panel_bench.py (variant 0 = the product kernel; 10 = x resident in the fc2
  * accumulators, the form the encoder uses). */
 int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,

@@ -83,6 +83,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
+// All-reduce over the four 16-lane rows of a wavefront (lanes l, l ^ 16, l ^ 32, l ^ 48) on the VALU: gfx950's row / half swaps
+// exchange whole 16- / 32-lane groups between two registers, so with both operands the same value the two results are
+// "my group's" and "the other group's" copy.  (__shfl_xor(v, 16) compiles to ds_bpermute: an LDS-pipe round trip plus an index
+// register per distance that the compiler keeps live across whole kernels.)
+//   v_permlane16_swap: odd rows of the first operand <-> even rows of the second;  v_permlane32_swap: upper half <-> lower half.
+__device__ __forceinline__ float rows4_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float w = __uint_as_float(a[0]) + __uint_as_float(a[1]);          // rows (0,1) and (2,3) summed pairwise, in every lane of the pair
+    const unsigned x = __float_as_uint(w);
+    auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float w = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned x = __float_as_uint(w);
+    auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 // erf(x) to ~1.2e-7 absolute (Abramowitz & Stegun 7.1.26 with the 5-term polynomial, evaluated in fp32): one
 // reciprocal, one exp, a Horner chain — about 15 VALU ops instead of the ~100 of the library erff with its branches,
 // which alone cost the fc1 epilogue ~100 us per launch at 100 M activations.  Error budget: |d gelu| <= 0.5 |x| 1.2e-7.

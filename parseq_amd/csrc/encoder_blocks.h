@@ -1,0 +1,662 @@
+// The whole ViT encoder stack as ONE persistent launch (bf16 throughput mode, E = 384, 128 tokens = one image per workgroup):
+//
+//     for every block:   x += proj(attention(qkv(LayerNorm1(x))));   x += fc2(gelu(fc1(LayerNorm2(x))))          (timm Block x depth)
+//
+// encoder_attn_fused.h and encoder_mlp.h (RESIDENT form) each keep the fp32 rows of x in the accumulators of their last GEMM
+// from the first load to the final store.  A workgroup owns the same 128 rows — one image — in both, and nothing but x crosses
+// from one to the other, so the two kernel bodies chain without x ever leaving the register file: this kernel loads x once,
+// walks all `depth` blocks, and stores x once.  Per forward at batch 512 that removes 2 x 12 launches' worth of prologue /
+// epilogue HBM bursts (x: 24 x 200 MB -> 200 MB) and every one of the 24 launch-wide synchronisation points at which the
+// slowest workgroup of a launch used to hold back the next launch.
+//
+// The two phases are device functions shared with two stand-alone branch kernels in this file (attn_branch_kernel,
+// mlp_branch_kernel), whose per-kernel parity tests therefore cover them, and against a chain of which the one-launch encoder is
+// tested bit for bit.  (encoder_attn_fused.h / encoder_mlp.h hold the first stand-alone forms, with their ablation variants.)
+//   attn_phase   72 weight stages (6 heads x 12) through ring slots 0-5, K / V^T images       (encoder_attn_fused.h)
+//   mlp_phase    144 weight stages (24 hidden chunks x 6) through ring slots 0-7               (encoder_mlp.h)
+// LDS map (bytes): [0, 96 K) ring slots 0-5 | [96 K, 132 K) ring slots 6-7 of the MLP phase, overlaid by the K and V^T images of
+// the attention phase (dead while the other phase runs; the stage barriers of either phase separate the last reads of one use
+// from the first writes of the other) | [132 K, +10.5 K) the phase's biases and LayerNorm parameters.
+#pragma once
+#include "common.h"
+#include "encoder_attn_fused.h"
+#include "encoder_mlp.h"
+#include "encoder_panel.h"
+
+namespace pq {
+
+// Per-block parameters, one entry per encoder block: ELEMENT offsets relative to two bases the kernel receives once — the bf16
+// weights (wqkv, wproj, w1, w2) relative to `wbase`, the fp32 vectors relative to `pbase`.  32-bit offsets (instead of twelve
+// 64-bit pointers) keep the scalar register file free, and the weights are addressed through ONE buffer descriptor.
+struct EncBlockParams {
+    unsigned ln1_w, ln1_b, wqkv, bqkv, wproj, bproj, ln2_w, ln2_b, w1, b1, w2, b2;
+};
+
+constexpr int EB_XREG_BYTES = 36864;         // ring slots 6-7 (32 KiB) / K image (18 KiB) + V^T image (17 KiB)
+template <int E>
+constexpr size_t enc_blocks_lds() { return (size_t)6 * 16384 + EB_XREG_BYTES + (size_t)(7 * E) * sizeof(float); }
+
+// ---- x <-> accumulators --------------------------------------------------------------------------------------------------
+// Accumulator layout (encoder_mlp.h): lane (r16, g), row tile j, tile pair q32 = (acc[(q32 >> 2) * 8 + 2 (q32 & 3)], [... + 1]) holds
+// columns 32 q32 + 8 g + [0, 8) of row 32 wid + 16 j + r16 — also the MFMA operand-fragment layout of k-step q32.
+template <int E>
+__device__ __forceinline__ void load_x_to_acc(const float* __restrict__ x, int m0, int M, int wid, int rr, int g, f32x4 (&acc)[E / 16][2]) {
+    constexpr int KSTEPS = E / 32;
+    const bool lo_half = rr < 8;
+    u32x4 raw0[2][KSTEPS], raw1[2][KSTEPS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int rbase = m0 + wid * 32 + j * 16 + (rr & 7);
+        const float* xlo = x + (size_t)min(rbase, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+        const float* xhi = x + (size_t)min(rbase + 8, M - 1) * E + 8 * g + (lo_half ? 0 : 4);
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            raw0[j][ks] = *reinterpret_cast<const u32x4*>(xlo + ks * 32);        // a piece of row (r16 & 7)
+            raw1[j][ks] = *reinterpret_cast<const u32x4*>(xhi + ks * 32);        // a piece of row (r16 & 7) + 8
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const u32x4 p0 = raw0[j][ks], p1 = raw1[j][ks];
+            const u32x4 got = swap_half_rows(lo_half ? p1 : p0);
+            const u32x4 ev = lo_half ? p0 : got, od = lo_half ? got : p1;
+            acc[(ks >> 2) * 8 + 2 * (ks & 3)][j] = f32x4{__uint_as_float(ev[0]), __uint_as_float(ev[1]), __uint_as_float(ev[2]), __uint_as_float(ev[3])};
+            acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j] = f32x4{__uint_as_float(od[0]), __uint_as_float(od[1]), __uint_as_float(od[2]), __uint_as_float(od[3])};
+        }
+}
+
+template <int E>
+__device__ __forceinline__ void store_acc_to_x(float* __restrict__ x, int m0, int M, int wid, int rr, int g, const f32x4 (&acc)[E / 16][2]) {
+    const bool lo_half = rr < 8;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int mrow = m0 + wid * 32 + j * 16;
+        const int r_first = mrow + (rr & 7), r_second = r_first + 8;
+        const int cbase = 8 * g + (lo_half ? 0 : 4);
+#pragma unroll
+        for (int q32 = 0; q32 < E / 32; ++q32) {
+            const f32x4 ta = acc[(q32 >> 2) * 8 + 2 * (q32 & 3)][j], tb = acc[(q32 >> 2) * 8 + 2 * (q32 & 3) + 1][j];
+            const u32x4 pa = {__float_as_uint(ta[0]), __float_as_uint(ta[1]), __float_as_uint(ta[2]), __float_as_uint(ta[3])};
+            const u32x4 pb = {__float_as_uint(tb[0]), __float_as_uint(tb[1]), __float_as_uint(tb[2]), __float_as_uint(tb[3])};
+            const u32x4 got = swap_half_rows(lo_half ? pb : pa);
+            const u32x4 first = lo_half ? pa : got, second = lo_half ? got : pb;
+            const int col = 32 * q32 + cbase;
+            if (r_first < M) *reinterpret_cast<u32x4*>(x + (size_t)r_first * E + col) = first;
+            if (r_second < M) *reinterpret_cast<u32x4*>(x + (size_t)r_second * E + col) = second;
+        }
+    }
+}
+
+// acc += bias[column] (bias in LDS, [E])
+template <int E>
+__device__ __forceinline__ void add_bias_to_acc(const float* sb, int g, f32x4 (&acc)[E / 16][2]) {
+#pragma unroll
+    for (int q32 = 0; q32 < E / 32; ++q32) {
+        const float4 b0 = *reinterpret_cast<const float4*>(sb + 32 * q32 + 8 * g), b1 = *reinterpret_cast<const float4*>(sb + 32 * q32 + 8 * g + 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4& ta = acc[(q32 >> 2) * 8 + 2 * (q32 & 3)][j];
+            f32x4& tb = acc[(q32 >> 2) * 8 + 2 * (q32 & 3) + 1][j];
+            ta[0] += b0.x; ta[1] += b0.y; ta[2] += b0.z; ta[3] += b0.w;
+            tb[0] += b1.x; tb[1] += b1.y; tb[2] += b1.z; tb[3] += b1.w;
+        }
+    }
+}
+
+// LayerNorm of the rows held in the accumulators -> bf16 operand fragments (statistics: own 96 values + the three lanes r16 + 16 k)
+template <int E>
+__device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16][2], const float* sgam, const float* sbet, float eps, int g,
+                                               bf16x8 (&afrag)[2][E / 32]) {
+    constexpr int KSTEPS = E / 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const f32x4 a = acc[(ks >> 2) * 8 + 2 * (ks & 3)][j], b = acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j];
+            s1 += ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3]));
+        }
+        s1 = rows4_sum(s1);
+        const float mean = s1 * (1.0f / E);
+        float s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const f32x4 a = acc[(ks >> 2) * 8 + 2 * (ks & 3)][j], b = acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j];
+            const float d0 = a[0] - mean, d1 = a[1] - mean, d2 = a[2] - mean, d3 = a[3] - mean;
+            const float d4 = b[0] - mean, d5 = b[1] - mean, d6 = b[2] - mean, d7 = b[3] - mean;
+            s2 += ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) + ((d4 * d4 + d5 * d5) + (d6 * d6 + d7 * d7));
+        }
+        s2 = rows4_sum(s2);
+        const float rstd = __builtin_amdgcn_rsqf(s2 * (1.0f / E) + eps);       // v_rsq_f32, 1 ulp
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            const f32x4 a = acc[(ks >> 2) * 8 + 2 * (ks & 3)][j], b = acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j];
+            const float4 ga = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g), gb = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g + 4);
+            const float4 ba = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g), bb = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g + 4);
+            bf16x8 f;
+            f[0] = static_cast<bf16_t>((a[0] - mean) * rstd * ga.x + ba.x); f[1] = static_cast<bf16_t>((a[1] - mean) * rstd * ga.y + ba.y);
+            f[2] = static_cast<bf16_t>((a[2] - mean) * rstd * ga.z + ba.z); f[3] = static_cast<bf16_t>((a[3] - mean) * rstd * ga.w + ba.w);
+            f[4] = static_cast<bf16_t>((b[0] - mean) * rstd * gb.x + bb.x); f[5] = static_cast<bf16_t>((b[1] - mean) * rstd * gb.y + bb.y);
+            f[6] = static_cast<bf16_t>((b[2] - mean) * rstd * gb.z + bb.z); f[7] = static_cast<bf16_t>((b[3] - mean) * rstd * gb.w + bb.w);
+            afrag[j][ks] = f;
+        }
+    }
+}
+
+// The lane id through an instruction the optimiser cannot see through: values derived from it are NOT loop-invariant to the
+// compiler, so the per-lane LDS offsets of a stage are recomputed (half a dozen VALU operations) where they are used instead of being
+// hoisted out of the head / chunk loops, kept live across them and — at 512 registers — spilled, which costs far more than the
+// arithmetic: a scratch reload inside the loop carries an s_waitcnt vmcnt(0) that also drains the LDS-DMA ring.
+__device__ __forceinline__ int opaque_lane() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// byte offset of lane (r16, g)'s first-k-step fragment inside a ring stage; the second k-step's is this ^ 64
+__device__ __forceinline__ int stage_frag_off(int ln) { const int r16 = ln & 15, g_ = ln >> 4; return r16 * 128 + ((g_ ^ (r16 & 7)) << 4); }
+
+// Per-lane constants of the weight stream (identical in both phases): BYTE offsets of this lane's four DMA source pieces relative
+// to the wave-uniform stage origin, for the three (row order, row pitch) combinations the two phases use.  Every DMA is
+//     buffer_load_dwordx4 voffset, s[rsrc], soffset offen lds
+// — one descriptor over the whole bf16 weight pack, the stage origin in an SGPR, one 32-bit VGPR per piece.  (With 64-bit per-lane
+// global pointers the compiler hoists four address pairs per matrix out of the loops, spills them, and every reload inside the
+// loop carries an s_waitcnt vmcnt(0) that drains the LDS-DMA pipeline.)
+struct StreamLane {
+    // A wave's four DMA pieces of a stage cover LDS rows 32 wid + 8 q + (lane >> 3), q = 0..3.  Under the pair permutation their
+    // source rows are row(q) = row(0) + {0, 16, 4, 20}[q] for every lane, so ONE per-lane byte offset per (row order, row pitch)
+    // combination is needed — recomputed from the (opaque) lane id at every issue rather than kept in a register — and the
+    // q-dependent part (a compile-time multiple of the row pitch) goes into the scalar offset operand of the buffer load.
+    enum Kind { K64 = 0, K128 = 1 };     // 64 rows x two 64-k halves | 128 rows x 64 k
+    // `origin`: wave-uniform BYTE offset of (row 0, k 0) of the stage inside the buffer `rsrc` describes; pitch: row pitch in elements
+    template <int KIND>
+    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned origin, int wid, int pitch, unsigned char* dst) {
+        const int lane = opaque_lane();
+        const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;          // XOR swizzle on the source (LDS row & 7 == lane >> 3)
+        const int rho = wid * 32 + (lane >> 3);                        // q = 0
+        const int i = rho >> 4, r16 = rho & 15;
+        unsigned voff;
+        if constexpr (KIND == K64) {
+            const int i4 = i & 3;
+            const int p64 = ((i4 >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i4 & 1) * 4 + (r16 & 3);
+            voff = (unsigned)(p64 * pitch + (rho >> 6) * 64 + src_chunk) * 2u;
+        } else {
+            const int p128 = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
+            voff = (unsigned)(p128 * pitch + src_chunk) * 2u;
+        }
+        constexpr unsigned kRowDelta[4] = {0, 16, 4, 20};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, voff,
+                                                     origin + kRowDelta[q] * 2u * (unsigned)pitch, 0, 0);
+    }
+};
+
+// One weight stage's 32 MFMAs with the ds_read / MFMA interleave pinned (16 fragment reads, 8 up front, one per MFMA pair after)
+#define PQ_STAGE_SCHED()                                                              \
+    do {                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
+        }                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                           \
+    } while (0)
+
+// ---- attention phase: acc += proj(attention(qkv(afrag)))  (bias of proj NOT added) ------------------------------------------
+// LDS: ring slots 0-5 at `ring`, K image at `kimg`, V^T image at `vimg`, qkv bias (3E floats) at `sbq`.  Must be entered with no
+// LDS-DMA in flight; returns with none in flight.  Every wave of the workgroup must call it (barriers inside).
+template <int E>
+__device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* kimg, unsigned char* vimg, const float* sbq,
+                                           __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off, float scale,
+                                           const StreamLane& sl, int wid, int rr, int g, const bf16x8 (&afrag)[2][E / 32],
+                                           f32x4 (&acc2)[E / 16][2]) {
+    constexpr int H = E / 64, KS1 = E / 128, NG = E / 128, SPH = 3 * KS1 + NG;
+    static_assert(E == 384 && SPH % AF_NST == 0, "written for E = 384");
+    auto issue_stage = [&](int h, int t) {            // t is a compile-time constant at every call site
+        unsigned char* dst = ring + (t % AF_NST) * AF_STAGE_BYTES + wid * 4096;
+        // wqkv_off / wproj_off: element offsets of the matrices inside the weight pack
+        if (t < 3 * KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, wid, E, dst);
+        else StreamLane::issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, wid, E, dst);
+    };
+    static_for<0, AF_DIST>([&](auto tc) { issue_stage(0, decltype(tc)::value); });
+    const float sc2 = scale * 1.44269504088896340736f;
+
+    for (int h = 0; h < H; ++h) {
+        f32x4 acc1[4][2];
+        bf16x8 qfrag[2][2], ofrag[2][2];
+        static_for<0, SPH>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            if constexpr (t >= SPH - (AF_DIST - 1)) {
+                if (h == H - 1) wait_vmcnt<4 * (SPH - 1 - t)>(); else wait_vmcnt<4 * (AF_DIST - 1)>();
+            } else {
+                wait_vmcnt<4 * (AF_DIST - 1)>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                constexpr int tn = (t + AF_DIST) % SPH;
+                const int hn = h + (t + AF_DIST) / SPH;
+                if (hn < H) issue_stage(hn, tn);
+            }
+            const int ln = opaque_lane();
+            const int rr = ln & 15, g = ln >> 4;                  // (shadow the arguments: see opaque_lane)
+            const int fo = stage_frag_off(ln);
+            const unsigned char* st0 = ring + (t % AF_NST) * AF_STAGE_BYTES + fo;
+            const unsigned char* st1 = ring + (t % AF_NST) * AF_STAGE_BYTES + (fo ^ 64);
+            bf16x8 wf0[8], wf1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(st0 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(st1 + i * 2048);
+            if constexpr (t < 3 * KS1) {
+                constexpr int ch = t / KS1, tt = t % KS1;
+                if constexpr (tt == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                }
+                if constexpr (ch < 2) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[0][(2 * tt + (i >> 2)) * 2], acc1[i & 3][0], 0, 0, 0);
+                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[1][(2 * tt + (i >> 2)) * 2], acc1[i & 3][1], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[0][(2 * tt + (i >> 2)) * 2 + 1], acc1[i & 3][0], 0, 0, 0);
+                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[1][(2 * tt + (i >> 2)) * 2 + 1], acc1[i & 3][1], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][(2 * tt + (i >> 2)) * 2], wf0[i], acc1[i & 3][0], 0, 0, 0);
+                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[1][(2 * tt + (i >> 2)) * 2], wf0[i], acc1[i & 3][1], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][(2 * tt + (i >> 2)) * 2 + 1], wf1[i], acc1[i & 3][0], 0, 0, 0);
+                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[1][(2 * tt + (i >> 2)) * 2 + 1], wf1[i], acc1[i & 3][1], 0, 0, 0);
+                    }
+                }
+                PQ_STAGE_SCHED();
+                if constexpr (tt == KS1 - 1 && ch < 2) {
+                    // K image row of this lane's token (32 wid + 16 j + r16): see encoder_attn_fused.h
+                    const int krow_j0 = 32 * wid + 16 * ((rr >> 2) & 1) + 4 * (rr >> 3) + (rr & 3);
+                    const float* bp0 = sbq + ch * E + h * 64 + 8 * g;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            bf16x8 f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp0[32 * pr + r]);
+                                f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp0[32 * pr + 4 + r]);
+                            }
+                            if constexpr (ch == 0) qfrag[j][pr] = f;
+                            else *reinterpret_cast<bf16x8*>(kimg + (krow_j0 + 8 * j) * AF_KROWB + 64 * pr + 16 * g) = f;
+                        }
+                }
+                if constexpr (tt == KS1 - 1 && ch == 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float bv = sbq[2 * E + h * 64 + ((i >> 1) & 1) * 32 + (rr >> 2) * 8 + (i & 1) * 4 + (rr & 3)];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float o4[4] = {acc1[i][j][0] + bv, acc1[i][j][1] + bv, acc1[i][j][2] + bv, acc1[i][j][3] + bv};
+                            store4<bf16_t>(reinterpret_cast<bf16_t*>(vimg + (16 * i + rr) * AF_VROWB) + 32 * wid + 16 * j + 4 * g, o4);
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    // S^T = K Q^T and the soft-max, one 16-query row tile at a time (32 score registers live instead of 64; the K
+                    // fragments are read twice, 16 extra ds_read_b128 per head)
+                    bf16x8 pfrag[2][4];
+                    float inv[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 sc[8];
+#pragma unroll
+                        for (int kt = 0; kt < 8; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                            for (int kt = 0; kt < 8; ++kt) {
+                                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + (16 * kt + rr) * AF_KROWB + 64 * ks + 16 * g);
+                                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfrag[j][ks], sc[kt], 0, 0, 0);
+                            }
+                        float mx = -INFINITY;
+#pragma unroll
+                        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+                        mx = rows4_max(mx);
+                        const float mc = mx * sc2;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) {
+                            bf16x8 f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float p0 = exp2f(sc[2 * ks][r] * sc2 - mc), p1 = exp2f(sc[2 * ks + 1][r] * sc2 - mc);
+                                sum += p0 + p1;
+                                f[r] = static_cast<bf16_t>(p0);
+                                f[4 + r] = static_cast<bf16_t>(p1);
+                            }
+                            pfrag[j][ks] = f;
+                        }
+                        sum = rows4_sum(sum);
+                        inv[j] = 1.0f / sum;
+                    }
+                    f32x4 ov[4][2];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) { ov[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vimg + (16 * dt + rr) * AF_VROWB + 64 * ks + 16 * g);
+                            ov[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfrag[0][ks], ov[dt][0], 0, 0, 0);
+                            ov[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfrag[1][ks], ov[dt][1], 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            bf16x8 f;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                f[r] = static_cast<bf16_t>(ov[2 * pr][j][r] * inv[j]);
+                                f[4 + r] = static_cast<bf16_t>(ov[2 * pr + 1][j][r] * inv[j]);
+                            }
+                            ofrag[j][pr] = f;
+                        }
+                }
+            } else {
+                constexpr int ng = t - 3 * KS1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], ofrag[0][0], acc2[ng * 8 + i][0], 0, 0, 0);
+                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], ofrag[1][0], acc2[ng * 8 + i][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], ofrag[0][1], acc2[ng * 8 + i][0], 0, 0, 0);
+                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], ofrag[1][1], acc2[ng * 8 + i][1], 0, 0, 0);
+                }
+                PQ_STAGE_SCHED();
+            }
+        });
+    }
+}
+
+// ---- MLP phase: acc += fc2(gelu(fc1(afrag) + b1))  (bias of fc2 NOT added) --------------------------------------------------
+// LDS: ring slots 0-7 at `ring` (128 KiB), fc1 bias (4E floats) at `sb1`.  The weight-stream schedule is encoder_mlp.h's.
+template <int E>
+__device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
+                                          const StreamLane& sl, int wid, int rr, int g, const bf16x8 (&afrag)[2][E / 32],
+                                          f32x4 (&acc2)[E / 16][2]) {
+    constexpr int F = 4 * E, KS1 = E / 128, NG = E / 128, KS2 = NG, SPC = KS1 + KS2, NCH = F / MLP_HC;
+    static_assert(KS1 == 3 && KS2 == 3 && MLP_NST == 8, "issue schedule: six stages per chunk, eight slots");
+    auto issue_stage = [&](int c, int t, int slot) {
+        unsigned char* dst = ring + slot * MLP_STAGE_BYTES + wid * 4096;
+        if (t < KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, wid, E, dst);
+        else StreamLane::issue<StreamLane::K128>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, wid, F, dst);
+    };
+#pragma unroll
+    for (int s = 0; s < SPC; ++s) issue_stage(0, s, s % MLP_NST);
+    for (int c = 0; c < NCH; ++c) {
+        f32x4 acc1[4][2];
+        bf16x8 hfrag[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        static_for<0, SPC>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int s = c * SPC + t;
+            {       // see encoder_mlp.h for the derivation of the wait counts
+                const bool last = c == NCH - 1;
+                if constexpr (t == 0) wait_vmcnt<20>();
+                else if constexpr (t == 1) wait_vmcnt<16>();
+                else if constexpr (t == 2) wait_vmcnt<12>();
+                else if constexpr (t == 3) { if (last) wait_vmcnt<8>(); else wait_vmcnt<24>(); }
+                else if constexpr (t == 4) { if (last) wait_vmcnt<4>(); else wait_vmcnt<20>(); }
+                else { if (last) wait_vmcnt<0>(); else wait_vmcnt<20>(); }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (t == 4 || t == 5) {
+                if (c + 1 < NCH) issue_stage(c + 1, t, (s + SPC) & (MLP_NST - 1));
+            }
+            const int ln = opaque_lane();
+            const int g = ln >> 4;                                // (shadows the argument: see opaque_lane)
+            const int fo = stage_frag_off(ln);
+            const unsigned char* st0 = ring + (s & (MLP_NST - 1)) * MLP_STAGE_BYTES + fo;
+            const unsigned char* st1 = ring + (s & (MLP_NST - 1)) * MLP_STAGE_BYTES + (fo ^ 64);
+            bf16x8 wf0[8], wf1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(st0 + i * 2048);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(st1 + i * 2048);
+            if constexpr (t < KS1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[0][(2 * t + (i >> 2)) * 2], acc1[i & 3][0], 0, 0, 0);
+                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[1][(2 * t + (i >> 2)) * 2], acc1[i & 3][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[0][(2 * t + (i >> 2)) * 2 + 1], acc1[i & 3][0], 0, 0, 0);
+                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[1][(2 * t + (i >> 2)) * 2 + 1], acc1[i & 3][1], 0, 0, 0);
+                }
+            } else {
+                constexpr int ng = t - KS1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], hfrag[0][0], acc2[ng * 8 + i][0], 0, 0, 0);
+                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], hfrag[1][0], acc2[ng * 8 + i][1], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], hfrag[0][1], acc2[ng * 8 + i][0], 0, 0, 0);
+                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], hfrag[1][1], acc2[ng * 8 + i][1], 0, 0, 0);
+                }
+            }
+            PQ_STAGE_SCHED();
+            if constexpr (t == KS1 - 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const float* bp = sb1 + c * MLP_HC + 32 * pr + 8 * g;
+                        bf16x8 f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
+                            f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
+                        }
+                        hfrag[j][pr] = f;
+                    }
+                if (c + 1 < NCH) {
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) issue_stage(c + 1, tn, ((c + 1) * SPC + tn) & (MLP_NST - 1));
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            }
+        });
+    }
+}
+
+// Copy `n` floats from global memory into LDS (all 256 threads; plain loads: call only while no LDS-DMA is in flight).
+__device__ __forceinline__ void params_to_lds(float* dst, const float* __restrict__ src, int n, int tid) {
+    for (int i = tid; i < n; i += 256) dst[i] = src[i];
+}
+
+template <int E>
+__global__ __launch_bounds__(256, 1)
+void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, unsigned wbytes, const float* __restrict__ pbase,
+                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M) {
+    constexpr int F = 4 * E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;                                  // slots 0-5 (attention) / 0-7 (MLP)
+    unsigned char* kimg = smem + 6 * 16384;                      // overlays ring slots 6-7
+    unsigned char* vimg = kimg + 128 * AF_KROWB;
+    float* sp = reinterpret_cast<float*>(smem + 6 * 16384 + EB_XREG_BYTES);     // phase parameters, <= 7E floats
+    static_assert(128 * AF_KROWB + 64 * AF_VROWB <= EB_XREG_BYTES && 2 * 16384 <= EB_XREG_BYTES, "overlay region");
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 128;
+    StreamLane sl;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, wbytes, 0x00020000);
+
+    f32x4 acc[E / 16][2];
+    bf16x8 afrag[2][E / 32];
+    load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+
+    for (int l = 0; l < depth; ++l) {
+        const EncBlockParams* bp = blocks + l;
+        // ---- attention branch: parameters bqkv (3E) | bproj (E) | ln1 gamma (E) | ln1 beta (E)
+        __syncthreads();                                         // everyone is done with the previous phase's parameters
+        params_to_lds(sp, pbase + bp->bqkv, 3 * E, tid);
+        params_to_lds(sp + 3 * E, pbase + bp->bproj, E, tid);
+        params_to_lds(sp + 4 * E, pbase + bp->ln1_w, E, tid);
+        params_to_lds(sp + 5 * E, pbase + bp->ln1_b, E, tid);
+        __syncthreads();
+        ln_acc_to_frag<E>(acc, sp + 4 * E, sp + 5 * E, eps, g, afrag);
+#if !defined(EB_ABLATE) || EB_ABLATE != 1
+        attn_phase<E>(ring, kimg, vimg, sp, wrsrc, bp->wqkv, bp->wproj, 0.125f, sl, wid, rr, g, afrag, acc);
+#endif
+        add_bias_to_acc<E>(sp + 3 * E, g, acc);
+        // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
+        __syncthreads();
+        params_to_lds(sp, pbase + bp->b1, F, tid);
+        params_to_lds(sp + F, pbase + bp->b2, E, tid);
+        params_to_lds(sp + F + E, pbase + bp->ln2_w, E, tid);
+        params_to_lds(sp + F + 2 * E, pbase + bp->ln2_b, E, tid);
+        __syncthreads();
+        ln_acc_to_frag<E>(acc, sp + F + E, sp + F + 2 * E, eps, g, afrag);
+#if !defined(EB_ABLATE) || EB_ABLATE != 2
+        mlp_phase<E>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, rr, g, afrag, acc);
+#endif
+        add_bias_to_acc<E>(sp + F, g, acc);
+    }
+    store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
+}
+
+// The two branches as stand-alone launches built from the SAME phase functions as enc_blocks_kernel (per-kernel parity tests and
+// the bit-exactness test of the one-launch encoder against a chain of these cover the shared code).
+template <int E>
+__global__ __launch_bounds__(256, 1)
+void attn_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, unsigned wbytes, unsigned wqkv_off, unsigned wproj_off,
+                        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ bqkv,
+                        const float* __restrict__ bproj, float eps, int M) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    unsigned char* kimg = smem + 6 * 16384;
+    unsigned char* vimg = kimg + 128 * AF_KROWB;
+    float* sp = reinterpret_cast<float*>(smem + 6 * 16384 + EB_XREG_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 128;
+    StreamLane sl;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, wbytes, 0x00020000);
+    f32x4 acc[E / 16][2];
+    bf16x8 afrag[2][E / 32];
+    load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+    params_to_lds(sp, bqkv, 3 * E, tid);
+    params_to_lds(sp + 3 * E, bproj, E, tid);
+    params_to_lds(sp + 4 * E, gamma, E, tid);
+    params_to_lds(sp + 5 * E, beta, E, tid);
+    __syncthreads();
+    ln_acc_to_frag<E>(acc, sp + 4 * E, sp + 5 * E, eps, g, afrag);
+    attn_phase<E>(ring, kimg, vimg, sp, wrsrc, wqkv_off, wproj_off, 0.125f, sl, wid, rr, g, afrag, acc);
+    add_bias_to_acc<E>(sp + 3 * E, g, acc);
+    store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
+}
+
+template <int E>
+__global__ __launch_bounds__(256, 1)
+void mlp_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, unsigned wbytes, unsigned w1_off, unsigned w2_off,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ b1,
+                       const float* __restrict__ b2, float eps, int M) {
+    constexpr int F = 4 * E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ring = smem;
+    float* sp = reinterpret_cast<float*>(smem + 6 * 16384 + EB_XREG_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 15, g = lane >> 4;
+    const int m0 = blockIdx.x * 128;
+    StreamLane sl;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, wbytes, 0x00020000);
+    f32x4 acc[E / 16][2];
+    bf16x8 afrag[2][E / 32];
+    load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+    params_to_lds(sp, b1, F, tid);
+    params_to_lds(sp + F, b2, E, tid);
+    params_to_lds(sp + F + E, gamma, E, tid);
+    params_to_lds(sp + F + 2 * E, beta, E, tid);
+    __syncthreads();
+    ln_acc_to_frag<E>(acc, sp + F + E, sp + F + 2 * E, eps, g, afrag);
+    mlp_phase<E>(ring, sp, wrsrc, w1_off, w2_off, sl, wid, rr, g, afrag, acc);
+    add_bias_to_acc<E>(sp + F, g, acc);
+    store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
+}
+
+// Two bf16 matrices addressed through one descriptor: base = the lower of the two addresses, element offsets from it.
+struct WPair { const bf16_t* base; size_t bytes; unsigned off_a, off_b; };
+inline bool make_wpair(const bf16_t* a, size_t a_elems, const bf16_t* b, size_t b_elems, WPair* out) {
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(a), pb = reinterpret_cast<uintptr_t>(b);
+    const uintptr_t lo = pa < pb ? pa : pb, hi = (pa + a_elems * 2 > pb + b_elems * 2) ? pa + a_elems * 2 : pb + b_elems * 2;
+    if (hi - lo >= ((uintptr_t)1 << 32) || ((pa | pb) & 1)) return false;
+    out->base = reinterpret_cast<const bf16_t*>(lo); out->bytes = (size_t)(hi - lo);
+    out->off_a = (unsigned)((pa - lo) / 2); out->off_b = (unsigned)((pb - lo) / 2);
+    return true;
+}
+
+template <int E>
+inline hipError_t launch_attn_branch(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* Wqkv, const float* bqkv,
+                                     const bf16_t* Wproj, const float* bproj, int M) {
+    WPair wp;
+    if (!make_wpair(Wqkv, (size_t)3 * E * E, Wproj, (size_t)E * E, &wp)) return hipErrorInvalidValue;
+    constexpr size_t lds = enc_blocks_lds<E>();
+    auto kern = attn_branch_kernel<E>;
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wp.base, (unsigned)wp.bytes, wp.off_a, wp.off_b, gamma, beta, bqkv, bproj, eps, M);
+    return hipGetLastError();
+}
+
+template <int E>
+inline hipError_t launch_mlp_branch(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1, const float* b1,
+                                    const bf16_t* W2, const float* b2, int M) {
+    WPair wp;
+    if (!make_wpair(W1, (size_t)4 * E * E, W2, (size_t)4 * E * E, &wp)) return hipErrorInvalidValue;
+    constexpr size_t lds = enc_blocks_lds<E>();
+    auto kern = mlp_branch_kernel<E>;
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wp.base, (unsigned)wp.bytes, wp.off_a, wp.off_b, gamma, beta, b1, b2, eps, M);
+    return hipGetLastError();
+}
+
+template <int E>
+inline hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
+                                    int depth, float eps, int M) {
+    constexpr size_t lds = enc_blocks_lds<E>();
+    if (wbytes >= ((size_t)1 << 32)) return hipErrorInvalidValue;       // one 32-bit buffer descriptor covers the weight pack
+    auto kern = enc_blocks_kernel<E>;
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M);
+    return hipGetLastError();
+}
+
+}  // namespace pq

@@ -25,6 +25,8 @@
 // Workgroup id -> tile mapping is XCD-aware: ids that land on the same XCD (id % 8, observed dispatch) walk the n-tiles
 // of the same m-tile back to back, so an A row-panel is fetched into one XCD's L2 once instead of up to 8 times.
 #pragma once
+#include <cstdlib>
+
 #include "common.h"
 
 namespace pq {
@@ -136,6 +138,9 @@ struct ALayerNorm {
 #pragma unroll
                 for (int i = 0; i < E / 64; ++i) v[j][i] = xr[i * 64 + lane];
             }
+            // every lane ends up with the row's mean / rstd (wave_sum broadcasts): lanes 0 .. RB-1 each keep one row's pair and
+            // store it — one unpredicated-by-row store for the RB rows instead of RB lane-0 stores under a saved exec mask
+            float my_mean = 0.f, my_rstd = 0.f;
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 float s = 0.f;
@@ -146,8 +151,9 @@ struct ALayerNorm {
 #pragma unroll
                 for (int i = 0; i < E / 64; ++i) { const float d = v[j][i] - mean; ss += d * d; }
                 const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / E) + eps);
-                if (lane == 0 && r0 + j < bm) { stats[2 * (r0 + j)] = mean; stats[2 * (r0 + j) + 1] = rstd; }
+                if (lane == j) { my_mean = mean; my_rstd = rstd; }
             }
+            if (lane < RB && r0 + lane < bm) { stats[2 * (r0 + lane)] = my_mean; stats[2 * (r0 + lane) + 1] = my_rstd; }
         }
     }
     static constexpr int kRaw = 4 / (int)sizeof(T);                 // fp32 source: 2 loads for a bf16 chunk, 1 for f32
@@ -636,11 +642,14 @@ inline hipError_t launch_gemm(hipStream_t s, const ALoad& aload, const T* W, int
         }
     }
     auto kern = gemm_kernel<T, BM, BN, WM, WN, KB, NBUF, false, ALoad, Epi, SPLIT>;
-    if (lds > 64 * 1024) {
+    // diagnostic (tools/x3_diag2.py): PARSEQ_GEMM_EXTRA_LDS=<bytes> pads the dynamic LDS request, e.g. to keep a second workgroup off the CU
+    static const size_t extra = getenv("PARSEQ_GEMM_EXTRA_LDS") ? (size_t)atol(getenv("PARSEQ_GEMM_EXTRA_LDS")) : 0;
+    const size_t lds_req = lds + extra;
+    if (lds_req > 64 * 1024) {
         static LdsAttr attr;                // one per template instantiation
-        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+        if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds_req); e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds, s, aload, W, ldw, M, N, K, mtiles, ntiles, epi);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(WM * WN * 64), lds_req, s, aload, W, ldw, M, N, K, mtiles, ntiles, epi);
     return hipGetLastError();
 }
 

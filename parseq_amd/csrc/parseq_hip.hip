@@ -24,6 +24,7 @@
 #include "encoder_panel.h"
 #include "encoder_mlp.h"
 #include "encoder_attn_fused.h"
+#include "encoder_blocks.h"
 #include "gemm.h"
 #include "rowops.h"
 #include "train_ops.h"
@@ -79,9 +80,9 @@ struct SplitScope {
 // -------------------------------------------------------------------------------------------------------------------
 // optional per-kernel-family timing with HIP events on the caller's stream (bench.py's roofline leg)
 // -------------------------------------------------------------------------------------------------------------------
-enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_ATTNF, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_DEC_PRE, T_DEC_POST, T_COUNT };
+enum ProfTag { T_PATCH, T_LN, T_QKV, T_ATTN, T_PROJ, T_FC1, T_FC2, T_MLP, T_ATTNF, T_BLOCKS, T_KVMEM, T_DEC_SA, T_DEC_GEMM, T_DEC_CA, T_DEC_LN, T_DEC_MISC, T_DEC_PRE, T_DEC_POST, T_COUNT };
 static const char* const kProfNames[T_COUNT] = {"enc.patch_embed_gemm", "enc.layernorm", "enc.qkv_gemm", "enc.attention", "enc.proj_gemm",
-                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "enc.mlp_fused", "enc.attn_fused", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
+                                                "enc.fc1_gelu_gemm", "enc.fc2_gemm", "enc.mlp_fused", "enc.attn_fused", "enc.blocks_fused", "dec.memory_kv_gemm", "dec.self_attention", "dec.gemm",
                                                 "dec.cross_attention", "dec.layernorm", "dec.misc", "dec.step_pre", "dec.step_post"};
 struct Profiler {
     bool enabled = false;
@@ -342,6 +343,9 @@ struct parseq_plan {
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
     bool fused_attn = getenv("PARSEQ_NO_FUSED_ATTN") == nullptr;   // diagnostics: qkv panel GEMM + attention + proj GEMM instead of encoder_attn_fused.h
     bool mlp_resident = getenv("PARSEQ_MLP_RELOAD") == nullptr;    // diagnostics: the fused MLP's first form (x re-read by the epilogue)
+    bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h
+    EncBlockParams* blocks_dev = nullptr;                           // [enc_depth] parameter pointers of encoder_blocks.h (bf16 mode)
+    std::vector<EncBlockParams> blocks_host;                        // source of the asynchronous upload (must outlive it)
     Profiler prof;
 };
 constexpr int LDT = 32;            // row pitch of token / mask arrays
@@ -390,6 +394,24 @@ static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, i
     if (M >= 4096 && !force_small) HIPCHK((launch_gemm<T, 128, 128, 2, 2, 128, 2>(s, a, W, ldw, M, N, K, epi)));
     else HIPCHK((launch_gemm<T, 64, 64, 2, 2, 768, 1>(s, a, W, ldw, M, N, K, epi)));
     return 0;
+}
+
+// out = epi(LayerNorm(x[M, E]; g, b, eps) W^T): the LayerNorm rides in the GEMM's A-operand loader (gemm.h ALayerNorm).  One
+// exception: bf16x3 products with the 128 x 128 tile configuration (M >= 4096).  That combination gives wrong values in a few rows
+// (rows 6, 7 mod 8 of the later 32-row groups of a tile) whenever two workgroups share a compute unit, non-deterministically
+// (tools/x3_diag2.py reproduces it in isolation; the f32 form of the same kernel, the 64 x 64 tiles and the plain row-major loader
+// with bf16x3 are all exact and deterministic).  Until that is understood the big-M bf16x3 case runs the LayerNorm as its own
+// kernel into `scratch` ([M, E] f32) and the GEMM with the row-major loader.
+template <typename T, int E, typename Epi>
+static int run_ln_gemm(hipStream_t s, const float* x, const float* g, const float* b, float eps, const T* W, int M, int N, const Epi& epi, void* scratch) {
+    if constexpr (sizeof(T) == 4) {
+        if (g_split && M >= 4096) {
+            if (!scratch) return fail(PARSEQ_E_STATE, "run_ln_gemm: no LayerNorm scratch");
+            CHK((run_layernorm<float>(s, x, g, b, reinterpret_cast<float*>(scratch), nullptr, M, E, eps)));
+            return run_gemm<T>(s, ARowMajor<T>{reinterpret_cast<const T*>(scratch), E}, W, E, M, N, E, epi);
+        }
+    }
+    return run_gemm<T>(s, ALayerNorm<T, E>{x, g, b, eps, 0, nullptr}, W, E, M, N, E, epi);
 }
 
 static EpiBase epi_base(int M, int N, const float* bias) { EpiBase b; b.M = M; b.N = N; b.bias = bias; return b; }
@@ -456,6 +478,22 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
         hipLaunchKernelGGL(cvt_f32_to_bf16_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<bf16_t*>(p->wpack), n);
         HIPCHK(hipGetLastError());
         if (!m->vitstr) CHK(build_tables<bf16_t>(p, s));
+        {   // parameter offsets of the encoder blocks for the one-launch encoder (encoder_blocks.h): element offsets, identical in
+            // the fp32 master and in the bf16 copy (both lay the tensors out alike)
+            p->blocks_host.resize(m->cfg.enc_depth);
+            auto off = [&](const std::string& key) { return (unsigned)m->params[m->index.at(key)].offset; };
+            for (int i = 0; i < m->cfg.enc_depth; ++i) {
+                const std::string b = m->enc + "blocks." + std::to_string(i) + ".";
+                EncBlockParams& e = p->blocks_host[i];
+                e.ln1_w = off(b + "norm1.weight"); e.ln1_b = off(b + "norm1.bias");
+                e.wqkv = off(b + "attn.qkv.weight"); e.bqkv = off(b + "attn.qkv.bias");
+                e.wproj = off(b + "attn.proj.weight"); e.bproj = off(b + "attn.proj.bias");
+                e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias");
+                e.w1 = off(b + "mlp.fc1.weight"); e.b1 = off(b + "mlp.fc1.bias");
+                e.w2 = off(b + "mlp.fc2.weight"); e.b2 = off(b + "mlp.fc2.bias");
+            }
+            HIPCHK(hipMemcpyAsync(p->blocks_dev, p->blocks_host.data(), p->blocks_host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice, s));
+        }
         if (p->wstep[0]) {       // decoder weights in MFMA-fragment order for the fused AR step
             const int E = m->cfg.embed_dim, Fd = E * m->cfg.dec_mlp_ratio;
             const Weights<bf16_t> W = weights_of<bf16_t>(p);
@@ -521,6 +559,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t o_t = carve(off, drows * E * 4), o_qc = carve(off, drows * E * 4);
     const size_t o_tok = carve(off, B * LDT * 4), o_kpm = carve(off, B * LDT), o_eos = carve(off, B);
     const size_t o_cloze = carve(off, npos * LDT), o_qmu = carve(off, npos * LDT), o_cnt = carve(off, 64);
+    const size_t o_blocks = carve(off, (size_t)c.enc_depth * sizeof(EncBlockParams));
     p->arena_bytes = off;
     hipError_t e = hipMalloc(&p->arena, off);
     if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
@@ -530,6 +569,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->x = (float*)(a + o_x); p->xn = a + o_xn; p->q = a + o_q; p->k = a + o_k; p->vt = a + o_vt; p->ao = a + o_ao; p->h = a + o_h;
     p->kmem = a + o_kmem; p->vmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
+    p->blocks_dev = reinterpret_cast<EncBlockParams*>(a + o_blocks);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
     int r = pack_weights(p, (hipStream_t)stream);
     if (r != 0) { (void)hipFree(p->arena); delete p; return r; }
@@ -659,10 +699,21 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         return (tiles > slots && rem > 0 && rem <= slots / 16) ? (tiles - rem) * 128 : M;
     };
     // encoder_attn_fused.h: LayerNorm + qkv + attention + proj + residual in one kernel, one image (128 tokens) per workgroup
+    // (one workgroup per image whatever the batch: with a partial last round of workgroups the fused kernels just run it — routing
+    // those images through other kernels would make an image's result depend on its position in the batch)
     const bool fused_attn = kBf16 && E == 384 && N == ATT_N && p->fused_attn;
-    const int Ma = fused_attn ? main_rows(1) : 0;
+    const int Ma = fused_attn ? M : 0;
     const int Mq = panel_qkv ? main_rows(2) : M, Mm = fused_mlp ? main_rows(1) : M;
-    for (int i = 0; i < c.enc_depth; ++i) {
+    // encoder_blocks.h: all blocks in ONE launch, x resident in registers from the first LayerNorm to the last residual
+    const bool fused_blocks = fused_attn && fused_mlp && p->fused_blocks && p->mlp_resident && M % 128 == 0;
+    if (fused_blocks) {
+        if constexpr (kBf16) {
+            ProfScope ps_(&p->prof, T_BLOCKS, s);
+            HIPCHK((launch_enc_blocks<384>(s, p->x, reinterpret_cast<const bf16_t*>(p->wpack), m->master_elems * sizeof(bf16_t), m->master,
+                                           p->blocks_dev, c.enc_depth, c.enc_ln_eps, M)));
+        }
+    }
+    for (int i = 0; i < (fused_blocks ? 0 : c.enc_depth); ++i) {
         const std::string b = pe + "blocks." + std::to_string(i) + ".";
         if (fused_attn && Ma == M) {
             if constexpr (kBf16) {
@@ -857,8 +908,8 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
         // model.py:100-102 with a caller-supplied tgt_query [B, Lq, E]: q-projection of norm_q(query) at run time (the position-query
         // tables do not apply), scores against the content-key table, residual onto the caller's query itself
         const float qscale = sqrtf(1.0f / (float)DEC_HD);
-        { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{user_query, m->p(d + "norm_q.weight"), m->p(d + "norm_q.bias"), c.dec_ln_eps, 0, nullptr},
-                         W.w(d + "self_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "self_attn.in_proj_bias"), p->qc, E, qscale)))); }
+        { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_ln_gemm<T, E>(s, user_query, m->p(d + "norm_q.weight"), m->p(d + "norm_q.bias"), c.dec_ln_eps,
+                         W.w(d + "self_attn.in_proj_weight"), M, E, epi_store<float>(M, E, m->p(d + "self_attn.in_proj_bias"), p->qc, E, qscale), p->tn))); }
         {
             ProfScope ps_(&p->prof, T_DEC_SA, s);
             hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
@@ -883,20 +934,20 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
                      epi_table(M, E, m->p(d + "self_attn.out_proj.bias"), p->t, E, m->p("pos_queries"), E, Lq, i0)))); }
     }
     // cross-attention against memory (head-split K / V^T cached in the plan); norm1 is fused into the q-projection's A operand
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), c.dec_ln_eps, 0, nullptr},
-                     W.w(d + "cross_attn.in_proj_weight"), E, M, E, E, epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E)))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_ln_gemm<T, E>(s, p->t, m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), c.dec_ln_eps,
+                     W.w(d + "cross_attn.in_proj_weight"), M, E, epi_store<float>(M, E, m->p(d + "cross_attn.in_proj_bias"), p->qc, E), p->tn))); }
     {
         ProfScope ps_(&p->prof, T_DEC_CA, s);
         CHK((run_cross_attention<T, E>(p, s, B, Lq, scale, ca)));
     }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{ca, E}, W.w(d + "cross_attn.out_proj.weight"), E, M, E, E, epi_resid(M, E, m->p(d + "cross_attn.out_proj.bias"), p->t, E)))); }
     // MLP (norm2 fused into linear1's A operand)
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps, 0, nullptr},
-                     W.w(d + "linear1.weight"), E, M, Fd, E, epi_gelu<T>(M, Fd, m->p(d + "linear1.bias"), hdn, Fd)))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_ln_gemm<T, E>(s, p->t, m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps,
+                     W.w(d + "linear1.weight"), M, Fd, epi_gelu<T>(M, Fd, m->p(d + "linear1.bias"), hdn, Fd), p->tn))); }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{hdn, Fd}, W.w(d + "linear2.weight"), Fd, M, E, Fd, epi_resid(M, E, m->p(d + "linear2.bias"), p->t, E)))); }
     // decoder.norm fused into the head's A operand
-    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ALayerNorm<T, E>{p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps, 0, nullptr},
-                     W.w("head.weight"), E, M, C, E, epi_store<float>(M, C, m->p("head.bias"), logits, C, 1.f, Lq, Ltot, i0)))); }
+    { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_ln_gemm<T, E>(s, p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps,
+                     W.w("head.weight"), M, C, epi_store<float>(M, C, m->p("head.bias"), logits, C, 1.f, Lq, Ltot, i0), p->tn))); }
     if (argmax_mode) {       // only meaningful for Lq == 1: greedy pick of position i0 into tok[:, i0 + 1]
         hipLaunchKernelGGL(ar_argmax_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, Ltot, C, p->tok, LDT, i0, B, c.eos_id,
                            p->eos_seen, eos_rows, ar_len, argmax_mode == 2 ? 1 : 0);
@@ -1076,8 +1127,12 @@ static int decode_entry(parseq_plan* p, const int32_t* tokens, int batch, int ct
         qm = p->qmask_user;
     }
     const bool keep_t = hidden_out != nullptr;
-    if (p->precision == PARSEQ_BF16) CHK((decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t, user_query)));
-    else CHK((decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, logits_out, q_len, 0, keep_t, user_query)));
+    // decode_pass writes logits[b][q_start + qi] of a [B][Ltot][C] tensor (the forward's layout).  Here the caller's tensor is
+    // [batch][q_len][C] with row qi: hand over the base shifted back by q_start rows, so that the rows written are exactly
+    // [b * q_len + qi] (writing at b * q_len + q_start + qi ran q_start rows past the end of the buffer for q_start > 0).
+    float* lbase = logits_out - (size_t)q_start * p->m->classes;
+    if (p->precision == PARSEQ_BF16) CHK((decode_pass<bf16_t>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, lbase, q_len, 0, keep_t, user_query)));
+    else CHK((decode_pass<float>(p, s, batch, ctx_len, q_start, q_len, qm, kpm, lbase, q_len, 0, keep_t, user_query)));
     if (hidden_out) {      // model.decode's return value: decoder.norm of the query stream (modules.py:124), fp32
         const parseq_model* m = p->m;
         CHK((run_layernorm<float>(s, p->t, m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), hidden_out, nullptr, batch * q_len,
@@ -1698,6 +1753,18 @@ extern "C" int parseq_op_linear(const void* A, const void* W, const float* bias,
     return op_linear_impl<float>((const float*)A, (const float*)W, bias, C, act, M, N, K, (hipStream_t)stream);
 }
 
+// C[M, N] (fp32) = LayerNorm(x[M, 384]; gamma, beta, eps) W^T + bias through the generic tile GEMM with the LayerNorm fused into the
+// A-operand loader (the decoder's q-projection / linear1 / head form); dtype PARSEQ_F32 or PARSEQ_BF16X3 (W then block-planar).
+extern "C" int parseq_op_ln_linear(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, float* C_,
+                                   int dtype, int M, int N, float eps, void* stream) {
+    CHK(check_arch());
+    if (!x || !gamma || !beta || !W || !C_ || M <= 0 || N <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
+    if (dtype != PARSEQ_F32 && dtype != PARSEQ_BF16X3) return fail(PARSEQ_E_INVALID, "dtype %d", dtype);
+    SplitScope ss(dtype == PARSEQ_BF16X3);
+    return run_gemm<float>((hipStream_t)stream, ALayerNorm<float, 384>{x, gamma, beta, eps, 0, nullptr}, (const float*)W, 384, M, N, 384,
+                           epi_store<float>(M, N, bias, C_, N));
+}
+
 extern "C" int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream) {
     CHK(check_arch());
     if (!src || !dst || numel <= 0 || (numel % 32)) return fail(PARSEQ_E_INVALID, "bad argument (numel must be a multiple of 32)");
@@ -1760,6 +1827,7 @@ extern "C" int parseq_op_mlp_variant(float* x, const float* gamma, const float* 
         case 4: HIPCHK((launch_fused_mlp<384, 4>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
         case 5: HIPCHK((launch_fused_mlp<384, 5>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
         case 10: HIPCHK((launch_fused_mlp<384, 0, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;   // x resident in the accumulators
+        case 11: HIPCHK((launch_mlp_branch<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;            // shared-phase form (encoder_blocks.h)
         case 16: {  // stamps of the resident form
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
             HIPCHK((launch_fused_mlp<384, 6, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }
@@ -1778,11 +1846,53 @@ extern "C" int parseq_op_attn_fused(float* x, const float* gamma, const float* b
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
         case 0: HIPCHK((launch_fused_attn<384, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M))); break;
+        case 1: HIPCHK((launch_attn_branch<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M))); break;   // shared-phase form (encoder_blocks.h)
         case 6: {   // phase time stamps behind the matrix (see parseq_op_mlp_variant)
             unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
             HIPCHK((launch_fused_attn<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M, dbg))); break; }
         default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
     }
+    return 0;
+}
+
+extern "C" int parseq_op_enc_blocks(float* x, const void* const* block_ptrs, int depth, int M, void* table_ws, void* stream) {
+    CHK(check_arch());
+    if (!x || !block_ptrs || !table_ws || depth <= 0 || M <= 0 || (M % 128)) return fail(PARSEQ_E_INVALID, "bad argument (M must be a multiple of 128: whole images)");
+    // the kernel addresses the bf16 matrices relative to one base through a 32-bit buffer descriptor and the fp32 vectors relative to
+    // another: take the lowest address of each kind as the base
+    static const int kW[4] = {2, 4, 8, 10};                                  // wqkv, wproj, w1, w2
+    static const size_t kWElems[4] = {(size_t)1152 * 384, (size_t)384 * 384, (size_t)1536 * 384, (size_t)384 * 1536};
+    uintptr_t wlo = ~(uintptr_t)0, whi = 0, plo = ~(uintptr_t)0, phi = 0;
+    for (int i = 0; i < depth; ++i) {
+        const void* const* q = block_ptrs + (size_t)i * 12;
+        for (int k = 0; k < 12; ++k) {
+            if (!q[k]) return fail(PARSEQ_E_INVALID, "block %d: null pointer %d", i, k);
+            const uintptr_t a = reinterpret_cast<uintptr_t>(q[k]);
+            int wi = -1;
+            for (int j = 0; j < 4; ++j) if (kW[j] == k) wi = j;
+            if (wi >= 0) { wlo = std::min(wlo, a); whi = std::max(whi, a + kWElems[wi] * 2); }
+            else { plo = std::min(plo, a); phi = std::max(phi, a + 1536 * 4); }
+        }
+    }
+    if (whi - wlo >= ((uintptr_t)1 << 32) || phi - plo >= ((uintptr_t)1 << 34) || (wlo & 1) || (plo & 3))
+        return fail(PARSEQ_E_INVALID, "block parameters are spread over more than 4 GiB of address space");
+    std::vector<EncBlockParams> host(depth);
+    for (int i = 0; i < depth; ++i) {
+        const void* const* q = block_ptrs + (size_t)i * 12;
+        unsigned o[12];
+        for (int k = 0; k < 12; ++k) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(q[k]);
+            const bool isw = k == 2 || k == 4 || k == 8 || k == 10;
+            if ((a - (isw ? wlo : plo)) % (isw ? 2 : 4)) return fail(PARSEQ_E_INVALID, "block %d: pointer %d is misaligned", i, k);
+            o[k] = (unsigned)((a - (isw ? wlo : plo)) / (isw ? 2 : 4));
+        }
+        EncBlockParams& e = host[i];
+        e.ln1_w = o[0]; e.ln1_b = o[1]; e.wqkv = o[2]; e.bqkv = o[3]; e.wproj = o[4]; e.bproj = o[5];
+        e.ln2_w = o[6]; e.ln2_b = o[7]; e.w1 = o[8]; e.b1 = o[9]; e.w2 = o[10]; e.b2 = o[11];
+    }
+    HIPCHK(hipMemcpy(table_ws, host.data(), host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice));      // test hook: synchronous upload
+    HIPCHK((launch_enc_blocks<384>((hipStream_t)stream, x, reinterpret_cast<const bf16_t*>(wlo), (size_t)(whi - wlo), reinterpret_cast<const float*>(plo),
+                                   reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M)));
     return 0;
 }
 

@@ -234,11 +234,17 @@ class _NativeBacked(nn.Module):
             images = images.float()
         return images.contiguous()
 
+    @staticmethod
+    def _version_of(t: Tensor):
+        """In-place-modification counter, or None for tensors that do not keep one (created under torch.inference_mode): an
+        in-place edit of such a tensor cannot be noticed, so it is never taken as "unchanged"."""
+        return None if t.is_inference() else t._version
+
     def _signature(self):
         # device, storage addresses and autograd versions of every parameter: load_state_dict, .to(), optimiser steps and
         # in-place ops (also under no_grad) change it; writes through `param.data` do not bump the version and are NOT seen
         params = list(self.parameters())
-        return (str(self._device), tuple(p.data_ptr() for p in params), tuple(p._version for p in params))
+        return (str(self._device), tuple(p.data_ptr() for p in params), tuple(self._version_of(p) for p in params))
 
     def _sync_native(self):
         st: _NativeState = self._native_state
@@ -383,11 +389,6 @@ class PARSeq(_NativeBacked):
         import weakref
         self._memory_key = (weakref.ref(memory), self._version_of(memory), self._native_state.signature)
 
-    @staticmethod
-    def _version_of(t: Tensor):
-        """In-place-modification counter, or None for tensors that do not keep one (created under torch.inference_mode): an
-        in-place edit of such a tensor cannot be noticed, so it is never taken as "the cached memory" — it is re-projected."""
-        return None if t.is_inference() else t._version
 
     def decode(self, tgt: Tensor, memory: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,
                tgt_padding_mask: Optional[Tensor] = None, tgt_query: Optional[Tensor] = None,

@@ -333,8 +333,10 @@ def test_validation_step_loss(golden):
 
 
 def test_batch_520_tail_tiles_bf16(golden):
-    """520 crops = 520 row tiles on 256 CUs: the 8 tiles left over after two whole rounds of the fused MLP kernel go through
-    the per-op kernels instead of costing a third round; those crops agree within the bf16 bar, the others bit for bit."""
+    """520 crops = 520 workgroups of the one-launch encoder on 256 CUs (two whole rounds and eight left over): an image's result
+    must not depend on how many other images are in the batch or where it sits — bit for bit the batch-8 result.  (Without
+    the one-launch encoder, PARSEQ_NO_FUSED_BLOCKS, the tail tiles of the fused MLP kernel go through the per-op kernels and
+    agree within the bf16 bar only.)"""
     g, _ = golden('parseq')
     m = make_model('parseq', 'bf16')
     idx = torch.arange(520) % 8
