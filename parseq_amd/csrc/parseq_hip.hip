@@ -312,6 +312,7 @@ __global__ void insert_cls_kernel(const float* __restrict__ xp, const float* __r
     reinterpret_cast<float4*>(x)[i4] = v;
 }
 
+constexpr int PQ_MAX_CHAINS = 8;
 struct parseq_plan {
     parseq_model* m = nullptr;
     int max_batch = 0;
@@ -337,7 +338,16 @@ struct parseq_plan {
     unsigned char* eos_seen = nullptr;
     unsigned char* cloze = nullptr;  // [npos][LDT]
     unsigned char* qmask_user = nullptr;  // [npos][LDT] staging for parseq_decode_logits
-    int* counters = nullptr;       // [0] eos_rows, [1] ar_len
+    int* counters = nullptr;       // per AR chain k: [2k] eos_rows, [2k + 1] ar_len
+    // AR decoding in sub-batches ("chains"): the fused AR step kernels are latency-bound chains of small launches that use a few
+    // dozen CUs each, so several independent sub-batches of the images CAN run their 26-step loops concurrently on side streams
+    // (fork after the encoder, join before the refinement; PARSEQ_AR_CHAINS=n).  Measured on MI355X at batch 512 this is a loss —
+    // 88.1 / 86.5 / 70.0 / 56.2 k images/s one forward at a time with 1 / 2 / 4 / 8 chains (profiles/r02_ar_chains_sweep.log):
+    // launches from several HIP streams are not dispatched concurrently enough to overlap 20-microsecond kernels, they add
+    // cross-queue dependency latency to every one of them — so the default is ONE chain; the mechanism stays as a tested option.
+    int ar_chains = 1;
+    hipStream_t chain_stream[PQ_MAX_CHAINS - 1] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[PQ_MAX_CHAINS - 1] = {};
     int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
     int num_cus = 256;             // compute units of the device (tail-round avoidance of the one- and two-workgroup-per-CU kernels)
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
@@ -526,6 +536,7 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
     return 0;
 }
 
+extern "C" void parseq_plan_destroy(parseq_plan* p);
 extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out) {
     if (!m || !out || max_batch <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
     if (precision != PARSEQ_F32 && precision != PARSEQ_BF16 && precision != PARSEQ_BF16X3) return fail(PARSEQ_E_INVALID, "precision %d", precision);
@@ -571,8 +582,14 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
     p->blocks_dev = reinterpret_cast<EncBlockParams*>(a + o_blocks);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
+    if (const char* e_ = getenv("PARSEQ_AR_CHAINS")) p->ar_chains = std::min(std::max(atoi(e_), 1), PQ_MAX_CHAINS);
+    bool ok_ = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; ok_ && k < PQ_MAX_CHAINS - 1; ++k)
+        ok_ = hipStreamCreateWithFlags(&p->chain_stream[k], hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok_) p->ar_chains = 1;                  // no side streams: single chain on the caller's stream
     int r = pack_weights(p, (hipStream_t)stream);
-    if (r != 0) { (void)hipFree(p->arena); delete p; return r; }
+    if (r != 0) { parseq_plan_destroy(p); return r; }
     *out = p;
     return 0;
 }
@@ -586,6 +603,11 @@ extern "C" int parseq_plan_refresh(parseq_plan* p, void* stream) {
 extern "C" void parseq_plan_destroy(parseq_plan* p) {
     if (!p) return;
     DevGuard dg(p->m->device);
+    for (int k = 0; k < PQ_MAX_CHAINS - 1; ++k) {
+        if (p->chain_stream[k]) { (void)hipStreamSynchronize(p->chain_stream[k]); (void)hipStreamDestroy(p->chain_stream[k]); }
+        if (p->ev_join[k]) (void)hipEventDestroy(p->ev_join[k]);
+    }
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->arena) (void)hipFree(p->arena);
     delete p;
 }
@@ -827,9 +849,11 @@ extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtyp
 // Cross-attention of Lq queries per image against the plan's cached memory K / V: tuned kernels for 128 memory tokens
 // (streaming AR kernel, MFMA multi-query kernel), the key-count-generic kernel otherwise.
 template <typename T, int E>
-static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca) {
+static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca, int b0 = 0) {
+    // b0: first image of a sub-batch (AR chains); `ca` is the caller's (already offset) output, q and the memory K / V are offset here
     const int H = p->m->cfg.dec_heads, NK = p->m->tokens;
-    const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
+    const T* kmem = reinterpret_cast<const T*>(p->kmem) + (size_t)b0 * NK * E; const T* vmem = reinterpret_cast<const T*>(p->vmem) + (size_t)b0 * NK * E;
+    const float* qc_ = p->qc + (size_t)b0 * Lq * E;
     if (NK != 128) {
         if constexpr (sizeof(T) == 2) {
             const int nt16 = (NK + 15) / 16;
@@ -838,7 +862,7 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
                 static LdsAttr attr_;                                                                                                    \
                 HIPCHK(attr_.ensure(reinterpret_cast<const void*>(dec_cross_attn_mfma_n_kernel<NT>), dec_cross_attn_mfma_n_lds<NT>()));  \
                 hipLaunchKernelGGL((dec_cross_attn_mfma_n_kernel<NT>), dim3((B * H + 1) / 2), dim3(128), dec_cross_attn_mfma_n_lds<NT>(), s, \
-                                   p->qc, kmem, vmem, H, Lq, NK, scale, ca, B * H);                                                      \
+                                   qc_, kmem, vmem, H, Lq, NK, scale, ca, B * H);                                                      \
                 HIPCHK(hipGetLastError());                                                                                                \
                 return 0;                                                                                                                 \
             }
@@ -847,13 +871,13 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
         }
         const size_t lds = dec_cross_attn_generic_lds(NK);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((dec_cross_attn_generic_kernel<T>), dim3(B * H), dim3(128), lds, s, p->qc, kmem, vmem, H, Lq, NK, scale, ca);
+        hipLaunchKernelGGL((dec_cross_attn_generic_kernel<T>), dim3(B * H), dim3(128), lds, s, qc_, kmem, vmem, H, Lq, NK, scale, ca);
     } else if (Lq == 1) {
-        hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, p->qc, kmem, vmem, scale, ca);
+        hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, qc_, kmem, vmem, scale, ca);
     } else if constexpr (sizeof(T) == 2) {
-        hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca, B * H);
+        hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
     } else {
-        hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, p->qc, kmem, vmem, H, Lq, scale, ca);
+        hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -972,15 +996,21 @@ static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int
 // The whole AR loop with the mid / cross-attention / mlp arrangement of decoder_step.h (bf16, E <= 384): step i's logits are
 // produced by the mid kernel of step i + 1 (and by one trailing finish-only launch after the last step).
 template <int E>
-static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing) {
+static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chain, int num_steps, float* logits_all, bool testing) {
+    // images [b0, b0 + Bc) of the batch: every per-row buffer is offset to the sub-batch, the counters are the chain's own
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
-    const int M = B, C = m->classes, npos = c.max_label_length + 1;
+    const int M = Bc, C = m->classes, npos = c.max_label_length + 1;
     const std::string d = "decoder.layers.0.";
-    int* eos_rows = p->counters; int* ar_len = p->counters + 1;
-    bf16_t* ca = reinterpret_cast<bf16_t*>(p->ca);
-    float* partial = reinterpret_cast<float*>(p->hdn);          // [ds_split][M][E] (the generic path's MLP hidden buffer is idle here)
-    float* tq = p->qc;                                          // t' lives in the q-projection buffer once the cross-attention has consumed it
+    int* eos_rows = p->counters + 2 * chain; int* ar_len = p->counters + 2 * chain + 1;
+    bf16_t* ca = reinterpret_cast<bf16_t*>(p->ca) + (size_t)b0 * E;
+    // linear2 partial sums [ds_split][M][E] f32 (the generic path's MLP hidden buffer is idle here): one region per chain
+    float* partial = reinterpret_cast<float*>(p->hdn) + (size_t)ds_split<E>() * b0 * E;
+    float* tq = p->qc + (size_t)b0 * E;                                   // t' lives in the q-projection buffer once the cross-attention has consumed it
+    float* t = p->t + (size_t)b0 * E;
+    int* tok = p->tok + (size_t)b0 * LDT;
+    unsigned char* eos_seen = p->eos_seen + b0;
+    float* logits = logits_all + (size_t)b0 * num_steps * C;
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
     static LdsAttr attr_mid, attr_mlp;
@@ -994,24 +1024,48 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, fl
             ProfScope ps_(&p->prof, T_DEC_PRE, s);
             hipLaunchKernelGGL((dec_step_mid_kernel<E>), grid, block, dec_step_mid_lds<E>(), s, do_finish, do_start, i, M,
                                tq, partial, m->p(d + "linear2.bias"), m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps,
-                               p->wstep[5], m->p("head.bias"), C, logits, num_steps, argmax_mode, c.eos_id, p->eos_seen, eos_rows, ar_len,
-                               p->stab, reinterpret_cast<const bf16_t*>(p->kvtab), p->tok, LDT, c.num_tokens, npos, p->wstep[0],
+                               p->wstep[5], m->p("head.bias"), C, logits, num_steps, argmax_mode, c.eos_id, eos_seen, eos_rows, ar_len,
+                               p->stab, reinterpret_cast<const bf16_t*>(p->kvtab), tok, LDT, c.num_tokens, npos, p->wstep[0],
                                m->p(d + "self_attn.out_proj.bias"), m->p("pos_queries"), m->p(d + "norm1.weight"), m->p(d + "norm1.bias"),
-                               p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), p->t, p->qc);
+                               p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), t, tq);
             HIPCHK(hipGetLastError());
         }
         if (!do_start) break;
         {
             ProfScope ps_(&p->prof, T_DEC_CA, s);
-            CHK((run_cross_attention<bf16_t, E>(p, s, B, 1, scale, ca)));
+            CHK((run_cross_attention<bf16_t, E>(p, s, Bc, 1, scale, ca, b0)));
         }
         {
             ProfScope ps_(&p->prof, T_DEC_POST, s);
-            hipLaunchKernelGGL((dec_step_mlp_kernel<E>), dim3(grid.x * ds_split<E>()), block, dec_step_mlp_lds<E>(), s, ca, p->t, p->wstep[2],
+            hipLaunchKernelGGL((dec_step_mlp_kernel<E>), dim3(grid.x * ds_split<E>()), block, dec_step_mlp_lds<E>(), s, ca, t, p->wstep[2],
                                m->p(d + "cross_attn.out_proj.bias"), m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps,
                                p->wstep[3], m->p(d + "linear1.bias"), p->wstep[4], tq, partial, M);
             HIPCHK(hipGetLastError());
         }
+    }
+    return 0;
+}
+
+// The fused AR loop over the whole batch as `chains` concurrent sub-batch loops: chain 0 on the caller's stream, the others on the
+// plan's side streams between a fork event (the encoder and the memory K / V projection are done) and join events.
+template <int E>
+static int ar_loop_chains(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing, int* chains_used) {
+    int chains = std::min(p->ar_chains, std::max(1, B / 64));                 // at least 64 images (4 row tiles) per chain
+    if (p->prof.enabled) chains = 1;                                          // per-family event timing brackets one stream
+    const int tiles = (B + DS_ROWS - 1) / DS_ROWS, per = (tiles + chains - 1) / chains * DS_ROWS;
+    chains = (B + per - 1) / per;
+    *chains_used = chains;
+    if (chains > 1) {
+        HIPCHK(hipEventRecord(p->ev_fork, s));
+        for (int k = 1; k < chains; ++k) HIPCHK(hipStreamWaitEvent(p->chain_stream[k - 1], p->ev_fork, 0));
+    }
+    for (int k = 0; k < chains; ++k) {
+        const int b0 = k * per, bc = std::min(per, B - b0);
+        CHK((ar_loop_fused<E>(p, k == 0 ? s : p->chain_stream[k - 1], b0, bc, k, num_steps, logits, testing)));
+    }
+    for (int k = 1; k < chains; ++k) {
+        HIPCHK(hipEventRecord(p->ev_join[k - 1], p->chain_stream[k - 1]));
+        HIPCHK(hipStreamWaitEvent(s, p->ev_join[k - 1], 0));
     }
     return 0;
 }
@@ -1023,7 +1077,8 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     const int C = m->classes;
     const bool ar = flags & PARSEQ_FLAG_DECODE_AR, testing = flags & PARSEQ_FLAG_TESTING;
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
-    hipLaunchKernelGGL(ar_init_kernel, dim3((B * LDT + 255) / 256), dim3(256), 0, s, p->tok, LDT, B, c.bos_id, c.pad_id, p->eos_seen, eos_rows, ar_len, num_steps);
+    int chains_used = 1;
+    hipLaunchKernelGGL(ar_init_kernel, dim3((B * LDT + 255) / 256), dim3(256), 0, s, p->tok, LDT, B, c.bos_id, c.pad_id, p->eos_seen, p->counters, 2 * PQ_MAX_CHAINS, num_steps);
     HIPCHK(hipGetLastError());
     if (ar) {
         // model.py:119-147.  All num_steps steps are always run (no per-step host sync); the step at which the reference
@@ -1031,8 +1086,8 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
         bool done = false;
         if constexpr (sizeof(T) == 2) {
             if (p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4 && !getenv("PARSEQ_STEP_PREPOST")) {
-                if (c.embed_dim == 384) { CHK((ar_loop_fused<384>(p, s, B, num_steps, logits, testing))); done = true; }
-                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192>(p, s, B, num_steps, logits, testing))); done = true; }
+                if (c.embed_dim == 384) { CHK((ar_loop_chains<384>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_chains<192>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
             }
         }
         for (int i = 0; !done && i < num_steps; ++i) {
@@ -1051,8 +1106,13 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     }
     int L = num_steps;
     if (ar && testing && refine_iters == 0) {
-        HIPCHK(hipMemcpyAsync(&L, ar_len, sizeof(int), hipMemcpyDeviceToHost, s));
+        // the reference stops after the first step at which EVERY row holds an EOS: each chain recorded that step for its own rows
+        // (num_steps if it never happened), the batch-level length is the maximum (the condition is monotone in the step)
+        int cnt[2 * PQ_MAX_CHAINS];
+        HIPCHK(hipMemcpyAsync(cnt, p->counters, sizeof(int) * 2 * chains_used, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        L = 0;
+        for (int k = 0; k < chains_used; ++k) L = std::max(L, cnt[2 * k + 1]);
     }
     if (out_len) *out_len = L;
     return 0;

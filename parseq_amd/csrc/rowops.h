@@ -156,12 +156,13 @@ void refine_prep_kernel(const float* __restrict__ logits, int L, int C, int* __r
     }
 }
 
+// counters: ncounters ints, pairs (rows that hold an EOS, step count the reference would have returned) per AR chain
 __global__ void ar_init_kernel(int* __restrict__ tok, int ldt, int B, int bos_id, int pad_id, unsigned char* __restrict__ eos_seen,
-                               int* __restrict__ eos_rows, int* __restrict__ ar_len, int num_steps) {
+                               int* __restrict__ counters, int ncounters, int num_steps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * ldt) tok[i] = (i % ldt == 0) ? bos_id : pad_id;
     if (i < B) eos_seen[i] = 0;
-    if (i == 0) { *eos_rows = 0; *ar_len = num_steps; }
+    if (i < ncounters) counters[i] = (i & 1) ? num_steps : 0;
 }
 
 // Device-side numeric half of `Tokenizer.decode(logits.softmax(-1))` (strhub/models/base.py:132-135,
