@@ -2,7 +2,7 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as the MI355X guide
 prescribes).  Values are KiB per dispatch; on gfx950 FETCH_SIZE counts 128-byte requests of wide coalesced reads at 64 B
 (MI355X_MICROARCH.md section HBM), so the fetch side is reported raw and doubled.
-Usage: python tools/pmc_summary.py <fetch_results.db> <write_results.db> [--json out.json]"""
+Usage: python tools/pmc_summary.py <fetch_results.db> <write_results.db> [--json out.json] [--batch B]"""
 import json
 import re
 import sqlite3
@@ -20,7 +20,7 @@ def per_kernel(path, counter):
     return {r[0]: (r[1], r[2], r[3]) for r in rows}
 
 
-FAMILY = {'fused_mlp_kernel': 'enc.mlp_fused', 'ln_panel_gemm_kernelILi384ENS_10PanelHeads': 'enc.qkv_gemm', 'attn_mfma_kernel': 'enc.attention',
+FAMILY = {'enc_blocks_kernel': 'enc.blocks_fused', 'fused_attn_kernel': 'enc.attn_fused', 'fused_mlp_kernel': 'enc.mlp_fused', 'ln_panel_gemm_kernelILi384ENS_10PanelHeads': 'enc.qkv_gemm', 'attn_mfma_kernel': 'enc.attention',
           'dec_cross_attn_ar_kernel': 'dec.cross_attention'}
 
 
@@ -28,6 +28,7 @@ def main():
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
     out = {}
+    batch = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 512
     print('| kernel | dispatches | FETCH_SIZE MB (raw / x2) | WRITE_SIZE MB | avg us (profiled) |')
     print('|---|---:|---:|---:|---:|')
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
@@ -37,7 +38,7 @@ def main():
         for pat, fam in FAMILY.items():
             if pat in k and fam not in out:
                 out[fam] = {'fetch_bytes_raw': f_kib * 1024, 'fetch_bytes_x2_gfx950_correction': 2 * f_kib * 1024, 'write_bytes': w_kib * 1024,
-                            'hbm_bytes': 2 * f_kib * 1024 + w_kib * 1024, 'dispatches': n}
+                            'hbm_bytes': 2 * f_kib * 1024 + w_kib * 1024, 'dispatches': n, 'batch': batch}
     if '--json' in sys.argv:
         json.dump(out, open(sys.argv[sys.argv.index('--json') + 1], 'w'), indent=1)
 
