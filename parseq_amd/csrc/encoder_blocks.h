@@ -12,11 +12,11 @@
 // The two phases are device functions shared with two stand-alone branch kernels in this file (attn_branch_kernel,
 // mlp_branch_kernel), whose per-kernel parity tests therefore cover them, and against a chain of which the one-launch encoder is
 // tested bit for bit.  (encoder_attn_fused.h / encoder_mlp.h hold the first stand-alone forms, with their ablation variants.)
-//   attn_phase   72 weight stages (6 heads x 12) through ring slots 0-5, K / V^T images       (encoder_attn_fused.h)
-//   mlp_phase    144 weight stages (24 hidden chunks x 6) through ring slots 0-7               (encoder_mlp.h)
-// LDS map (bytes): [0, 96 K) ring slots 0-5 | [96 K, 132 K) ring slots 6-7 of the MLP phase, overlaid by the K and V^T images of
-// the attention phase (dead while the other phase runs; the stage barriers of either phase separate the last reads of one use
-// from the first writes of the other) | [132 K, +10.5 K) the phase's biases and LayerNorm parameters.
+//   attn_phase   24 weight triples (6 heads x {q, k, v, proj}) through ring groups 0-1, K / V^T images   (encoder_attn_fused.h)
+//   mlp_phase    48 weight triples (24 hidden chunks x {fc1, fc2}) through ring groups 0-2               (encoder_mlp.h)
+// LDS map (bytes): [0, 96 K) ring groups 0-1 | [96 K, 144 K) ring group 2 of the MLP phase, overlaid by the K and V^T images of
+// the attention phase (dead while the other phase runs; the barriers of either phase separate the last reads of one use from
+// the first writes of the other) | [144 K, +10.5 K) the phase's biases and LayerNorm parameters.
 #pragma once
 #include "common.h"
 #include "encoder_attn_fused.h"
@@ -32,9 +32,9 @@ struct EncBlockParams {
     unsigned ln1_w, ln1_b, wqkv, bqkv, wproj, bproj, ln2_w, ln2_b, w1, b1, w2, b2;
 };
 
-constexpr int EB_XREG_BYTES = 36864;         // ring slots 6-7 (32 KiB) / K image (18 KiB) + V^T image (17 KiB)
+constexpr int EB_RING_BYTES = 9 * 16384;      // three groups of three 16 KiB weight stages; group 2 is overlaid by the K / V^T images
 template <int E>
-constexpr size_t enc_blocks_lds() { return (size_t)6 * 16384 + EB_XREG_BYTES + (size_t)(7 * E) * sizeof(float); }
+constexpr size_t enc_blocks_lds() { return (size_t)EB_RING_BYTES + (size_t)(7 * E) * sizeof(float); }
 
 // ---- x <-> accumulators --------------------------------------------------------------------------------------------------
 // Accumulator layout (encoder_mlp.h): lane (r16, g), row tile j, tile pair q32 = (acc[(q32 >> 2) * 8 + 2 (q32 & 3)], [... + 1]) holds
@@ -193,301 +193,305 @@ struct StreamLane {
     }
 };
 
-// One weight stage's 32 MFMAs with the ds_read / MFMA interleave pinned (16 fragment reads, 8 up front, one per MFMA pair after)
-#define PQ_STAGE_SCHED()                                                              \
-    do {                                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);                            \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                            \
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
-        }                                                                             \
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                           \
-    } while (0)
+// ---- weight TRIPLES ----------------------------------------------------------------------------------------------------------
+// Every GEMM of a block consumes its weights three 16 KiB stages at a time (a 64-wide q / k / v chunk, a 64-wide slice of proj, a
+// hidden chunk's W1 rows or W2 columns are each 3 stages), so the ring is organised in GROUPS of three slots and a triple runs
+// under ONE workgroup barrier: 96 MFMAs per wave between barriers instead of 32, and — with no barrier in the way — the fragment
+// reads of a half stage are issued under the MFMAs of the half stage before it (two 8-register buffers, ping-pong).  The next
+// triple's LDS-DMA pieces are issued at this triple's stage boundaries into a group whose last readers the triple's opening
+// barrier has already retired.
+constexpr int EB_GROUP_BYTES = 3 * 16384;
+#ifndef EB_ISSUE_SPLIT
+#define EB_ISSUE_SPLIT 1         // stages of the next triple issued at the three stage boundaries: 0 = 1/1/1, 1 = 2/1/0, 2 = 3/0/0
+#endif
+
+// mma(k, half, i, w): the two MFMAs (row tiles j = 0, 1) that consume weight fragment i of k-half `half` of stage k.
+// issue(k): called at the start of stage k (k = 0 after the first eight fragment reads have been issued).
+template <class Mma, class Issue>
+__device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, Issue&& issue) {
+    const int ln = opaque_lane();
+    const int fo0 = stage_frag_off(ln), fo1 = fo0 ^ 64;
+    bf16x8 wa[8], wb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(grp + fo0 + i * 2048);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(0);
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, 6>([&](auto bc) {
+        constexpr int b = decltype(bc)::value, k = b >> 1, half = b & 1, nb = b + 1;
+        if constexpr (half == 0 && b > 0) {
+            issue(k);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned char* src = grp + (nb >> 1) * 16384 + ((nb & 1) ? fo1 : fo0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if constexpr (b < 5) {
+                if constexpr (half) wa[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
+                else wb[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
+            }
+            if constexpr (half) mma(k, half, i, wb[i]); else mma(k, half, i, wa[i]);
+        }
+        if constexpr (b < 5) {
+#pragma unroll
+            for (int i_ = 0; i_ < 8; ++i_) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            }
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// which stages of the NEXT triple go out at stage boundary k of this one (EB_ISSUE_SPLIT)
+template <class F>
+__device__ __forceinline__ void issue_split(int k, F&& one) {
+#if EB_ISSUE_SPLIT == 0
+    one(k);
+#elif EB_ISSUE_SPLIT == 1
+    if (k == 0) { one(0); one(1); } else if (k == 1) one(2);
+#else
+    if (k == 0) { one(0); one(1); one(2); }
+#endif
+}
 
 // ---- attention phase: acc += proj(attention(qkv(afrag)))  (bias of proj NOT added) ------------------------------------------
-// LDS: ring slots 0-5 at `ring`, K image at `kimg`, V^T image at `vimg`, qkv bias (3E floats) at `sbq`.  Must be entered with no
-// LDS-DMA in flight; returns with none in flight.  Every wave of the workgroup must call it (barriers inside).
+// LDS: ring groups 0-1 at `ring` (stage t of a head: group (t / 3) & 1, slot t % 3), K image at `kimg`, V^T image at `vimg`, qkv bias
+// (3E floats) at `sbq`.  attn_prefetch must have been called (after a barrier that retired every earlier reader of groups 0-1);
+// returns with no LDS-DMA in flight.  Every wave of the workgroup must call it (barriers inside).
+template <int E>
+__device__ __forceinline__ void attn_issue_stage(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off,
+                                                 int wid, int h, int t) {
+    constexpr int KS1 = E / 128;
+    unsigned char* dst = ring + (((t / 3) & 1) * 3 + t % 3) * 16384 + wid * 4096;
+    if (t < 3 * KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, wid, E, dst);
+    else StreamLane::issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, wid, E, dst);
+}
+template <int E>
+__device__ __forceinline__ void attn_prefetch(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid) {
+    static_for<0, 3>([&](auto tc) { attn_issue_stage<E>(ring, wrsrc, wqkv_off, 0u, wid, 0, decltype(tc)::value); });
+}
+
 template <int E>
 __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* kimg, unsigned char* vimg, const float* sbq,
                                            __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off, float scale,
                                            const StreamLane& sl, int wid, int rr, int g, const bf16x8 (&afrag)[2][E / 32],
                                            f32x4 (&acc2)[E / 16][2]) {
-    constexpr int H = E / 64, KS1 = E / 128, NG = E / 128, SPH = 3 * KS1 + NG;
-    static_assert(E == 384 && SPH % AF_NST == 0, "written for E = 384");
-    auto issue_stage = [&](int h, int t) {            // t is a compile-time constant at every call site
-        unsigned char* dst = ring + (t % AF_NST) * AF_STAGE_BYTES + wid * 4096;
-        // wqkv_off / wproj_off: element offsets of the matrices inside the weight pack
-        if (t < 3 * KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, wid, E, dst);
-        else StreamLane::issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, wid, E, dst);
-    };
-    static_for<0, AF_DIST>([&](auto tc) { issue_stage(0, decltype(tc)::value); });
+    constexpr int H = E / 64, KS1 = E / 128, NG = E / 128;
+    static_assert(E == 384 && KS1 == 3 && NG == 3, "written for E = 384: every chunk is one triple");
     const float sc2 = scale * 1.44269504088896340736f;
 
     for (int h = 0; h < H; ++h) {
         f32x4 acc1[4][2];
         bf16x8 qfrag[2][2], ofrag[2][2];
-        static_for<0, SPH>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            if constexpr (t >= SPH - (AF_DIST - 1)) {
-                if (h == H - 1) wait_vmcnt<4 * (SPH - 1 - t)>(); else wait_vmcnt<4 * (AF_DIST - 1)>();
-            } else {
-                wait_vmcnt<4 * (AF_DIST - 1)>();
-            }
+        static_for<0, 4>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;               // 0 q, 1 k, 2 v (operand roles swapped: V^T), 3 proj
+            wait_vmcnt<0>();                                     // this triple (issued during the previous one) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            {
-                constexpr int tn = (t + AF_DIST) % SPH;
-                const int hn = h + (t + AF_DIST) / SPH;
-                if (hn < H) issue_stage(hn, tn);
+            if constexpr (u < 3) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
-            const int ln = opaque_lane();
-            const int rr = ln & 15, g = ln >> 4;                  // (shadow the arguments: see opaque_lane)
-            const int fo = stage_frag_off(ln);
-            const unsigned char* st0 = ring + (t % AF_NST) * AF_STAGE_BYTES + fo;
-            const unsigned char* st1 = ring + (t % AF_NST) * AF_STAGE_BYTES + (fo ^ 64);
-            bf16x8 wf0[8], wf1[8];
+            auto issue = [&](int k) {
+                issue_split(k, [&](int sn) {
+                    if constexpr (u < 3) attn_issue_stage<E>(ring, wrsrc, wqkv_off, wproj_off, wid, h, 3 * (u + 1) + sn);
+                    else if (h + 1 < H) attn_issue_stage<E>(ring, wrsrc, wqkv_off, wproj_off, wid, h + 1, sn);
+                });
+            };
+            const unsigned char* grp = ring + (u & 1) * EB_GROUP_BYTES;
+            if constexpr (u < 2) {
+                run_triple(grp, [&](int k, int half, int i, const bf16x8& w) {
+                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);
+                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[1][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][1], 0, 0, 0);
+                }, issue);
+                const int ln = opaque_lane();
+                const int rr = ln & 15, g = ln >> 4;              // (shadow the arguments: see opaque_lane)
+                // K image row of this lane's token (32 wid + 16 j + r16): see encoder_attn_fused.h
+                const int krow_j0 = 32 * wid + 16 * ((rr >> 2) & 1) + 4 * (rr >> 3) + (rr & 3);
+                const float* bp0 = sbq + u * E + h * 64 + 8 * g;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(st0 + i * 2048);
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(st1 + i * 2048);
-            if constexpr (t < 3 * KS1) {
-                constexpr int ch = t / KS1, tt = t % KS1;
-                if constexpr (tt == 0) {
+                    for (int pr = 0; pr < 2; ++pr) {
+                        bf16x8 f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                }
-                if constexpr (ch < 2) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[0][(2 * tt + (i >> 2)) * 2], acc1[i & 3][0], 0, 0, 0);
-                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[1][(2 * tt + (i >> 2)) * 2], acc1[i & 3][1], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[0][(2 * tt + (i >> 2)) * 2 + 1], acc1[i & 3][0], 0, 0, 0);
-                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[1][(2 * tt + (i >> 2)) * 2 + 1], acc1[i & 3][1], 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][(2 * tt + (i >> 2)) * 2], wf0[i], acc1[i & 3][0], 0, 0, 0);
-                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[1][(2 * tt + (i >> 2)) * 2], wf0[i], acc1[i & 3][1], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][(2 * tt + (i >> 2)) * 2 + 1], wf1[i], acc1[i & 3][0], 0, 0, 0);
-                        acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[1][(2 * tt + (i >> 2)) * 2 + 1], wf1[i], acc1[i & 3][1], 0, 0, 0);
-                    }
-                }
-                PQ_STAGE_SCHED();
-                if constexpr (tt == KS1 - 1 && ch < 2) {
-                    // K image row of this lane's token (32 wid + 16 j + r16): see encoder_attn_fused.h
-                    const int krow_j0 = 32 * wid + 16 * ((rr >> 2) & 1) + 4 * (rr >> 3) + (rr & 3);
-                    const float* bp0 = sbq + ch * E + h * 64 + 8 * g;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            bf16x8 f;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp0[32 * pr + r]);
-                                f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp0[32 * pr + 4 + r]);
-                            }
-                            if constexpr (ch == 0) qfrag[j][pr] = f;
-                            else *reinterpret_cast<bf16x8*>(kimg + (krow_j0 + 8 * j) * AF_KROWB + 64 * pr + 16 * g) = f;
+                        for (int r = 0; r < 4; ++r) {
+                            f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp0[32 * pr + r]);
+                            f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp0[32 * pr + 4 + r]);
                         }
-                }
-                if constexpr (tt == KS1 - 1 && ch == 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float bv = sbq[2 * E + h * 64 + ((i >> 1) & 1) * 32 + (rr >> 2) * 8 + (i & 1) * 4 + (rr & 3)];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float o4[4] = {acc1[i][j][0] + bv, acc1[i][j][1] + bv, acc1[i][j][2] + bv, acc1[i][j][3] + bv};
-                            store4<bf16_t>(reinterpret_cast<bf16_t*>(vimg + (16 * i + rr) * AF_VROWB) + 32 * wid + 16 * j + 4 * g, o4);
-                        }
+                        if constexpr (u == 0) qfrag[j][pr] = f;
+                        else *reinterpret_cast<bf16x8*>(kimg + (krow_j0 + 8 * j) * AF_KROWB + 64 * pr + 16 * g) = f;
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    asm volatile("" ::: "memory");
-                    // S^T = K Q^T and the soft-max, one 16-query row tile at a time (32 score registers live instead of 64; the K
-                    // fragments are read twice, 16 extra ds_read_b128 per head)
-                    bf16x8 pfrag[2][4];
-                    float inv[2];
+            } else if constexpr (u == 2) {
+                run_triple(grp, [&](int k, int half, int i, const bf16x8& w) {
+                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[0][(2 * k + (i >> 2)) * 2 + half], w, acc1[i & 3][0], 0, 0, 0);
+                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[1][(2 * k + (i >> 2)) * 2 + half], w, acc1[i & 3][1], 0, 0, 0);
+                }, issue);
+                const int ln = opaque_lane();
+                const int rr = ln & 15, g = ln >> 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float bv = sbq[2 * E + h * 64 + ((i >> 1) & 1) * 32 + (rr >> 2) * 8 + (i & 1) * 4 + (rr & 3)];
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        f32x4 sc[8];
-#pragma unroll
-                        for (int kt = 0; kt < 8; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                            for (int kt = 0; kt < 8; ++kt) {
-                                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + (16 * kt + rr) * AF_KROWB + 64 * ks + 16 * g);
-                                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfrag[j][ks], sc[kt], 0, 0, 0);
-                            }
-                        float mx = -INFINITY;
-#pragma unroll
-                        for (int kt = 0; kt < 8; ++kt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
-                        mx = rows4_max(mx);
-                        const float mc = mx * sc2;
-                        float sum = 0.f;
-#pragma unroll
-                        for (int ks = 0; ks < 4; ++ks) {
-                            bf16x8 f;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float p0 = exp2f(sc[2 * ks][r] * sc2 - mc), p1 = exp2f(sc[2 * ks + 1][r] * sc2 - mc);
-                                sum += p0 + p1;
-                                f[r] = static_cast<bf16_t>(p0);
-                                f[4 + r] = static_cast<bf16_t>(p1);
-                            }
-                            pfrag[j][ks] = f;
-                        }
-                        sum = rows4_sum(sum);
-                        inv[j] = 1.0f / sum;
+                        const float o4[4] = {acc1[i][j][0] + bv, acc1[i][j][1] + bv, acc1[i][j][2] + bv, acc1[i][j][3] + bv};
+                        store4<bf16_t>(reinterpret_cast<bf16_t*>(vimg + (16 * i + rr) * AF_VROWB) + 32 * wid + 16 * j + 4 * g, o4);
                     }
-                    f32x4 ov[4][2];
-#pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) { ov[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                        for (int dt = 0; dt < 4; ++dt) {
-                            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vimg + (16 * dt + rr) * AF_VROWB + 64 * ks + 16 * g);
-                            ov[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfrag[0][ks], ov[dt][0], 0, 0, 0);
-                            ov[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfrag[1][ks], ov[dt][1], 0, 0, 0);
-                        }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int pr = 0; pr < 2; ++pr) {
-                            bf16x8 f;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                f[r] = static_cast<bf16_t>(ov[2 * pr][j][r] * inv[j]);
-                                f[4 + r] = static_cast<bf16_t>(ov[2 * pr + 1][j][r] * inv[j]);
-                            }
-                            ofrag[j][pr] = f;
-                        }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // S^T = K Q^T and the soft-max, one 16-query row tile at a time (32 score registers live instead of 64; the K
+                // fragments are read twice, 16 extra ds_read_b128 per head)
+                bf16x8 pfrag[2][4];
+                float inv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 sc[8];
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int kt = 0; kt < 8; ++kt) {
+                            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + (16 * kt + rr) * AF_KROWB + 64 * ks + 16 * g);
+                            sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qfrag[j][ks], sc[kt], 0, 0, 0);
+                        }
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+                    mx = rows4_max(mx);
+                    const float mc = mx * sc2;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        bf16x8 f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p0 = exp2f(sc[2 * ks][r] * sc2 - mc), p1 = exp2f(sc[2 * ks + 1][r] * sc2 - mc);
+                            sum += p0 + p1;
+                            f[r] = static_cast<bf16_t>(p0);
+                            f[4 + r] = static_cast<bf16_t>(p1);
+                        }
+                        pfrag[j][ks] = f;
+                    }
+                    sum = rows4_sum(sum);
+                    inv[j] = 1.0f / sum;
+                }
+                f32x4 ov[4][2];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { ov[dt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[dt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vimg + (16 * dt + rr) * AF_VROWB + 64 * ks + 16 * g);
+                        ov[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfrag[0][ks], ov[dt][0], 0, 0, 0);
+                        ov[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pfrag[1][ks], ov[dt][1], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        bf16x8 f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f[r] = static_cast<bf16_t>(ov[2 * pr][j][r] * inv[j]);
+                            f[4 + r] = static_cast<bf16_t>(ov[2 * pr + 1][j][r] * inv[j]);
+                        }
+                        ofrag[j][pr] = f;
+                    }
             } else {
-                constexpr int ng = t - 3 * KS1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], ofrag[0][0], acc2[ng * 8 + i][0], 0, 0, 0);
-                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], ofrag[1][0], acc2[ng * 8 + i][1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], ofrag[0][1], acc2[ng * 8 + i][0], 0, 0, 0);
-                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], ofrag[1][1], acc2[ng * 8 + i][1], 0, 0, 0);
-                }
-                PQ_STAGE_SCHED();
+                run_triple(grp, [&](int k, int half, int i, const bf16x8& w) {
+                    acc2[k * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, ofrag[0][half], acc2[k * 8 + i][0], 0, 0, 0);
+                    acc2[k * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, ofrag[1][half], acc2[k * 8 + i][1], 0, 0, 0);
+                }, issue);
             }
         });
     }
 }
 
 // ---- MLP phase: acc += fc2(gelu(fc1(afrag) + b1))  (bias of fc2 NOT added) --------------------------------------------------
-// LDS: ring slots 0-7 at `ring` (128 KiB), fc1 bias (4E floats) at `sb1`.  The weight-stream schedule is encoder_mlp.h's.
+// LDS: ring groups 0-2 at `ring` (144 KiB; triple n of the phase — fc1 of chunk n / 2 when n is even, fc2 when odd — lives in group
+// n % 3), fc1 bias (4E floats) at `sb1`.  mlp_prefetch must have been called (after a barrier that retired every earlier reader of
+// groups 0-1); returns with no LDS-DMA in flight.
+template <int E>
+__device__ __forceinline__ void mlp_issue_stage(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
+                                                int wid, int c, int t, int group) {
+    constexpr int F = 4 * E, KS1 = E / 128;
+    unsigned char* dst = ring + group * EB_GROUP_BYTES + (t % 3) * 16384 + wid * 4096;
+    if (t < KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, wid, E, dst);
+    else StreamLane::issue<StreamLane::K128>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, wid, F, dst);
+}
+template <int E>
+__device__ __forceinline__ void mlp_prefetch(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int wid) {
+    static_for<0, 6>([&](auto tc) { constexpr int t = decltype(tc)::value; mlp_issue_stage<E>(ring, wrsrc, w1_off, w2_off, wid, 0, t, t / 3); });
+}
+
 template <int E>
 __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
                                           const StreamLane& sl, int wid, int rr, int g, const bf16x8 (&afrag)[2][E / 32],
                                           f32x4 (&acc2)[E / 16][2]) {
-    constexpr int F = 4 * E, KS1 = E / 128, NG = E / 128, KS2 = NG, SPC = KS1 + KS2, NCH = F / MLP_HC;
-    static_assert(KS1 == 3 && KS2 == 3 && MLP_NST == 8, "issue schedule: six stages per chunk, eight slots");
-    auto issue_stage = [&](int c, int t, int slot) {
-        unsigned char* dst = ring + slot * MLP_STAGE_BYTES + wid * 4096;
-        if (t < KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, wid, E, dst);
-        else StreamLane::issue<StreamLane::K128>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, wid, F, dst);
-    };
-#pragma unroll
-    for (int s = 0; s < SPC; ++s) issue_stage(0, s, s % MLP_NST);
+    constexpr int F = 4 * E, KS1 = E / 128, KS2 = E / 128, NCH = F / MLP_HC;
+    static_assert(KS1 == 3 && KS2 == 3, "every GEMM slice of a hidden chunk is one triple");
+    int gcur = 0;                                                // group of the triple about to run
     for (int c = 0; c < NCH; ++c) {
+        const bool more = c + 1 < NCH;
         f32x4 acc1[4][2];
         bf16x8 hfrag[2][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        static_for<0, SPC>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const int s = c * SPC + t;
-            {       // see encoder_mlp.h for the derivation of the wait counts
-                const bool last = c == NCH - 1;
-                if constexpr (t == 0) wait_vmcnt<20>();
-                else if constexpr (t == 1) wait_vmcnt<16>();
-                else if constexpr (t == 2) wait_vmcnt<12>();
-                else if constexpr (t == 3) { if (last) wait_vmcnt<8>(); else wait_vmcnt<24>(); }
-                else if constexpr (t == 4) { if (last) wait_vmcnt<4>(); else wait_vmcnt<20>(); }
-                else { if (last) wait_vmcnt<0>(); else wait_vmcnt<20>(); }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if constexpr (t == 4 || t == 5) {
-                if (c + 1 < NCH) issue_stage(c + 1, t, (s + SPC) & (MLP_NST - 1));
-            }
-            const int ln = opaque_lane();
-            const int g = ln >> 4;                                // (shadows the argument: see opaque_lane)
-            const int fo = stage_frag_off(ln);
-            const unsigned char* st0 = ring + (s & (MLP_NST - 1)) * MLP_STAGE_BYTES + fo;
-            const unsigned char* st1 = ring + (s & (MLP_NST - 1)) * MLP_STAGE_BYTES + (fo ^ 64);
-            bf16x8 wf0[8], wf1[8];
+        // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave)
+        wait_vmcnt<12>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
+            acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);
+            acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[1][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][1], 0, 0, 0);
+        }, [](int) {});
+        {
+            const int g = opaque_lane() >> 4;                    // (shadows the argument: see opaque_lane)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(st0 + i * 2048);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) wf1[i] = *reinterpret_cast<const bf16x8*>(st1 + i * 2048);
-            if constexpr (t < KS1) {
+                for (int pr = 0; pr < 2; ++pr) {
+                    const float* bp = sb1 + c * MLP_HC + 32 * pr + 8 * g;
+                    bf16x8 f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[0][(2 * t + (i >> 2)) * 2], acc1[i & 3][0], 0, 0, 0);
-                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], afrag[1][(2 * t + (i >> 2)) * 2], acc1[i & 3][1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[0][(2 * t + (i >> 2)) * 2 + 1], acc1[i & 3][0], 0, 0, 0);
-                    acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], afrag[1][(2 * t + (i >> 2)) * 2 + 1], acc1[i & 3][1], 0, 0, 0);
-                }
-            } else {
-                constexpr int ng = t - KS1;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], hfrag[0][0], acc2[ng * 8 + i][0], 0, 0, 0);
-                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[i], hfrag[1][0], acc2[ng * 8 + i][1], 0, 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    acc2[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], hfrag[0][1], acc2[ng * 8 + i][0], 0, 0, 0);
-                    acc2[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1[i], hfrag[1][1], acc2[ng * 8 + i][1], 0, 0, 0);
-                }
-            }
-            PQ_STAGE_SCHED();
-            if constexpr (t == KS1 - 1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int pr = 0; pr < 2; ++pr) {
-                        const float* bp = sb1 + c * MLP_HC + 32 * pr + 8 * g;
-                        bf16x8 f;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
-                            f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
-                        }
-                        hfrag[j][pr] = f;
+                    for (int r = 0; r < 4; ++r) {
+                        f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
+                        f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
                     }
-                if (c + 1 < NCH) {
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) issue_stage(c + 1, tn, ((c + 1) * SPC + tn) & (MLP_NST - 1));
+                    hfrag[j][pr] = f;
                 }
+        }
+        // the next chunk's fc1 triple goes into the group the fc1 barrier above has retired (two triples back), in the VALU-only gap
+        const int gnext2 = gcur == 0 ? 2 : gcur - 1;             // (gcur + 2) % 3
+        if (more) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            }
+            for (int tn = 0; tn < 3; ++tn) mlp_issue_stage<E>(ring, wrsrc, w1_off, w2_off, wid, c + 1, tn, gnext2);
+        }
+        gcur = gcur == 2 ? 0 : gcur + 1;
+        // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
+        if (more) wait_vmcnt<12>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const int gn2 = gcur == 0 ? 2 : gcur - 1;
+        run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
+            acc2[k * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hfrag[0][half], acc2[k * 8 + i][0], 0, 0, 0);
+            acc2[k * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hfrag[1][half], acc2[k * 8 + i][1], 0, 0, 0);
+        }, [&](int k) {
+            if (more) mlp_issue_stage<E>(ring, wrsrc, w1_off, w2_off, wid, c + 1, 3 + k, gn2);     // always 1/1/1: a whole chunk ahead
         });
+        gcur = gcur == 2 ? 0 : gcur + 1;
     }
 }
 
@@ -502,11 +506,11 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
                        const EncBlockParams* __restrict__ blocks, int depth, float eps, int M) {
     constexpr int F = 4 * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ring = smem;                                  // slots 0-5 (attention) / 0-7 (MLP)
-    unsigned char* kimg = smem + 6 * 16384;                      // overlays ring slots 6-7
+    unsigned char* ring = smem;                                  // groups 0-1 (attention) / 0-2 (MLP)
+    unsigned char* kimg = smem + 2 * EB_GROUP_BYTES;             // overlays ring group 2
     unsigned char* vimg = kimg + 128 * AF_KROWB;
-    float* sp = reinterpret_cast<float*>(smem + 6 * 16384 + EB_XREG_BYTES);     // phase parameters, <= 7E floats
-    static_assert(128 * AF_KROWB + 64 * AF_VROWB <= EB_XREG_BYTES && 2 * 16384 <= EB_XREG_BYTES, "overlay region");
+    float* sp = reinterpret_cast<float*>(smem + EB_RING_BYTES);  // phase parameters, <= 7E floats
+    static_assert(128 * AF_KROWB + 64 * AF_VROWB <= EB_GROUP_BYTES, "overlay region");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -522,28 +526,26 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
     for (int l = 0; l < depth; ++l) {
         const EncBlockParams* bp = blocks + l;
         // ---- attention branch: parameters bqkv (3E) | bproj (E) | ln1 gamma (E) | ln1 beta (E)
-        __syncthreads();                                         // everyone is done with the previous phase's parameters
+        __syncthreads();                                         // everyone is done with the previous phase's parameters and ring
+        attn_prefetch<E>(ring, wrsrc, bp->wqkv, wid);            // head 0's q triple lands behind the parameter copies and LayerNorm
         params_to_lds(sp, pbase + bp->bqkv, 3 * E, tid);
         params_to_lds(sp + 3 * E, pbase + bp->bproj, E, tid);
         params_to_lds(sp + 4 * E, pbase + bp->ln1_w, E, tid);
         params_to_lds(sp + 5 * E, pbase + bp->ln1_b, E, tid);
         __syncthreads();
         ln_acc_to_frag<E>(acc, sp + 4 * E, sp + 5 * E, eps, g, afrag);
-#if !defined(EB_ABLATE) || EB_ABLATE != 1
         attn_phase<E>(ring, kimg, vimg, sp, wrsrc, bp->wqkv, bp->wproj, 0.125f, sl, wid, rr, g, afrag, acc);
-#endif
         add_bias_to_acc<E>(sp + 3 * E, g, acc);
         // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
         __syncthreads();
+        mlp_prefetch<E>(ring, wrsrc, bp->w1, bp->w2, wid);       // chunk 0's two triples
         params_to_lds(sp, pbase + bp->b1, F, tid);
         params_to_lds(sp + F, pbase + bp->b2, E, tid);
         params_to_lds(sp + F + E, pbase + bp->ln2_w, E, tid);
         params_to_lds(sp + F + 2 * E, pbase + bp->ln2_b, E, tid);
         __syncthreads();
         ln_acc_to_frag<E>(acc, sp + F + E, sp + F + 2 * E, eps, g, afrag);
-#if !defined(EB_ABLATE) || EB_ABLATE != 2
         mlp_phase<E>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, rr, g, afrag, acc);
-#endif
         add_bias_to_acc<E>(sp + F, g, acc);
     }
     store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
@@ -558,9 +560,9 @@ void attn_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase,
                         const float* __restrict__ bproj, float eps, int M) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
-    unsigned char* kimg = smem + 6 * 16384;
+    unsigned char* kimg = smem + 2 * EB_GROUP_BYTES;
     unsigned char* vimg = kimg + 128 * AF_KROWB;
-    float* sp = reinterpret_cast<float*>(smem + 6 * 16384 + EB_XREG_BYTES);
+    float* sp = reinterpret_cast<float*>(smem + EB_RING_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rr = lane & 15, g = lane >> 4;
@@ -570,6 +572,7 @@ void attn_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase,
     f32x4 acc[E / 16][2];
     bf16x8 afrag[2][E / 32];
     load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+    attn_prefetch<E>(ring, wrsrc, wqkv_off, wid);
     params_to_lds(sp, bqkv, 3 * E, tid);
     params_to_lds(sp + 3 * E, bproj, E, tid);
     params_to_lds(sp + 4 * E, gamma, E, tid);
@@ -589,7 +592,7 @@ void mlp_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
     constexpr int F = 4 * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
-    float* sp = reinterpret_cast<float*>(smem + 6 * 16384 + EB_XREG_BYTES);
+    float* sp = reinterpret_cast<float*>(smem + EB_RING_BYTES);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rr = lane & 15, g = lane >> 4;
@@ -599,6 +602,7 @@ void mlp_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
     f32x4 acc[E / 16][2];
     bf16x8 afrag[2][E / 32];
     load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+    mlp_prefetch<E>(ring, wrsrc, w1_off, w2_off, wid);
     params_to_lds(sp, b1, F, tid);
     params_to_lds(sp + F, b2, E, tid);
     params_to_lds(sp + F + E, gamma, E, tid);
