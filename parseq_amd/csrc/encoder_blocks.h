@@ -25,6 +25,12 @@
 
 namespace pq {
 
+// Timing ablations (results are WRONG with any bit set; tools/enc_ablate.sh builds and times them): 1 GELU -> identity, 2 no
+// soft-max core, 4 no LDS-DMA issue, 8 no triple barriers, 16 fragment reads only once per triple
+#ifndef EB_ABLATE
+#define EB_ABLATE 0
+#endif
+
 // Per-block parameters, one entry per encoder block: ELEMENT offsets relative to two bases the kernel receives once — the bf16
 // weights (wqkv, wproj, w1, w2) relative to `wbase`, the fp32 vectors relative to `pbase`.  32-bit offsets (instead of twelve
 // 64-bit pointers) keep the scalar register file free, and the weights are addressed through ONE buffer descriptor.
@@ -186,6 +192,7 @@ struct StreamLane {
             voff = (unsigned)(p128 * pitch + src_chunk) * 2u;
         }
         constexpr unsigned kRowDelta[4] = {0, 16, 4, 20};
+        if constexpr ((EB_ABLATE & 4) != 0) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, voff,
@@ -226,13 +233,13 @@ __device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, 
         const unsigned char* src = grp + (nb >> 1) * 16384 + ((nb & 1) ? fo1 : fo0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if constexpr (b < 5) {
+            if constexpr (b < 5 && ((EB_ABLATE & 16) == 0 || b == 0)) {
                 if constexpr (half) wa[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
                 else wb[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
             }
             if constexpr (half) mma(k, half, i, wb[i]); else mma(k, half, i, wa[i]);
         }
-        if constexpr (b < 5) {
+        if constexpr (b < 5 && ((EB_ABLATE & 16) == 0 || b == 0)) {
 #pragma unroll
             for (int i_ = 0; i_ < 8; ++i_) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -290,7 +297,7 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
             constexpr int u = decltype(uc)::value;               // 0 q, 1 k, 2 v (operand roles swapped: V^T), 3 proj
             wait_vmcnt<0>();                                     // this triple (issued during the previous one) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if constexpr (u < 3) {
 #pragma unroll
@@ -345,6 +352,9 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                if constexpr ((EB_ABLATE & 2) != 0) {
+                    ofrag[0][0] = qfrag[0][0]; ofrag[0][1] = qfrag[0][1]; ofrag[1][0] = qfrag[1][0]; ofrag[1][1] = qfrag[1][1];
+                } else {
                 // S^T = K Q^T and the soft-max, one 16-query row tile at a time (32 score registers live instead of 64; the K
                 // fragments are read twice, 16 extra ds_read_b128 per head)
                 bf16x8 pfrag[2][4];
@@ -407,6 +417,7 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                         }
                         ofrag[j][pr] = f;
                     }
+                }
             } else {
                 run_triple(grp, [&](int k, int half, int i, const bf16x8& w) {
                     acc2[k * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, ofrag[0][half], acc2[k * 8 + i][0], 0, 0, 0);
@@ -450,7 +461,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave)
         wait_vmcnt<12>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
             acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);
@@ -466,8 +477,13 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                     bf16x8 f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
-                        f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
+                        if constexpr ((EB_ABLATE & 1) != 0) {
+                            f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp[r]);
+                            f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp[4 + r]);
+                        } else {
+                            f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
+                            f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
+                        }
                     }
                     hfrag[j][pr] = f;
                 }
@@ -482,7 +498,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
         if (more) wait_vmcnt<12>(); else wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int gn2 = gcur == 0 ? 2 : gcur - 1;
         run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
