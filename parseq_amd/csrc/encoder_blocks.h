@@ -384,7 +384,7 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                         bf16x8 f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float p0 = exp2f(sc[2 * ks][r] * sc2 - mc), p1 = exp2f(sc[2 * ks + 1][r] * sc2 - mc);
+                            const float p0 = __builtin_amdgcn_exp2f(sc[2 * ks][r] * sc2 - mc), p1 = __builtin_amdgcn_exp2f(sc[2 * ks + 1][r] * sc2 - mc);   // (v_exp_f32: a result below 2^-126 flushes to 0 instead of going through exp2f's denormal rescue)
                             sum += p0 + p1;
                             f[r] = static_cast<bf16_t>(p0);
                             f[4 + r] = static_cast<bf16_t>(p1);
@@ -470,23 +470,31 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         {
             const int g = opaque_lane() >> 4;                    // (shadows the argument: see opaque_lane)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                f32x2 xv[8], yv[8];
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     const float* bp = sb1 + c * MLP_HC + 32 * pr + 8 * g;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        xv[4 * pr + h2] = f32x2{acc1[2 * pr][j][2 * h2] + bp[2 * h2], acc1[2 * pr][j][2 * h2 + 1] + bp[2 * h2 + 1]};
+                        xv[4 * pr + 2 + h2] = f32x2{acc1[2 * pr + 1][j][2 * h2] + bp[4 + 2 * h2], acc1[2 * pr + 1][j][2 * h2 + 1] + bp[4 + 2 * h2 + 1]};
+                    }
+                }
+                if constexpr ((EB_ABLATE & 1) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) yv[e] = xv[e];
+                } else {
+                    gelu_poly_16(xv, yv);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
                     bf16x8 f;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if constexpr ((EB_ABLATE & 1) != 0) {
-                            f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp[r]);
-                            f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp[4 + r]);
-                        } else {
-                            f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
-                            f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) { f[2 * e] = static_cast<bf16_t>(yv[4 * pr + e][0]); f[2 * e + 1] = static_cast<bf16_t>(yv[4 * pr + e][1]); }
                     hfrag[j][pr] = f;
                 }
+            }
         }
         // the next chunk's fc1 triple goes into the group the fc1 barrier above has retired (two triples back), in the VALU-only gap
         const int gnext2 = gcur == 0 ? 2 : gcur - 1;             // (gcur + 2) % 3
