@@ -172,31 +172,34 @@ __device__ __forceinline__ int stage_frag_off(int ln) { const int r16 = ln & 15,
 struct StreamLane {
     // A wave's four DMA pieces of a stage cover LDS rows 32 wid + 8 q + (lane >> 3), q = 0..3.  Under the pair permutation their
     // source rows are row(q) = row(0) + {0, 16, 4, 20}[q] for every lane, so ONE per-lane byte offset per (row order, row pitch)
-    // combination is needed — recomputed from the (opaque) lane id at every issue rather than kept in a register — and the
-    // q-dependent part (a compile-time multiple of the row pitch) goes into the scalar offset operand of the buffer load.
+    // combination is needed — three registers for the whole kernel — and the q-dependent part (a compile-time multiple of the
+    // row pitch) goes into the scalar offset operand of the buffer load.  The four pieces share ONE M0 value: the instruction's
+    // immediate offset q * 1024 moves the LDS destination (LDS address = M0 base + immediate + 16 lane) and is taken back out
+    // of the memory address through the scalar offset.
     enum Kind { K64 = 0, K128 = 1 };     // 64 rows x two 64-k halves | 128 rows x 64 k
-    // `origin`: wave-uniform BYTE offset of (row 0, k 0) of the stage inside the buffer `rsrc` describes; pitch: row pitch in elements
-    template <int KIND>
-    static __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned origin, int wid, int pitch, unsigned char* dst) {
-        const int lane = opaque_lane();
+    unsigned v64, v128, v128w;           // K64 at pitch E | K128 at pitch E | K128 at pitch 4E
+    __device__ __forceinline__ StreamLane(int lane, int wid, int E) {
         const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;          // XOR swizzle on the source (LDS row & 7 == lane >> 3)
         const int rho = wid * 32 + (lane >> 3);                        // q = 0
-        const int i = rho >> 4, r16 = rho & 15;
-        unsigned voff;
-        if constexpr (KIND == K64) {
-            const int i4 = i & 3;
-            const int p64 = ((i4 >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i4 & 1) * 4 + (r16 & 3);
-            voff = (unsigned)(p64 * pitch + (rho >> 6) * 64 + src_chunk) * 2u;
-        } else {
-            const int p128 = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
-            voff = (unsigned)(p128 * pitch + src_chunk) * 2u;
-        }
-        constexpr unsigned kRowDelta[4] = {0, 16, 4, 20};
+        const int i = rho >> 4, r16 = rho & 15, i4 = i & 3;
+        const int p64 = ((i4 >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i4 & 1) * 4 + (r16 & 3);
+        const int p128 = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
+        v64 = (unsigned)(p64 * E + (rho >> 6) * 64 + src_chunk) * 2u;
+        v128 = (unsigned)(p128 * E + src_chunk) * 2u;
+        v128w = (unsigned)(p128 * 4 * E + src_chunk) * 2u;
+    }
+    // `origin`: wave-uniform BYTE offset of (row 0, k 0) of the stage inside the buffer `rsrc` describes; pitch: row pitch in elements
+    // (E, or 4E for KIND == K128 only)
+    template <int KIND, bool WIDE = false>
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned origin, int pitch, unsigned char* dst) const {
         if constexpr ((EB_ABLATE & 4) != 0) return;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16, voff,
-                                                     origin + kRowDelta[q] * 2u * (unsigned)pitch, 0, 0);
+        const unsigned voff = KIND == K64 ? v64 : (WIDE ? v128w : v128);
+        auto* l = (__attribute__((address_space(3))) void*)dst;
+        const unsigned rp = 2u * (unsigned)pitch;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 16u * rp - 1024u, 1024, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 4u * rp - 2048u, 2048, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 20u * rp - 3072u, 3072, 0);
     }
 };
 
@@ -269,16 +272,16 @@ __device__ __forceinline__ void issue_split(int k, F&& one) {
 // (3E floats) at `sbq`.  attn_prefetch must have been called (after a barrier that retired every earlier reader of groups 0-1);
 // returns with no LDS-DMA in flight.  Every wave of the workgroup must call it (barriers inside).
 template <int E>
-__device__ __forceinline__ void attn_issue_stage(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off,
+__device__ __forceinline__ void attn_issue_stage(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off,
                                                  int wid, int h, int t) {
     constexpr int KS1 = E / 128;
     unsigned char* dst = ring + (((t / 3) & 1) * 3 + t % 3) * 16384 + wid * 4096;
-    if (t < 3 * KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, wid, E, dst);
-    else StreamLane::issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, wid, E, dst);
+    if (t < 3 * KS1) sl.template issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, E, dst);
+    else sl.template issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, E, dst);
 }
 template <int E>
-__device__ __forceinline__ void attn_prefetch(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid) {
-    static_for<0, 3>([&](auto tc) { attn_issue_stage<E>(ring, wrsrc, wqkv_off, 0u, wid, 0, decltype(tc)::value); });
+__device__ __forceinline__ void attn_prefetch(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid) {
+    static_for<0, 3>([&](auto tc) { attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, 0u, wid, 0, decltype(tc)::value); });
 }
 
 template <int E>
@@ -305,8 +308,8 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
             }
             auto issue = [&](int k) {
                 issue_split(k, [&](int sn) {
-                    if constexpr (u < 3) attn_issue_stage<E>(ring, wrsrc, wqkv_off, wproj_off, wid, h, 3 * (u + 1) + sn);
-                    else if (h + 1 < H) attn_issue_stage<E>(ring, wrsrc, wqkv_off, wproj_off, wid, h + 1, sn);
+                    if constexpr (u < 3) attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, wproj_off, wid, h, 3 * (u + 1) + sn);
+                    else if (h + 1 < H) attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, wproj_off, wid, h + 1, sn);
                 });
             };
             const unsigned char* grp = ring + (u & 1) * EB_GROUP_BYTES;
@@ -433,16 +436,16 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
 // n % 3), fc1 bias (4E floats) at `sb1`.  mlp_prefetch must have been called (after a barrier that retired every earlier reader of
 // groups 0-1); returns with no LDS-DMA in flight.
 template <int E>
-__device__ __forceinline__ void mlp_issue_stage(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
+__device__ __forceinline__ void mlp_issue_stage(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
                                                 int wid, int c, int t, int group) {
     constexpr int F = 4 * E, KS1 = E / 128;
     unsigned char* dst = ring + group * EB_GROUP_BYTES + (t % 3) * 16384 + wid * 4096;
-    if (t < KS1) StreamLane::issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, wid, E, dst);
-    else StreamLane::issue<StreamLane::K128>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, wid, F, dst);
+    if (t < KS1) sl.template issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, E, dst);
+    else sl.template issue<StreamLane::K128, true>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, F, dst);
 }
 template <int E>
-__device__ __forceinline__ void mlp_prefetch(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int wid) {
-    static_for<0, 6>([&](auto tc) { constexpr int t = decltype(tc)::value; mlp_issue_stage<E>(ring, wrsrc, w1_off, w2_off, wid, 0, t, t / 3); });
+__device__ __forceinline__ void mlp_prefetch(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int wid) {
+    static_for<0, 6>([&](auto tc) { constexpr int t = decltype(tc)::value; mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, 0, t, t / 3); });
 }
 
 template <int E>
@@ -500,7 +503,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         const int gnext2 = gcur == 0 ? 2 : gcur - 1;             // (gcur + 2) % 3
         if (more) {
 #pragma unroll
-            for (int tn = 0; tn < 3; ++tn) mlp_issue_stage<E>(ring, wrsrc, w1_off, w2_off, wid, c + 1, tn, gnext2);
+            for (int tn = 0; tn < 3; ++tn) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, tn, gnext2);
         }
         gcur = gcur == 2 ? 0 : gcur + 1;
         // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
@@ -513,7 +516,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
             acc2[k * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hfrag[0][half], acc2[k * 8 + i][0], 0, 0, 0);
             acc2[k * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hfrag[1][half], acc2[k * 8 + i][1], 0, 0, 0);
         }, [&](int k) {
-            if (more) mlp_issue_stage<E>(ring, wrsrc, w1_off, w2_off, wid, c + 1, 3 + k, gn2);     // always 1/1/1: a whole chunk ahead
+            if (more) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, 3 + k, gn2);     // always 1/1/1: a whole chunk ahead
         });
         gcur = gcur == 2 ? 0 : gcur + 1;
     }
@@ -540,7 +543,7 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rr = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 128;
-    StreamLane sl;
+    const StreamLane sl(lane, wid, E);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, wbytes, 0x00020000);
 
     f32x4 acc[E / 16][2];
@@ -551,7 +554,7 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
         const EncBlockParams* bp = blocks + l;
         // ---- attention branch: parameters bqkv (3E) | bproj (E) | ln1 gamma (E) | ln1 beta (E)
         __syncthreads();                                         // everyone is done with the previous phase's parameters and ring
-        attn_prefetch<E>(ring, wrsrc, bp->wqkv, wid);            // head 0's q triple lands behind the parameter copies and LayerNorm
+        attn_prefetch<E>(sl, ring, wrsrc, bp->wqkv, wid);            // head 0's q triple lands behind the parameter copies and LayerNorm
         params_to_lds(sp, pbase + bp->bqkv, 3 * E, tid);
         params_to_lds(sp + 3 * E, pbase + bp->bproj, E, tid);
         params_to_lds(sp + 4 * E, pbase + bp->ln1_w, E, tid);
@@ -562,7 +565,7 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
         add_bias_to_acc<E>(sp + 3 * E, g, acc);
         // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
         __syncthreads();
-        mlp_prefetch<E>(ring, wrsrc, bp->w1, bp->w2, wid);       // chunk 0's two triples
+        mlp_prefetch<E>(sl, ring, wrsrc, bp->w1, bp->w2, wid);       // chunk 0's two triples
         params_to_lds(sp, pbase + bp->b1, F, tid);
         params_to_lds(sp + F, pbase + bp->b2, E, tid);
         params_to_lds(sp + F + E, pbase + bp->ln2_w, E, tid);
@@ -591,12 +594,12 @@ void attn_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase,
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rr = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 128;
-    StreamLane sl;
+    const StreamLane sl(lane, wid, E);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, wbytes, 0x00020000);
     f32x4 acc[E / 16][2];
     bf16x8 afrag[2][E / 32];
     load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
-    attn_prefetch<E>(ring, wrsrc, wqkv_off, wid);
+    attn_prefetch<E>(sl, ring, wrsrc, wqkv_off, wid);
     params_to_lds(sp, bqkv, 3 * E, tid);
     params_to_lds(sp + 3 * E, bproj, E, tid);
     params_to_lds(sp + 4 * E, gamma, E, tid);
@@ -621,12 +624,12 @@ void mlp_branch_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rr = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * 128;
-    StreamLane sl;
+    const StreamLane sl(lane, wid, E);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(wbase), 0, wbytes, 0x00020000);
     f32x4 acc[E / 16][2];
     bf16x8 afrag[2][E / 32];
     load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
-    mlp_prefetch<E>(ring, wrsrc, w1_off, w2_off, wid);
+    mlp_prefetch<E>(sl, ring, wrsrc, w1_off, w2_off, wid);
     params_to_lds(sp, b1, F, tid);
     params_to_lds(sp + F, b2, E, tid);
     params_to_lds(sp + F + E, gamma, E, tid);
