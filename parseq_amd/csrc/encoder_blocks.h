@@ -26,7 +26,7 @@
 namespace pq {
 
 // Timing ablations (results are WRONG with any bit set; tools/enc_ablate.sh builds and times them): 1 GELU -> identity, 2 no
-// soft-max core, 4 no LDS-DMA issue, 8 no triple barriers, 16 fragment reads only once per triple
+// soft-max core, 4 no LDS-DMA issue, 8 no triple barriers, 16 fragment reads only once per triple, 32 no waits for the LDS-DMA
 #ifndef EB_ABLATE
 #define EB_ABLATE 0
 #endif
@@ -190,16 +190,17 @@ struct StreamLane {
     }
     // `origin`: wave-uniform BYTE offset of (row 0, k 0) of the stage inside the buffer `rsrc` describes; pitch: row pitch in elements
     // (E, or 4E for KIND == K128 only)
+    // q = -1: all four pieces of the wave's share of the stage; q = 0..3: that piece only
     template <int KIND, bool WIDE = false>
-    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned origin, int pitch, unsigned char* dst) const {
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned origin, int pitch, unsigned char* dst, int q = -1) const {
         if constexpr ((EB_ABLATE & 4) != 0) return;
         const unsigned voff = KIND == K64 ? v64 : (WIDE ? v128w : v128);
         auto* l = (__attribute__((address_space(3))) void*)dst;
         const unsigned rp = 2u * (unsigned)pitch;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 16u * rp - 1024u, 1024, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 4u * rp - 2048u, 2048, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 20u * rp - 3072u, 3072, 0);
+        if (q < 0 || q == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin, 0, 0);
+        if (q < 0 || q == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 16u * rp - 1024u, 1024, 0);
+        if (q < 0 || q == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 4u * rp - 2048u, 2048, 0);
+        if (q < 0 || q == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 20u * rp - 3072u, 3072, 0);
     }
 };
 
@@ -211,12 +212,20 @@ struct StreamLane {
 // triple's LDS-DMA pieces are issued at this triple's stage boundaries into a group whose last readers the triple's opening
 // barrier has already retired.
 constexpr int EB_GROUP_BYTES = 3 * 16384;
+template <int N> __device__ __forceinline__ void eb_wait_vmcnt() { if constexpr ((EB_ABLATE & 32) == 0) wait_vmcnt<N>(); }
+#ifndef EB_F1_EARLY
+#define EB_F1_EARLY 1            // the next chunk's fc1 triple is issued at this chunk's fc1 stage boundaries (two triples ahead) instead of in the GELU stretch (one)
+#endif
 #ifndef EB_ISSUE_SPLIT
 #define EB_ISSUE_SPLIT 1         // stages of the next triple issued at the three stage boundaries: 0 = 1/1/1, 1 = 2/1/0, 2 = 3/0/0
 #endif
 
+#ifndef EB_PIECEWISE
+#define EB_PIECEWISE 0           // the four LDS-DMA pieces of a stage boundary go out one per eight MFMAs instead of back to back
+#endif
 // mma(k, half, i, w): the two MFMAs (row tiles j = 0, 1) that consume weight fragment i of k-half `half` of stage k.
-// issue(k): called at the start of stage k (k = 0 after the first eight fragment reads have been issued).
+// issue(k, q): the wave's LDS-DMA pieces due at stage k.  EB_PIECEWISE: q = 0..3, one call per eight MFMAs of the stage (the first
+// after the first eight fragment reads of the triple have been issued); otherwise one call per stage with q = -1 (all four).
 template <class Mma, class Issue>
 __device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, Issue&& issue) {
     const int ln = opaque_lane();
@@ -225,33 +234,38 @@ __device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, 
 #pragma unroll
     for (int i = 0; i < 8; ++i) wa[i] = *reinterpret_cast<const bf16x8*>(grp + fo0 + i * 2048);
     __builtin_amdgcn_sched_barrier(0);
-    issue(0);
-    __builtin_amdgcn_sched_barrier(0);
     static_for<0, 6>([&](auto bc) {
         constexpr int b = decltype(bc)::value, k = b >> 1, half = b & 1, nb = b + 1;
-        if constexpr (half == 0 && b > 0) {
-            issue(k);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        constexpr bool reads = b < 5 && ((EB_ABLATE & 16) == 0 || b == 0);
         const unsigned char* src = grp + (nb >> 1) * 16384 + ((nb & 1) ? fo1 : fo0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if constexpr (b < 5 && ((EB_ABLATE & 16) == 0 || b == 0)) {
-                if constexpr (half) wa[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
-                else wb[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
+        static_for<0, 2>([&](auto sc) {
+            constexpr int sub = decltype(sc)::value;
+            if constexpr (EB_PIECEWISE) {
+                issue(k, 2 * half + sub);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (half == 0 && sub == 0) {
+                issue(k, -1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (half) mma(k, half, i, wb[i]); else mma(k, half, i, wa[i]);
-        }
-        if constexpr (b < 5 && ((EB_ABLATE & 16) == 0 || b == 0)) {
 #pragma unroll
-            for (int i_ = 0; i_ < 8; ++i_) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            for (int i = 4 * sub; i < 4 * sub + 4; ++i) {
+                if constexpr (reads) {
+                    if constexpr (half) wa[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
+                    else wb[i] = *reinterpret_cast<const bf16x8*>(src + i * 2048);
+                }
+                if constexpr (half) mma(k, half, i, wb[i]); else mma(k, half, i, wa[i]);
             }
-        } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            if constexpr (reads) {
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     });
 }
 
@@ -273,11 +287,11 @@ __device__ __forceinline__ void issue_split(int k, F&& one) {
 // returns with no LDS-DMA in flight.  Every wave of the workgroup must call it (barriers inside).
 template <int E>
 __device__ __forceinline__ void attn_issue_stage(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off,
-                                                 int wid, int h, int t) {
+                                                 int wid, int h, int t, int q = -1) {
     constexpr int KS1 = E / 128;
     unsigned char* dst = ring + (((t / 3) & 1) * 3 + t % 3) * 16384 + wid * 4096;
-    if (t < 3 * KS1) sl.template issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, E, dst);
-    else sl.template issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, E, dst);
+    if (t < 3 * KS1) sl.template issue<StreamLane::K64>(wrsrc, (wqkv_off + (unsigned)(((t / KS1) * E + h * 64) * E + (t % KS1) * 128)) * 2u, E, dst, q);
+    else sl.template issue<StreamLane::K128>(wrsrc, (wproj_off + (unsigned)((t - 3 * KS1) * 128 * E + h * 64)) * 2u, E, dst, q);
 }
 template <int E>
 __device__ __forceinline__ void attn_prefetch(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid) {
@@ -298,7 +312,7 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
         bf16x8 qfrag[2][2], ofrag[2][2];
         static_for<0, 4>([&](auto uc) {
             constexpr int u = decltype(uc)::value;               // 0 q, 1 k, 2 v (operand roles swapped: V^T), 3 proj
-            wait_vmcnt<0>();                                     // this triple (issued during the previous one) has landed
+            eb_wait_vmcnt<0>();                                  // this triple (issued during the previous one) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -306,10 +320,10 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
-            auto issue = [&](int k) {
+            auto issue = [&](int k, int q) {
                 issue_split(k, [&](int sn) {
-                    if constexpr (u < 3) attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, wproj_off, wid, h, 3 * (u + 1) + sn);
-                    else if (h + 1 < H) attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, wproj_off, wid, h + 1, sn);
+                    if constexpr (u < 3) attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, wproj_off, wid, h, 3 * (u + 1) + sn, q);
+                    else if (h + 1 < H) attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, wproj_off, wid, h + 1, sn, q);
                 });
             };
             const unsigned char* grp = ring + (u & 1) * EB_GROUP_BYTES;
@@ -437,11 +451,11 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
 // groups 0-1); returns with no LDS-DMA in flight.
 template <int E>
 __device__ __forceinline__ void mlp_issue_stage(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
-                                                int wid, int c, int t, int group) {
+                                                int wid, int c, int t, int group, int q = -1) {
     constexpr int F = 4 * E, KS1 = E / 128;
     unsigned char* dst = ring + group * EB_GROUP_BYTES + (t % 3) * 16384 + wid * 4096;
-    if (t < KS1) sl.template issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, E, dst);
-    else sl.template issue<StreamLane::K128, true>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, F, dst);
+    if (t < KS1) sl.template issue<StreamLane::K64>(wrsrc, (w1_off + (unsigned)(c * MLP_HC * E + t * 128)) * 2u, E, dst, q);
+    else sl.template issue<StreamLane::K128, true>(wrsrc, (w2_off + (unsigned)((t - KS1) * 128 * F + c * MLP_HC)) * 2u, F, dst, q);
 }
 template <int E>
 __device__ __forceinline__ void mlp_prefetch(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int wid) {
@@ -462,14 +476,18 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave)
-        wait_vmcnt<12>();
+        eb_wait_vmcnt<12>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
             acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);
             acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[1][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][1], 0, 0, 0);
-        }, [](int) {});
+        }, [&](int k, int q) {
+#if EB_F1_EARLY
+            if (more) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, k, gcur == 0 ? 2 : gcur - 1, q);
+#endif
+        });
         {
             const int g = opaque_lane() >> 4;                    // (shadows the argument: see opaque_lane)
 #pragma unroll
@@ -501,13 +519,15 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         }
         // the next chunk's fc1 triple goes into the group the fc1 barrier above has retired (two triples back), in the VALU-only gap
         const int gnext2 = gcur == 0 ? 2 : gcur - 1;             // (gcur + 2) % 3
+#if !EB_F1_EARLY
         if (more) {
 #pragma unroll
             for (int tn = 0; tn < 3; ++tn) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, tn, gnext2);
         }
+#endif
         gcur = gcur == 2 ? 0 : gcur + 1;
         // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
-        if (more) wait_vmcnt<12>(); else wait_vmcnt<0>();
+        if (more) eb_wait_vmcnt<12>(); else eb_wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -515,8 +535,8 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
             acc2[k * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hfrag[0][half], acc2[k * 8 + i][0], 0, 0, 0);
             acc2[k * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, hfrag[1][half], acc2[k * 8 + i][1], 0, 0, 0);
-        }, [&](int k) {
-            if (more) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, 3 + k, gn2);     // always 1/1/1: a whole chunk ahead
+        }, [&](int k, int q) {
+            if (more) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, 3 + k, gn2, q);     // always 1/1/1: a whole chunk ahead
         });
         gcur = gcur == 2 ? 0 : gcur + 1;
     }
