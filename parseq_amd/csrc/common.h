@@ -145,24 +145,27 @@ __device__ __forceinline__ float gelu_poly(float x) {
     const float hx = 0.5f * x;
     return fmaf(hx, p * z, hx);
 }
-// gelu_poly over 16 values with the polynomial steps OUTERMOST: every step is eight independent v_pk_fma_f32, so no instruction
-// depends on the one before it.  Evaluated one element at a time the compiler emits each Horner chain as ten dependent packed
-// FMAs with an s_nop after every one of them (the wait state a dependent packed pair needs) — in a kernel with one wave per SIMD
-// those are issue slots nothing else can fill.  The empty asm between steps ties all eight accumulators to one program point:
-// instruction selection linearises pure arithmetic by chain again otherwise (sched_barrier only binds the later machine
-// scheduler).  Same operations in the same order per element: bit-identical to gelu_poly.
+// gelu_poly's polynomial over 16 values with the polynomial steps OUTERMOST: every step is eight independent v_pk_fma_f32, so no
+// instruction depends on the one before it.  Evaluated one element at a time the compiler emits each Horner chain as ten
+// dependent packed FMAs with an s_nop after every one of them (the wait state a dependent packed pair needs) — in a kernel with one
+// wave per SIMD those are issue slots nothing else can fill.  The empty asm between steps ties all eight accumulators to one
+// program point: instruction selection linearises pure arithmetic by chain again otherwise (sched_barrier only binds the later
+// machine scheduler).  The 1/sqrt(2) argument scaling and the final 0.5 are folded into the coefficients:
+//     gelu(x) = x (0.5 + c P'(c^2)),  c = clamp(x, +-3.5 sqrt 2),  P'_i = P_i / (2 sqrt 2 * 2^i)
+// — 14 packed operations per pair instead of 17; same polynomial, so the same 2e-4 absolute bound (not bit-identical to gelu_poly:
+// the coefficient products round differently).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void gelu_poly_16(const f32x2 (&x)[8], f32x2 (&y)[8]) {
     f32x2 z[8], t[8], p[8];
+    constexpr float kLim = 4.949747468305833f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const f32x2 u = x[e] * 0.70710678118654752440f;
-        z[e] = __builtin_elementwise_min(__builtin_elementwise_max(u, f32x2{-3.5f, -3.5f}), f32x2{3.5f, 3.5f});
+        z[e] = __builtin_elementwise_min(__builtin_elementwise_max(x[e], f32x2{-kLim, -kLim}), f32x2{kLim, kLim});
         t[e] = z[e] * z[e];
-        p[e] = __builtin_elementwise_fma(f32x2{-1.417363337807842e-09f, -1.417363337807842e-09f}, t[e], f32x2{9.542367251924588e-08f, 9.542367251924588e-08f});
+        p[e] = __builtin_elementwise_fma(f32x2{-9.78737526922973e-13f, -9.78737526922973e-13f}, t[e], f32x2{1.3178657407047493e-10f, 1.3178657407047493e-10f});
     }
-    constexpr float kC[8] = {-2.8274080250412226e-06f, 4.8881945986067876e-05f, -0.0005533255753107369f, 0.004382880870252848f,
-                             -0.025440679863095284f, 0.11156132817268372f, -0.3756689131259918f, 1.1283513307571411f};
+    constexpr float kC[8] = {-7.809685108155907e-09f, 2.700371522214307e-07f, -6.113441664158902e-06f, 9.684889951526828e-05f,
+                             -0.00112432982807442f, 0.00986072145863531f, -0.0664095089880922f, 0.3989324387696197f};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
@@ -171,10 +174,7 @@ __device__ __forceinline__ void gelu_poly_16(const f32x2 (&x)[8], f32x2 (&y)[8])
     }
     asm volatile("" : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]));
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const f32x2 hx = x[e] * 0.5f;
-        y[e] = __builtin_elementwise_fma(hx, p[e] * z[e], hx);
-    }
+    for (int e = 0; e < 8; ++e) y[e] = x[e] * __builtin_elementwise_fma(z[e], p[e], f32x2{0.5f, 0.5f});
 }
 template <typename T> __device__ __forceinline__ float gelu_for(float x);
 template <> __device__ __forceinline__ float gelu_for<float>(float x) { return gelu_erf(x); }
