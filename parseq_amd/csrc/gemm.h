@@ -181,6 +181,40 @@ struct ALayerNorm {
     }
 };
 
+// The same logical A with the row statistics precomputed in global memory (rowops.h ln_stats_kernel: stats[2 m] = mean,
+// stats[2 m + 1] = rstd): no LDS statistics, no prologue, no barrier before the main loop.  Used by the bf16x3 big-tile GEMMs.
+template <typename T, int E>
+struct ALayerNormStats {
+    const float* x; const float* gamma; const float* beta; const float* stats;
+    static constexpr int kStatsFloats = 0;
+    static constexpr bool kDirect = false;
+    __device__ __forceinline__ void prepare(int, int, int, float*) {}
+    static constexpr int kRaw = 4 / (int)sizeof(T);
+    struct Raw { u32x4 v[kRaw]; };
+    __device__ __forceinline__ Raw fetch(int m, int k) const {
+        Raw raw;
+#pragma unroll
+        for (int i = 0; i < kRaw; ++i) raw.v[i] = reinterpret_cast<const u32x4*>(x + (size_t)m * E + k)[i];
+        return raw;
+    }
+    __device__ __forceinline__ u32x4 finish(const Raw& raw, int m, int k) const {
+        constexpr int n = 16 / (int)sizeof(T);
+        const float2 st = *reinterpret_cast<const float2*>(stats + 2 * (size_t)m);
+        const float mean = st.x, rstd = st.y;
+        union { u32x4 u; T e[n]; } out;
+#pragma unroll
+        for (int i = 0; i < kRaw; ++i) {
+            const float4 gv = *reinterpret_cast<const float4*>(gamma + k + 4 * i);
+            const float4 bv = *reinterpret_cast<const float4*>(beta + k + 4 * i);
+            out.e[4 * i + 0] = from_f32<T>((__uint_as_float(raw.v[i][0]) - mean) * rstd * gv.x + bv.x);
+            out.e[4 * i + 1] = from_f32<T>((__uint_as_float(raw.v[i][1]) - mean) * rstd * gv.y + bv.y);
+            out.e[4 * i + 2] = from_f32<T>((__uint_as_float(raw.v[i][2]) - mean) * rstd * gv.z + bv.z);
+            out.e[4 * i + 3] = from_f32<T>((__uint_as_float(raw.v[i][3]) - mean) * rstd * gv.w + bv.w);
+        }
+        return out.u;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------------------------
 // Epilogues.  Two phases (the stores were the bottleneck of the first version: 8-byte-per-lane scattered stores ran the
 // encoder GEMMs store-issue-bound at ~1 TB/s; tools/gemm_bench.py, profiles/r01_gemm_sweep.md):

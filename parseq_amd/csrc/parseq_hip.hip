@@ -396,8 +396,16 @@ static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, i
     if constexpr (sizeof(T) == 4) {
         if (g_split) {      // bf16x3: W is the block-planar hi / lo copy, products are three bf16 MFMAs (gemm.h SPLIT)
             if (K % 32) return fail(PARSEQ_E_INVALID, "bf16x3 GEMM: K=%d is not a multiple of 32", K);
-            if (M >= 4096 && !force_small) HIPCHK((launch_gemm<T, 128, 128, 2, 2, 128, 2, ALoad, Epi, true>(s, a, W, ldw, M, N, K, epi)));
-            else HIPCHK((launch_gemm<T, 64, 64, 2, 2, 768, 1, ALoad, Epi, true>(s, a, W, ldw, M, N, K, epi)));
+#ifndef PQ_X3_KB
+#define PQ_X3_KB 128
+#define PQ_X3_NBUF 2
+#endif
+            if (M >= 4096 && !force_small) HIPCHK((launch_gemm<T, 128, 128, 2, 2, PQ_X3_KB, PQ_X3_NBUF, ALoad, Epi, true>(s, a, W, ldw, M, N, K, epi)));
+#ifndef PQ_X3_SMALL_BM
+#define PQ_X3_SMALL_BM 32
+#define PQ_X3_SMALL_KB 1536
+#endif
+            else HIPCHK((launch_gemm<T, PQ_X3_SMALL_BM, PQ_X3_SMALL_BM, 2, 2, PQ_X3_SMALL_KB, 1, ALoad, Epi, true>(s, a, W, ldw, M, N, K, epi)));
             return 0;
         }
     }
@@ -410,13 +418,25 @@ static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, i
 // exception: bf16x3 products with the 128 x 128 tile configuration (M >= 4096).  That combination gives wrong values in a few rows
 // (rows 6, 7 mod 8 of the later 32-row groups of a tile) whenever two workgroups share a compute unit, non-deterministically
 // (tools/x3_diag2.py reproduces it in isolation; the f32 form of the same kernel, the 64 x 64 tiles and the plain row-major loader
-// with bf16x3 are all exact and deterministic).  Until that is understood the big-M bf16x3 case runs the LayerNorm as its own
-// kernel into `scratch` ([M, E] f32) and the GEMM with the row-major loader.
+// with bf16x3 are all exact and deterministic).  It is NOT the statistics prologue: a loader that takes mean / rstd precomputed from
+// global memory (gemm.h ALayerNormStats + rowops.h ln_stats_kernel: no LDS statistics, no extra barrier; -DPQ_X3_LN_STATS=1) fails the
+// same way (test_baseline_configs_distinct_crops: max |d| 0.12 teacher-forced), so what the failing combinations share is a
+// finish() that issues its own global loads (gamma / beta / statistics) between the stage's MFMAs and the split LDS stores.
+// Until that is understood the big-M bf16x3 case runs the LayerNorm as its own kernel into `scratch` ([M, E] f32) and the GEMM with
+// the row-major loader.
 template <typename T, int E, typename Epi>
 static int run_ln_gemm(hipStream_t s, const float* x, const float* g, const float* b, float eps, const T* W, int M, int N, const Epi& epi, void* scratch) {
     if constexpr (sizeof(T) == 4) {
         if (g_split && M >= 4096) {
             if (!scratch) return fail(PARSEQ_E_STATE, "run_ln_gemm: no LayerNorm scratch");
+#ifndef PQ_X3_LN_STATS
+#define PQ_X3_LN_STATS 0          // diagnostic build: see the comment above (the defect reproduces with this loader too)
+#endif
+            if (PQ_X3_LN_STATS) {       // row statistics only (M x 2 floats); the GEMM's loader normalises from them
+                hipLaunchKernelGGL((ln_stats_kernel<E>), dim3((M + 3) / 4), dim3(256), 0, s, x, reinterpret_cast<float*>(scratch), M, eps);
+                HIPCHK(hipGetLastError());
+                return run_gemm<T>(s, ALayerNormStats<T, E>{x, g, b, reinterpret_cast<const float*>(scratch)}, W, E, M, N, E, epi);
+            }
             CHK((run_layernorm<float>(s, x, g, b, reinterpret_cast<float*>(scratch), nullptr, M, E, eps)));
             return run_gemm<T>(s, ARowMajor<T>{reinterpret_cast<const T*>(scratch), E}, W, E, M, N, E, epi);
         }

@@ -8,6 +8,35 @@ namespace pq {
 // LayerNorm over the last dim E (E = 192 * VEC, VEC in {1, 2, 4}).  x fp32 [M, E] -> out TO [M, E] and optionally a
 // second fp32 copy (the encoder's final norm is both the API's `memory` output and the decoder K/V GEMM operand).
 // torch.nn.LayerNorm semantics: biased variance, y = (x - mean) / sqrt(var + eps) * w + b  (ViT eps 1e-6, decoder 1e-5).
+// LayerNorm statistics only: stats[2 m] = mean, stats[2 m + 1] = 1 / sqrt(var + eps) of row m (wave per row, the same two passes
+// as layernorm_kernel).  Feeds gemm.h's ALayerNormStats loader: the rows are read once more by the GEMM, nothing is written back.
+template <int E>
+__global__ __launch_bounds__(256)
+void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int M, float eps) {
+    constexpr int VEC = E / 192;
+    static_assert(E % 192 == 0 && (VEC == 1 || VEC == 2 || VEC == 4), "unsupported embed dim");
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * E;
+    float v[3][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { v[it][j] = xr[e0 + j]; s += v[it][j]; }
+    }
+    const float mean = wave_sum(s) * (1.0f / E);
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float d = v[it][j] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / E) + eps);
+    if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
+}
+
 template <typename TO, int E>
 __global__ __launch_bounds__(256)
 void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
