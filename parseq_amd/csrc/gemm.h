@@ -29,6 +29,10 @@
 
 #include "common.h"
 
+#ifndef PQ_DIAG_X3
+#define PQ_DIAG_X3 0     // bf16x3 co-residency defect hunt (tools/x3_diag2.py); see PQ_LSTORE
+#endif
+
 namespace pq {
 
 // Stage geometry.  KB = bytes of K per LDS stage: 128 for the encoder's M = batch*128 GEMMs (double-buffered), 768 for
@@ -116,6 +120,23 @@ struct APatch {
     }
 };
 
+// (x - mean) * rstd * gamma + beta for four elements, every intermediate pinned to a scalar-f32 register (the empty asm keeps the
+// SLP vectoriser from fusing neighbours into v_pk_mul_f32 / v_pk_fma_f32).  Not a micro-optimisation: with packed f32 arithmetic
+// here, the bf16x3 form of the 128 x 128-tile GEMM (whose LDS store path continues with v_cvt_pk_bf16_f32 / subtract / convert
+// on the same registers) produced wrong values in lanes 48-63 of the staging pass — rows 6, 7 mod 8 of a tile, some k-chunks of
+// them — non-deterministically and only while two workgroups shared a compute unit.  Draining VMEM before the stores, unmerged
+// 8-byte LDS stores and wait states between the converts and the stores all left it in place; this form is exact and
+// deterministic on every shape tools/x3_diag2.py runs (the cause at the instruction level is not identified).
+__device__ __forceinline__ void ln_apply4(const u32x4& raw, float mean, float rstd, const float4& gv, const float4& bv, float (&o)[4]) {
+    float d0 = __uint_as_float(raw[0]) - mean, d1 = __uint_as_float(raw[1]) - mean, d2 = __uint_as_float(raw[2]) - mean, d3 = __uint_as_float(raw[3]) - mean;
+    asm volatile("" : "+v"(d0)); asm volatile("" : "+v"(d1)); asm volatile("" : "+v"(d2)); asm volatile("" : "+v"(d3));
+    d0 *= rstd; asm volatile("" : "+v"(d0)); d1 *= rstd; asm volatile("" : "+v"(d1));
+    d2 *= rstd; asm volatile("" : "+v"(d2)); d3 *= rstd; asm volatile("" : "+v"(d3));
+    d0 = d0 * gv.x + bv.x; asm volatile("" : "+v"(d0)); d1 = d1 * gv.y + bv.y; asm volatile("" : "+v"(d1));
+    d2 = d2 * gv.z + bv.z; asm volatile("" : "+v"(d2)); d3 = d3 * gv.w + bv.w; asm volatile("" : "+v"(d3));
+    o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
+}
+
 // LayerNorm fused into the A operand: logical A[m][k] = LayerNorm(x[m])[k] rounded to T, with x the fp32 residual
 // stream [M, E].  prepare() computes mean / rstd of the tile's rows (wave per row, two-pass, exactly like
 // layernorm_kernel) into LDS; load() normalises on the fly.  Removes a kernel boundary and the normalised-activation
@@ -172,10 +193,9 @@ struct ALayerNorm {
         for (int i = 0; i < kRaw; ++i) {
             const float4 gv = *reinterpret_cast<const float4*>(gamma + k + 4 * i);
             const float4 bv = *reinterpret_cast<const float4*>(beta + k + 4 * i);
-            out.e[4 * i + 0] = from_f32<T>((__uint_as_float(raw.v[i][0]) - mean) * rstd * gv.x + bv.x);
-            out.e[4 * i + 1] = from_f32<T>((__uint_as_float(raw.v[i][1]) - mean) * rstd * gv.y + bv.y);
-            out.e[4 * i + 2] = from_f32<T>((__uint_as_float(raw.v[i][2]) - mean) * rstd * gv.z + bv.z);
-            out.e[4 * i + 3] = from_f32<T>((__uint_as_float(raw.v[i][3]) - mean) * rstd * gv.w + bv.w);
+            float o[4];
+            ln_apply4(raw.v[i], mean, rstd, gv, bv, o);
+            out.e[4 * i + 0] = from_f32<T>(o[0]); out.e[4 * i + 1] = from_f32<T>(o[1]); out.e[4 * i + 2] = from_f32<T>(o[2]); out.e[4 * i + 3] = from_f32<T>(o[3]);
         }
         return out.u;
     }
@@ -206,10 +226,9 @@ struct ALayerNormStats {
         for (int i = 0; i < kRaw; ++i) {
             const float4 gv = *reinterpret_cast<const float4*>(gamma + k + 4 * i);
             const float4 bv = *reinterpret_cast<const float4*>(beta + k + 4 * i);
-            out.e[4 * i + 0] = from_f32<T>((__uint_as_float(raw.v[i][0]) - mean) * rstd * gv.x + bv.x);
-            out.e[4 * i + 1] = from_f32<T>((__uint_as_float(raw.v[i][1]) - mean) * rstd * gv.y + bv.y);
-            out.e[4 * i + 2] = from_f32<T>((__uint_as_float(raw.v[i][2]) - mean) * rstd * gv.z + bv.z);
-            out.e[4 * i + 3] = from_f32<T>((__uint_as_float(raw.v[i][3]) - mean) * rstd * gv.w + bv.w);
+            float o[4];
+            ln_apply4(raw.v[i], mean, rstd, gv, bv, o);
+            out.e[4 * i + 0] = from_f32<T>(o[0]); out.e[4 * i + 1] = from_f32<T>(o[1]); out.e[4 * i + 2] = from_f32<T>(o[2]); out.e[4 * i + 3] = from_f32<T>(o[3]);
         }
         return out.u;
     }
@@ -507,8 +526,12 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
             rw[it] = *reinterpret_cast<const u32x4*>(W + (size_t)w_row[it] * ldw + (k_ < K ? k_ : klast)); \
         }                                                                                             \
     }
+#if 0
+#define PQ_DIAG_X3_DOC 0 /* bf16x3 co-residency defect hunt (tools/x3_diag2.py): 1 drain VMEM before the stage's LDS stores, 2 two volatile 8-byte stores instead of a mergeable pair, 4 wait states between the converts and the stores, 8 LayerNorm loader without packed f32 math */
+#endif
 #define PQ_LSTORE(buf, k0)                                                                                             \
     {                                                                                                                  \
+        if constexpr (SPLIT && PQ_DIAG_X3 == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                          \
             const int c_ = it * NT + tid, k_ = (k0) + a_col[it];                                                       \
             const u32x4 v0_ = aload.finish(ra[it], a_row[it], k_ < K ? k_ : klast);                                    \
@@ -517,8 +540,14 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
                 uint2 hi_, lo_;                                                                                        \
                 split4(v_, hi_, lo_);                                                                                  \
                 unsigned char* d_ = As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + ((c_ % CPR) >> 3) * 128 + ((c_ % CPR) & 7) * 8; \
-                *reinterpret_cast<uint2*>(d_) = hi_;                                                                   \
-                *reinterpret_cast<uint2*>(d_ + 64) = lo_;                                                              \
+                if constexpr (PQ_DIAG_X3 == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(hi_.x), "+v"(hi_.y), "+v"(lo_.x), "+v"(lo_.y)); \
+                if constexpr (PQ_DIAG_X3 == 2) {                                                                       \
+                    *reinterpret_cast<volatile unsigned long long*>(d_) = (unsigned long long)hi_.x | ((unsigned long long)hi_.y << 32);      \
+                    *reinterpret_cast<volatile unsigned long long*>(d_ + 64) = (unsigned long long)lo_.x | ((unsigned long long)lo_.y << 32); \
+                } else {                                                                                               \
+                    *reinterpret_cast<uint2*>(d_) = hi_;                                                               \
+                    *reinterpret_cast<uint2*>(d_ + 64) = lo_;                                                          \
+                }                                                                                                      \
             } else {                                                                                                   \
                 *reinterpret_cast<u32x4*>(As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + (c_ % CPR) * 16) = v_;             \
             }                                                                                                          \

@@ -415,22 +415,19 @@ static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, i
 }
 
 // out = epi(LayerNorm(x[M, E]; g, b, eps) W^T): the LayerNorm rides in the GEMM's A-operand loader (gemm.h ALayerNorm).  One
-// exception: bf16x3 products with the 128 x 128 tile configuration (M >= 4096).  That combination gives wrong values in a few rows
-// (rows 6, 7 mod 8 of the later 32-row groups of a tile) whenever two workgroups share a compute unit, non-deterministically
-// (tools/x3_diag2.py reproduces it in isolation; the f32 form of the same kernel, the 64 x 64 tiles and the plain row-major loader
-// with bf16x3 are all exact and deterministic).  It is NOT the statistics prologue: a loader that takes mean / rstd precomputed from
-// global memory (gemm.h ALayerNormStats + rowops.h ln_stats_kernel: no LDS statistics, no extra barrier; -DPQ_X3_LN_STATS=1) fails the
-// same way (test_baseline_configs_distinct_crops: max |d| 0.12 teacher-forced), so what the failing combinations share is a
-// finish() that issues its own global loads (gamma / beta / statistics) between the stage's MFMAs and the split LDS stores.
-// Until that is understood the big-M bf16x3 case runs the LayerNorm as its own kernel into `scratch` ([M, E] f32) and the GEMM with
-// the row-major loader.
+// exception, now for speed only: bf16x3 products with the 128 x 128 tile configuration (M >= 4096) run the LayerNorm as its own
+// kernel into `scratch` ([M, E] f32) and the GEMM with the row-major loader — or, with -DPQ_X3_LN_STATS=1, a statistics-only pass
+// and the ALayerNormStats loader; both fused forms measured no faster than the separate launch (the split GEMM is bound by its LDS
+// staging pass, which the loader's arithmetic lengthens).  History: this combination used to give wrong values in rows 6, 7 mod 8 of
+// a tile whenever two workgroups shared a compute unit; the cause was in the loader's packed-f32 arithmetic (gemm.h ln_apply4),
+// not in the statistics prologue, and is fixed there — tools/x3_diag2.py is the reproducer, exact and deterministic since.
 template <typename T, int E, typename Epi>
 static int run_ln_gemm(hipStream_t s, const float* x, const float* g, const float* b, float eps, const T* W, int M, int N, const Epi& epi, void* scratch) {
     if constexpr (sizeof(T) == 4) {
         if (g_split && M >= 4096) {
             if (!scratch) return fail(PARSEQ_E_STATE, "run_ln_gemm: no LayerNorm scratch");
 #ifndef PQ_X3_LN_STATS
-#define PQ_X3_LN_STATS 0          // diagnostic build: see the comment above (the defect reproduces with this loader too)
+#define PQ_X3_LN_STATS 0
 #endif
             if (PQ_X3_LN_STATS) {       // row statistics only (M x 2 floats); the GEMM's loader normalises from them
                 hipLaunchKernelGGL((ln_stats_kernel<E>), dim3((M + 3) / 4), dim3(256), 0, s, x, reinterpret_cast<float*>(scratch), M, eps);
@@ -442,6 +439,17 @@ static int run_ln_gemm(hipStream_t s, const float* x, const float* g, const floa
         }
     }
     return run_gemm<T>(s, ALayerNorm<T, E>{x, g, b, eps, 0, nullptr}, W, E, M, N, E, epi);
+}
+
+// run_ln_gemm with the embedding width chosen at run time (the encoder's per-op path)
+template <typename T, typename Epi>
+static int run_ln_gemm_e(hipStream_t s, int E, const float* x, const float* g, const float* b, float eps, const T* W, int M, int N, const Epi& epi, void* scratch) {
+    switch (E) {
+        case 192: return run_ln_gemm<T, 192>(s, x, g, b, eps, W, M, N, epi, scratch);
+        case 384: return run_ln_gemm<T, 384>(s, x, g, b, eps, W, M, N, epi, scratch);
+        case 768: return run_ln_gemm<T, 768>(s, x, g, b, eps, W, M, N, epi, scratch);
+        default: return fail(PARSEQ_E_INVALID, "LayerNorm-fused GEMM: E=%d not in {192, 384, 768}", E);
+    }
 }
 
 static EpiBase epi_base(int M, int N, const float* bias) { EpiBase b; b.M = M; b.N = N; b.bias = bias; return b; }
@@ -733,6 +741,10 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const bool panel_qkv = kBf16 && (E == 192 || E == 384) && (3 * E) % PN_BN == 0;
     const bool panel_fc1 = kBf16 && (E == 192 || E == 384) && F % PN_BN == 0;
     const bool fused_mlp = kBf16 && E == 384 && c.enc_mlp_ratio == 4;      // encoder_mlp.h: LayerNorm + fc1 + GELU + fc2 + residual in one kernel
+#ifndef PQ_X3_LN_IN_GEMM
+#define PQ_X3_LN_IN_GEMM 0      // measured: qkv 270 + 48 us (LayerNorm launch) vs 319 us fused, fc1 360 + 48 vs 429: the loader's arithmetic costs what the launch did
+#endif
+    const bool ln_in_gemm = PQ_X3_LN_IN_GEMM && !kBf16 && g_split && M >= 4096 && (E == 192 || E == 384 || E == 768);
     // A kernel that holds `per_cu` workgroups of 128 rows per CU finishes in whole rounds of per_cu * CUs row tiles.  When
     // the row count leaves a few tiles over (ViTSTR: 512 x 129 rows = 516 tiles on 256 CUs), those tiles would cost a whole
     // extra round; instead the leading whole rounds go to the fused kernel and the tail rows to the generic kernels.
@@ -779,11 +791,16 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                 }
             }
         } else {
-            { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
             EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
             eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N;
             eq.tr_from = N == ATT_N ? 2 : 3;      // the 128-token kernels of this path read V^T, the generic one row-major V
-            { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
+            if (ln_in_gemm) {       // bf16x3: row statistics in a 12 us pass, the LayerNorm itself in the GEMM's A-loader (run_ln_gemm)
+                ProfScope ps_(&p->prof, T_QKV, s);
+                CHK((run_ln_gemm_e<T>(s, E, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), M, 3 * E, eq, xn)));
+            } else {
+                { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
+                { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
+            }
         }
         { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv || N != ATT_N, N))); }
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
@@ -814,8 +831,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                 else HIPCHK((launch_ln_panel_gemm<192>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"), m->p(b + "mlp.fc1.bias"), M, F, pg)));
             }
         } else {
-            { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
-            { ProfScope ps_(&p->prof, T_FC1, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "mlp.fc1.weight"), E, M, F, E, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F)))); }
+            if (ln_in_gemm) {
+                ProfScope ps_(&p->prof, T_FC1, s);
+                CHK((run_ln_gemm_e<T>(s, E, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"), M, F, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F), xn)));
+            } else {
+                { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm<T>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), xn, nullptr, M, E, c.enc_ln_eps))); }
+                { ProfScope ps_(&p->prof, T_FC1, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "mlp.fc1.weight"), E, M, F, E, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F)))); }
+            }
         }
         { ProfScope ps_(&p->prof, T_FC2, s); CHK((run_gemm<T>(s, ARowMajor<T>{h, F}, W.w(b + "mlp.fc2.weight"), F, M, E, F, epi_resid(M, E, m->p(b + "mlp.fc2.bias"), p->x, E)))); }
     }

@@ -27,3 +27,12 @@ for M in (208, 4096, 13312):
             rep_d = max(float((outs[0] - o).abs().max()) for o in outs[1:])
             badrows = (err.amax(1) > 1e-3).nonzero().flatten().tolist()
             print(f'ln_linear {nm:7s} M={M} N={N}: max|d| {float(err.max()):.3e}  run-to-run {rep_d:.3e}  bad rows {len(badrows)} {badrows[:12]}')
+            if badrows:
+                r = badrows[0]
+                # what would the row be if its A operand were all zeros (bias only), or LayerNorm with the neighbour row's statistics?
+                print('   row', r, 'got', [round(float(v), 4) for v in outs[0][r, :5]], 'want', [round(float(v), 4) for v in want[r, :5]], 'bias', [round(float(v), 4) for v in b[:5]])
+                xn = torch.nn.functional.layer_norm(x.double(), (E,), gamma.double(), beta.double(), 1e-5)
+                hi = xn.float().bfloat16().double()
+                for nm2, cand in (('hi-plane only', hi[r] @ W.double().T + b.double()), ('lo-plane only', (xn[r] - hi[r]) @ W.double().T + b.double()),
+                                  ('other 32-row group same lane', xn[(r + 32) % M] @ W.double().T + b.double())):
+                    print(f'      |got - {nm2}| max {float((outs[0][r].double() - cand).abs().max()):.3e}')
