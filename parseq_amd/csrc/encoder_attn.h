@@ -155,6 +155,8 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
 }
 
+// SPLIT_OUT: `ao` is written as block-planar hi | lo bf16 pairs (the A operand of the proj GEMM in its PAIRS form, gemm.h) instead of f32
+template <bool SPLIT_OUT = false>
 __global__ __launch_bounds__(256)
 void attn_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vt,
                        float* __restrict__ ao, int heads, float scale) {
@@ -265,9 +267,21 @@ void attn_split_kernel(const float* __restrict__ q, const float* __restrict__ k,
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-            *reinterpret_cast<float4*>(orow + nt * 32 + rg * 8) = make_float4(ot[nt][rg * 4 + 0] * inv, ot[nt][rg * 4 + 1] * inv,
-                                                                              ot[nt][rg * 4 + 2] * inv, ot[nt][rg * 4 + 3] * inv);
+        for (int rg = 0; rg < 4; ++rg) {
+            const float o4[4] = {ot[nt][rg * 4 + 0] * inv, ot[nt][rg * 4 + 1] * inv, ot[nt][rg * 4 + 2] * inv, ot[nt][rg * 4 + 3] * inv};
+            if constexpr (SPLIT_OUT) {
+                // column c = h * 64 + nt * 32 + rg * 8 + 4 * hi of the row: block c / 32, chunk (c % 32) / 4
+                const int c = h * ATT_HD + nt * 32 + rg * 8 + 4 * hi;
+                unsigned char* d = reinterpret_cast<unsigned char*>(ao) + (((size_t)b * ATT_N + q0 + qi) * E + (c & ~31)) * 4 + ((c & 31) >> 2) * 8;
+                union { uint2 u; bf16_t e[4]; } hh, ll;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { hh.e[i] = static_cast<bf16_t>(o4[i]); ll.e[i] = static_cast<bf16_t>(o4[i] - static_cast<float>(hh.e[i])); }
+                *reinterpret_cast<uint2*>(d) = hh.u;
+                *reinterpret_cast<uint2*>(d + 64) = ll.u;
+            } else {
+                *reinterpret_cast<float4*>(orow + nt * 32 + rg * 8) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+            }
+        }
 }
 
 // attn_mfma_kernel for any token count N <= 32 * NT32 (129 tokens for ViTSTR, 196 for

@@ -302,6 +302,30 @@ struct EpiGelu : EpiBase {
     __device__ __forceinline__ void store_m(int, int, const S*) const {}
 };
 
+// out = gelu(acc + bias) written as block-planar hi | lo bf16 pairs (the A operand of a PAIRS GEMM): element n of row m lives in
+// block n / 32 of the row — 128 bytes: hi of the block's 32 elements, then lo — so a 4-element chunk is 8 bytes in each half.
+struct EpiGeluSplit : EpiBase {
+    using S = float;
+    unsigned char* out; int ldo;            // ldo: row pitch in logical (f32-sized) elements
+    __device__ __forceinline__ void xform_n4(int m, int n, float* v) const {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = gelu_for<float>(v[j] + b(n + j));
+    }
+    __device__ __forceinline__ void store_n(int m, int n, const S* c) const {
+        if (n + 4 > N) return;
+        union { uint2 u; bf16_t e[4]; } h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h.e[i] = static_cast<bf16_t>(c[i]);
+            l.e[i] = static_cast<bf16_t>(c[i] - static_cast<float>(h.e[i]));
+        }
+        unsigned char* d = out + ((size_t)m * ldo + (n & ~31)) * 4 + ((n & 31) >> 2) * 8;
+        *reinterpret_cast<uint2*>(d) = h.u;
+        *reinterpret_cast<uint2*>(d + 64) = l.u;
+    }
+    __device__ __forceinline__ void store_m(int, int, const S*) const {}
+};
+
 // x[m][n] += acc + bias   (fp32 residual stream, in place).  The old x values are fetched for ALL of a thread's chunks
 // at the start of the epilogue (kPrefetch), so their latency hides under the LDS staging pass instead of being paid
 // once per chunk in a load -> add -> store chain (that chain ran proj / fc2 at 2.7 TB/s).
@@ -383,7 +407,7 @@ __device__ __forceinline__ void split4(const u32x4& v, uint2& hi, uint2& lo) {
     hi = h.u; lo = l.u;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, bool DIRECT, typename ALoad, typename Epi, bool SPLIT = false>
+template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, bool DIRECT, typename ALoad, typename Epi, bool SPLIT = false, bool PAIRS = false>
 __global__ __launch_bounds__(WM * WN * 64)
 void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, int N, int K, int mtiles, int ntiles,
                  const Epi epi) {
@@ -398,6 +422,10 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
     static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/thread mismatch");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS stages");
     static_assert(!SPLIT || (sizeof(T) == 4 && !DIRECT && KB % 128 == 0), "split-bf16 products: f32 storage, register-staged loop, whole 32-element blocks");
+    // PAIRS: BOTH operands already hold block-planar hi | lo bf16 pairs in memory (a 32-element block of the logical f32 matrix is 64 B
+    // of hi + 64 B of lo = one 128-byte stage row), seen here as bf16 matrices of twice the logical K.  The direct-to-LDS loop moves
+    // them untouched; the two 64-byte halves of a stage row are then the hi and the lo fragments of ONE k-step instead of two k-steps.
+    static_assert(!PAIRS || (DIRECT && sizeof(T) == 2 && !SPLIT), "pre-split operands: bf16 view, direct-to-LDS loop");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                                  // [NBUF][BM][ROWB]
@@ -475,6 +503,28 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
             const unsigned char* Wb = Ws + cur * BN * KB + w_off;
             const unsigned char* Pb = tr ? Ab : Wb;
             const unsigned char* Qb = tr ? Wb : Ab;
+            if constexpr (PAIRS) {
+                const int so_h = (g4 ^ sx) * 16, so_l = ((4 + g4) ^ sx) * 16;
+                Frag<T> ph[TM], pl[TM], qh[TN], ql[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ph[i].v = *reinterpret_cast<const decltype(ph[i].v)*>(Pb + i * 16 * KB + so_h);
+                    pl[i].v = *reinterpret_cast<const decltype(pl[i].v)*>(Pb + i * 16 * KB + so_l);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    qh[j].v = *reinterpret_cast<const decltype(qh[j].v)*>(Qb + j * 16 * KB + so_h);
+                    ql[j].v = *reinterpret_cast<const decltype(ql[j].v)*>(Qb + j * 16 * KB + so_l);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        mma16(acc[i][j], pl[i], qh[j]);          // small terms first
+                        mma16(acc[i][j], ph[i], ql[j]);
+                        mma16(acc[i][j], ph[i], qh[j]);
+                    }
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int so = ((kk * 4 + g4) ^ sx) * 16;
@@ -487,6 +537,7 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) mma16(acc[i][j], fp[i], fq[j]);
+            }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA into the other buffer has landed
             __syncthreads();                                     // ... and so has everybody else's; buffer `cur` is free
@@ -685,6 +736,23 @@ constexpr size_t gemm_lds_bytes() {
     const size_t stage_n = (size_t)BM * (BN * SSZ + 16), stage_m = (size_t)BN * (BM * SSZ + 16);   // epilogue staging tile
     const size_t stage = stage_n > stage_m ? stage_n : stage_m;
     return pipe > stage ? pipe : stage;
+}
+
+// Both operands pre-split (gemm_kernel PAIRS): A and W are bf16 views [M][2 K_logical] / [N][2 K_logical]; K = 2 K_logical must be a
+// multiple of 64 (whole 32-element blocks of the logical matrices).
+template <int BM, int BN, int WM, int WN, typename Epi>
+inline hipError_t launch_gemm_pairs(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi) {
+    const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
+    const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
+    constexpr size_t lds = gemm_lds_bytes<BM, BN, 128, 2, 0, (int)sizeof(typename Epi::S)>();
+    if (K % 64) return hipErrorInvalidValue;
+    auto kd = gemm_kernel<bf16_t, BM, BN, WM, WN, 128, 2, true, ARowMajor<bf16_t>, Epi, false, true>;
+    if (lds > 64 * 1024) {
+        static LdsAttr attr_d;
+        if (hipError_t e = attr_d.ensure(reinterpret_cast<const void*>(kd), lds); e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kd, dim3(grid), dim3(WM * WN * 64), lds, s, ARowMajor<bf16_t>{A, lda}, W, ldw, M, N, K, mtiles, ntiles, epi);
+    return hipGetLastError();
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int KB, int NBUF, typename ALoad, typename Epi, bool SPLIT = false>

@@ -390,6 +390,17 @@ static int run_layernorm(hipStream_t s, const float* x, const float* w, const fl
     return 0;
 }
 
+static int run_layernorm_split(hipStream_t s, const float* x, const float* w, const float* b, unsigned char* out, int rows, int E, float eps) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    switch (E) {
+        case 384: hipLaunchKernelGGL((layernorm_split_kernel<384>), grid, block, 0, s, x, w, b, out, rows, eps); break;
+        case 768: hipLaunchKernelGGL((layernorm_split_kernel<768>), grid, block, 0, s, x, w, b, out, rows, eps); break;
+        default: return fail(PARSEQ_E_INVALID, "split layernorm: E=%d not in {384, 768}", E);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // GEMM dispatch: big tiles for the encoder's M = batch * 128 rows, small tiles for the decoder's M = batch (* 26).
 template <typename T, typename ALoad, typename Epi>
 static int run_gemm(hipStream_t s, const ALoad& a, const T* W, int ldw, int M, int N, int K, const Epi& epi, bool force_small = false) {
@@ -663,7 +674,7 @@ extern "C" int parseq_plan_get_profile(parseq_plan* p, int index, const char** n
 // encoder
 // -------------------------------------------------------------------------------------------------------------------
 template <typename T>
-static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads, bool v_rowmajor = false, int tokens = ATT_N) {
+static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt, T* ao, int bh, int heads, bool v_rowmajor = false, int tokens = ATT_N, bool split_out = false) {
     const float scale = 1.0f / sqrtf((float)ATT_HD);
     if (tokens != ATT_N) {
         if (!v_rowmajor) return fail(PARSEQ_E_INVALID, "token-count-generic attention expects row-major V");
@@ -692,9 +703,15 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
         else hipLaunchKernelGGL(attn_mfma_kernel<false>, dim3(bh), dim3(256), 0, s, q, k, vt, ao, heads, scale);
     } else if (g_split) {
         if (v_rowmajor) return fail(PARSEQ_E_INVALID, "bf16x3 attention expects V^T");
-        static LdsAttr attr;
-        HIPCHK(attr.ensure(reinterpret_cast<const void*>(attn_split_kernel), attn_split_lds()));
-        hipLaunchKernelGGL(attn_split_kernel, dim3(bh), dim3(256), attn_split_lds(), s, q, k, vt, ao, heads, scale);
+        if (split_out) {
+            static LdsAttr attr_s;
+            HIPCHK(attr_s.ensure(reinterpret_cast<const void*>(attn_split_kernel<true>), attn_split_lds()));
+            hipLaunchKernelGGL(attn_split_kernel<true>, dim3(bh), dim3(256), attn_split_lds(), s, q, k, vt, ao, heads, scale);
+        } else {
+            static LdsAttr attr;
+            HIPCHK(attr.ensure(reinterpret_cast<const void*>(attn_split_kernel<false>), attn_split_lds()));
+            hipLaunchKernelGGL(attn_split_kernel<false>, dim3(bh), dim3(256), attn_split_lds(), s, q, k, vt, ao, heads, scale);
+        }
     } else {
         if (v_rowmajor) return fail(PARSEQ_E_INVALID, "f32 attention expects V^T");
         constexpr size_t lds = (size_t)2 * ATT_N * ATT_HD * sizeof(float);
@@ -741,6 +758,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const bool panel_qkv = kBf16 && (E == 192 || E == 384) && (3 * E) % PN_BN == 0;
     const bool panel_fc1 = kBf16 && (E == 192 || E == 384) && F % PN_BN == 0;
     const bool fused_mlp = kBf16 && E == 384 && c.enc_mlp_ratio == 4;      // encoder_mlp.h: LayerNorm + fc1 + GELU + fc2 + residual in one kernel
+    // bf16x3, big M: activations travel between the encoder's kernels already split into block-planar hi | lo bf16 pairs — the
+    // LayerNorm, the attention kernel and the fc1 + GELU epilogue write that form, and the four GEMMs of a block run the
+    // direct-to-LDS loop on both operands (gemm.h PAIRS) instead of converting their A tile in every column tile's workgroup.
+#ifndef PQ_X3_PRESPLIT
+#define PQ_X3_PRESPLIT 1
+#endif
+    const bool presplit = PQ_X3_PRESPLIT && !kBf16 && g_split && M >= 4096 && N == ATT_N && (E == 384 || E == 768);
 #ifndef PQ_X3_LN_IN_GEMM
 #define PQ_X3_LN_IN_GEMM 0      // measured: qkv 270 + 48 us (LayerNorm launch) vs 319 us fused, fc1 360 + 48 vs 429: the loader's arithmetic costs what the launch did
 #endif
@@ -794,7 +818,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             EpiHeads<T> eq; static_cast<EpiBase&>(eq) = epi_base(M, 3 * E, m->p(b + "attn.qkv.bias"));
             eq.seg[0] = q; eq.seg[1] = k; eq.seg[2] = vt; eq.E = E; eq.heads = H; eq.hd = ATT_HD; eq.tokens = N;
             eq.tr_from = N == ATT_N ? 2 : 3;      // the 128-token kernels of this path read V^T, the generic one row-major V
-            if (ln_in_gemm) {       // bf16x3: row statistics in a 12 us pass, the LayerNorm itself in the GEMM's A-loader (run_ln_gemm)
+            if (presplit) {
+                if constexpr (!kBf16) {
+                    { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm_split(s, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), reinterpret_cast<unsigned char*>(xn), M, E, c.enc_ln_eps))); }
+                    ProfScope ps_(&p->prof, T_QKV, s);
+                    HIPCHK((launch_gemm_pairs<128, 128, 2, 2>(s, reinterpret_cast<const bf16_t*>(xn), 2 * E, reinterpret_cast<const bf16_t*>(W.w(b + "attn.qkv.weight")), 2 * E, M, 3 * E, 2 * E, eq)));
+                }
+            } else if (ln_in_gemm) {       // bf16x3: row statistics in a 12 us pass, the LayerNorm itself in the GEMM's A-loader (run_ln_gemm)
                 ProfScope ps_(&p->prof, T_QKV, s);
                 CHK((run_ln_gemm_e<T>(s, E, p->x, m->p(b + "norm1.weight"), m->p(b + "norm1.bias"), c.enc_ln_eps, W.w(b + "attn.qkv.weight"), M, 3 * E, eq, xn)));
             } else {
@@ -802,7 +832,12 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                 { ProfScope ps_(&p->prof, T_QKV, s); CHK((run_gemm<T>(s, ARowMajor<T>{xn, E}, W.w(b + "attn.qkv.weight"), E, M, 3 * E, E, eq))); }
             }
         }
-        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv || N != ATT_N, N))); }
+        { ProfScope ps_(&p->prof, T_ATTN, s); CHK((run_enc_attention<T>(s, q, k, vt, ao, B * H, H, panel_qkv || N != ATT_N, N, presplit))); }
+        if (presplit) {
+            ProfScope ps_(&p->prof, T_PROJ, s);
+            HIPCHK((launch_gemm_pairs<128, 128, 2, 2>(s, reinterpret_cast<const bf16_t*>(ao), 2 * E, reinterpret_cast<const bf16_t*>(W.w(b + "attn.proj.weight")), 2 * E, M, E, 2 * E,
+                                                        epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E))));
+        } else
         { ProfScope ps_(&p->prof, T_PROJ, s); CHK((run_gemm<T>(s, ARowMajor<T>{ao, E}, W.w(b + "attn.proj.weight"), E, M, E, E, epi_resid(M, E, m->p(b + "attn.proj.bias"), p->x, E)))); }
         }
         if (fused_mlp) {
@@ -831,7 +866,18 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                 else HIPCHK((launch_ln_panel_gemm<192>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"), m->p(b + "mlp.fc1.bias"), M, F, pg)));
             }
         } else {
-            if (ln_in_gemm) {
+            if (presplit) {
+                if constexpr (!kBf16) {
+                    { ProfScope ps_(&p->prof, T_LN, s); CHK((run_layernorm_split(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), reinterpret_cast<unsigned char*>(xn), M, E, c.enc_ln_eps))); }
+                    EpiGeluSplit eg; static_cast<EpiBase&>(eg) = epi_base(M, F, m->p(b + "mlp.fc1.bias")); eg.out = reinterpret_cast<unsigned char*>(h); eg.ldo = F;
+                    { ProfScope ps_(&p->prof, T_FC1, s);
+                      HIPCHK((launch_gemm_pairs<128, 128, 2, 2>(s, reinterpret_cast<const bf16_t*>(xn), 2 * E, reinterpret_cast<const bf16_t*>(W.w(b + "mlp.fc1.weight")), 2 * E, M, F, 2 * E, eg))); }
+                    ProfScope ps_(&p->prof, T_FC2, s);
+                    HIPCHK((launch_gemm_pairs<128, 128, 2, 2>(s, reinterpret_cast<const bf16_t*>(h), 2 * F, reinterpret_cast<const bf16_t*>(W.w(b + "mlp.fc2.weight")), 2 * F, M, E, 2 * F,
+                                                                epi_resid(M, E, m->p(b + "mlp.fc2.bias"), p->x, E))));
+                }
+                continue;
+            } else if (ln_in_gemm) {
                 ProfScope ps_(&p->prof, T_FC1, s);
                 CHK((run_ln_gemm_e<T>(s, E, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"), M, F, epi_gelu<T>(M, F, m->p(b + "mlp.fc1.bias"), h, F), xn)));
             } else {

@@ -37,6 +37,52 @@ void ln_stats_kernel(const float* __restrict__ x, float* __restrict__ stats, int
     if (lane == 0) { stats[2 * (size_t)row] = mean; stats[2 * (size_t)row + 1] = rstd; }
 }
 
+// LayerNorm whose output is written as block-planar hi | lo bf16 pairs (bf16x3 mode: the A operand of a PAIRS GEMM, gemm.h): the 32
+// elements [32 b, 32 b + 32) of a row occupy bytes [128 b, 128 b + 64) (hi) and [128 b + 64, 128 b + 128) (lo) of the row.
+template <int E>
+__global__ __launch_bounds__(256)
+void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                            unsigned char* __restrict__ out, int M, float eps) {
+    constexpr int VEC = E / 192;
+    static_assert(E % 192 == 0 && (VEC == 2 || VEC == 4), "unsupported embed dim");
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * E;
+    float v[3][VEC];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { v[it][j] = xr[e0 + j]; s += v[it][j]; }
+    }
+    const float mean = wave_sum(s) * (1.0f / E);
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < 3; ++it)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float d = v[it][j] - mean; ss += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * (1.0f / E) + eps);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int e0 = (it * 64 + lane) * VEC;
+        bf16_t hi[VEC], lo[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float y = (v[it][j] - mean) * rstd * w[e0 + j] + b[e0 + j];
+            hi[j] = static_cast<bf16_t>(y);
+            lo[j] = static_cast<bf16_t>(y - static_cast<float>(hi[j]));
+        }
+        unsigned char* d = out + ((size_t)row * E + (e0 & ~31)) * 4 + (e0 & 31) * 2;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            *reinterpret_cast<bf16_t*>(d + 2 * j) = hi[j];
+            *reinterpret_cast<bf16_t*>(d + 64 + 2 * j) = lo[j];
+        }
+    }
+}
+
 template <typename TO, int E>
 __global__ __launch_bounds__(256)
 void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
