@@ -297,6 +297,12 @@ int parseq_op_linear(const void* A, const void* W, const float* bias, void* C, i
  * parseq_op_split_pack). */
 int parseq_op_ln_linear(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, float* C, int dtype,
                         int M, int N, float eps, void* stream);
+/* bf16x3, both operands pre-split (the encoder's big-M form): ws[M * 384 * 4 bytes] receives LayerNorm(x[M, 384]; gamma, beta, eps) as
+ * block-planar hi | lo bf16 pairs (layernorm_split_kernel), then C[M, N] (fp32) = ws W^T + bias with W from parseq_op_split_pack,
+ * through the direct-to-LDS GEMM that reads both operands as pairs.  act != 0: C is instead written as gelu(...) in the same
+ * block-planar pair layout (N a multiple of 32; C is N * 4 bytes per row) — the fc1 epilogue of that path. */
+int parseq_op_ln_linear_pairs(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* C, void* ws,
+                              int act, int M, int N, float eps, void* stream);
 /* dtype = PARSEQ_BF16X3: A is f32 [M, K], K a multiple of 32; W must be the block-planar hi / lo copy of the f32 weight that
  * parseq_op_split_pack(src f32 [numel], dst [numel * 4 bytes]) produces (numel a multiple of 32); C as for PARSEQ_F32. */
 int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream);

@@ -28,7 +28,10 @@ namespace pq {
 
 constexpr int DS_ROWS = 16;     // rows per workgroup
 constexpr int DS_NW = 8;        // waves per workgroup; 16-wide output column tiles are dealt round-robin to waves
-constexpr int DS_RING = 8;      // 1-KB LDS slots per wave: fragment copies in flight (64 KB per CU)
+#ifndef PQ_DS_RING
+#define PQ_DS_RING 8
+#endif
+constexpr int DS_RING = PQ_DS_RING;      // 1-KB LDS slots per wave: fragment copies in flight (64 KB per CU)
 constexpr int DS_LA = 2;        // fragments read ahead from LDS into registers (hides the ds_read latency behind MFMAs)
 
 // Fragment-ordered weights.  A [N][K] row-major weight is re-packed once per weight set (frag_pack_kernel) into

@@ -1913,6 +1913,25 @@ extern "C" int parseq_op_ln_linear(const float* x, const float* gamma, const flo
                            epi_store<float>(M, N, bias, C_, N));
 }
 
+extern "C" int parseq_op_ln_linear_pairs(const float* x, const float* gamma, const float* beta, const void* W, const float* bias, void* C_, void* ws,
+                                         int act, int M, int N, float eps, void* stream) {
+    CHK(check_arch());
+    if (!x || !gamma || !beta || !W || !C_ || !ws || M <= 0 || N <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
+    if (act && (N % 32)) return fail(PARSEQ_E_INVALID, "pair-layout output: N=%d is not a multiple of 32", N);
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int E = 384;
+    CHK((run_layernorm_split(s, x, gamma, beta, reinterpret_cast<unsigned char*>(ws), M, E, eps)));
+    const bf16_t* A2 = reinterpret_cast<const bf16_t*>(ws);
+    const bf16_t* W2 = reinterpret_cast<const bf16_t*>(W);
+    if (act) {
+        EpiGeluSplit eg; static_cast<EpiBase&>(eg) = epi_base(M, N, bias); eg.out = reinterpret_cast<unsigned char*>(C_); eg.ldo = N;
+        HIPCHK((launch_gemm_pairs<128, 128, 2, 2>(s, A2, 2 * E, W2, 2 * E, M, N, 2 * E, eg)));
+    } else {
+        HIPCHK((launch_gemm_pairs<128, 128, 2, 2>(s, A2, 2 * E, W2, 2 * E, M, N, 2 * E, epi_store<float>(M, N, bias, (float*)C_, N))));
+    }
+    return 0;
+}
+
 extern "C" int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream) {
     CHK(check_arch());
     if (!src || !dst || numel <= 0 || (numel % 32)) return fail(PARSEQ_E_INVALID, "bad argument (numel must be a multiple of 32)");

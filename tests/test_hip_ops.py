@@ -60,6 +60,46 @@ def test_linear_bf16x3(M, N, K):
     assert (one - want.float()).abs().max() > 20 * err
 
 
+def _unpack_pairs(buf, rows, cols):
+    """Block-planar hi | lo bf16 pairs (32 logical elements -> 64 B of hi + 64 B of lo) back to f32 hi + lo."""
+    raw = buf.view(torch.bfloat16).reshape(rows, cols // 32, 2, 32).float()
+    return (raw[:, :, 0] + raw[:, :, 1]).reshape(rows, cols)
+
+
+@pytest.mark.parametrize('M,N', [(4096, 384), (8192, 1536), (1000, 1152), (130, 96)])
+def test_ln_linear_pairs_bf16x3(M, N):
+    """The bf16x3 encoder's big-M form: layernorm_split_kernel writes the A operand as hi | lo pairs, gemm_kernel<PAIRS> reads both
+    operands as pairs through the direct-to-LDS loop.  Against fp64 on unrounded operands, and (act) the pair-layout GELU epilogue."""
+    nat, lib = native()
+    E = 384
+    x = _gen(M, E, seed=14) * 1.3 + 0.2
+    gamma, beta = torch.rand(E, generator=torch.Generator().manual_seed(15)) + 0.5, 0.1 * _gen(E, seed=16)
+    W = _gen(N, E, seed=17) / E ** 0.5
+    bias = 0.1 * _gen(N, seed=18)
+    xn = torch.nn.functional.layer_norm(x.double(), (E,), gamma.double(), beta.double(), 1e-6)
+    want = xn @ W.double().T + bias.double()
+    xd, gd, bd, Wd, biasd = x.to(DEV), gamma.to(DEV), beta.to(DEV), W.to(DEV).contiguous(), bias.to(DEV)
+    Wp = torch.empty(N * E, dtype=torch.float32, device=DEV)
+    nat.check(lib.parseq_op_split_pack(nat.ptr(Wd), nat.ptr(Wp), N * E, nat.stream_ptr()))
+    ws = torch.empty(M * E, dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+    nat.check(lib.parseq_op_ln_linear_pairs(nat.ptr(xd), nat.ptr(gd), nat.ptr(bd), nat.ptr(Wp), nat.ptr(biasd), nat.ptr(out), nat.ptr(ws), 0, M, N, 1e-6, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    # the LayerNorm output itself, unpacked from the pair layout: hi + lo carries ~16 mantissa bits
+    err_ln, msg_ln = report(f'layernorm_split {M}x{E}', _unpack_pairs(ws.cpu(), M, E), xn.float())
+    assert err_ln <= 1e-4, msg_ln
+    err, msg = report(f'ln + linear pairs {M}x{N}', out, want.float())
+    assert err <= 1e-4, msg
+    one = (xn.float().bfloat16().double() @ W.bfloat16().double().T + bias.double()).float()
+    assert (one - want.float()).abs().max() > 20 * err          # really better than one bf16 product
+    if N % 32 == 0:
+        out2 = torch.zeros(M * N, dtype=torch.float32, device=DEV)
+        nat.check(lib.parseq_op_ln_linear_pairs(nat.ptr(xd), nat.ptr(gd), nat.ptr(bd), nat.ptr(Wp), nat.ptr(biasd), nat.ptr(out2), nat.ptr(ws), 1, M, N, 1e-6, nat.stream_ptr()))
+        torch.cuda.synchronize()
+        err2, msg2 = report(f'ln + linear + gelu, pair-layout output {M}x{N}', _unpack_pairs(out2.cpu(), M, N), torch.nn.functional.gelu(want).float())
+        assert err2 <= 1e-4, msg2
+
+
 @pytest.mark.parametrize('M,N,K', LINEAR_SHAPES)
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_linear(M, N, K, dtype):
