@@ -246,6 +246,11 @@ class _NativeBacked(nn.Module):
         params = list(self.parameters())
         return (str(self._device), tuple(p.data_ptr() for p in params), tuple(self._version_of(p) for p in params))
 
+    def mark_dirty(self):
+        """Force the next forward / encode / decode to re-upload every parameter.  Needed only after writes the signature cannot
+        see: in-place edits through `param.data` (checkpoint averaging, EMA) do not bump a tensor's version counter."""
+        self._native_state.signature = None
+
     def _sync_native(self):
         st: _NativeState = self._native_state
         sig = self._signature()

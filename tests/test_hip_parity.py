@@ -273,6 +273,17 @@ def test_weight_update_refreshes_native_state(golden):
             m.model.head.bias.sub_(1.0)          # (edits through `.data` do not bump the tensor version and are not tracked)
         base = _run(m, images, 'nar0')
         assert torch.allclose(shifted - base, torch.ones_like(base), atol=2e-2 if precision == 'bf16' else 1e-5)
+        # a write through `.data` (EMA / checkpoint-averaging idiom) is invisible to the version counters: mark_dirty() is the
+        # explicit way to have it uploaded
+        m.model.head.bias.data += 1.0
+        stale = _run(m, images, 'nar0')
+        assert torch.equal(stale, base)
+        m.model.mark_dirty()
+        seen = _run(m, images, 'nar0')
+        m.model.head.bias.data -= 1.0
+        m.model.mark_dirty()
+        assert torch.allclose(seen - base, torch.ones_like(base), atol=2e-2 if precision == 'bf16' else 1e-5)
+        assert torch.equal(_run(m, images, 'nar0'), base)
 
 
 def test_slots_and_streams_give_identical_results(models, golden, name):
