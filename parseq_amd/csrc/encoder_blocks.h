@@ -163,12 +163,14 @@ __device__ __forceinline__ int opaque_lane() {
 // byte offset of lane (r16, g)'s first-k-step fragment inside a ring stage; the second k-step's is this ^ 64
 __device__ __forceinline__ int stage_frag_off(int ln) { const int r16 = ln & 15, g_ = ln >> 4; return r16 * 128 + ((g_ ^ (r16 & 7)) << 4); }
 
-// Per-lane constants of the weight stream (identical in both phases): BYTE offsets of this lane's four DMA source pieces relative
-// to the wave-uniform stage origin, for the three (row order, row pitch) combinations the two phases use.  Every DMA is
-//     buffer_load_dwordx4 voffset, s[rsrc], soffset offen lds
-// — one descriptor over the whole bf16 weight pack, the stage origin in an SGPR, one 32-bit VGPR per piece.  (With 64-bit per-lane
-// global pointers the compiler hoists four address pairs per matrix out of the loops, spills them, and every reload inside the
-// loop carries an s_waitcnt vmcnt(0) that drains the LDS-DMA pipeline.)
+// Per-lane constants of the weight stream (identical in both phases): the BYTE offset of this lane's DMA source relative to the
+// wave-uniform stage origin, for the three (row order, row pitch) combinations the two phases use — computed once per kernel.
+// Every DMA is
+//     buffer_load_dwordx4 voffset, s[rsrc], soffset offen offset:imm lds
+// — one descriptor over the whole bf16 weight pack, the stage origin (+ the piece's row delta) in an SGPR, ONE 32-bit VGPR for all
+// four pieces of a stage.  (With 64-bit per-lane global pointers the compiler hoists four address pairs per matrix out of the
+// loops, spills them, and every reload inside the loop carries an s_waitcnt vmcnt(0) that drains the LDS-DMA pipeline; with the
+// offsets recomputed at every issue — the round's intermediate form — the address arithmetic was 5 % of the kernel.)
 struct StreamLane {
     // A wave's four DMA pieces of a stage cover LDS rows 32 wid + 8 q + (lane >> 3), q = 0..3.  Under the pair permutation their
     // source rows are row(q) = row(0) + {0, 16, 4, 20}[q] for every lane, so ONE per-lane byte offset per (row order, row pitch)
