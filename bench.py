@@ -289,6 +289,8 @@ def main():
         cfg.setdefault('enc_num_heads', cfg.get('num_heads'))
         dom = max((k for k in fam if gemm_flops(k, B, cfg)), key=lambda k: fam[k]['share'])
         fl = gemm_flops(dom, B, cfg)
+        if dom == 'enc.blocks_fused' and 'dec.memory_kv_gemm' not in fam:
+            fl += gemm_flops('dec.memory_kv_gemm', B, cfg)       # the decoder's K / V projection of memory rides in the same launch (its tail)
         ach = fl / (fam[dom]['avg_us'] * 1e-6) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # HBM bytes/launch from rocprofv3 --pmc passes, if collected

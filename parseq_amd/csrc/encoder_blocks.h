@@ -37,6 +37,15 @@ namespace pq {
 struct EncBlockParams {
     unsigned ln1_w, ln1_b, wqkv, bqkv, wproj, bproj, ln2_w, ln2_b, w1, b1, w2, b2;
 };
+// Optional tail of the one-launch encoder (parseq_forward: nobody asked for `memory` itself): the encoder's final LayerNorm and the
+// decoder's cross-attention K / V projection of the result, straight from the resident rows — the final LayerNorm launch, the
+// bf16 copy of memory, the K / V GEMM launch and the store of x all disappear.  Element offsets like EncBlockParams; wkv / bkv point
+// at the K rows of in_proj_weight / in_proj_bias (the K | V part, 2E rows); kmem / vmem: [B][heads][128][hd] bf16, hd = 32.
+struct EncTailParams {
+    unsigned norm_w, norm_b, wkv, bkv;
+    bf16_t* kmem; bf16_t* vmem;          // kmem == nullptr: no tail, x is stored instead
+    int heads;
+};
 
 constexpr int EB_RING_BYTES = 9 * 16384;      // three groups of three 16 KiB weight stages; group 2 is overlaid by the K / V^T images
 template <int E>
@@ -544,6 +553,62 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
     }
 }
 
+// ---- tail: K | V = LayerNorm_final(x) Wkv^T + bkv, head-split bf16, for the decoder's cross-attention ---------------------------
+// Twelve 64-wide output chunks (six of K, six of V; a chunk = two 32-wide decoder heads), each one weight triple in the q / k
+// chunk form of attn_phase, alternating between ring groups 0 and 1.  `sbkv`: the 2E biases in LDS.  The first triple must have
+// been issued (kv_prefetch); returns with no LDS-DMA in flight.
+template <int E>
+__device__ __forceinline__ void kv_issue_stage(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int wid, int c, int t, int q = -1) {
+    unsigned char* dst = ring + ((c & 1) * 3 + t) * 16384 + wid * 4096;
+    sl.template issue<StreamLane::K64>(wrsrc, (wkv_off + (unsigned)(c * 64 * E + t * 128)) * 2u, E, dst, q);
+}
+template <int E>
+__device__ __forceinline__ void kv_prefetch(const StreamLane& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int wid) {
+    static_for<0, 3>([&](auto tc) { kv_issue_stage<E>(sl, ring, wrsrc, wkv_off, wid, 0, decltype(tc)::value); });
+}
+template <int E>
+__device__ __forceinline__ void kv_phase(unsigned char* ring, const float* sbkv, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, const StreamLane& sl,
+                                         int wid, int image, int heads, bf16_t* __restrict__ kmem, bf16_t* __restrict__ vmem,
+                                         const bf16x8 (&afrag)[2][E / 32]) {
+    constexpr int NC = 2 * E / 64;
+    static_assert(E == 384, "written for E = 384: every 64-wide chunk is one triple");
+    for (int c = 0; c < NC; ++c) {
+        f32x4 acc1[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        eb_wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        run_triple(ring + (c & 1) * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
+            acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);
+            acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[1][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][1], 0, 0, 0);
+        }, [&](int k, int q) {
+            if (c + 1 < NC) issue_split(k, [&](int sn) { kv_issue_stage<E>(sl, ring, wrsrc, wkv_off, wid, c + 1, sn, q); });
+        });
+        // lane (r16, g), row tile j, pair pr: units 64 c + 32 pr + 8 g + [0, 8) of token 32 wid + 16 j + r16 — one 16-byte piece of
+        // the (token, head 2 c' + pr) row of K (c < NC / 2) or V
+        const int ln = opaque_lane();
+        const int rr = ln & 15, g = ln >> 4;
+        bf16_t* dst = c < NC / 2 ? kmem : vmem;
+        const int cc = c < NC / 2 ? c : c - NC / 2;
+        const float* bp0 = sbkv + c * 64 + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                bf16x8 f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp0[32 * pr + r]);
+                    f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp0[32 * pr + 4 + r]);
+                }
+                const int token = 32 * wid + 16 * j + rr;
+                *reinterpret_cast<bf16x8*>(dst + (((size_t)image * heads + 2 * cc + pr) * 128 + token) * 32 + 8 * g) = f;
+            }
+    }
+}
+
 // Copy `n` floats from global memory into LDS (all 256 threads; plain loads: call only while no LDS-DMA is in flight).
 __device__ __forceinline__ void params_to_lds(float* dst, const float* __restrict__ src, int n, int tid) {
     for (int i = tid; i < n; i += 256) dst[i] = src[i];
@@ -552,7 +617,7 @@ __device__ __forceinline__ void params_to_lds(float* dst, const float* __restric
 template <int E>
 __global__ __launch_bounds__(256, 1)
 void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, unsigned wbytes, const float* __restrict__ pbase,
-                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M) {
+                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, const EncTailParams tail) {
     constexpr int F = 4 * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                                  // groups 0-1 (attention) / 0-2 (MLP)
@@ -597,7 +662,19 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
         mlp_phase<E>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, rr, g, afrag, acc);
         add_bias_to_acc<E>(sp + F, g, acc);
     }
-    store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
+    if (tail.kmem == nullptr) {
+        store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
+        return;
+    }
+    // ---- tail: parameters bkv (2E) | final norm gamma (E) | beta (E)
+    __syncthreads();
+    kv_prefetch<E>(sl, ring, wrsrc, tail.wkv, wid);
+    params_to_lds(sp, pbase + tail.bkv, 2 * E, tid);
+    params_to_lds(sp + 2 * E, pbase + tail.norm_w, E, tid);
+    params_to_lds(sp + 3 * E, pbase + tail.norm_b, E, tid);
+    __syncthreads();
+    ln_acc_to_frag<E>(acc, sp + 2 * E, sp + 3 * E, eps, g, afrag);
+    kv_phase<E>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, afrag);
 }
 
 // The two branches as stand-alone launches built from the SAME phase functions as enc_blocks_kernel (per-kernel parity tests and
@@ -702,13 +779,13 @@ inline hipError_t launch_mlp_branch(hipStream_t s, float* x, const float* gamma,
 
 template <int E>
 inline hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
-                                    int depth, float eps, int M) {
+                                    int depth, float eps, int M, const EncTailParams& tail = EncTailParams{0, 0, 0, 0, nullptr, nullptr, 0}) {
     constexpr size_t lds = enc_blocks_lds<E>();
     if (wbytes >= ((size_t)1 << 32)) return hipErrorInvalidValue;       // one 32-bit buffer descriptor covers the weight pack
     auto kern = enc_blocks_kernel<E>;
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M);
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M, tail);
     return hipGetLastError();
 }
 

@@ -356,6 +356,8 @@ struct parseq_plan {
     bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h
     EncBlockParams* blocks_dev = nullptr;                           // [enc_depth] parameter pointers of encoder_blocks.h (bf16 mode)
     std::vector<EncBlockParams> blocks_host;                        // source of the asynchronous upload (must outlive it)
+    EncTailParams enc_tail{0, 0, 0, 0, nullptr, nullptr, 0};        // final norm + memory K / V projection inside the one-launch encoder (offsets; pointers filled per call)
+    bool fused_tail = getenv("PARSEQ_NO_FUSED_TAIL") == nullptr;    // diagnostics: final LayerNorm and K / V GEMM as their own launches
     Profiler prof;
 };
 constexpr int LDT = 32;            // row pitch of token / mask arrays
@@ -542,6 +544,13 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
                 e.w2 = off(b + "mlp.fc2.weight"); e.b2 = off(b + "mlp.fc2.bias");
             }
             HIPCHK(hipMemcpyAsync(p->blocks_dev, p->blocks_host.data(), p->blocks_host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice, s));
+            if (!m->vitstr) {
+                const int E_ = m->cfg.embed_dim;
+                p->enc_tail.norm_w = off(m->enc + "norm.weight"); p->enc_tail.norm_b = off(m->enc + "norm.bias");
+                p->enc_tail.wkv = off("decoder.layers.0.cross_attn.in_proj_weight") + (unsigned)E_ * E_;
+                p->enc_tail.bkv = off("decoder.layers.0.cross_attn.in_proj_bias") + (unsigned)E_;
+                p->enc_tail.heads = m->cfg.dec_heads;
+            }
         }
         if (p->wstep[0]) {       // decoder weights in MFMA-fragment order for the fused AR step
             const int E = m->cfg.embed_dim, Fd = E * m->cfg.dec_mlp_ratio;
@@ -786,9 +795,17 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const bool fused_blocks = fused_attn && fused_mlp && p->fused_blocks && p->mlp_resident && M % 128 == 0;
     if (fused_blocks) {
         if constexpr (kBf16) {
-            ProfScope ps_(&p->prof, T_BLOCKS, s);
-            HIPCHK((launch_enc_blocks<384>(s, p->x, reinterpret_cast<const bf16_t*>(p->wpack), m->master_elems * sizeof(bf16_t), m->master,
-                                           p->blocks_dev, c.enc_depth, c.enc_ln_eps, M)));
+            // parseq_forward (nobody asked for `memory` itself): the final LayerNorm and the decoder's K / V projection of memory ride
+            // in the same launch (encoder_blocks.h kv_phase) and the encoder is done
+            const bool tail = p->fused_tail && memory_out == nullptr && !m->vitstr && c.dec_heads * DEC_HD == E;
+            EncTailParams et = p->enc_tail;
+            if (tail) { et.kmem = reinterpret_cast<bf16_t*>(p->kmem); et.vmem = reinterpret_cast<bf16_t*>(p->vmem); }
+            {
+                ProfScope ps_(&p->prof, T_BLOCKS, s);
+                HIPCHK((launch_enc_blocks<384>(s, p->x, reinterpret_cast<const bf16_t*>(p->wpack), m->master_elems * sizeof(bf16_t), m->master,
+                                               p->blocks_dev, c.enc_depth, c.enc_ln_eps, M, et)));
+            }
+            if (tail) { p->last_batch = B; return 0; }
         }
     }
     for (int i = 0; i < (fused_blocks ? 0 : c.enc_depth); ++i) {
