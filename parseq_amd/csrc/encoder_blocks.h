@@ -204,14 +204,25 @@ struct StreamLane {
     // q = -1: all four pieces of the wave's share of the stage; q = 0..3: that piece only
     template <int KIND, bool WIDE = false>
     __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rsrc, unsigned origin, int pitch, unsigned char* dst, int q = -1) const {
+        issue_v(rsrc, KIND == K64 ? v64 : (WIDE ? v128w : v128), origin, pitch, dst, q);
+    }
+    // the same with the per-lane offset given (a row pitch other than E / 4E: the patch-embedding weights)
+    static __device__ __forceinline__ void issue_v(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned origin, int pitch, unsigned char* dst, int q = -1) {
         if constexpr ((EB_ABLATE & 4) != 0) return;
-        const unsigned voff = KIND == K64 ? v64 : (WIDE ? v128w : v128);
         auto* l = (__attribute__((address_space(3))) void*)dst;
         const unsigned rp = 2u * (unsigned)pitch;
         if (q < 0 || q == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin, 0, 0);
         if (q < 0 || q == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 16u * rp - 1024u, 1024, 0);
         if (q < 0 || q == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 4u * rp - 2048u, 2048, 0);
         if (q < 0 || q == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin + 20u * rp - 3072u, 3072, 0);
+    }
+    // per-lane byte offset of the K128 form at an arbitrary row pitch
+    static __device__ __forceinline__ unsigned voff128(int lane, int wid, int pitch) {
+        const int src_chunk = ((lane & 7) ^ (lane >> 3)) * 8;
+        const int rho = wid * 32 + (lane >> 3);
+        const int i = rho >> 4, r16 = rho & 15;
+        const int p128 = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
+        return (unsigned)(p128 * pitch + src_chunk) * 2u;
     }
 };
 
@@ -553,6 +564,76 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
     }
 }
 
+// ---- head: x = patches Wpe^T + (bias + pos_embed), the (4, 8) patch embedding of a 32 x 128 crop, straight into the accumulators ----
+// Optional (images == nullptr: x is loaded instead).  A crop is 8 x 16 patches = the workgroup's 128 tokens; K = 3 * 4 * 8 = 96 with
+// k = 32 c + 8 ky + kx (timm PatchEmbed's Conv2d weight flattened), so k-step s of the MFMA is channel s and a lane's eight k-slots
+// (8 g + [0, 8)) are ONE run of eight pixels: row 4 gy + g, columns 8 gx .. 8 gx + 7 of channel s.  The 384 x 96 weight streams as
+// six stages (three 128-row groups x two 64-k halves, the second half only 32 k wide: its upper k-step is never multiplied) = two
+// triples.  posb: [128][E] f32 = pos_embed + bias (built once per plan); img_dtype: PARSEQ_BF16 / PARSEQ_F32 / PARSEQ_U8 as in
+// include/parseq_hip.h (1 / 0 / 2) — u8 pixels get the reference transform ((v / 255 - 0.5) / 0.5, strhub/data/module.py:78-81)
+// before the bf16 rounding, exactly as gemm.h's APatch loader does.
+struct EncHeadParams {
+    const void* images; int img_dtype;
+    unsigned wpe;                  // element offset of patch_embed.proj.weight in the bf16 pack
+    const float* posb;
+};
+constexpr int EB_IMG_F32 = 0, EB_IMG_BF16 = 1, EB_IMG_U8 = 2;      // = PARSEQ_F32 / PARSEQ_BF16 / PARSEQ_U8
+
+template <int E>
+__device__ __forceinline__ void patch_head(const EncHeadParams& hp, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, int wid, int lane, int image,
+                                           f32x4 (&acc)[E / 16][2]) {
+    static_assert(E == 384, "three 128-row groups");
+    constexpr int PK = 96, IH = 32, IW = 128;
+    const int rr = lane & 15, g = lane >> 4;
+    // the weight stream first (24 pieces per wave), then the table and the pixels
+    const unsigned vpe = StreamLane::voff128(lane, wid, PK);
+    static_for<0, 6>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, ng = st >> 1, kh = st & 1;
+        StreamLane::issue_v(wrsrc, vpe, (hp.wpe + (unsigned)(ng * 128 * PK + kh * 64)) * 2u, PK, ring + st * 16384 + wid * 4096);
+    });
+    load_x_to_acc<E>(hp.posb, 0, 128, wid, rr, g, acc);
+    bf16x8 pfrag[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int token = 32 * wid + 16 * j + rr, gy = token >> 4, gx = token & 15;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t e0 = (((size_t)image * 3 + c) * IH + gy * 4 + g) * IW + gx * 8;
+            bf16x8 f;
+            if (hp.img_dtype == EB_IMG_BF16) {
+                f = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(hp.images) + e0);
+            } else if (hp.img_dtype == EB_IMG_F32) {
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(hp.images) + e0);
+                const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(hp.images) + e0 + 4);
+                f[0] = static_cast<bf16_t>(a.x); f[1] = static_cast<bf16_t>(a.y); f[2] = static_cast<bf16_t>(a.z); f[3] = static_cast<bf16_t>(a.w);
+                f[4] = static_cast<bf16_t>(b.x); f[5] = static_cast<bf16_t>(b.y); f[6] = static_cast<bf16_t>(b.z); f[7] = static_cast<bf16_t>(b.w);
+            } else {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(hp.images) + e0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned v = ((i < 4 ? u.x : u.y) >> (8 * (i & 3))) & 0xffu;
+                    f[i] = static_cast<bf16_t>(((float)v / 255.0f - 0.5f) / 0.5f);
+                }
+            }
+            pfrag[j][c] = f;
+        }
+    }
+    static_for<0, 2>([&](auto tc) {
+        constexpr int T = decltype(tc)::value;
+        if constexpr (T == 0) eb_wait_vmcnt<12>(); else eb_wait_vmcnt<0>();       // (plain loads above were waited for by their uses)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        run_triple(ring + T * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
+            const int st = 3 * T + k, ng = st >> 1, s32 = 2 * (st & 1) + half;       // constants after inlining
+            if (s32 < 3) {
+                acc[ng * 8 + i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, pfrag[0][s32], acc[ng * 8 + i][0], 0, 0, 0);
+                acc[ng * 8 + i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, pfrag[1][s32], acc[ng * 8 + i][1], 0, 0, 0);
+            }
+        }, [](int, int) {});
+    });
+}
+
 // ---- tail: K | V = LayerNorm_final(x) Wkv^T + bkv, head-split bf16, for the decoder's cross-attention ---------------------------
 // Twelve 64-wide output chunks (six of K, six of V; a chunk = two 32-wide decoder heads), each one weight triple in the q / k
 // chunk form of attn_phase, alternating between ring groups 0 and 1.  `sbkv`: the 2E biases in LDS.  The first triple must have
@@ -617,7 +698,7 @@ __device__ __forceinline__ void params_to_lds(float* dst, const float* __restric
 template <int E>
 __global__ __launch_bounds__(256, 1)
 void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, unsigned wbytes, const float* __restrict__ pbase,
-                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, const EncTailParams tail) {
+                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, const EncTailParams tail, const EncHeadParams head) {
     constexpr int F = 4 * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                                  // groups 0-1 (attention) / 0-2 (MLP)
@@ -635,7 +716,8 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
 
     f32x4 acc[E / 16][2];
     bf16x8 afrag[2][E / 32];
-    load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+    if (head.images) patch_head<E>(head, ring, wrsrc, wid, lane, blockIdx.x, acc);
+    else load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
 
     for (int l = 0; l < depth; ++l) {
         const EncBlockParams* bp = blocks + l;
@@ -779,13 +861,14 @@ inline hipError_t launch_mlp_branch(hipStream_t s, float* x, const float* gamma,
 
 template <int E>
 inline hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
-                                    int depth, float eps, int M, const EncTailParams& tail = EncTailParams{0, 0, 0, 0, nullptr, nullptr, 0}) {
+                                    int depth, float eps, int M, const EncTailParams& tail = EncTailParams{0, 0, 0, 0, nullptr, nullptr, 0},
+                                    const EncHeadParams& head = EncHeadParams{nullptr, 0, 0, nullptr}) {
     constexpr size_t lds = enc_blocks_lds<E>();
     if (wbytes >= ((size_t)1 << 32)) return hipErrorInvalidValue;       // one 32-bit buffer descriptor covers the weight pack
     auto kern = enc_blocks_kernel<E>;
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M, tail);
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M, tail, head);
     return hipGetLastError();
 }
 

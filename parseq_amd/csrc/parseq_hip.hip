@@ -358,6 +358,9 @@ struct parseq_plan {
     std::vector<EncBlockParams> blocks_host;                        // source of the asynchronous upload (must outlive it)
     EncTailParams enc_tail{0, 0, 0, 0, nullptr, nullptr, 0};        // final norm + memory K / V projection inside the one-launch encoder (offsets; pointers filled per call)
     bool fused_tail = getenv("PARSEQ_NO_FUSED_TAIL") == nullptr;    // diagnostics: final LayerNorm and K / V GEMM as their own launches
+    float* posb = nullptr;                                          // [tokens][E] pos_embed + patch-embed bias (the one-launch encoder's head)
+    unsigned wpe_off = 0;                                           // element offset of patch_embed.proj.weight in the weight pack
+    bool fused_head = getenv("PARSEQ_NO_FUSED_HEAD") == nullptr;    // diagnostics: patch embedding as its own launch
     Profiler prof;
 };
 constexpr int LDT = 32;            // row pitch of token / mask arrays
@@ -550,6 +553,12 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
                 p->enc_tail.wkv = off("decoder.layers.0.cross_attn.in_proj_weight") + (unsigned)E_ * E_;
                 p->enc_tail.bkv = off("decoder.layers.0.cross_attn.in_proj_bias") + (unsigned)E_;
                 p->enc_tail.heads = m->cfg.dec_heads;
+                // head of the one-launch encoder: pos_embed + patch-embed bias as one table
+                p->wpe_off = off(m->enc + "patch_embed.proj.weight");
+                const int rows_ = m->tokens;
+                hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)(((size_t)rows_ * E_ + 255) / 256)), dim3(256), 0, s, m->p(m->enc + "pos_embed"),
+                                   m->p(m->enc + "patch_embed.proj.bias"), p->posb, rows_, E_);
+                HIPCHK(hipGetLastError());
             }
         }
         if (p->wstep[0]) {       // decoder weights in MFMA-fragment order for the fused AR step
@@ -619,6 +628,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t o_tok = carve(off, B * LDT * 4), o_kpm = carve(off, B * LDT), o_eos = carve(off, B);
     const size_t o_cloze = carve(off, npos * LDT), o_qmu = carve(off, npos * LDT), o_cnt = carve(off, 64);
     const size_t o_blocks = carve(off, (size_t)c.enc_depth * sizeof(EncBlockParams));
+    const size_t o_posb = carve(off, N * E * 4);
     p->arena_bytes = off;
     hipError_t e = hipMalloc(&p->arena, off);
     if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
@@ -629,6 +639,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->kmem = a + o_kmem; p->vmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
     p->blocks_dev = reinterpret_cast<EncBlockParams*>(a + o_blocks);
+    p->posb = reinterpret_cast<float*>(a + o_posb);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
     if (const char* e_ = getenv("PARSEQ_AR_CHAINS")) p->ar_chains = std::min(std::max(atoi(e_), 1), PQ_MAX_CHAINS);
     bool ok_ = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -745,7 +756,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const std::string& pe = m->enc;
     const int Np = m->patch_tokens, Mp = B * Np;
     APatch<T, TI> ap{images, 3, c.img_h, c.img_w, c.patch_h, c.patch_w, c.img_w / c.patch_w, Np};
-    if (!m->vitstr) {
+    // bf16, PARSeq-S geometry: the patch embedding is the head of the one-launch encoder (encoder_blocks.h patch_head); same conditions
+    // as `fused_blocks` below plus the (4, 8)-patch / 32 x 128-crop layout the head is written for
+    const bool head_in_launch = sizeof(T) == 2 && !m->vitstr && p->fused_head && p->fused_blocks && p->fused_attn && p->mlp_resident &&
+                                E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128;
+    if (head_in_launch) {
+        // nothing here: x is produced inside the launch
+    } else if (!m->vitstr) {
         ProfScope ps_(&p->prof, T_PATCH, s);
         CHK((run_gemm<T>(s, ap, W.w(pe + "patch_embed.proj.weight"), m->patch_k, Mp, E, m->patch_k,
                          epi_table(Mp, E, m->p(pe + "patch_embed.proj.bias"), p->x, E, m->p(pe + "pos_embed"), E, Np, 0))));
@@ -800,10 +817,15 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             const bool tail = p->fused_tail && memory_out == nullptr && !m->vitstr && c.dec_heads * DEC_HD == E;
             EncTailParams et = p->enc_tail;
             if (tail) { et.kmem = reinterpret_cast<bf16_t*>(p->kmem); et.vmem = reinterpret_cast<bf16_t*>(p->vmem); }
+            EncHeadParams eh{nullptr, 0, 0, nullptr};
+            if (head_in_launch) {
+                eh.images = images; eh.img_dtype = sizeof(TI) == 1 ? EB_IMG_U8 : (sizeof(TI) == 2 ? EB_IMG_BF16 : EB_IMG_F32);
+                eh.wpe = p->wpe_off; eh.posb = p->posb;
+            }
             {
                 ProfScope ps_(&p->prof, T_BLOCKS, s);
                 HIPCHK((launch_enc_blocks<384>(s, p->x, reinterpret_cast<const bf16_t*>(p->wpack), m->master_elems * sizeof(bf16_t), m->master,
-                                               p->blocks_dev, c.enc_depth, c.enc_ln_eps, M, et)));
+                                               p->blocks_dev, c.enc_depth, c.enc_ln_eps, M, et, eh)));
             }
             if (tail) { p->last_batch = B; return 0; }
         }

@@ -8,6 +8,13 @@ namespace pq {
 // LayerNorm over the last dim E (E = 192 * VEC, VEC in {1, 2, 4}).  x fp32 [M, E] -> out TO [M, E] and optionally a
 // second fp32 copy (the encoder's final norm is both the API's `memory` output and the decoder K/V GEMM operand).
 // torch.nn.LayerNorm semantics: biased variance, y = (x - mean) / sqrt(var + eps) * w + b  (ViT eps 1e-6, decoder 1e-5).
+// out[r][c] = a[r][c] + v[c]   (pos_embed + patch-embed bias: the table the one-launch encoder's head starts its accumulators from)
+__global__ __launch_bounds__(256)
+void add_rowvec_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out, int rows, int cols) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)rows * cols) out[i] = a[i] + v[i % cols];
+}
+
 // LayerNorm statistics only: stats[2 m] = mean, stats[2 m + 1] = 1 / sqrt(var + eps) of row m (wave per row, the same two passes
 // as layernorm_kernel).  Feeds gemm.h's ALayerNormStats loader: the rows are read once more by the GEMM, nothing is written back.
 template <int E>
