@@ -291,6 +291,8 @@ def main():
         fl = gemm_flops(dom, B, cfg)
         if dom == 'enc.blocks_fused' and 'dec.memory_kv_gemm' not in fam:
             fl += gemm_flops('dec.memory_kv_gemm', B, cfg)       # the decoder's K / V projection of memory rides in the same launch (its tail)
+        if dom == 'enc.blocks_fused' and 'enc.patch_embed_gemm' not in fam:
+            fl += 2.0 * B * 128 * cfg['embed_dim'] * 3 * cfg['patch_size'][0] * cfg['patch_size'][1]      # ... and the patch embedding (its head)
         ach = fl / (fam[dom]['avg_us'] * 1e-6) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # HBM bytes/launch from rocprofv3 --pmc passes, if collected
