@@ -220,14 +220,14 @@ def main():
             if in_flight <= 1:
                 logits = mdl(x, max_length)
                 if dist is not None:
-                    logits = all_gather_logits(logits, uniform=True)      # fixed shapes: one collective, no host sync
+                    logits = all_gather_logits(logits, uniform=True, force=args.force_dist)      # fixed shapes: one collective, no host sync
             else:       # batch k runs on stream k % S with workspace k % S: its encoder overlaps batch k-1's AR decode
                 k = counter[0] % in_flight
                 counter[0] += 1
                 with torch.cuda.stream(streams[k]):
                     logits = mdl(x, max_length, slot=k)
                     if dist is not None:
-                        logits = all_gather_logits(logits, uniform=True)      # fixed shapes: one collective, no host sync
+                        logits = all_gather_logits(logits, uniform=True, force=args.force_dist)      # fixed shapes: one collective, no host sync
         return logits
 
     def timed(mdl, x, in_flight, steps, warmup):

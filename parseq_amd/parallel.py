@@ -20,7 +20,7 @@ def shard_bounds(n: int, world: int, rank: int):
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_logits(logits: Tensor, group=None, uniform: bool = False) -> Tensor:
+def all_gather_logits(logits: Tensor, group=None, uniform: bool = False, force: bool = False) -> Tensor:
     """[b_local, L, C] on every rank -> [sum b_local, L, C] on every rank (rank order).
 
     uniform=True: the caller guarantees identical shapes on every rank (fixed per-GPU batch, forced steps or
@@ -34,7 +34,7 @@ def all_gather_logits(logits: Tensor, group=None, uniform: bool = False) -> Tens
     """
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:          # force: run the collective anyway (bench.py --force-dist, a one-rank self-test)
         return logits
     logits = logits.contiguous()
     if uniform:
