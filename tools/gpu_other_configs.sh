@@ -1,3 +1,4 @@
+# bench.py on the other BASELINE / model configurations: profiles/r02_other_configs.log.
 mkdir -p gpurun_out
 run() { timeout 300 python bench.py --no-cpu-baseline --no-parity --no-profile --steps 40 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '->', d['value'], d['sequential_value'])"; }
 run --batch 1024 --refine-iters 2

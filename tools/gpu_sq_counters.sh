@@ -1,3 +1,4 @@
+# SQ counter passes (separate rocprofv3 --pmc runs) over the one-launch encoder: profiles/r02_enc_blocks_sq_counters.md.
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z0-9_]*" | sort -u | tr '\n' ' ' > gpurun_out/r2_sq_counters.txt; wc -w gpurun_out/r2_sq_counters.txt

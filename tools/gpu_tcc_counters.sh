@@ -1,3 +1,4 @@
+# L2 hit / miss and memory-side read-request counters for the decoder kernels and the encoder: profiles/r02_tcc_l2_counters.md.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 i=0

@@ -1,3 +1,4 @@
+# Round-end validation on one MI355X (through gpurun): full GPU test suite, bench.py, rocprofv3 kernel stats, PMC FETCH / WRITE / MFMA-busy passes; summaries land in gpurun_out/ and are copied to profiles/ by hand.
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
