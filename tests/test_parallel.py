@@ -108,6 +108,29 @@ def test_two_rank_gloo_sharded_forward(n_images):
     assert all(r[1] and r[2] and r[3] for r in results), results
 
 
+def _one_rank_worker(port, q):
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        x = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
+        same = all_gather_logits(x, uniform=True)                       # world 1: returned as is
+        forced = all_gather_logits(x, uniform=True, force=True)         # the collective really runs (bench.py --force-dist)
+        q.put((same is x, bool(torch.equal(forced, x)), forced.data_ptr() != x.data_ptr()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_forced_collective():
+    """bench.py --force-dist: with a one-rank group the gather is skipped unless forced; forced, it returns an equal copy."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    pr = ctx.Process(target=_one_rank_worker, args=(_free_port(), q))
+    pr.start()
+    got = q.get(timeout=120)
+    pr.join(timeout=60)
+    assert got == (True, True, True)
+
+
 def _grad_worker(rank, world, port, q):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
