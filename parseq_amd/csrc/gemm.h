@@ -32,6 +32,9 @@
 #ifndef PQ_DIAG_X3
 #define PQ_DIAG_X3 0     // bf16x3 co-residency defect hunt (tools/x3_diag2.py); see PQ_LSTORE
 #endif
+#ifndef PQ_PAIRS_RING
+#define PQ_PAIRS_RING 2   // LDS stages of the pre-split (PAIRS) GEMM loop: 2 = the two-buffer direct-to-LDS loop, two workgroups per CU (default); 4 = a counted-vmcnt ring, one workgroup per CU — measured slower (qkv 254 -> 305 us, fc1 347 -> 430, fc2 233 -> 261)
+#endif
 
 namespace pq {
 
@@ -491,11 +494,70 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[it] + (k0)),        \
                     (__attribute__((address_space(3))) void*)(Ws + (buf) * BN * KB + (wu * W_LI + it) * 1024), 16, 0, 0);  \
         }
+        const int g4 = lane >> 4, sx = frow & 7;
+        const int a_off = (wm * (BM / WM) + frow) * KB, w_off = (wn * (BN / WN) + frow) * KB;
+#ifndef PQ_PAIRS_RING
+#define PQ_PAIRS_RING 2
+#endif
+        if constexpr (PAIRS && PQ_PAIRS_RING > 2) {
+            // ---- pre-split operands: a ring of four 32 KiB stages, stage kt + 3 issued while stage kt is multiplied, counted vmcnt, one raw
+            // barrier per k-step.  One k-step is only 48 MFMAs per wave (0.35 us) against ~1 us from issue to landing: with two buffers every
+            // k-step waited for its own data (the second workgroup on the CU hid half of that); 128 KiB of LDS means one workgroup per CU.
+            constexpr int NB = PQ_PAIRS_RING, PCS = A_LI + W_LI;
+            unsigned char* As4 = smem;
+            unsigned char* Ws4 = smem + NB * BM * KB;
+#define PQ_DLOAD4(buf, k0)                                                                                                 \
+            {                                                                                                              \
+                _Pragma("unroll") for (int it = 0; it < A_LI; ++it)                                                        \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + (k0)),    \
+                        (__attribute__((address_space(3))) void*)(As4 + (buf) * BM * KB + (wu * A_LI + it) * 1024), 16, 0, 0); \
+                _Pragma("unroll") for (int it = 0; it < W_LI; ++it)                                                        \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[it] + (k0)),    \
+                        (__attribute__((address_space(3))) void*)(Ws4 + (buf) * BN * KB + (wu * W_LI + it) * 1024), 16, 0, 0); \
+            }
+            for (int st = 0; st < NB - 1 && st < nk; ++st) PQ_DLOAD4(st, st * BK)
+            for (int kt = 0; kt < nk; ++kt) {
+                const int ahead = nk - 1 - kt;                       // stages issued beyond kt: min(ahead, NB - 2)
+                if (ahead >= NB - 2) wait_vmcnt<(NB - 2) * PCS>();
+                else if (ahead == 1) wait_vmcnt<PCS>();
+                else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                        // stage kt landed for everyone; stage kt - 1's buffer retired
+                asm volatile("" ::: "memory");
+                if (kt + NB - 1 < nk) PQ_DLOAD4((kt + NB - 1) % NB, (kt + NB - 1) * BK)
+                const unsigned char* Ab = As4 + (kt % NB) * BM * KB + a_off;
+                const unsigned char* Wb = Ws4 + (kt % NB) * BN * KB + w_off;
+                const unsigned char* Pb = tr ? Ab : Wb;
+                const unsigned char* Qb = tr ? Wb : Ab;
+                const int so_h = (g4 ^ sx) * 16, so_l = ((4 + g4) ^ sx) * 16;
+                Frag<T> ph[TM], pl[TM], qh[TN], ql[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ph[i].v = *reinterpret_cast<const decltype(ph[i].v)*>(Pb + i * 16 * KB + so_h);
+                    pl[i].v = *reinterpret_cast<const decltype(pl[i].v)*>(Pb + i * 16 * KB + so_l);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    qh[j].v = *reinterpret_cast<const decltype(qh[j].v)*>(Qb + j * 16 * KB + so_h);
+                    ql[j].v = *reinterpret_cast<const decltype(ql[j].v)*>(Qb + j * 16 * KB + so_l);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        mma16(acc[i][j], pl[i], qh[j]);          // small terms first
+                        mma16(acc[i][j], ph[i], ql[j]);
+                        mma16(acc[i][j], ph[i], qh[j]);
+                    }
+            }
+#undef PQ_DLOAD4
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // every wave has read the last stage: the ring becomes the epilogue's staging tile
+            asm volatile("" ::: "memory");
+        } else {
         PQ_DLOAD(0, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int g4 = lane >> 4, sx = frow & 7;
-        const int a_off = (wm * (BM / WM) + frow) * KB, w_off = (wn * (BN / WN) + frow) * KB;
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) PQ_DLOAD(cur ^ 1, (kt + 1) * BK)
@@ -541,6 +603,7 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's DMA into the other buffer has landed
             __syncthreads();                                     // ... and so has everybody else's; buffer `cur` is free
+        }
         }
 #undef PQ_DLOAD
     } else {
@@ -744,7 +807,9 @@ template <int BM, int BN, int WM, int WN, typename Epi>
 inline hipError_t launch_gemm_pairs(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi) {
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-    constexpr size_t lds = gemm_lds_bytes<BM, BN, 128, 2, 0, (int)sizeof(typename Epi::S)>();
+    constexpr size_t ring = PQ_PAIRS_RING > 2 ? (size_t)PQ_PAIRS_RING * (BM + BN) * 128 : 0;
+    constexpr size_t lds2 = gemm_lds_bytes<BM, BN, 128, 2, 0, (int)sizeof(typename Epi::S)>();
+    constexpr size_t lds = ring > lds2 ? ring : lds2;
     if (K % 64) return hipErrorInvalidValue;
     auto kd = gemm_kernel<bf16_t, BM, BN, WM, WN, 128, 2, true, ARowMajor<bf16_t>, Epi, false, true>;
     if (lds > 64 * 1024) {
