@@ -225,6 +225,11 @@ int parseq_cross_entropy(const float* logits, const int32_t* targets, int rows, 
  * the model's fp32 master weights, every tensor starting at a multiple of 8 floats.  -1 for a bad index. */
 int64_t parseq_model_param_offset(const parseq_model* m, int index);
 int64_t parseq_model_grad_elems(const parseq_model* m);
+/* Arithmetic of the training step's matrix products (reference: `precision: bf16-mixed`, /root/reference/train.py:62-64):
+ * PARSEQ_F32 (default) = exact fp32 products on v_mfma_f32_16x16x4_f32; PARSEQ_BF16 = both operands of every aligned Linear
+ * product (forward, dX, dW) rounded to bfloat16 on their way into LDS, fp32 accumulate, fp32 master weights / activations /
+ * gradients in memory.  Attention products, LayerNorm, soft-max, loss and the optimiser stay fp32 in both modes. */
+int parseq_model_set_train_precision(parseq_model* m, int precision);
 
 /* Loss of the K-permutation training objective (system.py:168-199, dropout off) for a batch whose encoder output is
  * `memory`, and its gradients — what `loss.backward()` leaves in `.grad` of every decoder-side parameter (decoder.*,

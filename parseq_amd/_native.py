@@ -68,6 +68,7 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_model_param_offset': (C.c_int64, [C.c_void_p, C.c_int]),
     'parseq_model_grad_elems': (C.c_int64, [C.c_void_p]),
+    'parseq_model_set_train_precision': (C.c_int, [C.c_void_p, C.c_int]),
     'parseq_train_decoder_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'parseq_train_decoder_workspace_offset': (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p]),
     'parseq_train_decoder': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

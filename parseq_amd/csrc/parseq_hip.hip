@@ -139,6 +139,7 @@ struct parseq_model {
     std::string enc;          // key prefix of the encoder parameters: "encoder." (PARSeq) or "" (ViTSTR)
     int patch_k = 0;          // 3 * patch_h * patch_w
     int classes = 0;          // num_tokens - 2
+    int train_precision = PARSEQ_F32;     // training step: PARSEQ_F32 (exact products) or PARSEQ_BF16 (GEMM operands rounded to bf16)
     std::vector<ParamSpec> params;
     std::unordered_map<std::string, int> index;
     float* master = nullptr;  // device, all parameters fp32 back to back (each 16-byte aligned)
@@ -1398,6 +1399,7 @@ constexpr size_t TRAIN_SCRATCH_FLOATS = (size_t)16 << 20;
 struct TrainCtx {
     hipStream_t s;
     float* scratch;      // TRAIN_SCRATCH_FLOATS floats
+    bool bf16_ops = false;      // GEMM operands rounded to bf16 (parseq_model_set_train_precision), fp32 accumulate and everything else
 };
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1410,16 +1412,24 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
     // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
     const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
     const bool b_ok = aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0));
-    if (M % MG_BM == 0 && N % MG_BN == 0 && K % MG_BK == 0 && a_ok && b_ok && cx.scratch) {
-        const int tiles = (M / MG_BM) * (N / MG_BN);
+    // bf16-operand mode: edge tiles allowed (the 95-class head, the 96-wide patch rows) as long as an outer-contiguous operand has whole
+    // groups of four and at least one of them
+    const bool bf16 = cx.bf16_ops && K % BG_BK == 0 && a_ok && b_ok && cx.scratch && M >= 16 && N >= 16 &&
+                      (sak == 1 || M % 4 == 0) && (sbk == 1 || N % 4 == 0);
+    if (bf16 || (M % MG_BM == 0 && N % MG_BN == 0 && K % MG_BK == 0 && a_ok && b_ok && cx.scratch)) {
+        const int bk = bf16 ? BG_BK : MG_BK;
+        const int gm_ = (M + MG_BM - 1) / MG_BM, gn_ = (N + MG_BN - 1) / MG_BN;
+        const int tiles = gm_ * gn_;
         int splits = 1;
         if (tiles < 256) {
-            splits = std::min((512 + tiles - 1) / tiles, K / (4 * MG_BK));
+            splits = std::min((512 + tiles - 1) / tiles, K / (4 * bk));
             splits = (int)std::min<size_t>((size_t)std::max(splits, 1), TRAIN_SCRATCH_FLOATS / ((size_t)M * N));
             splits = std::max(splits, 1);
         }
-        const int k_chunk = ((K + splits - 1) / splits + MG_BK - 1) / MG_BK * MG_BK;
+        const int k_chunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
         splits = (K + k_chunk - 1) / k_chunk;
+        if (bf16) hipLaunchKernelGGL(mfma_bgemm_kernel, dim3(gn_, gm_, splits), dim3(256), 0, s, a, k_chunk, cx.scratch);
+        else
         hipLaunchKernelGGL(mfma_sgemm_kernel, dim3(N / MG_BN, M / MG_BM, splits), dim3(256), 0, s, a, k_chunk, cx.scratch);
         HIPCHK(hipGetLastError());
         if (splits > 1) {
@@ -1527,6 +1537,12 @@ extern "C" int64_t parseq_model_param_offset(const parseq_model* m, int index) {
     return (int64_t)m->params[index].offset;
 }
 extern "C" int64_t parseq_model_grad_elems(const parseq_model* m) { return m ? (int64_t)m->master_elems : 0; }
+extern "C" int parseq_model_set_train_precision(parseq_model* m, int precision) {
+    if (!m) return fail(PARSEQ_E_INVALID, "null model");
+    if (precision != PARSEQ_F32 && precision != PARSEQ_BF16) return fail(PARSEQ_E_INVALID, "training precision %d (PARSEQ_F32 or PARSEQ_BF16)", precision);
+    m->train_precision = precision;
+    return 0;
+}
 
 // Where a named intermediate of the LAST permutation (or an accumulator) lives in the workspace, in floats; -1 if unknown.  For tests.
 extern "C" int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, int batch, int ctx_len, int num_perms, const char* name) {
@@ -1587,7 +1603,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_content = w + o.d_content; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
     float* row_loss = w + o.row_loss; float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
     const size_t ME = (size_t)M * E, MF = (size_t)M * F;
-    const TrainCtx cx{s, w + o.scratch};
+    const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
 
     // ---- shared by all permutations: the content rows before dropout, and the memory's K / V (model.py:95-98, modules.py:74) ----
     hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content0);
@@ -1747,7 +1763,7 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     const float eps = m->cfg.enc_ln_eps;
     float* w = reinterpret_cast<float*>(workspace);
     auto P = [&](const std::string& key) { return m->p(m->enc + key); };
-    const TrainCtx cx{s, w + o.scratch};
+    const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
     hipLaunchKernelGGL(patches_kernel, dim3(MS), dim3(256), 0, s, images, m->cfg.img_h, m->cfg.img_w, m->cfg.patch_h, m->cfg.patch_w, w + o.patches);
     HIPCHK(hipGetLastError());
     CHK(lin_fwd(cx, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
@@ -1784,7 +1800,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* n = w + o.n; float* hact = w + o.hact; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
-    const TrainCtx cx{s, w + o.scratch};
+    const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
     CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps));
     for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
         const std::string p = "blocks." + std::to_string(i) + ".";

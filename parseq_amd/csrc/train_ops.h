@@ -166,6 +166,119 @@ void mfma_sgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
         }
 }
 
+// The same contraction with bf16 OPERANDS (every element of A and B rounded to bfloat16, round-to-nearest-even, on its way into LDS),
+// fp32 products and accumulation on v_mfma_f32_16x16x32_bf16, fp32 master data in memory: the training step's "bf16" mode
+// (BASELINE configs[4] trains bf16-mixed; the gate is oracle.decoder_backward.rounding('bf16'): cosine >= 0.9996 per gradient tensor).
+// K % 32 == 0; M and N arbitrary (edge tiles: see bg_fetch).  128 x 128 block tile, four waves of 64 x 64, 32 of K per stage; operands sit in LDS as
+// [outer][k] bf16 rows of 80 bytes (64 + 16 pad: the 16 lanes of a ds_read_b128 group fall on distinct banks), so a lane's MFMA operand
+// is one ds_read_b128 whichever way the matrix lies in memory; two LDS stages, the next stage's global loads are issued before the
+// current stage's MFMAs and converted / stored after them (one barrier per stage).  Split-K and epilogue exactly as mfma_sgemm_kernel.
+constexpr int BG_BK = 32, BG_LD = 40;       // elements
+
+// `limit`: number of valid outer indices (rows of A / columns of B): tiles may hang over the edge — over-the-edge lanes re-read the last
+// valid row (k-contiguous operand) or the last valid group of four (outer-contiguous operand; limit % 4 == 0 there) and their products
+// land in accumulator rows / columns the epilogue does not store.
+__device__ __forceinline__ void bg_fetch(const float* __restrict__ base, long s_outer, long s_k, int outer0, int limit, int k0, bool k_fast, float4 (&r)[4], int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it;
+        if (k_fast) { const int o = min(outer0 + (idx >> 3), limit - 1), k4 = idx & 7; r[it] = *reinterpret_cast<const float4*>(base + (size_t)o * s_outer + k0 + 4 * k4); }
+        else { const int k = idx >> 5, o = min(outer0 + 4 * (idx & 31), limit - 4); r[it] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + k) * s_k + o); }
+    }
+}
+__device__ __forceinline__ void bg_park(bf16_t (*tile)[BG_LD], bool k_fast, const float4 (&r)[4], int tid) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it;
+        const float v[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
+        if (k_fast) {
+            const int o = idx >> 3, k4 = idx & 7;
+            union { uint2 u; bf16_t e[4]; } h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) h.e[i] = static_cast<bf16_t>(v[i]);
+            *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
+        } else {
+            const int k = idx >> 5, o4 = idx & 31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tile[4 * o4 + i][k] = static_cast<bf16_t>(v[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) bf16_t As[2][MG_BM][BG_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][MG_BN][BG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * MG_BM, n0 = blockIdx.x * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    float4 ra[4], rb[4];
+    if (kbeg < kend) {
+        bg_fetch(a.A, a.sam, a.sak, m0, a.M, kbeg, a_kfast, ra, tid);
+        bg_fetch(a.B, a.sbn, a.sbk, n0, a.N, kbeg, b_kfast, rb, tid);
+        bg_park(As[0], a_kfast, ra, tid);
+        bg_park(Bs[0], b_kfast, rb, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BG_BK) {
+        const bool more = k0 + BG_BK < kend;
+        if (more) {
+            bg_fetch(a.A, a.sam, a.sak, m0, a.M, k0 + BG_BK, a_kfast, ra, tid);
+            bg_fetch(a.B, a.sbn, a.sbk, n0, a.N, k0 + BG_BK, b_kfast, rb, tid);
+        }
+        bf16x8 av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const bf16x8*>(&As[cur][wm + 16 * i + r16][8 * g]);
+            bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn + 16 * i + r16][8 * g]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        if (more) {
+            bg_park(As[cur ^ 1], a_kfast, ra, tid);
+            bg_park(Bs[cur ^ 1], b_kfast, rb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // lane holds D[row = 16 i + 4 g + r][col = 16 j + r16]
+    const bool direct = gridDim.z == 1;
+    float* out = direct ? a.C : partial + (size_t)blockIdx.z * a.M * a.N;
+    const long ldo = direct ? a.ldc : a.N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gm = m0 + wm + 16 * i + 4 * g + r;
+            if (gm >= a.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gn = n0 + wn + 16 * j + r16;
+                if (gn >= a.N) continue;
+                float v = acc[i][j][r];
+                float* c = out + (size_t)gm * ldo + gn;
+                if (direct) {
+                    v *= a.alpha;
+                    if (a.bias) v += a.bias[gn];
+                    if (a.R) v += a.R[(size_t)(gm % a.rper) * a.ldr + gn];
+                    if (a.accumulate) v += *c;
+                }
+                *c = v;
+            }
+        }
+}
+
 __global__ __launch_bounds__(256)
 void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, int splits) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)a.M * a.N;

@@ -61,6 +61,15 @@ def loss_denominator(labels, num_perms: int) -> int:
     return (chars + len(labels)) * min(num_perms, 2) + chars * max(num_perms - 2, 0)
 
 
+def _set_train_precision(system, native):
+    """`system.train_precision`: 'fp32' (default; exact products, the gradient-parity gate) or 'bf16' (GEMM operands rounded to
+    bfloat16, fp32 accumulate and master weights — the reference trains `bf16-mixed`, train.py:62-64)."""
+    mode = getattr(system, 'train_precision', 'fp32')
+    if mode not in ('fp32', 'bf16'):
+        raise ValueError(f"train_precision must be 'fp32' or 'bf16', got {mode!r}")
+    _native.check(_native.lib().parseq_model_set_train_precision(native, _native.PARSEQ_BF16 if mode == 'bf16' else _native.PARSEQ_F32))
+
+
 def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None,
                      dropout: Optional[float] = None, seed: Optional[int] = None) -> DecoderBackward:
     """One training batch up to and including the decoder's backward.  `perms` defaults to a fresh draw from the system's
@@ -90,6 +99,7 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
     if seed is None:
         seed = int(system.rng.integers(0, 2 ** 63)) if dropout > 0 else 0
     native = model._sync_native().model
+    _set_train_precision(system, native)
     flat = torch.zeros(lib.parseq_model_grad_elems(native), dtype=torch.float32, device=dev)
     dmemory = torch.empty_like(memory)
     ws_bytes = lib.parseq_train_decoder_workspace_bytes(native, B, L, K)
@@ -114,6 +124,7 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
     if images.dtype != torch.float32:
         images = ((images.float() / 255.0) - 0.5) / 0.5 if images.dtype == torch.uint8 else images.float()
     native = model._sync_native().model
+    _set_train_precision(system, native)
     B = images.shape[0]
     ws_bytes = lib.parseq_train_encoder_workspace_bytes(native, B)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=images.device)

@@ -588,3 +588,50 @@ def test_batch_64_step_uses_the_matrix_core_gemms():
         if err > tol:
             bad.append((key, err, tol))
     assert not bad, bad
+
+
+@pytest.mark.gpu
+def test_bf16_operand_step_within_the_rounding_budget():
+    """system.train_precision = 'bf16' (parseq_model_set_train_precision: both operands of every aligned Linear product rounded to
+    bfloat16, fp32 accumulate, fp32 everything else — train_ops.h mfma_bgemm_kernel) on the batch-64 step whose Linears all take the
+    matrix-core path: loss and all 175 gradients against the EXACT fp32 CPU backward, within the budget
+    test_bf16_operand_rounding_budget measured for this rounding (loss 5e-4 relative, per-tensor L2 error <= 6e-2, cosine >= 0.998) —
+    and visibly not the fp32 path (median per-tensor error above 1e-4)."""
+    from gpu_util import DEV, make_model
+    from oracle import decoder_backward as DB, encoder_backward as EB
+    from parseq_amd.train import loss_and_grads
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    gen = torch.Generator().manual_seed(99)
+    images = synth_images(64, cfg, seed=77)
+    lengths = torch.randint(1, 26, (64,), generator=gen).tolist()
+    lengths[5] = 25
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+    m.rng = np.random.default_rng(8)
+    torch.manual_seed(9)
+    res = loss_and_grads(m, images.to(DEV), labels)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        memory, saved = EB.forward(sd, cfg, images)
+        want_loss, _, want, dmem = DB.loss_and_grads(sd, cfg, memory, m.tokenizer.encode(labels), res.perms, O.attn_masks_from_perm)
+        want.update(EB.backward(sd, cfg, saved, dmem))
+    assert abs(float(res.loss) - float(want_loss)) <= 5e-4 * float(want_loss)
+    rel, cos = [], []
+    for key, ref in want.items():
+        a, b = ref.double().flatten(), res.grads[key].cpu().double().flatten()
+        if float(a.norm()) < 1e-7:
+            continue
+        rel.append((float((a - b).norm() / a.norm()), key))
+        cos.append(float(a @ b / (a.norm() * b.norm())))
+    rel.sort()
+    print(f'bf16-operand step: per-tensor L2 error median {rel[len(rel) // 2][0]:.2e}, worst {rel[-1][0]:.2e} ({rel[-1][1]}), min cosine {min(cos):.5f}')
+    assert 1e-4 < rel[len(rel) // 2][0] < 2e-2 and rel[-1][0] < 6e-2 and min(cos) > 0.998
+    # the switch is per model and reversible: back in fp32 the same call meets the fp32 gate again
+    m.train_precision = 'fp32'
+    m.rng = np.random.default_rng(8)
+    torch.manual_seed(9)
+    res32 = loss_and_grads(m, images.to(DEV), labels, res.perms)
+    key = 'encoder.blocks.0.mlp.fc1.weight'
+    assert float((res32.grads[key].cpu() - want[key]).abs().max()) <= 3e-4 * float(want[key].abs().max()) + 1e-7

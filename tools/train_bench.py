@@ -3,8 +3,8 @@
 forward + backward + gradient averaging across ranks + clip + AdamW, synthetic crops and labels resident on the device.
 
 Not the headline metric (bench.py measures that); same protocol: W warm-up steps, K timed steps bracketed by a barrier and a
-device synchronise, max over ranks, one JSON line from rank 0.  The step computes in fp32 (first correct version, see
-DESIGN.md section 9): `dtype` says so.
+device synchronise, max over ranks, one JSON line from rank 0.  `--train-precision bf16` (default) rounds the operands of the
+Linear products to bfloat16 (fp32 accumulate, fp32 master weights); `fp32` is the exact-product gate mode.
 
     python tools/train_bench.py [--batch 384] [--steps 3] [--warmup 1]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_bench.py --gpus 8
@@ -30,6 +30,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=384, help='crops per GPU per step (configs/main.yaml:15)')
     ap.add_argument('--model', default='parseq')
+    ap.add_argument('--train-precision', default='bf16', choices=['fp32', 'bf16'], help="GEMM operands of the step: exact fp32 products, or rounded to bf16 (fp32 accumulate / master weights)")
     args = ap.parse_args()
     world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
     dev = torch.device('cuda', local_rank)
@@ -44,6 +45,7 @@ def main():
     from parseq_amd.train import TrainStep
     torch.manual_seed(0)
     system = create_model(args.model, precision='bf16').to(dev)
+    system.train_precision = args.train_precision
     B = args.batch
     g = torch.Generator().manual_seed(1234 + rank)
     ih, iw = system.hparams.img_size
@@ -79,11 +81,12 @@ def main():
         print(json.dumps({
             'metric': 'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW', 'value': round(world * B * args.steps / el, 1),
             'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * el / args.steps, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if args.train_precision == 'fp32' else 'bf16', 'data': 'synthetic',
             'final_loss': round(float(loss), 4),
             'config': {'workload': f'{args.model} training step, batch={B}/GPU, labels of 1..25 characters (sequence length 26), 6 permutations, '
-                                   f'dropout {system.hparams.dropout if system.training else 0} (decoder, 8 sites per pass), fp32 first-correct-version kernels '
-                                   f'(BASELINE.json configs[4] asks for bf16)',
+                                   f'dropout {system.hparams.dropout if system.training else 0} (decoder, 8 sites per pass), Linear products '
+                                   f'{"exact fp32 on the f32 matrix cores" if args.train_precision == "fp32" else "with bf16 operands / fp32 accumulate / fp32 master weights"}, '
+                                   f'attention / LayerNorm / loss / AdamW fp32 (BASELINE.json configs[4] trains bf16-mixed)',
                        'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-reduce of the flat gradient buffer' if world > 1 else '')}}))
     if dist is not None:
         dist.destroy_process_group()
