@@ -183,24 +183,28 @@ __device__ __forceinline__ void bg_fetch(const float* __restrict__ base, long s_
     for (int it = 0; it < 4; ++it) {
         const int idx = tid + 256 * it;
         if (k_fast) { const int o = min(outer0 + (idx >> 3), limit - 1), k4 = idx & 7; r[it] = *reinterpret_cast<const float4*>(base + (size_t)o * s_outer + k0 + 4 * k4); }
-        else { const int k = idx >> 5, o = min(outer0 + 4 * (idx & 31), limit - 4); r[it] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + k) * s_k + o); }
+        else { const int k = 4 * (tid >> 5) + it, o = min(outer0 + 4 * (tid & 31), limit - 4); r[it] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + k) * s_k + o); }      // four CONSECUTIVE k of the same four outer indices per thread
     }
 }
 __device__ __forceinline__ void bg_park(bf16_t (*tile)[BG_LD], bool k_fast, const float4 (&r)[4], int tid) {
+    if (k_fast) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = tid + 256 * it;
-        const float v[4] = {r[it].x, r[it].y, r[it].z, r[it].w};
-        if (k_fast) {
-            const int o = idx >> 3, k4 = idx & 7;
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it, o = idx >> 3, k4 = idx & 7;
+            union { uint2 u; bf16_t e[4]; } h;
+            h.e[0] = static_cast<bf16_t>(r[it].x); h.e[1] = static_cast<bf16_t>(r[it].y); h.e[2] = static_cast<bf16_t>(r[it].z); h.e[3] = static_cast<bf16_t>(r[it].w);
+            *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
+        }
+    } else {
+        // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index
+        const int kq = tid >> 5, o4 = tid & 31;
+        const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             union { uint2 u; bf16_t e[4]; } h;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) h.e[i] = static_cast<bf16_t>(v[i]);
-            *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
-        } else {
-            const int k = idx >> 5, o4 = idx & 31;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) tile[4 * o4 + i][k] = static_cast<bf16_t>(v[i]);
+            for (int it = 0; it < 4; ++it) h.e[it] = static_cast<bf16_t>(v[it][i]);
+            *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = h.u;
         }
     }
 }
