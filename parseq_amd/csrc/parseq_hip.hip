@@ -1400,6 +1400,7 @@ struct TrainCtx {
     hipStream_t s;
     float* scratch;      // TRAIN_SCRATCH_FLOATS floats
     bool bf16_ops = false;      // GEMM operands rounded to bf16 (parseq_model_set_train_precision), fp32 accumulate and everything else
+    size_t scratch_floats = TRAIN_SCRATCH_FLOATS;      // what of `scratch` the split-K partials / column sums may use (lin_bwd carves its padded copies off the end)
 };
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1423,7 +1424,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         int splits = 1;
         if (tiles < 256) {
             splits = std::min((512 + tiles - 1) / tiles, K / (4 * bk));
-            splits = (int)std::min<size_t>((size_t)std::max(splits, 1), TRAIN_SCRATCH_FLOATS / ((size_t)M * N));
+            splits = (int)std::min<size_t>((size_t)std::max(splits, 1), cx.scratch_floats / ((size_t)M * N));
             splits = std::max(splits, 1);
         }
         const int k_chunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
@@ -1445,7 +1446,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
 static int colsum(const TrainCtx& cx, const float* A, long lda, int M, int N, float* out, bool accumulate) {
     hipStream_t s = cx.s;
     constexpr int CHUNKS = 64;
-    if (M >= 2048 && cx.scratch && (size_t)CHUNKS * N <= TRAIN_SCRATCH_FLOATS) {
+    if (M >= 2048 && cx.scratch && (size_t)CHUNKS * N <= cx.scratch_floats) {
         const int rows_per = (M + CHUNKS - 1) / CHUNKS;
         hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, CHUNKS), dim3(1024), 0, s, A, lda, M, N, cx.scratch, 0, rows_per);
         HIPCHK(hipGetLastError());
@@ -1463,6 +1464,26 @@ static int lin_fwd(const TrainCtx& cx, const float* x, const float* W, const flo
 }
 // dW[N, K] += dy[M, N]^T x[M, K];  db[N] += column sums of dy;  dx[M, K] = dy W   (dx may be null)
 static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const float* dy, float* dW, float* db, float* dx, int M, int N, int K) {
+    // bf16-operand mode, output width not a multiple of 4 (the 95-class head): rows of dy are not 16-byte aligned and N is no multiple of
+    // the 32-deep k-step, so both products would fall to the VALU kernel (10 % of the step).  Instead dy and W are copied into zero-padded
+    // [M, Np] / [Np, K] buffers (Np = N rounded up to 32) carved off the end of the scratch, both products run on the matrix cores, and the
+    // first N rows of the padded dW are added to the gradient.
+    const int Np = (N + 31) / 32 * 32;
+    const size_t reserve = (size_t)M * Np + 2 * (size_t)Np * K;
+    if (cx.bf16_ops && N % 4 != 0 && cx.scratch && M % 4 == 0 && K % 4 == 0 && reserve + ((size_t)4 << 20) <= cx.scratch_floats) {
+        hipStream_t s = cx.s;
+        TrainCtx c2 = cx; c2.scratch_floats = cx.scratch_floats - reserve;
+        float* dyp = cx.scratch + c2.scratch_floats; float* Wp = dyp + (size_t)M * Np; float* dWp = Wp + (size_t)Np * K;
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)(((size_t)M * Np + 255) / 256)), dim3(256), 0, s, dy, M, N, dyp, M, Np);
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)(((size_t)Np * K + 255) / 256)), dim3(256), 0, s, W, N, K, Wp, Np, K);
+        HIPCHK(hipGetLastError());
+        CHK(sgemm(c2, dyp, 1, Np, x, K, 1, nullptr, nullptr, 0, 0, dWp, K, Np, K, M, 1.f, false));
+        hipLaunchKernelGGL(add_into_kernel, dim3((unsigned)(((size_t)N * K + 255) / 256)), dim3(256), 0, s, dWp, dW, (size_t)N * K);
+        HIPCHK(hipGetLastError());
+        CHK(colsum(c2, dy, N, M, N, db, true));
+        if (dx) CHK(sgemm(c2, dyp, Np, 1, Wp, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, Np, 1.f, false));
+        return 0;
+    }
     CHK(sgemm(cx, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true));
     CHK(colsum(cx, dy, N, M, N, db, true));
     if (dx) CHK(sgemm(cx, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false));

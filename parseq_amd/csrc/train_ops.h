@@ -283,6 +283,20 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
         }
 }
 
+// dst[Rd, Cd] = src[Rs, Cs] in its top-left corner, zeros elsewhere (Rd >= Rs, Cd >= Cs)
+__global__ __launch_bounds__(256)
+void pad_copy_kernel(const float* __restrict__ src, int Rs, int Cs, float* __restrict__ dst, int Rd, int Cd) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Rd * Cd) return;
+    const int r = (int)(i / Cd), c = (int)(i % Cd);
+    dst[i] = (r < Rs && c < Cs) ? src[(size_t)r * Cs + c] : 0.f;
+}
+__global__ __launch_bounds__(256)
+void add_into_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 __global__ __launch_bounds__(256)
 void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, int splits) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)a.M * a.N;
