@@ -1668,7 +1668,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         CHK(dropout_add(cx, pm, t1, t2, ME, drop, site(S_CA_OUT)));
         CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, M, E, eps)));
         CHK(lin_fwd(cx, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((MF + 255) / 256)), dim3(256), 0, s, hpre, hact, MF);
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((MF + 1023) / 1024)), dim3(256), 0, s, hpre, hact, MF);
         HIPCHK(hipGetLastError());
         if (drop.thresh) CHK(dropout_add(cx, hact, nullptr, hact, MF, drop, site(S_FF_HIDDEN)));
         CHK(lin_fwd(cx, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, M, E, F));
@@ -1687,7 +1687,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         CHK(dropout_add(cx, d_b, nullptr, pm, ME, drop, site(S_FF_OUT)));
         CHK(lin_bwd(cx, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                  // d_h = d hact
         if (drop.thresh) CHK(dropout_add(cx, d_h, nullptr, d_h, MF, drop, site(S_FF_HIDDEN)));
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((MF + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, MF);                      // d_h = d hpre
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((MF + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, MF);                      // d_h = d hpre
         HIPCHK(hipGetLastError());
         CHK(lin_bwd(cx, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, M, F, E));                   // d_a = d n2
         CHK(ln_bwd(cx, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
@@ -1799,7 +1799,7 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
         CHK(lin_fwd(cx, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), w + o.n, nullptr, MS, E, eps)));
         CHK(lin_fwd(cx, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E));
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, w + o.hact, elems);
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, w + o.hact, elems);
         HIPCHK(hipGetLastError());
         CHK(lin_fwd(cx, w + o.hact, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
     }
@@ -1827,10 +1827,10 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, hact, elems);
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, hact, elems);
         HIPCHK(hipGetLastError());
         CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F));
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, s, hpre, d_h, d_h, elems);
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, elems);
         HIPCHK(hipGetLastError());
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n, nullptr, MS, E, eps)));
         CHK(lin_bwd(cx, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));

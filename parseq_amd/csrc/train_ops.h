@@ -389,17 +389,28 @@ void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 // exact-erf GELU and its derivative (F.gelu default; modules.py:43,77)
 __global__ __launch_bounds__(256)
 void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) act[i] = gelu_erf(pre[i]);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;      // four elements per thread (16-byte accesses); the tail one by one
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(pre + i);
+        *reinterpret_cast<float4*>(act + i) = make_float4(gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w));
+    } else {
+        for (size_t j = i; j < n; ++j) act[j] = gelu_erf(pre[j]);
+    }
+}
+__device__ __forceinline__ float gelu_grad(float v) {
+    const float cdf = 0.5f * (1.0f + fast_erf(v * 0.70710678118654752440f));
+    const float pdf = __expf(-0.5f * v * v) * 0.39894228040143267794f;
+    return fmaf(v, pdf, cdf);
 }
 __global__ __launch_bounds__(256)
 void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dact, float* __restrict__ dpre, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = pre[i];
-    const float cdf = 0.5f * (1.0f + fast_erf(v * 0.70710678118654752440f));
-    const float pdf = __expf(-0.5f * v * v) * 0.39894228040143267794f;
-    dpre[i] = dact[i] * fmaf(v, pdf, cdf);
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(pre + i), d = *reinterpret_cast<const float4*>(dact + i);
+        *reinterpret_cast<float4*>(dpre + i) = make_float4(d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w));
+    } else {
+        for (size_t j = i; j < n; ++j) dpre[j] = dact[j] * gelu_grad(pre[j]);
+    }
 }
 
 // y = a + b (elementwise)
