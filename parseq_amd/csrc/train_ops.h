@@ -430,26 +430,43 @@ void train_content_kernel(const float* __restrict__ emb, const float* __restrict
         out[(size_t)row * E + c] = scale * e[c] + (j ? posq[(size_t)(j - 1) * E + c] : 0.f);
 }
 
-// d emb[v] += scale * sum over the rows whose token is v, rows visited in order (deterministic; one workgroup per token id)
+// d emb[v] += scale * sum over the rows whose token is v, rows visited in ascending order (deterministic; one workgroup per token id).
+// The B * L token ids are scanned 256 at a time (one compare per thread, the four waves' ballots through LDS) instead of one after the
+// other by the whole workgroup — the first form spent 2.4 ms per step on 9 984 dependent loads; the summation order is unchanged.
 __global__ __launch_bounds__(256)
 void embed_bwd_kernel(const float* __restrict__ dcontent, const int* __restrict__ tok, int ldt, int B, int L, int E, float scale,
                       float* __restrict__ demb) {
-    const int v = blockIdx.x;
+    __shared__ unsigned long long hits[4];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = B * L;
     float acc[3] = {0.f, 0.f, 0.f};                              // E <= 768
-    for (int b = 0; b < B; ++b)
-        for (int j = 0; j < L; ++j) {
-            if (tok[b * ldt + j] != v) continue;                  // uniform across the workgroup
-            const float* row = dcontent + ((size_t)b * L + j) * E;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        bool hit = false;
+        if (i < n) { const int b = i / L, j = i - b * L; hit = tok[b * ldt + j] == v; }
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) hits[wave] = m;
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int c = threadIdx.x + 256 * i;
-                if (c < E) acc[i] += row[c];
+        for (int w = 0; w < 4; ++w) {
+            unsigned long long mm = hits[w];                      // the same in every thread
+            while (mm) {
+                const int bit = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                const float* row = dcontent + (size_t)(base + w * 64 + bit) * E;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int c = tid + 256 * k;
+                    if (c < E) acc[k] += row[c];
+                }
             }
         }
+        __syncthreads();
+    }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int c = threadIdx.x + 256 * i;
-        if (c < E) demb[(size_t)v * E + c] += scale * acc[i];
+    for (int k = 0; k < 3; ++k) {
+        const int c = tid + 256 * k;
+        if (c < E) demb[(size_t)v * E + c] += scale * acc[k];
     }
 }
 
