@@ -334,6 +334,16 @@ int parseq_op_attn_fused(float* x, const float* gamma, const float* beta, const 
  * bias, W1 bf16 [1536, 384], b1 fp32 [1536], W2 bf16 [384, 1536], b2 fp32 [384].  table_ws: device scratch of depth * 48 bytes.
  * Test hook (the product path builds the table once per plan); uploads the table synchronously. */
 int parseq_op_enc_blocks(float* x, const void* const* block_ptrs, int depth, int M, void* table_ws, void* stream);
+/* `depth` encoder blocks in one launch in the bf16x3 arithmetic (encoder_blocks_x3.h), in place on x[M, 384] (fp32), M a multiple of 128.
+ * master: ONE fp32 device buffer holding every parameter of the blocks, each tensor on a 32-element boundary; pack: its block-planar
+ * hi | lo copy (parseq_op_split_pack over the whole buffer, master_elems * 4 bytes); offsets: HOST array of depth * 12 element offsets
+ * into master, per block: norm1 weight, norm1 bias, Wqkv [1152, 384], bqkv, Wproj [384, 384], bproj, norm2 weight, norm2 bias,
+ * W1 [1536, 384], b1, W2 [384, 1536], b2.  table_ws: device scratch of depth * 48 bytes; scratch: device, M / 128 * 393216 bytes.
+ * kmem / vmem != NULL (fp32 [M / 128][12][128][32]) with tail_offsets (HOST: final norm weight, bias, Wkv [768, 384], bkv [768]):
+ * x is not stored; the launch ends with the decoder's K | V = LayerNorm(x) Wkv^T + bkv (timm forward_features' norm, modules.py:33-34).
+ * Test hook (the product path builds the tables once per plan); uploads the table synchronously. */
+int parseq_op_enc_blocks_x3(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
+                            int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream);
 /* Ablation variants of parseq_op_mlp for tools/panel_bench.py (variant 0 = the product kernel; 10 = x resident in the fc2
  * accumulators, the form the encoder uses). */
 int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,

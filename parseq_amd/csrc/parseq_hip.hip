@@ -25,6 +25,7 @@
 #include "encoder_mlp.h"
 #include "encoder_attn_fused.h"
 #include "encoder_blocks.h"
+#include "encoder_blocks_x3.h"
 #include "gemm.h"
 #include "rowops.h"
 #include "train_ops.h"
@@ -355,6 +356,7 @@ struct parseq_plan {
     bool fused_attn = getenv("PARSEQ_NO_FUSED_ATTN") == nullptr;   // diagnostics: qkv panel GEMM + attention + proj GEMM instead of encoder_attn_fused.h
     bool mlp_resident = getenv("PARSEQ_MLP_RELOAD") == nullptr;    // diagnostics: the fused MLP's first form (x re-read by the epilogue)
     bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h
+    bool fused_x3 = getenv("PARSEQ_NO_FUSED_X3") == nullptr;          // diagnostics: bf16x3 encoder through the per-op kernels instead of encoder_blocks_x3.h
     EncBlockParams* blocks_dev = nullptr;                           // [enc_depth] parameter pointers of encoder_blocks.h (bf16 mode)
     std::vector<EncBlockParams> blocks_host;                        // source of the asynchronous upload (must outlive it)
     EncTailParams enc_tail{0, 0, 0, 0, nullptr, nullptr, 0};        // final norm + memory K / V projection inside the one-launch encoder (offsets; pointers filled per call)
@@ -524,6 +526,33 @@ static int build_tables(parseq_plan* p, hipStream_t s) {
     return 0;
 }
 
+// Element offsets of every encoder block's parameters (encoder_blocks.h EncBlockParams) and of the tail's — identical in the fp32
+// master, the bf16 copy and the block-planar bf16x3 pack (all three lay the tensors out alike).
+static int build_block_table(parseq_plan* p, hipStream_t s) {
+    const parseq_model* m = p->m;
+    p->blocks_host.resize(m->cfg.enc_depth);
+    auto off = [&](const std::string& key) { return (unsigned)m->params[m->index.at(key)].offset; };
+    for (int i = 0; i < m->cfg.enc_depth; ++i) {
+        const std::string b = m->enc + "blocks." + std::to_string(i) + ".";
+        EncBlockParams& e = p->blocks_host[i];
+        e.ln1_w = off(b + "norm1.weight"); e.ln1_b = off(b + "norm1.bias");
+        e.wqkv = off(b + "attn.qkv.weight"); e.bqkv = off(b + "attn.qkv.bias");
+        e.wproj = off(b + "attn.proj.weight"); e.bproj = off(b + "attn.proj.bias");
+        e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias");
+        e.w1 = off(b + "mlp.fc1.weight"); e.b1 = off(b + "mlp.fc1.bias");
+        e.w2 = off(b + "mlp.fc2.weight"); e.b2 = off(b + "mlp.fc2.bias");
+    }
+    HIPCHK(hipMemcpyAsync(p->blocks_dev, p->blocks_host.data(), p->blocks_host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice, s));
+    if (!m->vitstr) {
+        const int E_ = m->cfg.embed_dim;
+        p->enc_tail.norm_w = off(m->enc + "norm.weight"); p->enc_tail.norm_b = off(m->enc + "norm.bias");
+        p->enc_tail.wkv = off("decoder.layers.0.cross_attn.in_proj_weight") + (unsigned)E_ * E_;
+        p->enc_tail.bkv = off("decoder.layers.0.cross_attn.in_proj_bias") + (unsigned)E_;
+        p->enc_tail.heads = m->cfg.dec_heads;
+    }
+    return 0;
+}
+
 static int pack_weights(parseq_plan* p, hipStream_t s) {
     const parseq_model* m = p->m;
     for (const auto& ps : m->params)
@@ -535,25 +564,10 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
         if (!m->vitstr) CHK(build_tables<bf16_t>(p, s));
         {   // parameter offsets of the encoder blocks for the one-launch encoder (encoder_blocks.h): element offsets, identical in
             // the fp32 master and in the bf16 copy (both lay the tensors out alike)
-            p->blocks_host.resize(m->cfg.enc_depth);
+            CHK(build_block_table(p, s));
             auto off = [&](const std::string& key) { return (unsigned)m->params[m->index.at(key)].offset; };
-            for (int i = 0; i < m->cfg.enc_depth; ++i) {
-                const std::string b = m->enc + "blocks." + std::to_string(i) + ".";
-                EncBlockParams& e = p->blocks_host[i];
-                e.ln1_w = off(b + "norm1.weight"); e.ln1_b = off(b + "norm1.bias");
-                e.wqkv = off(b + "attn.qkv.weight"); e.bqkv = off(b + "attn.qkv.bias");
-                e.wproj = off(b + "attn.proj.weight"); e.bproj = off(b + "attn.proj.bias");
-                e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias");
-                e.w1 = off(b + "mlp.fc1.weight"); e.b1 = off(b + "mlp.fc1.bias");
-                e.w2 = off(b + "mlp.fc2.weight"); e.b2 = off(b + "mlp.fc2.bias");
-            }
-            HIPCHK(hipMemcpyAsync(p->blocks_dev, p->blocks_host.data(), p->blocks_host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice, s));
             if (!m->vitstr) {
                 const int E_ = m->cfg.embed_dim;
-                p->enc_tail.norm_w = off(m->enc + "norm.weight"); p->enc_tail.norm_b = off(m->enc + "norm.bias");
-                p->enc_tail.wkv = off("decoder.layers.0.cross_attn.in_proj_weight") + (unsigned)E_ * E_;
-                p->enc_tail.bkv = off("decoder.layers.0.cross_attn.in_proj_bias") + (unsigned)E_;
-                p->enc_tail.heads = m->cfg.dec_heads;
                 // head of the one-launch encoder: pos_embed + patch-embed bias as one table
                 p->wpe_off = off(m->enc + "patch_embed.proj.weight");
                 const int rows_ = m->tokens;
@@ -583,6 +597,7 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
             const size_t n = m->master_elems;
             hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<unsigned char*>(p->wpack), n);
             HIPCHK(hipGetLastError());
+            CHK(build_block_table(p, s));      // the one-launch encoder of this precision (encoder_blocks_x3.h)
         }
         SplitScope ss(p->precision == PARSEQ_BF16X3);
         if (!m->vitstr) CHK(build_tables<float>(p, s));
@@ -831,7 +846,25 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             if (tail) { p->last_batch = B; return 0; }
         }
     }
-    for (int i = 0; i < (fused_blocks ? 0 : c.enc_depth); ++i) {
+    bool blocks_done = fused_blocks;
+    if constexpr (!kBf16) {
+        // bf16x3, PARSeq-S geometry: the twelve blocks — and, when nobody asked for `memory` itself, the final LayerNorm and the decoder's
+        // K / V projection of it — in one launch with x resident in registers (encoder_blocks_x3.h); the MLP hidden buffer (idle on this
+        // path) is the launch's per-image scratch (the parked residual stream and the attention output, 384 KiB per image)
+        if (g_split && p->fused_x3 && p->fused_blocks && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && M % 128 == 0) {
+            const bool tail = p->fused_tail && memory_out == nullptr && c.dec_heads * DEC_HD == E;
+            x3::EncTailX3 et{p->enc_tail.norm_w, p->enc_tail.norm_b, p->enc_tail.wkv, p->enc_tail.bkv, nullptr, nullptr, p->enc_tail.heads};
+            if (tail) { et.kmem = reinterpret_cast<float*>(p->kmem); et.vmem = reinterpret_cast<float*>(p->vmem); }
+            {
+                ProfScope ps_(&p->prof, T_BLOCKS, s);
+                HIPCHK((x3::launch_enc_blocks_x3<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev, c.enc_depth,
+                                                      c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), et)));
+            }
+            if (tail) { p->last_batch = B; return 0; }
+            blocks_done = true;
+        }
+    }
+    for (int i = 0; i < (blocks_done ? 0 : c.enc_depth); ++i) {
         const std::string b = pe + "blocks." + std::to_string(i) + ".";
         if (fused_attn && Ma == M) {
             if constexpr (kBf16) {
@@ -2139,6 +2172,33 @@ extern "C" int parseq_op_enc_blocks(float* x, const void* const* block_ptrs, int
     HIPCHK(hipMemcpy(table_ws, host.data(), host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice));      // test hook: synchronous upload
     HIPCHK((launch_enc_blocks<384>((hipStream_t)stream, x, reinterpret_cast<const bf16_t*>(wlo), (size_t)(whi - wlo), reinterpret_cast<const float*>(plo),
                                    reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M)));
+    return 0;
+}
+
+// `depth` encoder blocks in one launch in the bf16x3 arithmetic (encoder_blocks_x3.h).  `master`: ONE f32 buffer holding every parameter
+// of the blocks (each tensor on a 32-element boundary); `pack`: its block-planar hi | lo copy (parseq_op_split_pack over the whole
+// buffer); offsets: HOST array of depth * 12 element offsets into `master`, per block in EncBlockParams order (norm1 w, b, Wqkv, bqkv,
+// Wproj, bproj, norm2 w, b, W1, b1, W2, b2).  tail_offsets (HOST, 4 element offsets: final norm w, b, Wkv [768, 384], bkv [768]) with
+// kmem / vmem (f32 [M / 128][12][128][32]) != NULL: instead of storing x the launch ends with K | V = LayerNorm(x) Wkv^T + bkv.
+extern "C" int parseq_op_enc_blocks_x3(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
+                                       int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream) {
+    CHK(check_arch());
+    if (!x || !master || !pack || !offsets || !table_ws || !scratch || depth <= 0 || M <= 0 || (M % 128) || master_elems <= 0 || (master_elems % 32))
+        return fail(PARSEQ_E_INVALID, "bad argument (M must be a multiple of 128: whole images; master_elems a multiple of 32)");
+    if ((kmem || vmem) && (!kmem || !vmem || !tail_offsets)) return fail(PARSEQ_E_INVALID, "tail: kmem, vmem and tail_offsets go together");
+    std::vector<EncBlockParams> host(depth);
+    for (int i = 0; i < depth; ++i) {
+        const uint32_t* o = offsets + (size_t)i * 12;
+        for (int k = 0; k < 12; ++k) if (o[k] % 32 || (int64_t)o[k] >= master_elems) return fail(PARSEQ_E_INVALID, "block %d: offset %d (%u) is not a 32-element boundary inside the buffer", i, k, o[k]);
+        EncBlockParams& e = host[i];
+        e.ln1_w = o[0]; e.ln1_b = o[1]; e.wqkv = o[2]; e.bqkv = o[3]; e.wproj = o[4]; e.bproj = o[5];
+        e.ln2_w = o[6]; e.ln2_b = o[7]; e.w1 = o[8]; e.b1 = o[9]; e.w2 = o[10]; e.b2 = o[11];
+    }
+    HIPCHK(hipMemcpy(table_ws, host.data(), host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice));      // test hook: synchronous upload
+    x3::EncTailX3 et{0, 0, 0, 0, nullptr, nullptr, 12};
+    if (kmem) { et.norm_w = tail_offsets[0]; et.norm_b = tail_offsets[1]; et.wkv = tail_offsets[2]; et.bkv = tail_offsets[3]; et.kmem = kmem; et.vmem = vmem; }
+    HIPCHK((x3::launch_enc_blocks_x3<384>((hipStream_t)stream, x, pack, (size_t)master_elems * sizeof(float), master,
+                                          reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M, scratch, et)));
     return 0;
 }
 

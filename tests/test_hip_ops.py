@@ -287,3 +287,82 @@ def test_encoder_blocks_one_launch(images, depth):
     d = (xd.cpu() - want).abs()
     assert err <= 1.5e-2 * 4 ** (depth - 1), msg
     assert d.mean() <= 3e-4 * 30 ** (depth - 1), f'mean |d| {d.mean():.3e}'
+
+
+def _ref_block_exact(x, P):
+    """One timm Block in fp64, no rounding anywhere (the bf16x3 arithmetic is held to the exact result)."""
+    M, E = x.shape
+    images = M // 128
+    ln = torch.nn.functional.layer_norm(x, (E,), P['g1'].double(), P['b1n'].double(), 1e-6)
+    qkv = (ln @ P['Wqkv'].double().T + P['bqkv'].double()).view(images, 128, 3, 6, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    p = torch.softmax((q @ k.transpose(-1, -2)) * 0.125, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(M, E)
+    x = x + o @ P['Wproj'].double().T + P['bproj'].double()
+    ln2 = torch.nn.functional.layer_norm(x, (E,), P['g2'].double(), P['b2n'].double(), 1e-6)
+    hid = torch.nn.functional.gelu(ln2 @ P['W1'].double().T + P['b1'].double())
+    return x + hid @ P['W2'].double().T + P['b2'].double()
+
+
+@pytest.mark.parametrize('images,depth,tail', [(1, 1, False), (3, 2, False), (40, 3, True), (2, 12, True)])
+def test_encoder_blocks_x3_one_launch(images, depth, tail):
+    """encoder_blocks_x3.h: `depth` blocks (+ the final LayerNorm and the decoder's K | V projection as the tail) in one launch in the
+    bf16x3 arithmetic, against an UNROUNDED fp64 reference; distinct parameters per block; repeated launches bit-identical."""
+    nat, lib = native()
+    E, F = 384, 1536
+    M = images * 128
+    x = _gen(M, E, seed=41, scale=1.0) + 0.1
+    order = ('g1', 'b1n', 'Wqkv', 'bqkv', 'Wproj', 'bproj', 'g2', 'b2n', 'W1', 'b1', 'W2', 'b2')
+    blocks = []
+    for l in range(depth):
+        sd = 1000 + 100 * l
+        blocks.append({'g1': 1 + 0.1 * _gen(E, seed=sd + 1), 'b1n': 0.1 * _gen(E, seed=sd + 2),
+                       'Wqkv': _gen(3 * E, E, seed=sd + 3) * 1.5 / E ** 0.5, 'bqkv': 0.1 * _gen(3 * E, seed=sd + 4),
+                       'Wproj': _gen(E, E, seed=sd + 5) / E ** 0.5, 'bproj': 0.1 * _gen(E, seed=sd + 6),
+                       'g2': 1 + 0.1 * _gen(E, seed=sd + 7), 'b2n': 0.1 * _gen(E, seed=sd + 8),
+                       'W1': _gen(F, E, seed=sd + 9) / E ** 0.5, 'b1': 0.1 * _gen(F, seed=sd + 10),
+                       'W2': _gen(E, F, seed=sd + 11) / F ** 0.5, 'b2': 0.1 * _gen(E, seed=sd + 12)})
+    T = {'gn': 1 + 0.1 * _gen(E, seed=91), 'bn': 0.1 * _gen(E, seed=92), 'Wkv': _gen(2 * E, E, seed=93) / E ** 0.5, 'bkv': 0.1 * _gen(2 * E, seed=94)}
+    tensors = [P[k] for P in blocks for k in order] + [T[k] for k in ('gn', 'bn', 'Wkv', 'bkv')]
+    offs, total = [], 0
+    for t in tensors:
+        offs.append(total)
+        total += (t.numel() + 31) // 32 * 32
+    master = torch.zeros(total, dtype=torch.float32)
+    for t, o in zip(tensors, offs):
+        master[o:o + t.numel()] = t.reshape(-1)
+    md = master.to(DEV)
+    pack = torch.empty(total, dtype=torch.float32, device=DEV)
+    nat.check(lib.parseq_op_split_pack(nat.ptr(md), nat.ptr(pack), total, nat.stream_ptr()))
+    o32 = (C.c_uint32 * (12 * depth))(*offs[:12 * depth])
+    t32 = (C.c_uint32 * 4)(*offs[12 * depth:])
+    table = torch.empty(depth * 48, dtype=torch.uint8, device=DEV)
+    scratch = torch.empty(images * 393216 // 4, dtype=torch.float32, device=DEV)
+    outs = []
+    for rep in range(2):
+        xd = x.to(DEV).clone()
+        kmem = torch.full((images, 12, 128, 32), float('nan'), dtype=torch.float32, device=DEV)
+        vmem = torch.full((images, 12, 128, 32), float('nan'), dtype=torch.float32, device=DEV)
+        nat.check(lib.parseq_op_enc_blocks_x3(nat.ptr(xd), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32,
+                                              nat.ptr(kmem) if tail else None, nat.ptr(vmem) if tail else None, nat.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((xd, kmem, vmem))
+    want = x.double()
+    for P in blocks:
+        want = _ref_block_exact(want, P)
+    scale = float(want.abs().max())
+    tol = 2e-5 * depth * max(scale, 1.0)        # ~2^-16 relative per product, a handful of products per block
+    if tail:
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), 'repeated launches differ (K / V)'
+        kv = torch.nn.functional.layer_norm(want, (E,), T['gn'].double(), T['bn'].double(), 1e-6) @ T['Wkv'].double().T + T['bkv'].double()
+        kw = kv[:, :E].view(images, 128, 12, 32).permute(0, 2, 1, 3)
+        vw = kv[:, E:].view(images, 128, 12, 32).permute(0, 2, 1, 3)
+        ek, msgk = report(f'x3 blocks tail K images={images} depth={depth}', outs[0][1], kw.float())
+        ev, msgv = report(f'x3 blocks tail V images={images} depth={depth}', outs[0][2], vw.float())
+        assert ek <= tol and ev <= tol, msgk + ' | ' + msgv
+    else:
+        assert torch.equal(outs[0][0], outs[1][0]), 'repeated launches differ'
+        err, msg = report(f'x3 blocks images={images} depth={depth}', outs[0][0], want.float())
+        assert err <= tol, msg
+        # and it must really be better than single bf16 products (a path that dropped the lo terms would sit at ~1e-2)
+        assert err <= 1e-3
