@@ -171,6 +171,7 @@ def main():
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--force-dist', action='store_true', help='self-test: initialise the RCCL process group and run the collectives even with one rank')
+    ap.add_argument('--repeats', type=int, default=5, help='repetitions of the K-step timed region; the median is reported, min / max alongside')
     ap.add_argument('--streams', type=int, default=2, help='batches in flight for `value` (independent workspaces on separate HIP streams); '
                     'the one-call-at-a-time figure is always measured too and reported as sequential_value')
     args = ap.parse_args()
@@ -251,8 +252,21 @@ def main():
             el = float(t.item())
         return el, out_
 
-    elapsed, out = timed(model, images, args.streams, args.steps, args.warmup)
-    seq_elapsed, _ = timed(model, images, 1, args.steps, args.warmup) if args.streams > 1 else (elapsed, None)
+    # The K-step timed region is repeated `--repeats` times inside the run (each repeat: warm-up, barrier + synchronise, EXACTLY K steps,
+    # synchronise + barrier, MAX over ranks) and the MEDIAN repeat is the one reported; min / max show the spread, which on one box is
+    # ~1 % and between boxes ~5 % (reference bench.py:43-49 reports median / IQR the same way).
+    def repeated(mdl, x, in_flight, steps, warmup, repeats):
+        runs = []
+        for r in range(repeats):
+            el, out_ = timed(mdl, x, in_flight, steps, warmup if r == 0 else 1)
+            runs.append(el)
+        srt = sorted(runs)
+        return srt[len(srt) // 2], out_, {'n': repeats, 'steps_each': steps, 'ms_per_step_min': round(1e3 * srt[0] / steps, 4),
+                                          'ms_per_step_median': round(1e3 * srt[len(srt) // 2] / steps, 4),
+                                          'ms_per_step_max': round(1e3 * srt[-1] / steps, 4)}
+
+    elapsed, out, spread = repeated(model, images, args.streams, args.steps, args.warmup, args.repeats)
+    seq_elapsed, _, seq_spread = repeated(model, images, 1, args.steps, args.warmup, args.repeats) if args.streams > 1 else (elapsed, None, spread)
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * B * args.steps / elapsed
 
@@ -263,12 +277,14 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.precision, 'data': 'synthetic',
         'sequential_value': round(world * B * args.steps / seq_elapsed, 1), 'sequential_ms_per_step': round(1e3 * seq_elapsed / args.steps, 4),
+        'repeats': {'value': spread, 'sequential_value': seq_spread},
         'config': {'workload': f'{args.model} {args.precision}, {ih}x{iw} crops, {B} crops per step per GPU, AR decode '
                                f'({"natural exit" if args.natural_exit else "26 steps forced"}) + {args.refine_iters} refine iter '
                                f'({named if named else "not a BASELINE.json configuration"}); random-init weights (reference init, seed 0); '
                                f'inputs resident in HBM as {"bf16" if args.precision == "bf16" else "fp32"}; '
-                               f'value = {args.streams} steps in flight on separate HIP streams ({args.streams * B} crops resident per GPU), '
-                               f'sequential_value = one step at a time (the reference\'s call pattern)',
+                               f'sequential_value = one step at a time (the reference\'s call pattern: the apples-to-apples figure for this configuration), '
+                               f'value = {args.streams} steps in flight on separate HIP streams ({args.streams * B} crops resident per GPU); '
+                               f'value_at_tolerance = the same measurement in the precision that meets the 1e-3 logit tolerance',
                    'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-gather of logits' if world > 1 else ''),
                    'output_shape': list(out.shape), 'steps_in_flight': args.streams},
     }
@@ -331,9 +347,26 @@ def main():
                 el = time.perf_counter() - t0
                 result['exact_value'] = round(B * ksteps / el, 1)
                 result['exact_precision'] = args.exact_precision
+                # one forward at a time in the exact precision as well
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(ksteps):
+                    step(exact, images32, 1)
+                torch.cuda.synchronize()
+                result['exact_sequential_value'] = round(B * ksteps / (time.perf_counter() - t0), 1)
         except Exception as e:      # parity evidence must never take the throughput line down with it; say what happened
             result['parity'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
+        # the headline, unambiguous: `value` is the timed dtype's throughput; whether that dtype meets the north star's 1e-3 / argmax bar
+        # on the timed weights and inputs is stated next to it, with the throughput of the mode that does
+        par = result.get('parity') or {}
+        if args.precision == args.exact_precision:
+            result['value_at_tolerance'] = result['value']
+            result['tolerance_met_by_timed_dtype'] = True
+        else:
+            result['value_at_tolerance'] = result.get('exact_value')
+            met = par.get('max_abs_vs_fp32')
+            result['tolerance_met_by_timed_dtype'] = bool(met is not None and met <= 1e-3 and par.get('argmax_agree') == 1.0)
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

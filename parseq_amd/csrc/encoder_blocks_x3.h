@@ -25,19 +25,32 @@
 namespace pq {
 namespace x3 {
 
+// Timing ablations (results are WRONG with any bit set; tools/x3_variants.sh builds them, tools/x3_variant_bench.py times them):
+// 1 GELU -> identity, 2 no exp in the soft-max, 4 no LDS-DMA issue, 8 no park / unpark / O round trip, 16 no pair barriers, 32 no waits for
+// the LDS-DMA
+#ifndef X3_ABLATE
+#define X3_ABLATE 0
+#endif
 #ifndef X3_MLP_RING
-#define X3_MLP_RING 4          // pair groups of the MLP phase
+#define X3_MLP_RING 3          // pair groups of the MLP phase
 #endif
 #ifndef X3_AHEAD
 #define X3_AHEAD 2             // weight-fragment positions read ahead of the MFMAs
 #endif
 constexpr int STAGE = 16384, PAIRB = 2 * STAGE;
 constexpr int KIMG_B = 128 * AF_KROWB, VIMG_B = 64 * AF_VROWB;           // one plane of the K / V^T image
-constexpr int ATT_RING_B = 2 * PAIRB, MLP_RING_B = 4 * PAIRB;
-constexpr int IMG_OFF = ATT_RING_B;                                      // K hi | K lo | V^T hi | V^T lo
-constexpr int PARAM_OFF = IMG_OFF + 2 * KIMG_B + 2 * VIMG_B;             // 137216 >= MLP_RING_B
-static_assert(PARAM_OFF >= MLP_RING_B, "the MLP ring must end below the parameter block");
-template <int E> constexpr size_t enc_blocks_x3_lds() { return (size_t)PARAM_OFF + (size_t)(7 * E) * sizeof(float); }
+// LDS map.  Head loop: a ring of HEADS_SLOTS single stages | the K hi, K lo, V^T hi, V^T lo image planes | 6E parameter floats.
+// proj / MLP / tail: X3_MLP_RING pair groups | 7E parameter floats (proj reads its bias from the head loop's block, which its ring does not reach).
+constexpr int HEADS_SLOTS = 5;
+constexpr int IMG_OFF = HEADS_SLOTS * STAGE;                             // 81920
+constexpr int HEADS_PARAM_OFF = IMG_OFF + 2 * KIMG_B + 2 * VIMG_B;       // 153600
+constexpr int MLP_RING_B = X3_MLP_RING * PAIRB;
+constexpr int MLP_PARAM_OFF = MLP_RING_B;
+template <int E> constexpr size_t enc_blocks_x3_lds() {
+    constexpr size_t a = (size_t)HEADS_PARAM_OFF + (size_t)(6 * E) * sizeof(float), b = (size_t)MLP_PARAM_OFF + (size_t)(7 * E) * sizeof(float);
+    return a > b ? a : b;
+}
+static_assert(enc_blocks_x3_lds<384>() <= 163840 && MLP_RING_B + 7 * 384 * 4 <= HEADS_PARAM_OFF, "LDS map");
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -46,6 +59,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
         lo[i] = static_cast<bf16_t>(v[i] - static_cast<float>(hi[i]));           // exact residual, rounded once
     }
 }
+
+__device__ __forceinline__ float x3_gelu(float x) { if constexpr ((X3_ABLATE & 1) != 0) return x; else return gelu_erf(x); }
+__device__ __forceinline__ float x3_exp2(float x) { if constexpr ((X3_ABLATE & 2) != 0) return x; else return __builtin_amdgcn_exp2f(x); }
 
 // acc[j] += A B^T for the two row tiles j of the wave, A / B given as (hi, lo) fragments; small terms first, the two row tiles
 // interleaved so that no MFMA waits for the one before it
@@ -70,47 +86,82 @@ __device__ __forceinline__ void mma3_1(f32x4& c, const bf16x8& ah, const bf16x8&
 
 // Per-lane DMA source offsets in BYTES of the block-planar pack (StreamLane of encoder_blocks.h with 4-byte elements: the row
 // order and the source swizzle are the same, a stage row is 128 bytes = one k-block's hi | lo halves).
+#ifndef X3_SOFTMAX_JOINT
+#define X3_SOFTMAX_JOINT 1     // 1: the soft-max / P V section runs both row tiles at once (K / V^T fragments read once; 100 more live registers)
+#endif
+#ifndef X3_PARK_TILES
+#define X3_PARK_TILES 8        // accumulator tiles (of 24) that leave the register file for the head loop
+#endif
+#ifndef X3_ISSUE_MODE
+#define X3_ISSUE_MODE 0        // LDS-DMA pieces of a later pair: 0 = a stage's four at each stage boundary, 1 = all eight at the pair's start, 2 = one per two positions (12 MFMAs)
+#endif
+#ifndef X3_VOFF_RECOMPUTE
+#define X3_VOFF_RECOMPUTE 0    // 1: the per-lane DMA offsets are recomputed at every stage issue instead of living in three registers
+#endif
 struct StreamLaneX {
-    unsigned v64, v128, v128w;           // 64 rows x two k-blocks at pitch 4E bytes | 128 rows x one k-block at pitch 4E | at pitch 16E
-    __device__ __forceinline__ StreamLaneX(int lane, int wid, int E) {
+#if X3_VOFF_RECOMPUTE
+    int wid, E;
+    __device__ __forceinline__ StreamLaneX(int, int wid_, int E_) : wid(wid_), E(E_) {}
+#else
+    unsigned v64_, v128_, v128w_;
+    __device__ __forceinline__ StreamLaneX(int lane, int wid, int E) { v64_ = calc<0>(lane, wid, E); v128_ = calc<1>(lane, wid, E); v128w_ = calc<2>(lane, wid, E); }
+#endif
+    // KIND 0: 64 rows x two k-blocks at pitch 4E bytes | 1: 128 rows x one k-block at pitch 4E | 2: at pitch 16E
+    template <int KIND> static __device__ __forceinline__ unsigned calc(int lane, int wid, int E) {
         const int sc = ((lane & 7) ^ (lane >> 3)) * 16;
         const int rho = wid * 32 + (lane >> 3);
         const int i = rho >> 4, r16 = rho & 15, i4 = i & 3;
-        const int p64 = ((i4 >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i4 & 1) * 4 + (r16 & 3);
-        const int p128 = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
-        v64 = (unsigned)(p64 * 4 * E + (rho >> 6) * 128 + sc);
-        v128 = (unsigned)(p128 * 4 * E + sc);
-        v128w = (unsigned)(p128 * 16 * E + sc);
+        if constexpr (KIND == 0) {
+            const int p64 = ((i4 >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i4 & 1) * 4 + (r16 & 3);
+            return (unsigned)(p64 * 4 * E + (rho >> 6) * 128 + sc);
+        } else {
+            const int p128 = (i >> 2) * 64 + ((i >> 1) & 1) * 32 + (r16 >> 2) * 8 + (i & 1) * 4 + (r16 & 3);
+            return (unsigned)(p128 * (KIND == 1 ? 4 : 16) * E + sc);
+        }
+    }
+    template <int KIND> __device__ __forceinline__ unsigned voff() const {
+#if X3_VOFF_RECOMPUTE
+        return calc<KIND>(opaque_lane(), wid, E);
+#else
+        return KIND == 0 ? v64_ : (KIND == 1 ? v128_ : v128w_);
+#endif
     }
 };
 // one stage (the wave's four 1-KiB pieces): origin_b = byte offset of (row 0, k-block 0) of the stage in the pack, pitch_b = row pitch in bytes
-__device__ __forceinline__ void issue_stage(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned origin_b, unsigned pitch_b, unsigned char* dst) {
-    StreamLane::issue_v(rsrc, voff, origin_b, (int)(pitch_b >> 1), dst, -1);
+__device__ __forceinline__ void issue_stage(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned origin_b, unsigned pitch_b, unsigned char* dst, int q = -1) {
+    if constexpr ((X3_ABLATE & 4) != 0) return;
+    StreamLane::issue_v(rsrc, voff, origin_b, (int)(pitch_b >> 1), dst, q);      // q = -1: all four pieces, 0..3: that piece
 }
 
 // ---- a PAIR of stages under one barrier ---------------------------------------------------------------------------------------
 // mma(s, i, wh, wl): the six MFMAs that consume the (hi, lo) weight fragments of tile i (16 LDS rows) of stage s.
 // issue(s): the wave's LDS-DMA pieces due at stage s (one stage of a later pair).  Fragment reads run two positions ahead of the
 // MFMAs through three rotating register pairs.
-template <int AHEAD = 2, class Mma, class Issue>
-__device__ __forceinline__ void run_pair(const unsigned char* grp, Mma&& mma, Issue&& issue) {
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// mid(): called between the two stages (after stage 0's MFMAs)
+template <int AHEAD = 2, class Mma, class Issue, class Mid = NoMid>
+__device__ __forceinline__ void run_pair2(const unsigned char* st0, const unsigned char* st1, Mma&& mma, Issue&& issue, Mid&& mid = Mid{}) {
     const int ln = opaque_lane();
     const int fo0 = stage_frag_off(ln), fo1 = fo0 ^ 64;
     constexpr int NB = AHEAD + 1;
     bf16x8 wh[NB], wl[NB];
     static_for<0, AHEAD>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
-        wh[n] = *reinterpret_cast<const bf16x8*>(grp + n * 2048 + fo0); wl[n] = *reinterpret_cast<const bf16x8*>(grp + n * 2048 + fo1);
+        wh[n] = *reinterpret_cast<const bf16x8*>(st0 + n * 2048 + fo0); wl[n] = *reinterpret_cast<const bf16x8*>(st0 + n * 2048 + fo1);
     });
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 16>([&](auto nc) {
         constexpr int n = decltype(nc)::value, s = n >> 3, i = n & 7, nn = n + AHEAD;
-        if constexpr (i == 0) {
-            issue(s);
+        if constexpr (n == 8) mid();
+        if constexpr (X3_ISSUE_MODE == 2) {
+            if constexpr ((i & 1) == 0) { issue(s, i >> 1); __builtin_amdgcn_sched_barrier(0); }
+        } else if constexpr (X3_ISSUE_MODE == 0 ? i == 0 : n == 0) {
+            issue(s, -1);
+            if constexpr (X3_ISSUE_MODE == 1) issue(1, -1);
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (nn < 16) {
-            const unsigned char* src = grp + (nn >> 3) * STAGE + (nn & 7) * 2048;
+            const unsigned char* src = ((nn >> 3) ? st1 : st0) + (nn & 7) * 2048;
             wh[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo0);
             wl[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo1);
         }
@@ -127,9 +178,15 @@ __device__ __forceinline__ void run_pair(const unsigned char* grp, Mma&& mma, Is
     });
 }
 
+template <int AHEAD = 2, class Mma, class Issue, class Mid = NoMid>
+__device__ __forceinline__ void run_pair(const unsigned char* grp, Mma&& mma, Issue&& issue, Mid&& mid = Mid{}) {
+    run_pair2<AHEAD>(grp, grp + STAGE, mma, issue, mid);
+}
+
+template <int N> __device__ __forceinline__ void x3_wait_vmcnt() { if constexpr ((X3_ABLATE & 32) == 0) wait_vmcnt<N>(); }
 __device__ __forceinline__ void pair_fence() {          // the pair about to run has landed (caller waited vmcnt); all waves are past the previous one
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((X3_ABLATE & 16) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
@@ -203,14 +260,14 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16][2], co
 template <int E>
 __device__ __forceinline__ void park_acc(const f32x4 (&acc)[E / 16][2], float* __restrict__ dst, int tid) {
 #pragma unroll
-    for (int i = 0; i < E / 16; ++i)
+    for (int i = 0; i < X3_PARK_TILES; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(dst + ((size_t)(2 * i + j) * 256 + tid) * 4) = acc[i][j];
 }
 template <int E>
 __device__ __forceinline__ void unpark_acc(f32x4 (&acc)[E / 16][2], const float* __restrict__ src, int tid) {
 #pragma unroll
-    for (int i = 0; i < E / 16; ++i)
+    for (int i = 0; i < X3_PARK_TILES; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = *reinterpret_cast<const f32x4*>(src + ((size_t)(2 * i + j) * 256 + tid) * 4);
 }
@@ -220,16 +277,21 @@ __device__ __forceinline__ void unpark_acc(f32x4 (&acc)[E / 16][2], const float*
 // two pair groups (pair m = 9 h + n of the phase lives in group m & 1), then S^T = K Q^T, the soft-max and O^T = V^T P^T from the
 // K / V^T image planes.  O of head h: pieces ((2 h + j) * 2 + kb) * 2 + {0 hi, 1 lo} of `obuf` (piece-major like park_acc): exactly
 // the k-block 2 h + kb operand of the proj GEMM for row tile j.  heads_prefetch must have been called; returns with no LDS-DMA in flight.
+// Stage sigma = 2 (9 h + n) + s of the phase (pair n of head h, stage s) lives in ring slot sigma % HEADS_SLOTS and is issued three
+// stages ahead of its pair: at the start of pair m stage 2 m + 2 may still be in flight; stages 2 m + 3 and 2 m + 4 go out at the two
+// stage boundaries of pair m, into the slots the pair's opening barrier has retired.
 template <int E>
-__device__ __forceinline__ void heads_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid, int h, int n, int s) {
-    unsigned char* dst = ring + ((h + n) & 1) * PAIRB + s * STAGE + wid * 4096;
+__device__ __forceinline__ void heads_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid, int sigma, int q = -1) {
+    const int m = sigma >> 1, s = sigma & 1, h = m / 9, n = m - 9 * h;
+    unsigned char* dst = ring + (sigma % HEADS_SLOTS) * STAGE + wid * 4096;
     const int u = n / 3, pp = n - 3 * u, t = 2 * pp + s;
-    issue_stage(wrsrc, sl.v64, (wqkv_off + (unsigned)((u * E + h * 64) * E + t * 64)) * 4u, 4u * E, dst);
+    issue_stage(wrsrc, sl.template voff<0>(), (wqkv_off + (unsigned)((u * E + h * 64) * E + t * 64)) * 4u, 4u * E, dst, q);
 }
 template <int E>
 __device__ __forceinline__ void heads_prefetch(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int wid) {
-    heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, 0, 0, 0);
-    heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, 0, 0, 1);
+    heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, 0);
+    heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, 1);
+    heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, 2);
 }
 
 template <int E, int AHEAD>
@@ -247,24 +309,23 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
         bf16x8 qh[2][2], ql[2][2];
         static_for<0, 9>([&](auto nc) {
             constexpr int n = decltype(nc)::value, u = n / 3, pp = n % 3;
-            wait_vmcnt<0>();                                     // this pair (issued during the previous one) has landed
+            const int m = 9 * h + n;                             // pair index of the phase
+            if (m + 1 < 9 * H) x3_wait_vmcnt<4>(); else x3_wait_vmcnt<0>();      // this pair has landed; the stage after it may be in flight
             pair_fence();
             if constexpr (pp == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             }
-            auto issue = [&](int s) {
-                if constexpr (n < 8) heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, h, n + 1, s);
-                else if (h + 1 < H) heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, h + 1, 0, s);
-            };
-            const unsigned char* grp = ring + ((h + n) & 1) * PAIRB;
+            auto issue = [&](int s, int q) { if (2 * m + 3 + s < 18 * H) heads_issue<E>(sl, ring, wrsrc, wqkv_off, wid, 2 * m + 3 + s, q); };
+            const unsigned char* st0 = ring + ((2 * m) % HEADS_SLOTS) * STAGE;
+            const unsigned char* st1 = ring + ((2 * m + 1) % HEADS_SLOTS) * STAGE;
             if constexpr (u < 2) {
-                run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+                run_pair2<AHEAD>(st0, st1, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                     const int kb = 4 * pp + 2 * s + (i >> 2);
                     mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
             } else {
-                run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+                run_pair2<AHEAD>(st0, st1, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                     const int kb = 4 * pp + 2 * s + (i >> 2);
                     mma3_a(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
@@ -317,6 +378,102 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+#if X3_SOFTMAX_JOINT
+                // S^T = K Q^T, soft-max, O^T = V^T P^T for both 16-query row tiles at once: every K / V^T fragment is read once
+                f32x4 sc[2][8];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt) { sc[0][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; sc[1][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                {   // 16 positions (k-step ks = n / 8, key tile kt = n % 8), image fragments read X3_AHEAD positions ahead of their MFMAs
+                    constexpr int NB = X3_AHEAD + 1;
+                    bf16x8 fh[NB], fl[NB];
+                    const int base = rr * AF_KROWB + 16 * g;
+                    static_for<0, X3_AHEAD>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value, off = 16 * (n & 7) * AF_KROWB + 64 * (n >> 3);
+                        fh[n] = *reinterpret_cast<const bf16x8*>(kimg_h + base + off); fl[n] = *reinterpret_cast<const bf16x8*>(kimg_l + base + off);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, 16>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value, ks = n >> 3, kt = n & 7, nn = n + X3_AHEAD;
+                        if constexpr (nn < 16) {
+                            constexpr int off = 16 * (nn & 7) * AF_KROWB + 64 * (nn >> 3);
+                            fh[nn % NB] = *reinterpret_cast<const bf16x8*>(kimg_h + base + off); fl[nn % NB] = *reinterpret_cast<const bf16x8*>(kimg_l + base + off);
+                        }
+                        mma3_w(sc[0][kt], sc[1][kt], fh[n % NB], fl[n % NB], qh[0][ks], ql[0][ks], qh[1][ks], ql[1][ks]);
+                        if constexpr (nn < 16) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        } else __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+                bf16x8 ph[2][4], pl[2][4];
+                float inv[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[j][kt][r]);
+                    mx = rows4_max(mx);
+                    const float mc = mx * sc2;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = x3_exp2(sc[j][2 * ks][r] * sc2 - mc);
+                            v[4 + r] = x3_exp2(sc[j][2 * ks + 1][r] * sc2 - mc);
+                            sum += v[r] + v[4 + r];
+                        }
+                        split8(v, ph[j][ks], pl[j][ks]);
+                    }
+                    sum = rows4_sum(sum);
+                    inv[j] = 1.0f / sum;
+                }
+                f32x4 ov[2][4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { ov[0][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[1][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                {   // 16 positions (k-step ks = n / 4, d tile dt = n % 4)
+                    constexpr int NB = X3_AHEAD + 1;
+                    bf16x8 fh[NB], fl[NB];
+                    const int base = rr * AF_VROWB + 16 * g;
+                    static_for<0, X3_AHEAD>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value, off = 16 * (n & 3) * AF_VROWB + 64 * (n >> 2);
+                        fh[n] = *reinterpret_cast<const bf16x8*>(vimg_h + base + off); fl[n] = *reinterpret_cast<const bf16x8*>(vimg_l + base + off);
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                    static_for<0, 16>([&](auto nc) {
+                        constexpr int n = decltype(nc)::value, ks = n >> 2, dt = n & 3, nn = n + X3_AHEAD;
+                        if constexpr (nn < 16) {
+                            constexpr int off = 16 * (nn & 3) * AF_VROWB + 64 * (nn >> 2);
+                            fh[nn % NB] = *reinterpret_cast<const bf16x8*>(vimg_h + base + off); fl[nn % NB] = *reinterpret_cast<const bf16x8*>(vimg_l + base + off);
+                        }
+                        mma3_w(ov[0][dt], ov[1][dt], fh[n % NB], fl[n % NB], ph[0][ks], pl[0][ks], ph[1][ks], pl[1][ks]);
+                        if constexpr (nn < 16) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                        } else __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = ov[j][2 * pr][r] * inv[j]; v[4 + r] = ov[j][2 * pr + 1][r] * inv[j]; }
+                        bf16x8 fh, fl;
+                        split8(v, fh, fl);
+                        float* o = obuf + ((size_t)((((2 * h + j) * 2 + pr) * 2) * 256) + tid) * 4;
+                        if constexpr ((X3_ABLATE & 8) == 0) {
+                            *reinterpret_cast<bf16x8*>(o) = fh;
+                            *reinterpret_cast<bf16x8*>(o + 256 * 4) = fl;
+                        } else { asm volatile("" :: "v"(fh), "v"(fl)); }
+                    }
+#else
                 // S^T = K Q^T, soft-max, O^T = V^T P^T — one 16-query row tile at a time
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -345,8 +502,8 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                         float v[8];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            v[r] = __builtin_amdgcn_exp2f(sc[2 * ks][r] * sc2 - mc);
-                            v[4 + r] = __builtin_amdgcn_exp2f(sc[2 * ks + 1][r] * sc2 - mc);
+                            v[r] = x3_exp2(sc[2 * ks][r] * sc2 - mc);
+                            v[4 + r] = x3_exp2(sc[2 * ks + 1][r] * sc2 - mc);
                             sum += v[r] + v[4 + r];
                         }
                         split8(v, ph[ks], pl[ks]);
@@ -372,10 +529,13 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                         bf16x8 fh, fl;
                         split8(v, fh, fl);
                         float* o = obuf + ((size_t)((((2 * h + j) * 2 + pr) * 2) * 256) + tid) * 4;
-                        *reinterpret_cast<bf16x8*>(o) = fh;
-                        *reinterpret_cast<bf16x8*>(o + 256 * 4) = fl;
+                        if constexpr ((X3_ABLATE & 8) == 0) {
+                            *reinterpret_cast<bf16x8*>(o) = fh;
+                            *reinterpret_cast<bf16x8*>(o + 256 * 4) = fl;
+                        } else { asm volatile("" :: "v"(fh), "v"(fl)); }
                     }
                 }
+#endif
             }
         });
     }
@@ -385,10 +545,10 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
 // A K = 384 GEMM with the operand (oh, ol) resident like the LayerNorm'd operand of fc1: 36 stages of 128 rows x one k-block, stage
 // t = (k-block t / 3, row group t % 3), 18 pairs through the MLP ring (pair n in group n % RING, issued during pair n - (RING - 1)).
 template <int E, int RING>
-__device__ __forceinline__ void proj_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, int wid, int n, int s) {
+__device__ __forceinline__ void proj_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, int wid, int n, int s, int q = -1) {
     const int t = 2 * n + s, kb = t / 3, ng = t - 3 * kb;
     unsigned char* dst = ring + (n % RING) * PAIRB + s * STAGE + wid * 4096;
-    issue_stage(wrsrc, sl.v128, (wproj_off + (unsigned)(ng * 128 * E + kb * 32)) * 4u, 4u * E, dst);
+    issue_stage(wrsrc, sl.template voff<1>(), (wproj_off + (unsigned)(ng * 128 * E + kb * 32)) * 4u, 4u * E, dst, q);
 }
 template <int E, int RING>
 __device__ __forceinline__ void proj_prefetch(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, int wid) {
@@ -405,12 +565,12 @@ __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_
     static_for<0, NP>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
         constexpr int behind = (NP - 1 - n) < (D - 1) ? (NP - 1 - n) : (D - 1);       // pairs issued after this one and still in flight
-        wait_vmcnt<8 * behind>();
+        x3_wait_vmcnt<8 * behind>();
         pair_fence();
         run_pair<AHEAD>(ring + (n % RING) * PAIRB, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
             const int t = 2 * n + s, kb = t / 3, ng = t % 3;
             mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, oh[0][kb], ol[0][kb], oh[1][kb], ol[1][kb]);
-        }, [&](int s) { if constexpr (n + D < NP) proj_issue<E, RING>(sl, ring, wrsrc, wproj_off, wid, n + D, s); });
+        }, [&](int s, int q) { if constexpr (n + D < NP) proj_issue<E, RING>(sl, ring, wrsrc, wproj_off, wid, n + D, s, q); });
     });
 }
 
@@ -421,13 +581,13 @@ __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_
 // Pair n of the phase (0 .. 6 * chunks) lives in group n % RING and is issued during pair n - (RING - 1).
 template <int E, int RING>
 __device__ __forceinline__ void mlp_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
-                                          int wid, int c, int r, int s) {
+                                          int wid, int c, int r, int s, int q = -1) {
     constexpr int F = 4 * E;
     unsigned char* dst = ring + ((6 * c + r) % RING) * PAIRB + s * STAGE + wid * 4096;
-    if (r < 3) issue_stage(wrsrc, sl.v64, (w1_off + (unsigned)(c * 64 * E + (2 * r + s) * 64)) * 4u, 4u * E, dst);
+    if (r < 3) issue_stage(wrsrc, sl.template voff<0>(), (w1_off + (unsigned)(c * 64 * E + (2 * r + s) * 64)) * 4u, 4u * E, dst, q);
     else {
         const int t = 2 * (r - 3) + s, kb = t / 3, ng = t - 3 * kb;
-        issue_stage(wrsrc, sl.v128w, (w2_off + (unsigned)(ng * 128 * F + c * 64 + kb * 32)) * 4u, 4u * F, dst);
+        issue_stage(wrsrc, sl.template voff<2>(), (w2_off + (unsigned)(ng * 128 * F + c * 64 + kb * 32)) * 4u, 4u * F, dst, q);
     }
 }
 template <int E, int RING>
@@ -444,10 +604,10 @@ __device__ __forceinline__ void gelu_frag(const f32x4 (&acc1)[4][2], const float
     for (int j = 0; j < 2; ++j) {
         float v[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = gelu_erf(acc1[2 * pr][j][q] + bp[32 * pr + q]);
+        for (int q = 0; q < 4; ++q) v[q] = x3_gelu(acc1[2 * pr][j][q] + bp[32 * pr + q]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[4 + q] = gelu_erf(acc1[2 * pr + 1][j][q] + bp[32 * pr + 4 + q]);
+        for (int q = 0; q < 4; ++q) v[4 + q] = x3_gelu(acc1[2 * pr + 1][j][q] + bp[32 * pr + 4 + q]);
         __builtin_amdgcn_sched_barrier(0);
         split8(v, hh[j], hl[j]);
         __builtin_amdgcn_sched_barrier(0);
@@ -473,15 +633,15 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         static_for<0, 6>([&](auto rc) {
             constexpr int r = decltype(rc)::value;
             // in flight behind this pair: the next D - 1 pairs (8 pieces per wave each), fewer at the end of the phase
-            if (!last) wait_vmcnt<8 * (D - 1)>(); else wait_vmcnt<8 * ((5 - r) < (D - 1) ? (5 - r) : (D - 1))>();
+            if (!last) x3_wait_vmcnt<8 * (D - 1)>(); else x3_wait_vmcnt<8 * ((5 - r) < (D - 1) ? (5 - r) : (D - 1))>();
             pair_fence();
             const int g = opaque_lane() >> 4;
             const float* bp = sb1 + c * 64 + 8 * g;
-            auto issue = [&](int s) {
-                if constexpr (r + D < 6) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c, r + D, s);
-                else if (!last) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, r + D - 6, s);
-                if constexpr (r == 4) { if (s == 1) gelu_frag(acc1, bp, 1, hh, hl); }      // (k-block 0, row group 2) was stage 0 of this pair
+            auto issue = [&](int s, int q) {
+                if constexpr (r + D < 6) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c, r + D, s, q);
+                else if (!last) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, r + D - 6, s, q);
             };
+            auto mid = [&]() { if constexpr (r == 4) gelu_frag(acc1, bp, 1, hh, hl); };      // (k-block 0, row group 2) was stage 0 of pair 4
             const unsigned char* grp = ring + ((6 * c + r) % RING) * PAIRB;
             if constexpr (r < 3) {
                 if (al1_lds != nullptr) {
@@ -501,7 +661,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                 run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                     const int t = 2 * (r - 3) + s, ng = t % 3;
                     mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
-                }, issue);
+                }, issue, mid);
             }
             if constexpr (r == 2) gelu_frag(acc1, bp, 0, hh, hl);
         });
@@ -509,31 +669,41 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
 }
 
 // ---- tail: K | V = LayerNorm_final(x) Wkv^T + bkv, head-split f32 [B][heads][128][32] (the storage type of precision bf16x3) ----
-template <int E>
-__device__ __forceinline__ void kv_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int wid, int m, int s) {
-    // pair m = 3 c + pp of the tail, stage s
+template <int E, int RING>
+__device__ __forceinline__ void kv_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int wid, int m, int s, int q = -1) {
+    // pair m = 3 c + pp of the tail (group m % RING, issued RING - 1 pairs ahead), stage s
     const int c = m / 3, pp = m - 3 * c;
-    unsigned char* dst = ring + (m & 1) * PAIRB + s * STAGE + wid * 4096;
-    issue_stage(wrsrc, sl.v64, (wkv_off + (unsigned)(c * 64 * E + (2 * pp + s) * 64)) * 4u, 4u * E, dst);
+    unsigned char* dst = ring + (m % RING) * PAIRB + s * STAGE + wid * 4096;
+    issue_stage(wrsrc, sl.template voff<0>(), (wkv_off + (unsigned)(c * 64 * E + (2 * pp + s) * 64)) * 4u, 4u * E, dst, q);
 }
-template <int E>
+template <int E, int RING>
+__device__ __forceinline__ void kv_prefetch(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int wid) {
+    static_for<0, RING - 1>([&](auto mc) {
+        kv_issue<E, RING>(sl, ring, wrsrc, wkv_off, wid, decltype(mc)::value, 0);
+        kv_issue<E, RING>(sl, ring, wrsrc, wkv_off, wid, decltype(mc)::value, 1);
+    });
+}
+template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void kv_phase(unsigned char* ring, const float* sbkv, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, const StreamLaneX& sl,
                                          int wid, int image, int heads, float* __restrict__ kmem, float* __restrict__ vmem,
                                          const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32]) {
-    constexpr int NC = 2 * E / 64;
+    constexpr int NC = 2 * E / 64, NP = 3 * NC, D = RING - 1;
     for (int c = 0; c < NC; ++c) {
         f32x4 acc1[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         static_for<0, 3>([&](auto pc) {
             constexpr int pp = decltype(pc)::value;
-            wait_vmcnt<0>();
-            pair_fence();
             const int m = 3 * c + pp;
-            run_pair(ring + (m & 1) * PAIRB, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+            static_for<0, D>([&](auto dc) {        // pairs behind this one still in flight: min(D - 1, NP - 1 - m)
+                constexpr int d = decltype(dc)::value;
+                if ((NP - 1 - m < D - 1 ? NP - 1 - m : D - 1) == d) x3_wait_vmcnt<8 * d>();
+            });
+            pair_fence();
+            run_pair<AHEAD>(ring + (m % RING) * PAIRB, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                 const int kb = 4 * pp + 2 * s + (i >> 2);
                 mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
-            }, [&](int s) { if (m + 1 < 3 * NC) kv_issue<E>(sl, ring, wrsrc, wkv_off, wid, m + 1, s); });
+            }, [&](int s, int q) { if (m + D < NP) kv_issue<E, RING>(sl, ring, wrsrc, wkv_off, wid, m + D, s, q); });
         });
         const int ln = opaque_lane();
         const int rr = ln & 15, g = ln >> 4;
@@ -570,7 +740,8 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
     unsigned char* img = smem + IMG_OFF;
-    float* sp = reinterpret_cast<float*>(smem + PARAM_OFF);
+    float* sph = reinterpret_cast<float*>(smem + HEADS_PARAM_OFF);      // head loop (and proj's bias)
+    float* sp = reinterpret_cast<float*>(smem + MLP_PARAM_OFF);        // MLP, tail
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -590,23 +761,23 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
         // ---- attention branch, head loop: parameters bqkv (3E) | bproj (E) | ln1 gamma (E) | ln1 beta (E)
         __syncthreads();
         heads_prefetch<E>(sl, ring, wrsrc, bp->wqkv, wid);
-        params_to_lds(sp, pbase + bp->bqkv, 3 * E, tid);
-        params_to_lds(sp + 3 * E, pbase + bp->bproj, E, tid);
-        params_to_lds(sp + 4 * E, pbase + bp->ln1_w, E, tid);
-        params_to_lds(sp + 5 * E, pbase + bp->ln1_b, E, tid);
+        params_to_lds(sph, pbase + bp->bqkv, 3 * E, tid);
+        params_to_lds(sph + 3 * E, pbase + bp->bproj, E, tid);
+        params_to_lds(sph + 4 * E, pbase + bp->ln1_w, E, tid);
+        params_to_lds(sph + 5 * E, pbase + bp->ln1_b, E, tid);
         __syncthreads();
 #ifdef X3_MARK
         asm volatile("; X3MARK LN1");
 #endif
-        ln_acc_to_frag<E>(acc, sp + 4 * E, sp + 5 * E, eps, g, ah, al);
+        ln_acc_to_frag<E>(acc, sph + 4 * E, sph + 5 * E, eps, g, ah, al);
 #ifdef X3_MARK
         asm volatile("; X3MARK PARK");
 #endif
-        park_acc<E>(acc, xbuf, tid);
+        if constexpr ((X3_ABLATE & 8) == 0) park_acc<E>(acc, xbuf, tid);
 #ifdef X3_MARK
         asm volatile("; X3MARK HEADS");
 #endif
-        heads_phase<E, X3_AHEAD>(ring, img, sp, wrsrc, bp->wqkv, 0.125f, sl, wid, tid, ah, al, obuf);
+        heads_phase<E, X3_AHEAD>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, wid, tid, ah, al, obuf);
         // ---- attention branch, proj: x and the O fragments come back (each lane re-reads what it wrote)
         __syncthreads();                                                // every wave is done with the K / V^T images and the ring
 #ifdef X3_MARK
@@ -617,7 +788,8 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
         // the 192 + 32 registers alive across the head loop, the very thing the round trip is for)
         const float* xback = xbuf; const float* oback = obuf;
         asm volatile("" : "+s"(xback), "+s"(oback) :: "memory");
-        unpark_acc<E>(acc, xback, tid);
+        if constexpr ((X3_ABLATE & 8) == 0) unpark_acc<E>(acc, xback, tid);
+        if constexpr ((X3_ABLATE & 8) == 0)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -630,7 +802,7 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
         asm volatile("; X3MARK PROJ");
 #endif
         proj_phase<E, X3_MLP_RING, X3_AHEAD>(ring, wrsrc, bp->wproj, sl, wid, ah, al, acc);
-        add_bias_to_acc<E>(sp + 3 * E, g, acc);
+        add_bias_to_acc<E>(sph + 3 * E, g, acc);
         // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
         __syncthreads();
 #ifdef X3_MARK
@@ -661,14 +833,13 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
     }
     // ---- tail: parameters bkv (2E) | final norm gamma (E) | beta (E)
     __syncthreads();
-    kv_issue<E>(sl, ring, wrsrc, tail.wkv, wid, 0, 0);
-    kv_issue<E>(sl, ring, wrsrc, tail.wkv, wid, 0, 1);
+    kv_prefetch<E, X3_MLP_RING>(sl, ring, wrsrc, tail.wkv, wid);
     params_to_lds(sp, pbase + tail.bkv, 2 * E, tid);
     params_to_lds(sp + 2 * E, pbase + tail.norm_w, E, tid);
     params_to_lds(sp + 3 * E, pbase + tail.norm_b, E, tid);
     __syncthreads();
     ln_acc_to_frag<E>(acc, sp + 2 * E, sp + 3 * E, eps, g, ah, al);
-    kv_phase<E>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, ah, al);
+    kv_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, ah, al);
 }
 
 template <int E>

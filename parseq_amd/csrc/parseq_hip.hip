@@ -356,7 +356,8 @@ struct parseq_plan {
     bool fused_attn = getenv("PARSEQ_NO_FUSED_ATTN") == nullptr;   // diagnostics: qkv panel GEMM + attention + proj GEMM instead of encoder_attn_fused.h
     bool mlp_resident = getenv("PARSEQ_MLP_RELOAD") == nullptr;    // diagnostics: the fused MLP's first form (x re-read by the epilogue)
     bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h
-    bool fused_x3 = getenv("PARSEQ_NO_FUSED_X3") == nullptr;          // diagnostics: bf16x3 encoder through the per-op kernels instead of encoder_blocks_x3.h
+    bool fused_x3 = getenv("PARSEQ_NO_FUSED_X3") == nullptr;
+         // diagnostics: bf16x3 encoder through the per-op kernels instead of encoder_blocks_x3.h
     EncBlockParams* blocks_dev = nullptr;                           // [enc_depth] parameter pointers of encoder_blocks.h (bf16 mode)
     std::vector<EncBlockParams> blocks_host;                        // source of the asynchronous upload (must outlive it)
     EncTailParams enc_tail{0, 0, 0, 0, nullptr, nullptr, 0};        // final norm + memory K / V projection inside the one-launch encoder (offsets; pointers filled per call)
@@ -1323,6 +1324,8 @@ extern "C" int parseq_forward(parseq_plan* p, const void* images, int images_dty
     if (refine_iters < 0) return fail(PARSEQ_E_INVALID, "refine_iters %d", refine_iters);
     hipStream_t s = (hipStream_t)stream;
     CHK(encode_dispatch(p, images, images_dtype, batch, nullptr, s));
+    // (A decoder stream of its own with hipStreamCreateWithPriority(greatest), forked and joined by events, was measured and removed:
+    // 121 -> 108 k img/s with two forwards in flight, 107 -> 58 k one at a time — profiles/r03_decoder_priority_stream_ab.md.)
     if (p->precision == PARSEQ_BF16) return forward_impl<bf16_t>(p, batch, flags, refine_iters, num_steps, logits_out, out_len, s);
     return forward_impl<float>(p, batch, flags, refine_iters, num_steps, logits_out, out_len, s);
 }

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Times builds of the bf16x3 one-launch encoder (parseq_amd/lib/x3v/*.so, tools/x3_variants.sh) against each other on one GPU:
+PARSeq-S shapes, batch 512, 12 blocks + tail, random weights; interleaved rounds, median and min per build; the first build
+is the reference for a max-abs difference of the K rows (ablation builds are wrong by construction: the column says by how much)."""
+import ctypes as C
+import glob
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from parseq_amd import _native as nat   # noqa: E402
+
+lib = nat.lib()
+DEV = 'cuda'
+E, F, depth, images = 384, 1536, 12, int(os.environ.get('X3_IMAGES', '512'))
+M = images * 128
+g = torch.Generator().manual_seed(0)
+shapes = [(E,), (E,), (3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (F, E), (F,), (E, F), (E,)]
+tens, offs, total = [], [], 0
+for l in range(depth):
+    for i, sh in enumerate(shapes):
+        t = torch.randn(*sh, generator=g)
+        if len(sh) == 2:
+            t = t / sh[1] ** 0.5
+        elif i in (0, 6):
+            t = 1 + 0.1 * t
+        else:
+            t = 0.1 * t
+        tens.append(t); offs.append(total); total += (t.numel() + 31) // 32 * 32
+tail = [1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g), torch.randn(2 * E, E, generator=g) / E ** 0.5, 0.1 * torch.randn(2 * E, generator=g)]
+for t in tail:
+    tens.append(t); offs.append(total); total += (t.numel() + 31) // 32 * 32
+master = torch.zeros(total)
+for t, o in zip(tens, offs):
+    master[o:o + t.numel()] = t.reshape(-1)
+md = master.to(DEV)
+pack = torch.empty(total, dtype=torch.float32, device=DEV)
+nat.check(lib.parseq_op_split_pack(nat.ptr(md), nat.ptr(pack), total, nat.stream_ptr()))
+o32 = (C.c_uint32 * (12 * depth))(*offs[:12 * depth]); t32 = (C.c_uint32 * 4)(*offs[12 * depth:])
+table = torch.empty(depth * 48, dtype=torch.uint8, device=DEV)
+scratch = torch.empty(images * 393216 // 4, dtype=torch.float32, device=DEV)
+x0 = torch.randn(M, E, generator=g).to(DEV)
+kmem = torch.empty(images, 12, 128, 32, device=DEV); vmem = torch.empty_like(kmem)
+names = sys.argv[1:] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
+libs = {}
+for n in names:
+    L = C.CDLL(os.path.join(ROOT, 'parseq_amd/lib/x3v', n + '.so'))
+    L.x3_variant_run.restype = C.c_int
+    L.x3_variant_run.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)] + [C.c_void_p] * 3
+    libs[n] = L
+
+
+def run(L):
+    x = x0.clone()
+    r = L.x3_variant_run(nat.ptr(x), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32, nat.ptr(kmem), nat.ptr(vmem), nat.stream_ptr())
+    assert r == 0, r
+
+
+times = {n: [] for n in names}
+ref = None
+diffs = {}
+for rnd in range(int(os.environ.get('X3_ROUNDS', '5'))):
+    for n in names:
+        run(libs[n]); torch.cuda.synchronize()
+        if rnd == 0:
+            if ref is None:
+                ref = kmem.clone()
+            diffs[n] = float((kmem - ref).abs().max())
+        x = x0.clone()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        L = libs[n]
+        r = L.x3_variant_run(nat.ptr(x), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32, nat.ptr(kmem), nat.ptr(vmem), nat.stream_ptr())
+        b.record(); torch.cuda.synchronize()
+        times[n].append(a.elapsed_time(b))
+print(f'| build | median ms | min ms | max|dK| vs {names[0]} |\n|---|---:|---:|---:|')
+for n in names:
+    t = sorted(times[n])
+    print(f'| {n} | {t[len(t) // 2]:.3f} | {t[0]:.3f} | {diffs[n]:.3e} |')
