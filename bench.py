@@ -140,10 +140,31 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
     return out, exact
 
 
+# PARSEQ_BENCH_STUB=1 — a test seam, never a measurement: the multi-rank plumbing of this file (spawn_ranks -> process group -> step /
+# timed / repeated -> all_gather_logits(uniform=True) -> ONE JSON line from rank 0) runs on CPU with the gloo backend and a stand-in
+# for the model that does no recognition work at all.  tests/test_parallel.py drives it at world size 2 (there is no multi-GPU box to
+# test the launcher on); the line it prints says "stub": true and its `value` means nothing.
+STUB = os.environ.get('PARSEQ_BENCH_STUB') == '1'
+
+
+class _StubModel(torch.nn.Module):
+    """Shape-only stand-in (PARSEQ_BENCH_STUB=1): [B, 3, H, W] -> [B, 26, 95] logits that depend on the input and nothing else."""
+
+    class _HP(dict):
+        __getattr__ = dict.__getitem__
+
+    def __init__(self):
+        super().__init__()
+        self.hparams = self._HP(img_size=(32, 128))
+
+    def forward(self, x, max_length=None, slot=0):
+        return x.float().mean(dim=(1, 2, 3))[:, None, None].expand(x.shape[0], 26, 95).contiguous()
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` from a plain shell: check the box, then re-exec under torch.distributed.run."""
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not STUB:
         raise SystemExit(f'bench.py --gpus {n}: this box exposes {have} GPU(s); refusing to measure fewer than asked')
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
@@ -183,23 +204,34 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit(f'rank {rank}: no GPU with index {local_rank} on this box ({torch.cuda.device_count()} visible)')
-    dev = torch.device('cuda', local_rank)
-    torch.cuda.set_device(dev)
+    if STUB:
+        dev = torch.device('cpu')
+        args.no_profile = args.no_cpu_baseline = args.no_parity = True
+        torch.cuda.synchronize = lambda *a, **k: None          # this process only: the timed-region code below runs unchanged
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f'rank {rank}: no GPU with index {local_rank} on this box ({torch.cuda.device_count()} visible)')
+        dev = torch.device('cuda', local_rank)
+        torch.cuda.set_device(dev)
     dist = None
     if world > 1 or args.force_dist:
         os.environ.setdefault('MASTER_PORT', '29533'); os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)       # 'nccl' is RCCL on ROCm
+        if STUB:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)       # 'nccl' is RCCL on ROCm
 
     from parseq_amd import create_model
     from parseq_amd.parallel import all_gather_logits
     torch.manual_seed(0)
-    model = create_model(args.model, decode_ar=True, refine_iters=args.refine_iters, precision=args.precision)
-    sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
-    model = model.eval().to(dev)
+    if STUB:
+        model, sd_cpu = _StubModel(), {}
+    else:
+        model = create_model(args.model, decode_ar=True, refine_iters=args.refine_iters, precision=args.precision)
+        sd_cpu = {k: v.detach().clone() for k, v in model.model.state_dict().items()}
+        model = model.eval().to(dev)
 
     def make_model(precision):
         m = create_model(args.model, decode_ar=True, refine_iters=args.refine_iters, precision=precision)
@@ -213,7 +245,9 @@ def main():
     images = images32.bfloat16() if args.precision == 'bf16' else images32
     max_length = None if args.natural_exit else 25
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1))]
+    import contextlib
+    streams = [None if STUB else torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1))]
+    on_stream = (lambda st: contextlib.nullcontext()) if STUB else torch.cuda.stream
     counter = [0]
 
     def step(mdl, x, in_flight):
@@ -225,7 +259,7 @@ def main():
             else:       # batch k runs on stream k % S with workspace k % S: its encoder overlaps batch k-1's AR decode
                 k = counter[0] % in_flight
                 counter[0] += 1
-                with torch.cuda.stream(streams[k]):
+                with on_stream(streams[k]):
                     logits = mdl(x, max_length, slot=k)
                     if dist is not None:
                         logits = all_gather_logits(logits, uniform=True, force=args.force_dist)      # fixed shapes: one collective, no host sync
@@ -275,7 +309,7 @@ def main():
         'metric': 'images/sec (32x128 crops) PARSeq-S AR+refine' if args.model == 'parseq' else f'images/sec ({ih}x{iw} crops) {args.model} AR+refine', 'value': round(value, 1), 'unit': 'images/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': args.precision, 'data': 'synthetic',
+        'dtype': args.precision, 'data': 'synthetic' if not STUB else 'stub (PARSEQ_BENCH_STUB=1: plumbing self-test on CPU, no recognition work, value is meaningless)',
         'sequential_value': round(world * B * args.steps / seq_elapsed, 1), 'sequential_ms_per_step': round(1e3 * seq_elapsed / args.steps, 4),
         'repeats': {'value': spread, 'sequential_value': seq_spread},
         'config': {'workload': f'{args.model} {args.precision}, {ih}x{iw} crops, {B} crops per step per GPU, AR decode '
@@ -288,8 +322,10 @@ def main():
                    'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-gather of logits' if world > 1 else ''),
                    'output_shape': list(out.shape), 'steps_in_flight': args.streams},
     }
+    if STUB:
+        result['stub'] = True
     gf = GFLOP_PER_IMG.get((args.model, args.refine_iters))
-    if gf:
+    if gf and not STUB:
         result['end_to_end_tflops'] = round(value * gf / 1e3, 2)
         result['end_to_end_frac_of_mfma_peak'] = round(value * gf / 1e3 / (PEAK[args.precision] * world), 4)
 
@@ -335,25 +371,17 @@ def main():
             par, exact = parity_block(args, model, make_model, images, max_length, oracle_logits)
             result['parity'] = par
             if args.precision != args.exact_precision:
-                # the mode that meets 1e-3: timed the same way at the same batch, fewer steps
-                ksteps = max(10, args.steps // 5)
-                for _ in range(3):
-                    step(exact, images32, args.streams)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(ksteps):
-                    step(exact, images32, args.streams)
-                torch.cuda.synchronize()
-                el = time.perf_counter() - t0
-                result['exact_value'] = round(B * ksteps / el, 1)
+                # the mode that meets 1e-3: timed exactly like `value` — the same batch, the same K steps per timed region, the median of
+                # (at most three) repeats, min / max alongside
+                xrep = min(3, args.repeats)
+                el, _, xspread = repeated(exact, images32, args.streams, args.steps, 3, xrep)
+                result['exact_value'] = round(B * args.steps / el, 1)
                 result['exact_precision'] = args.exact_precision
                 # one forward at a time in the exact precision as well
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(ksteps):
-                    step(exact, images32, 1)
-                torch.cuda.synchronize()
-                result['exact_sequential_value'] = round(B * ksteps / (time.perf_counter() - t0), 1)
+                el1, _, xspread1 = repeated(exact, images32, 1, args.steps, 1, xrep)
+                result['exact_sequential_value'] = round(B * args.steps / el1, 1)
+                result['repeats']['exact_value'] = xspread
+                result['repeats']['exact_sequential_value'] = xspread1
         except Exception as e:      # parity evidence must never take the throughput line down with it; say what happened
             result['parity'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:

@@ -334,6 +334,15 @@ int parseq_op_attn_fused(float* x, const float* gamma, const float* beta, const 
  * bias, W1 bf16 [1536, 384], b1 fp32 [1536], W2 bf16 [384, 1536], b2 fp32 [384].  table_ws: device scratch of depth * 48 bytes.
  * Test hook (the product path builds the table once per plan); uploads the table synchronously. */
 int parseq_op_enc_blocks(float* x, const void* const* block_ptrs, int depth, int M, void* table_ws, void* stream);
+/* The head and the tail of the one-launch encoder with no blocks in between (encoder_blocks.h patch_head / kv_phase; M a multiple of
+ * 128 = whole 32 x 128 crops of 8 x 16 patches).  images != NULL ([M / 128, 3, 32, 128], images_dtype PARSEQ_F32 / PARSEQ_BF16 /
+ * PARSEQ_U8): x = patches(images) Wpe^T + posb in the accumulators — timm PatchEmbed (4, 8) + bias + pos_embed, Wpe bf16 [384, 96] =
+ * the Conv2d weight flattened (k = 32 c + 8 ky + kx), posb fp32 [128, 384] = pos_embed + bias; otherwise x[M, 384] (fp32) is loaded.
+ * kmem != NULL: the launch ends with K | V = LayerNorm(x; norm_w, norm_b, eps 1e-6) Wkv^T + bkv (Wkv bf16 [768, 384], bkv fp32 [768];
+ * strhub/models/parseq/modules.py:33-34 on timm's final norm) written as bf16 [M / 128][12][128][32] into kmem / vmem; otherwise x is
+ * stored.  Test hook for the two phases the product path only runs inside parseq_forward. */
+int parseq_op_enc_head_tail(float* x, const void* images, int images_dtype, const void* wpe, const float* posb, const float* norm_w,
+                            const float* norm_b, const void* wkv, const float* bkv, void* kmem, void* vmem, int M, void* stream);
 /* `depth` encoder blocks in one launch in the bf16x3 arithmetic (encoder_blocks_x3.h), in place on x[M, 384] (fp32), M a multiple of 128.
  * master: ONE fp32 device buffer holding every parameter of the blocks, each tensor on a 32-element boundary; pack: its block-planar
  * hi | lo copy (parseq_op_split_pack over the whole buffer, master_elems * 4 bytes); offsets: HOST array of depth * 12 element offsets

@@ -97,6 +97,8 @@ SIGNATURES = {
     'parseq_op_mlp_variant': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'parseq_op_attn_fused': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'parseq_op_enc_blocks': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'parseq_op_enc_head_tail': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'parseq_op_enc_blocks_x3': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_op_encoder_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -97,14 +97,15 @@ void dec_self_attn_kernel(const float* __restrict__ stab, const T* __restrict__ 
     out[(size_t)w * E + t] = from_f32<T>(acc);
 }
 
-// Wave-per-row variant of dec_self_attn_kernel for bf16 storage and <= 16 heads: no LDS, no block barriers.
+// Wave-per-row variant of dec_self_attn_kernel for <= 16 heads: no LDS, no block barriers.
 // Lane l works for head h = l >> 2: it scores keys j = (l & 3) + 4 c (c < 8), the quad reduces max / sum over DPP, and the
 // same lane then mixes value columns d = 8 l .. 8 l + 7 (which belong to head l >> 2), probabilities quad-broadcast.
-template <int E>
+// T = bf16_t (bf16 mode) or float (bf16x3 mode: f32 tables and output, the same arithmetic as dec_self_attn_kernel<float>).
+template <int E, typename T = bf16_t>
 __global__ __launch_bounds__(256)
-void dec_self_attn_wave_kernel(const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, const int* __restrict__ tok,
+void dec_self_attn_wave_kernel(const float* __restrict__ stab, const T* __restrict__ kvtab, const int* __restrict__ tok,
                                int ldt, int ntok, int npos, const unsigned char* __restrict__ qmask, int ldq,
-                               const unsigned char* __restrict__ kpm, int ldk, int Lk, int i0, int Lq, bf16_t* __restrict__ out,
+                               const unsigned char* __restrict__ kpm, int ldk, int Lk, int i0, int Lq, T* __restrict__ out,
                                int rows) {
     constexpr int H = E / DEC_HD;
     static_assert(H <= 16 && DEC_HD == 32 && DEC_MAXL == 32, "lane mapping: <= 16 heads of 32, <= 32 keys");
@@ -146,17 +147,30 @@ void dec_self_attn_wave_kernel(const float* __restrict__ stab, const bf16_t* __r
             const int j = 4 * c + qq;
             if (j < Lk) {
                 const int tj = __builtin_amdgcn_readlane(tokv, j);
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+                if constexpr (sizeof(T) == 4) {
+                    const f32x4* vp = reinterpret_cast<const f32x4*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+                    const f32x4 v0 = vp[0], v1 = vp[1];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+                    for (int i = 0; i < 4; ++i) { acc[i] = fmaf(pq4[qq], v0[i], acc[i]); acc[4 + i] = fmaf(pq4[qq], v1[i], acc[4 + i]); }
+                } else {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+                }
             }
         }
     }
     if (live) {
-        bf16x8 o;
+        if constexpr (sizeof(T) == 4) {
+            f32x4* op = reinterpret_cast<f32x4*>(out + (size_t)w * E + d0);
+            op[0] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            op[1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        } else {
+            bf16x8 o;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
-        *reinterpret_cast<bf16x8*>(out + (size_t)w * E + d0) = o;
+            for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
+            *reinterpret_cast<bf16x8*>(out + (size_t)w * E + d0) = o;
+        }
     }
 }
 
@@ -483,6 +497,142 @@ void dec_cross_attn_multi_mfma_kernel(const float* __restrict__ qc, const bf16_t
                 const float o[4] = {acco[qt][dt][0], acco[qt][dt][1], acco[qt][dt][2], acco[qt][dt][3]};
                 store4<bf16_t>(out + ((size_t)b * Lq + qi) * E + h * DEC_HD + 16 * dt + 4 * g, o);
             }
+        }
+    }
+}
+
+// bf16x3 form of dec_cross_attn_multi_mfma_kernel: K, V and the output are f32 (the bf16x3 mode's storage); every MFMA operand
+// is a bf16 pair (hi, lo = value - hi) and every product three MFMAs (hi lo + lo hi + hi hi, fp32 accumulate) — K and V are split
+// as they are loaded, queries and probabilities exactly as in the bf16 kernel.  Two waves per workgroup (the V tile takes two
+// LDS planes per wave).  Replaces the VALU kernel dec_cross_attn_multi_kernel<float> for 128 memory tokens (250 -> ~60 us).
+__global__ __launch_bounds__(128)
+void dec_cross_attn_multi_mfma_x3_kernel(const float* __restrict__ qc, const float* __restrict__ kmem, const float* __restrict__ vmem,
+                                         int H, int Lq, float scale, float* __restrict__ out, int BH) {
+    constexpr int NK = 128, VP = DEC_HD + 2, WAVES = 2;
+    __shared__ __attribute__((aligned(16))) bf16_t sv[WAVES][2][NK * VP];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+    const int bh = blockIdx.x * WAVES + wid;
+    if (bh >= BH) return;
+    const int b = bh / H, h = bh - b * H, E = H * DEC_HD;
+    const float* kg = kmem + (size_t)bh * NK * DEC_HD;
+    const float* vg = vmem + (size_t)bh * NK * DEC_HD;
+    // V: 16-byte piece p = 64 c + lane of the [key][32] tile -> key = p >> 3, d = 4 (p & 7); all loads issued first
+    f32x4 vraw[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) vraw[c] = *reinterpret_cast<const f32x4*>(vg + (size_t)(64 * c + lane) * 4);
+    // K fragments: lane (key = 16 kt + r16, g) takes d = 8 g .. 8 g + 7
+    Frag<bf16_t> khi[8], klo[8];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(kg + (kt * 16 + r16) * DEC_HD + 8 * g);
+        const f32x4 x0 = src[0], x1 = src[1];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t h0 = from_f32<bf16_t>(x0[i]), h1 = from_f32<bf16_t>(x1[i]);
+            khi[kt].v[i] = h0; klo[kt].v[i] = from_f32<bf16_t>(x0[i] - to_f32(h0));
+            khi[kt].v[4 + i] = h1; klo[kt].v[4 + i] = from_f32<bf16_t>(x1[i] - to_f32(h1));
+        }
+    }
+    Frag<bf16_t> qhi[2], qlo[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = 16 * qt + r16;
+        float qv[8];
+        if (qi < Lq) {
+            const float4* src = reinterpret_cast<const float4*>(qc + ((size_t)b * Lq + qi) * E + h * DEC_HD + 8 * g);
+            const float4 x0 = src[0], x1 = src[1];
+            qv[0] = x0.x; qv[1] = x0.y; qv[2] = x0.z; qv[3] = x0.w; qv[4] = x1.x; qv[5] = x1.y; qv[6] = x1.z; qv[7] = x1.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float x = qv[i] * scale;
+            const bf16_t hi = from_f32<bf16_t>(x);
+            qhi[qt].v[i] = hi;
+            qlo[qt].v[i] = from_f32<bf16_t>(x - to_f32(hi));
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int key = 8 * c + (lane >> 3), d = 4 * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16_t hi = from_f32<bf16_t>(vraw[c][i]);
+            sv[wid][0][key * VP + d + i] = hi;
+            sv[wid][1][key * VP + d + i] = from_f32<bf16_t>(vraw[c][i] - to_f32(hi));
+        }
+    }
+    f32x4 accs[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) {
+            accs[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(accs[qt][kt], khi[kt], qlo[qt]);
+            mma16(accs[qt][kt], klo[kt], qhi[qt]);
+            mma16(accs[qt][kt], khi[kt], qhi[qt]);
+        }
+    Frag<bf16_t> phi[2][4], plo[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, accs[qt][kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = expf(accs[qt][kt][r] - mx); accs[qt][kt][r] = e; sum += e; }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const float pv = accs[qt][2 * kk + (sl >> 2)][sl & 3] * inv;
+                const bf16_t hi = from_f32<bf16_t>(pv);
+                phi[qt][kk].v[sl] = hi;
+                plo[qt][kk].v[sl] = from_f32<bf16_t>(pv - to_f32(hi));
+            }
+    }
+    __builtin_amdgcn_wave_barrier();                    // this wave's V planes are in LDS (wave-private region)
+    f32x4 acco[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) acco[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            Frag<bf16_t> vh, vl;
+#pragma unroll
+            for (int sl = 0; sl < 8; ++sl) {
+                const int at = (32 * kk + 16 * (sl >> 2) + 4 * g + (sl & 3)) * VP + 16 * dt + r16;
+                vh.v[sl] = sv[wid][0][at];
+                vl.v[sl] = sv[wid][1][at];
+            }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                mma16(acco[qt][dt], vh, plo[qt][kk]);
+                mma16(acco[qt][dt], vl, phi[qt][kk]);
+                mma16(acco[qt][dt], vh, phi[qt][kk]);
+            }
+        }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qi = 16 * qt + r16;
+        if (qi < Lq) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                *reinterpret_cast<f32x4*>(out + ((size_t)b * Lq + qi) * E + h * DEC_HD + 16 * dt + 4 * g) = acco[qt][dt];
         }
     }
 }

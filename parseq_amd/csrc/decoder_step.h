@@ -55,6 +55,28 @@ void frag_pack_kernel(const bf16_t* __restrict__ W, int N, int K, int ldw, bf16_
 }
 constexpr size_t frag_pack_elems(int N, int K) { return (size_t)((N + 15) / 16) * 16 * K; }
 
+// bf16x3 arithmetic: the same fragment order with every 1-KB unit followed by its residual plane,
+//   Wp[tile][kp][half][plane][lane][8],  plane 0 = bf16(W), plane 1 = bf16(W - plane 0)
+// (2 x frag_pack_elems bf16 elements), packed from the fp32 master.  A product is three MFMAs: W_hi A_lo + W_hi A_hi on the
+// hi unit, W_lo A_hi on the lo unit that follows it in the stream; the activations are split where they are parked in LDS.
+__global__ __launch_bounds__(256)
+void frag_pack_x3_kernel(const float* __restrict__ W, int N, int K, int ldw, bf16_t* __restrict__ out, int tiles) {
+    const int KP = K / 64;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece per thread
+    if (idx >= (size_t)tiles * KP * 4 * 64) return;
+    const int lane = (int)(idx & 63), plane = (int)((idx >> 6) & 1), half = (int)((idx >> 7) & 1);
+    const int kp = (int)((idx >> 8) % KP), tile = (int)((idx >> 8) / KP);
+    const int n = tile * 16 + (lane & 15), k = 64 * kp + 16 * (lane >> 4) + 8 * half;
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float f = n < N ? W[(size_t)n * ldw + k + i] : 0.f;
+        const bf16_t hi = static_cast<bf16_t>(f);
+        o[i] = plane ? static_cast<bf16_t>(f - static_cast<float>(hi)) : hi;
+    }
+    *reinterpret_cast<bf16x8*>(out + idx * 8) = o;
+}
+
 // acc[t] += Wp[tile (w + DS_NW t)] (16 x K)  x  A^T (K x 16 rows).  Result layout: lane (m = lane & 15, g = lane >> 4)
 // holds columns n = 16 tile + 4 g + r (r = 0..3) of row m.  Tiles past `tiles` recompute the last tile (discarded).
 // Unit u = ((kp * TN) + t) * 2 + half is one 1-KB fragment; unit u lives in the wave's ring slot u % DS_RING.
@@ -63,37 +85,39 @@ constexpr size_t frag_pack_elems(int N, int K) { return (size_t)((N + 15) / 16) 
 // the block barrier and the LayerNorm that separate two GEMMs.  ds_wave_gemm<..., true> then skips its own prologue.
 // kp0 / tile_kp: multiply against the k-slice [64 kp0, 64 kp0 + K) of a matrix packed with tile_kp k-chunks per tile
 // (0 = the whole matrix, K / 64 chunks per tile).
-template <int K, int TN>
+// PL = planes per fragment: 1 (bf16 weights) or 2 (bf16x3: hi unit, lo unit); unit u = (((kp * TN) + t) * 2 + half) * PL + plane.
+template <int K, int TN, int PL = 1>
 __device__ __forceinline__ void ds_prefetch(const bf16_t* __restrict__ Wp, int tiles, int wave, unsigned char* wring, int kp0 = 0, int tile_kp = 0) {
     const int lane = threadIdx.x & 63;
-    constexpr int KP = K / 64, U = KP * TN * 2, PRE = U < DS_RING ? U : DS_RING;
+    constexpr int KP = K / 64, U = KP * TN * 2 * PL, PRE = U < DS_RING ? U : DS_RING;
     if (tile_kp == 0) tile_kp = KP;
     static_for<0, PRE>([&](auto uc) {
-        constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
+        constexpr int u = decltype(uc)::value, kp = u / (2 * PL * TN), t = (u / (2 * PL)) % TN, half = (u / PL) & 1, plane = u % PL;
         int tile = wave + DS_NW * t;
         tile = tile < tiles ? tile : tiles - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (size_t)tile * tile_kp * 1024 + lane * 8 + ((kp0 + kp) * 2 + half) * 512),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wp + (size_t)tile * tile_kp * (1024 * PL) + lane * 8 + (((kp0 + kp) * 2 + half) * PL + plane) * 512),
                                          (__attribute__((address_space(3))) void*)(wring + (u % DS_RING) * 1024), 16, 0, 0);
     });
 }
 
-template <int K, int TN, bool PREFETCHED = false>
+// PL == 2 (bf16x3): a_lds is the hi plane of the activations, a_lds + a_lo the lo plane (same pitch).
+template <int K, int TN, bool PREFETCHED = false, int PL = 1>
 __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const bf16_t* __restrict__ Wp, int tiles,
-                                             int wave, unsigned char* wring, f32x4 (&acc)[TN], int kp0 = 0, int tile_kp = 0) {
+                                             int wave, unsigned char* wring, f32x4 (&acc)[TN], int kp0 = 0, int tile_kp = 0, int a_lo = 0) {
     const int lane = threadIdx.x & 63, r16 = lane & 15, g = lane >> 4;
-    constexpr int KP = K / 64, U = KP * TN * 2, PRE = U < DS_RING ? U : DS_RING;
+    constexpr int KP = K / 64, U = KP * TN * 2 * PL, PRE = U < DS_RING ? U : DS_RING;
     if (tile_kp == 0) tile_kp = KP;
     const bf16_t* wp[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
         int tile = wave + DS_NW * t;
         tile = tile < tiles ? tile : tiles - 1;
-        wp[t] = Wp + (size_t)tile * tile_kp * 1024 + (size_t)kp0 * 1024 + lane * 8;
+        wp[t] = Wp + (size_t)tile * tile_kp * (1024 * PL) + (size_t)kp0 * (1024 * PL) + lane * 8;
     }
     const bf16_t* ap = a_lds + r16 * lda + 16 * g;
     auto issue = [&](auto uc) {
-        constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[t] + (kp * 2 + half) * 512),
+        constexpr int u = decltype(uc)::value, kp = u / (2 * PL * TN), t = (u / (2 * PL)) % TN, half = (u / PL) & 1, plane = u % PL;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wp[t] + ((kp * 2 + half) * PL + plane) * 512),
                                          (__attribute__((address_space(3))) void*)(wring + (u % DS_RING) * 1024), 16, 0, 0);
     };
     // Software pipeline per wave: unit u + DS_RING is copied global -> LDS while unit u + DS_LA is read LDS -> registers
@@ -107,16 +131,21 @@ __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const
     };
     if constexpr (!PREFETCHED) static_for<0, PRE>(issue);
     static_for<0, (DS_LA < U ? DS_LA : U)>([&](auto vc) { fetch(vc, std::integral_constant<int, PRE>{}); });
-    Frag<bf16_t> a0, a1;
+    Frag<bf16_t> a0, a1, a0l, a1l;
     static_for<0, U>([&](auto uc) {
-        constexpr int u = decltype(uc)::value, kp = u / (2 * TN), t = (u / 2) % TN, half = u & 1;
-        if constexpr (t == 0 && half == 0) {
+        constexpr int u = decltype(uc)::value, kp = u / (2 * PL * TN), t = (u / (2 * PL)) % TN, half = (u / PL) & 1, plane = u % PL;
+        if constexpr (t == 0 && half == 0 && plane == 0) {
             a0.v = *reinterpret_cast<const bf16x8*>(ap + 64 * kp);
             a1.v = *reinterpret_cast<const bf16x8*>(ap + 64 * kp + 8);
+            if constexpr (PL == 2) {
+                a0l.v = *reinterpret_cast<const bf16x8*>(ap + a_lo + 64 * kp);
+                a1l.v = *reinterpret_cast<const bf16x8*>(ap + a_lo + 64 * kp + 8);
+            }
         }
         constexpr int issued = (u + DS_RING < U) ? u + DS_RING : U;
         if constexpr (u + DS_LA < U) fetch(std::integral_constant<int, u + DS_LA>{}, std::integral_constant<int, issued>{});
-        mma16(acc[t], wbuf[u % (DS_LA + 1)], half ? a1 : a0);
+        if constexpr (PL == 2 && plane == 0) mma16(acc[t], wbuf[u % (DS_LA + 1)], half ? a1l : a0l);      // W_hi A_lo (small term first)
+        mma16(acc[t], wbuf[u % (DS_LA + 1)], half ? a1 : a0);                                            // W_hi A_hi, or W_lo A_hi on a lo unit
         // slot u % DS_RING is free once unit u's fragment has been consumed by the MFMA above (order pinned below)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (u + DS_RING < U) issue(std::integral_constant<int, u + DS_RING>{});
@@ -124,9 +153,10 @@ __device__ __forceinline__ void ds_wave_gemm(const bf16_t* a_lds, int lda, const
 }
 
 // LayerNorm of rows 2w, 2w + 1 of the fp32 residual tile (pitch PT) into the bf16 A buffer (pitch PA).
-template <int E>
+// X3: the row is written as a bf16 pair, hi plane at abuf, lo plane (value - hi) at abuf + a_lo.
+template <int E, bool X3 = false>
 __device__ __forceinline__ void ds_layernorm_rows(const float* tl, int PT, bf16_t* abuf, int PA, const float* __restrict__ gw,
-                                                  const float* __restrict__ gb, float eps, int wave) {
+                                                  const float* __restrict__ gb, float eps, int wave, int a_lo = 0) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
@@ -138,11 +168,15 @@ __device__ __forceinline__ void ds_layernorm_rows(const float* tl, int PT, bf16_
         float ss = 0.f;
 #pragma unroll
         for (int i = 0; i < E / 64; ++i) { const float d = v[i] - mean; ss += d * d; }
-        const float rstd = __builtin_amdgcn_rsqf(wave_sum(ss) * (1.0f / E) + eps);
+        const float var = wave_sum(ss) * (1.0f / E) + eps;
+        const float rstd = X3 ? 1.0f / sqrtf(var) : __builtin_amdgcn_rsqf(var);
 #pragma unroll
         for (int i = 0; i < E / 64; ++i) {
             const int c = lane + 64 * i;
-            abuf[row * PA + c] = from_f32<bf16_t>((v[i] - mean) * rstd * gw[c] + gb[c]);
+            const float y = (v[i] - mean) * rstd * gw[c] + gb[c];
+            const bf16_t hi = from_f32<bf16_t>(y);
+            abuf[row * PA + c] = hi;
+            if constexpr (X3) abuf[a_lo + row * PA + c] = from_f32<bf16_t>(y - to_f32(hi));
         }
     }
 }
@@ -151,9 +185,10 @@ __device__ __forceinline__ void ds_layernorm_rows(const float* tl, int PT, bf16_
 // h = l >> 2: it scores keys j = (l & 3) + 4 c, the quad reduces max / sum over DPP, and the same lane then mixes value
 // columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.  tokv: lane j holds token j
 // of the row's context (j < Lk).  Result: bf16 row of E values at `arow` (LDS).
-template <int E>
-__device__ __forceinline__ void ds_self_attn_row(const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, int tokv, int ntok,
-                                                 int npos, int Lk, int pos, bf16_t* arow) {
+// X3: the K | V table is f32 and the result row is written as a bf16 pair (hi at arow, lo at arow + a_lo).
+template <int E, bool X3 = false>
+__device__ __forceinline__ void ds_self_attn_row(const float* __restrict__ stab, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ kvtab,
+                                                 int tokv, int ntok, int npos, int Lk, int pos, bf16_t* arow, int a_lo = 0) {
     static_assert(DEC_HD == 32 && DEC_MAXL == 32, "lane mapping assumes 32-wide heads and <= 32 keys");
     constexpr int H = E / DEC_HD;
     const int lane = threadIdx.x & 63;
@@ -189,17 +224,25 @@ __device__ __forceinline__ void ds_self_attn_row(const float* __restrict__ stab,
             const int j = 4 * c + qq;
             if (j < Lk) {
                 const int tj = __builtin_amdgcn_readlane(tokv, j);
-                const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+                if constexpr (X3) {
+                    const f32x4* vp = reinterpret_cast<const f32x4*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+                    const f32x4 v0 = vp[0], v1 = vp[1];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+                    for (int i = 0; i < 4; ++i) { acc[i] = fmaf(pq4[qq], v0[i], acc[i]); acc[4 + i] = fmaf(pq4[qq], v1[i], acc[4 + i]); }
+                } else {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+                }
             }
         }
     }
     if (live) {
-        bf16x8 o;
+        bf16x8 o, ol;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = from_f32<bf16_t>(acc[i]);
+        for (int i = 0; i < 8; ++i) { o[i] = from_f32<bf16_t>(acc[i]); ol[i] = from_f32<bf16_t>(acc[i] - to_f32(o[i])); }
         *reinterpret_cast<bf16x8*>(arow + d0) = o;
+        if constexpr (X3) *reinterpret_cast<bf16x8*>(arow + a_lo + d0) = ol;
     }
 }
 
@@ -429,14 +472,19 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
 // =====================================================================================================================
 template <int E> constexpr int ds_split() { return E >= 384 ? 4 : 2; }   // workgroups per row tile in dec_step_mlp_kernel
 
-template <int E> constexpr size_t dec_step_mid_lds() { return (size_t)DS_ROWS * ((E + 8) * 2 + (E + 4) * 4 + 128 * 4) + (size_t)DS_NW * DS_RING * 1024; }
-template <int E> constexpr size_t dec_step_mlp_lds() {
-    return (size_t)DS_ROWS * ((E + 8) * 2 + (4 * E / ds_split<E>() + 8) * 2 + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
+// X3 (bf16x3 arithmetic): every bf16 activation buffer is a hi plane followed by a lo plane
+template <int E, bool X3 = false> constexpr size_t dec_step_mid_lds() {
+    return (size_t)DS_ROWS * ((E + 8) * 2 * (X3 ? 2 : 1) + (E + 4) * 4 + 128 * 4) + (size_t)DS_NW * DS_RING * 1024;
+}
+template <int E, bool X3 = false> constexpr size_t dec_step_mlp_lds() {
+    return (size_t)DS_ROWS * (((E + 8) * 2 + (4 * E / ds_split<E>() + 8) * 2) * (X3 ? 2 : 1) + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
 }
 
 // tq: fp32 [M][E], t' of the step being finished (written by dec_step_mlp_kernel split 0); partial: fp32 [DS_SPLIT][M][E].
 // pos: the step being started (its query position); the step being finished is pos - 1.  Lk = pos + 1 context tokens.
-template <int E>
+// X3: bf16x3 arithmetic — Wh / Wo / Wq are frag_pack_x3_kernel packs, kvtab is f32, every MFMA operand a bf16 pair; the
+// element-wise parts (table soft-max, LayerNorm, residuals, pick) are the same fp32 code.
+template <int E, bool X3 = false>
 __global__ __launch_bounds__(64 * DS_NW)
 void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                          // finish
@@ -445,15 +493,16 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                          const float* __restrict__ bh, int C, float* __restrict__ logits, int Ltot, int argmax_mode, int eos_id,
                          unsigned char* __restrict__ eos_seen, int* __restrict__ eos_rows, int* __restrict__ ar_len,
                          // start
-                         const float* __restrict__ stab, const bf16_t* __restrict__ kvtab, int* __restrict__ tok, int ldt, int ntok,
+                         const float* __restrict__ stab, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ kvtab, int* __restrict__ tok, int ldt, int ntok,
                          int npos, const bf16_t* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ pos_queries,
                          const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16_t* __restrict__ Wq,
                          const float* __restrict__ bq, float* __restrict__ t_out, float* __restrict__ qc_out) {
     constexpr int PA = E + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW, PL = 128, RPW = DS_ROWS / DS_NW;
     constexpr int DS_SPLIT = ds_split<E>();
+    constexpr int NPL = X3 ? 2 : 1, ALO = DS_ROWS * PA;                 // planes per operand; element offset of the lo plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
-    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
-    float* tl = reinterpret_cast<float*>(abuf + DS_ROWS * PA);         // [DS_ROWS][PT]
+    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [NPL][DS_ROWS][PA]
+    float* tl = reinterpret_cast<float*>(abuf + NPL * DS_ROWS * PA);    // [DS_ROWS][PT]
     float* lg = tl + DS_ROWS * PT;                                     // [DS_ROWS][PL]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     unsigned char* wring = reinterpret_cast<unsigned char*>(lg + DS_ROWS * PL) + wave * DS_RING * 1024;
@@ -475,14 +524,14 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             for (int sp = 0; sp < DS_SPLIT; ++sp) v += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * M * E + gr);
             *reinterpret_cast<f32x4*>(tl + row * PT + c) = v;
         }
-        ds_prefetch<E, 1>(Wh, (C + 15) / 16, wave, wring);
+        ds_prefetch<E, 1, NPL>(Wh, (C + 15) / 16, wave, wring);
         __syncthreads();
-        ds_layernorm_rows<E>(tl, PT, abuf, PA, lnf_w, lnf_b, eps, wave);
+        ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, lnf_w, lnf_b, eps, wave, ALO);
         __syncthreads();
         {
             f32x4 acc[1] = {};
-            ds_wave_gemm<E, 1, true>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc);
-            if (do_start) ds_prefetch<E, TN>(Wo, TILES, wave, wring);
+            ds_wave_gemm<E, 1, true, NPL>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc, 0, 0, ALO);
+            if (do_start) ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
             const int n = wave * 16 + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -522,7 +571,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             }
         }
     } else if (do_start) {
-        ds_prefetch<E, TN>(Wo, TILES, wave, wring);
+        ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
     }
     if (!do_start) return;
 
@@ -534,14 +583,14 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
         const int b = min(row0 + row, M - 1);
         int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
         if (picked[rr] >= 0 && lane == pos) tokv = picked[rr];
-        ds_self_attn_row<E>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + row * PA);
+        ds_self_attn_row<E, X3>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + row * PA, ALO);
     }
     __syncthreads();
     {   // t = pos_queries[pos] + sa @ Wo^T + bo
         const float* posq = pos_queries + (size_t)pos * E;
         f32x4 acc[TN] = {};
-        ds_wave_gemm<E, TN, true>(abuf, PA, Wo, TILES, wave, wring, acc);
-        ds_prefetch<E, TN>(Wq, TILES, wave, wring);
+        ds_wave_gemm<E, TN, true, NPL>(abuf, PA, Wo, TILES, wave, wring, acc, 0, 0, ALO);
+        ds_prefetch<E, TN, NPL>(Wq, TILES, wave, wring);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -556,11 +605,11 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
         }
     }
     __syncthreads();
-    ds_layernorm_rows<E>(tl, PT, abuf, PA, ln1_w, ln1_b, eps, wave);
+    ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, ln1_w, ln1_b, eps, wave, ALO);
     __syncthreads();
     {   // qc = norm1(t) @ Wq^T + bq
         f32x4 acc[TN] = {};
-        ds_wave_gemm<E, TN, true>(abuf, PA, Wq, TILES, wave, wring, acc);
+        ds_wave_gemm<E, TN, true, NPL>(abuf, PA, Wq, TILES, wave, wring, acc, 0, 0, ALO);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -576,9 +625,11 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
 
 // grid: row tiles x DS_SPLIT.  ca bf16 [M][E]; t_in fp32 [M][E] (from the mid kernel); tq_out fp32 [M][E] receives
 // t' = t + ca @ Wco^T + bco (split 0 only); partial fp32 [DS_SPLIT][M][E] receives this split's share of h @ W2^T.
-template <int E>
+// X3: ca is f32 (the f32 cross-attention kernel's output), split into a bf16 pair as it is staged; GELU is the fp32 mode's
+// erf form; Wco / W1 / W2 are frag_pack_x3_kernel packs.
+template <int E, bool X3 = false>
 __global__ __launch_bounds__(64 * DS_NW)
-void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict__ t_in, const bf16_t* __restrict__ Wco,
+void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::type* __restrict__ ca, const float* __restrict__ t_in, const bf16_t* __restrict__ Wco,
                          const float* __restrict__ bco, const float* __restrict__ ln2_w, const float* __restrict__ ln2_b, float eps,
                          const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
                          float* __restrict__ tq_out, float* __restrict__ partial, int M) {
@@ -586,10 +637,11 @@ void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict_
     constexpr int F = 4 * E, FS = F / DS_SPLIT, PA = E + 8, PH = FS + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW;
     constexpr int TN1 = FS / 16 / DS_NW;                      // linear1: column tiles per wave in this split
     static_assert(FS % (16 * DS_NW) == 0 && FS % 64 == 0, "hidden width must split evenly over the workgroups and waves");
+    constexpr int PL = X3 ? 2 : 1, ALO = DS_ROWS * PA, HLO = DS_ROWS * PH;   // planes per operand; element offsets of the lo planes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
-    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [DS_ROWS][PA]
-    bf16_t* hbuf = abuf + DS_ROWS * PA;                                // [DS_ROWS][PH]
-    float* tl = reinterpret_cast<float*>(hbuf + DS_ROWS * PH);         // [DS_ROWS][PT]
+    bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [PL][DS_ROWS][PA]
+    bf16_t* hbuf = abuf + PL * DS_ROWS * PA;                           // [PL][DS_ROWS][PH]
+    float* tl = reinterpret_cast<float*>(hbuf + PL * DS_ROWS * PH);    // [DS_ROWS][PT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
     unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
     const int rt = blockIdx.x / DS_SPLIT, sp = blockIdx.x - rt * DS_SPLIT;
@@ -598,19 +650,32 @@ void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict_
     for (int i = threadIdx.x; i < DS_ROWS * (E / 8); i += 64 * DS_NW) {
         const int row = i / (E / 8), c = (i - row * (E / 8)) * 8;
         const int gr = min(row0 + row, M - 1);
-        *reinterpret_cast<bf16x8*>(abuf + row * PA + c) = *reinterpret_cast<const bf16x8*>(ca + (size_t)gr * E + c);
+        if constexpr (X3) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(ca + (size_t)gr * E + c);
+            const f32x4 v0 = src[0], v1 = src[1];
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                hi[j] = from_f32<bf16_t>(v0[j]); lo[j] = from_f32<bf16_t>(v0[j] - to_f32(hi[j]));
+                hi[4 + j] = from_f32<bf16_t>(v1[j]); lo[4 + j] = from_f32<bf16_t>(v1[j] - to_f32(hi[4 + j]));
+            }
+            *reinterpret_cast<bf16x8*>(abuf + row * PA + c) = hi;
+            *reinterpret_cast<bf16x8*>(abuf + ALO + row * PA + c) = lo;
+        } else {
+            *reinterpret_cast<bf16x8*>(abuf + row * PA + c) = *reinterpret_cast<const bf16x8*>(ca + (size_t)gr * E + c);
+        }
     }
     for (int i = threadIdx.x; i < DS_ROWS * (E / 4); i += 64 * DS_NW) {
         const int row = i / (E / 4), c = (i - row * (E / 4)) * 4;
         const int gr = min(row0 + row, M - 1);
         *reinterpret_cast<f32x4*>(tl + row * PT + c) = *reinterpret_cast<const f32x4*>(t_in + (size_t)gr * E + c);
     }
-    ds_prefetch<E, TN>(Wco, TILES, wave, wring);           // after the activation loads (in-order return, see the mid kernel)
+    ds_prefetch<E, TN, PL>(Wco, TILES, wave, wring);           // after the activation loads (in-order return, see the mid kernel)
     __syncthreads();
     {   // t' = t + ca @ Wco^T + bco   (every split needs it for norm2; split 0 publishes it)
         f32x4 acc[TN] = {};
-        ds_wave_gemm<E, TN, true>(abuf, PA, Wco, TILES, wave, wring, acc);
-        ds_prefetch<E, TN1>(W1 + (size_t)sp * (FS / 16) * (E / 64) * 1024, FS / 16, wave, wring);
+        ds_wave_gemm<E, TN, true, PL>(abuf, PA, Wco, TILES, wave, wring, acc, 0, 0, ALO);
+        ds_prefetch<E, TN1, PL>(W1 + (size_t)sp * (FS / 16) * (E / 64) * (1024 * PL), FS / 16, wave, wring);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int tile = wave + DS_NW * t;
@@ -626,24 +691,33 @@ void dec_step_mlp_kernel(const bf16_t* __restrict__ ca, const float* __restrict_
         }
     }
     __syncthreads();
-    ds_layernorm_rows<E>(tl, PT, abuf, PA, ln2_w, ln2_b, eps, wave);
+    ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, ln2_w, ln2_b, eps, wave, ALO);
     __syncthreads();
     {   // h[:, split] = gelu(norm2(t') @ W1[split]^T + b1[split])
         f32x4 acc[TN1] = {};
-        ds_wave_gemm<E, TN1, true>(abuf, PA, W1 + (size_t)sp * (FS / 16) * (E / 64) * 1024, FS / 16, wave, wring, acc);
-        ds_prefetch<FS, TN>(W2, TILES, wave, wring, sp * (FS / 64), F / 64);
+        ds_wave_gemm<E, TN1, true, PL>(abuf, PA, W1 + (size_t)sp * (FS / 16) * (E / 64) * (1024 * PL), FS / 16, wave, wring, acc, 0, 0, ALO);
+        ds_prefetch<FS, TN, PL>(W2, TILES, wave, wring, sp * (FS / 64), F / 64);
 #pragma unroll
         for (int t = 0; t < TN1; ++t) {
             const int n = (wave + DS_NW * t) * 16 + 4 * g;
             const float4 bv = *reinterpret_cast<const float4*>(b1 + sp * FS + n);
-            const float o[4] = {gelu_poly(acc[t][0] + bv.x), gelu_poly(acc[t][1] + bv.y), gelu_poly(acc[t][2] + bv.z), gelu_poly(acc[t][3] + bv.w)};
-            store4<bf16_t>(hbuf + r16 * PH + n, o);
+            if constexpr (X3) {
+                const float o[4] = {gelu_erf(acc[t][0] + bv.x), gelu_erf(acc[t][1] + bv.y), gelu_erf(acc[t][2] + bv.z), gelu_erf(acc[t][3] + bv.w)};
+                float ol[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ol[j] = o[j] - to_f32(from_f32<bf16_t>(o[j]));
+                store4<bf16_t>(hbuf + r16 * PH + n, o);
+                store4<bf16_t>(hbuf + HLO + r16 * PH + n, ol);
+            } else {
+                const float o[4] = {gelu_poly(acc[t][0] + bv.x), gelu_poly(acc[t][1] + bv.y), gelu_poly(acc[t][2] + bv.z), gelu_poly(acc[t][3] + bv.w)};
+                store4<bf16_t>(hbuf + r16 * PH + n, o);
+            }
         }
     }
     __syncthreads();
     {   // partial[split] = h[:, split] @ W2[:, split]^T
         f32x4 acc[TN] = {};
-        ds_wave_gemm<FS, TN, true>(hbuf, PH, W2, TILES, wave, wring, acc, sp * (FS / 64), F / 64);
+        ds_wave_gemm<FS, TN, true, PL>(hbuf, PH, W2, TILES, wave, wring, acc, sp * (FS / 64), F / 64, HLO);
         float* dst = partial + (size_t)sp * M * E;
 #pragma unroll
         for (int t = 0; t < TN; ++t) {

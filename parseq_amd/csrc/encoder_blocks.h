@@ -578,6 +578,10 @@ struct EncHeadParams {
     const float* posb;
 };
 constexpr int EB_IMG_F32 = 0, EB_IMG_BF16 = 1, EB_IMG_U8 = 2;      // = PARSEQ_F32 / PARSEQ_BF16 / PARSEQ_U8
+// StreamLane::issue_v forms the scalar offset of a stage's third piece as origin + 4 * (row pitch in bytes) - 2048: with the head's
+// 192-byte rows the weight must start at least 2048 - 768 bytes = 640 elements into the buffer the descriptor covers, or that offset
+// wraps below zero and the piece reads as zeros.  (The E- and 4E-pitch streams of the blocks have 4 * pitch >= 3072 bytes: no condition.)
+constexpr unsigned EB_HEAD_MIN_WPE = 640;
 
 template <int E>
 __device__ __forceinline__ void patch_head(const EncHeadParams& hp, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, int wid, int lane, int image,

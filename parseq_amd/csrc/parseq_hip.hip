@@ -599,6 +599,21 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
             hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<unsigned char*>(p->wpack), n);
             HIPCHK(hipGetLastError());
             CHK(build_block_table(p, s));      // the one-launch encoder of this precision (encoder_blocks_x3.h)
+            if (p->wstep[0]) {       // decoder weights as hi | lo fragment pairs for the fused AR step, from the fp32 master
+                const int E = m->cfg.embed_dim, Fd = E * m->cfg.dec_mlp_ratio;
+                const std::string d = "decoder.layers.0.";
+                struct { const float* w; int N, K; } src[6] = {
+                    {m->p(d + "self_attn.out_proj.weight"), E, E}, {m->p(d + "cross_attn.in_proj_weight"), E, E},
+                    {m->p(d + "cross_attn.out_proj.weight"), E, E}, {m->p(d + "linear1.weight"), Fd, E},
+                    {m->p(d + "linear2.weight"), E, Fd}, {m->p("head.weight"), m->classes, E}};
+                for (int i = 0; i < 6; ++i) {
+                    const int tiles = (src[i].N + 15) / 16;
+                    const size_t pieces = (size_t)tiles * (src[i].K / 64) * 256;
+                    hipLaunchKernelGGL(frag_pack_x3_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, s, src[i].w, src[i].N, src[i].K,
+                                       src[i].K, p->wstep[i], tiles);
+                    HIPCHK(hipGetLastError());
+                }
+            }
         }
         SplitScope ss(p->precision == PARSEQ_BF16X3);
         if (!m->vitstr) CHK(build_tables<float>(p, s));
@@ -624,11 +639,13 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, m->device) == hipSuccess && prop.multiProcessorCount > 0) p->num_cus = prop.multiProcessorCount; }
     size_t off = 0;
     const size_t o_wpack = carve(off, precision == PARSEQ_BF16 ? m->master_elems * 2 : (precision == PARSEQ_BF16X3 ? m->master_elems * 4 : 0));
-    const bool step_ok = !m->vitstr && precision == PARSEQ_BF16 && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
+    // fused AR step (decoder_step.h): bf16 fragment packs, or hi | lo pairs of them in the bf16x3 arithmetic (twice the elements)
+    const bool step_ok = !m->vitstr && (precision == PARSEQ_BF16 || precision == PARSEQ_BF16X3) && E <= 384 && E % 64 == 0 && c.dec_mlp_ratio == 4;
+    const size_t step_planes = precision == PARSEQ_BF16X3 ? 2 : 1;
     const size_t step_elems[6] = {frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(E, E), frag_pack_elems(Fd, E),
                                   frag_pack_elems(E, Fd), frag_pack_elems(m->classes, E)};
     size_t o_wstep[6];
-    for (int i = 0; i < 6; ++i) o_wstep[i] = carve(off, step_ok ? step_elems[i] * 2 : 0);
+    for (int i = 0; i < 6; ++i) o_wstep[i] = carve(off, step_ok ? step_elems[i] * 2 * step_planes : 0);
     const size_t o_kvtab = carve(off, npos * c.num_tokens * 2 * E * ts);
     const size_t o_qself = carve(off, npos * E * 4);
     const size_t o_ctab = carve(off, npos * c.num_tokens * E * ts);
@@ -776,7 +793,8 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     // bf16, PARSeq-S geometry: the patch embedding is the head of the one-launch encoder (encoder_blocks.h patch_head); same conditions
     // as `fused_blocks` below plus the (4, 8)-patch / 32 x 128-crop layout the head is written for
     const bool head_in_launch = sizeof(T) == 2 && !m->vitstr && p->fused_head && p->fused_blocks && p->fused_attn && p->mlp_resident &&
-                                E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128;
+                                E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128 &&
+                                p->wpe_off >= EB_HEAD_MIN_WPE;     // see EB_HEAD_MIN_WPE (always true with pos_embed ahead of the weight)
     if (head_in_launch) {
         // nothing here: x is produced inside the launch
     } else if (!m->vitstr) {
@@ -1039,7 +1057,10 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
     } else if constexpr (sizeof(T) == 2) {
         hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
     } else {
-        hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca);
+        if (g_split)      // bf16x3: the matrix-core kernel on bf16 pairs
+            hipLaunchKernelGGL(dec_cross_attn_multi_mfma_x3_kernel, dim3((B * H + 1) / 2), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
+        else
+            hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca);
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -1111,9 +1132,18 @@ static int decode_pass_e(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, i
         if constexpr (sizeof(T) == 2 && E <= 512)
             hipLaunchKernelGGL((dec_self_attn_wave_kernel<E>), dim3((M + 3) / 4), dim3(256), 0, s, p->stab, reinterpret_cast<const bf16_t*>(p->kvtab),
                                p->tok, LDT, c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, reinterpret_cast<bf16_t*>(sa), M);
-        else
-            hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
-                               c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, sa);
+        else {
+            bool wave_form = false;
+            if constexpr (sizeof(T) == 4 && E <= 512) wave_form = g_split;      // bf16x3: the same wave-per-row form on the f32 tables
+            if constexpr (sizeof(T) == 4 && E <= 512) {
+                if (wave_form)
+                    hipLaunchKernelGGL((dec_self_attn_wave_kernel<E, float>), dim3((M + 3) / 4), dim3(256), 0, s, p->stab, reinterpret_cast<const float*>(p->kvtab),
+                                       p->tok, LDT, c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, reinterpret_cast<float*>(sa), M);
+            }
+            if (!wave_form)
+                hipLaunchKernelGGL((dec_self_attn_kernel<T, E>), dim3(M), dim3(E), 0, s, p->stab, reinterpret_cast<const T*>(p->kvtab), p->tok, LDT,
+                                   c.num_tokens, npos, qmask, LDT, kpm, LDT, Lk, i0, Lq, sa);
+        }
         HIPCHK(hipGetLastError());
     }
     { ProfScope ps_(&p->prof, T_DEC_GEMM, s); CHK((run_gemm<T>(s, ARowMajor<T>{sa, E}, W.w(d + "self_attn.out_proj.weight"), E, M, E, E,
@@ -1155,9 +1185,10 @@ static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int
     }
 }
 
-// The whole AR loop with the mid / cross-attention / mlp arrangement of decoder_step.h (bf16, E <= 384): step i's logits are
-// produced by the mid kernel of step i + 1 (and by one trailing finish-only launch after the last step).
-template <int E>
+// The whole AR loop with the mid / cross-attention / mlp arrangement of decoder_step.h (bf16 or, X3, the bf16x3 arithmetic on f32
+// storage; E <= 384): step i's logits are produced by the mid kernel of step i + 1 (and by one trailing finish-only launch after
+// the last step).
+template <int E, bool X3 = false>
 static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chain, int num_steps, float* logits_all, bool testing) {
     // images [b0, b0 + Bc) of the batch: every per-row buffer is offset to the sub-batch, the counters are the chain's own
     const parseq_model* m = p->m;
@@ -1165,7 +1196,8 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chai
     const int M = Bc, C = m->classes, npos = c.max_label_length + 1;
     const std::string d = "decoder.layers.0.";
     int* eos_rows = p->counters + 2 * chain; int* ar_len = p->counters + 2 * chain + 1;
-    bf16_t* ca = reinterpret_cast<bf16_t*>(p->ca) + (size_t)b0 * E;
+    using TS = typename std::conditional<X3, float, bf16_t>::type;      // storage type of kvtab, the memory K / V and ca
+    TS* ca = reinterpret_cast<TS*>(p->ca) + (size_t)b0 * E;
     // linear2 partial sums [ds_split][M][E] f32 (the generic path's MLP hidden buffer is idle here): one region per chain
     float* partial = reinterpret_cast<float*>(p->hdn) + (size_t)ds_split<E>() * b0 * E;
     float* tq = p->qc + (size_t)b0 * E;                                   // t' lives in the q-projection buffer once the cross-attention has consumed it
@@ -1176,18 +1208,18 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chai
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
     static LdsAttr attr_mid, attr_mlp;
-    HIPCHK(attr_mid.ensure(reinterpret_cast<const void*>(dec_step_mid_kernel<E>), dec_step_mid_lds<E>()));
-    HIPCHK(attr_mlp.ensure(reinterpret_cast<const void*>(dec_step_mlp_kernel<E>), dec_step_mlp_lds<E>()));
+    HIPCHK(attr_mid.ensure(reinterpret_cast<const void*>(dec_step_mid_kernel<E, X3>), dec_step_mid_lds<E, X3>()));
+    HIPCHK(attr_mlp.ensure(reinterpret_cast<const void*>(dec_step_mlp_kernel<E, X3>), dec_step_mlp_lds<E, X3>()));
     for (int i = 0; i <= num_steps; ++i) {
         const int do_finish = i > 0, do_start = i < num_steps;
         // the pick of position i - 1 feeds step i: needed while there is a step to start
         const int argmax_mode = do_start ? (testing ? 2 : 1) : 0;
         {
             ProfScope ps_(&p->prof, T_DEC_PRE, s);
-            hipLaunchKernelGGL((dec_step_mid_kernel<E>), grid, block, dec_step_mid_lds<E>(), s, do_finish, do_start, i, M,
+            hipLaunchKernelGGL((dec_step_mid_kernel<E, X3>), grid, block, (dec_step_mid_lds<E, X3>()), s, do_finish, do_start, i, M,
                                tq, partial, m->p(d + "linear2.bias"), m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps,
                                p->wstep[5], m->p("head.bias"), C, logits, num_steps, argmax_mode, c.eos_id, eos_seen, eos_rows, ar_len,
-                               p->stab, reinterpret_cast<const bf16_t*>(p->kvtab), tok, LDT, c.num_tokens, npos, p->wstep[0],
+                               p->stab, reinterpret_cast<const TS*>(p->kvtab), tok, LDT, c.num_tokens, npos, p->wstep[0],
                                m->p(d + "self_attn.out_proj.bias"), m->p("pos_queries"), m->p(d + "norm1.weight"), m->p(d + "norm1.bias"),
                                p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), t, tq);
             HIPCHK(hipGetLastError());
@@ -1195,11 +1227,11 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chai
         if (!do_start) break;
         {
             ProfScope ps_(&p->prof, T_DEC_CA, s);
-            CHK((run_cross_attention<bf16_t, E>(p, s, Bc, 1, scale, ca, b0)));
+            CHK((run_cross_attention<TS, E>(p, s, Bc, 1, scale, ca, b0)));
         }
         {
             ProfScope ps_(&p->prof, T_DEC_POST, s);
-            hipLaunchKernelGGL((dec_step_mlp_kernel<E>), dim3(grid.x * ds_split<E>()), block, dec_step_mlp_lds<E>(), s, ca, t, p->wstep[2],
+            hipLaunchKernelGGL((dec_step_mlp_kernel<E, X3>), dim3(grid.x * ds_split<E>()), block, (dec_step_mlp_lds<E, X3>()), s, ca, t, p->wstep[2],
                                m->p(d + "cross_attn.out_proj.bias"), m->p(d + "norm2.weight"), m->p(d + "norm2.bias"), c.dec_ln_eps,
                                p->wstep[3], m->p(d + "linear1.bias"), p->wstep[4], tq, partial, M);
             HIPCHK(hipGetLastError());
@@ -1210,7 +1242,7 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chai
 
 // The fused AR loop over the whole batch as `chains` concurrent sub-batch loops: chain 0 on the caller's stream, the others on the
 // plan's side streams between a fork event (the encoder and the memory K / V projection are done) and join events.
-template <int E>
+template <int E, bool X3 = false>
 static int ar_loop_chains(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing, int* chains_used) {
     int chains = std::min(p->ar_chains, std::max(1, B / 64));                 // at least 64 images (4 row tiles) per chain
     if (p->prof.enabled) chains = 1;                                          // per-family event timing brackets one stream
@@ -1223,7 +1255,7 @@ static int ar_loop_chains(parseq_plan* p, hipStream_t s, int B, int num_steps, f
     }
     for (int k = 0; k < chains; ++k) {
         const int b0 = k * per, bc = std::min(per, B - b0);
-        CHK((ar_loop_fused<E>(p, k == 0 ? s : p->chain_stream[k - 1], b0, bc, k, num_steps, logits, testing)));
+        CHK((ar_loop_fused<E, X3>(p, k == 0 ? s : p->chain_stream[k - 1], b0, bc, k, num_steps, logits, testing)));
     }
     for (int k = 1; k < chains; ++k) {
         HIPCHK(hipEventRecord(p->ev_join[k - 1], p->chain_stream[k - 1]));
@@ -1250,6 +1282,12 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
             if (p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4 && !getenv("PARSEQ_STEP_PREPOST")) {
                 if (c.embed_dim == 384) { CHK((ar_loop_chains<384>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
                 else if (c.embed_dim == 192) { CHK((ar_loop_chains<192>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
+            }
+        } else {
+            // bf16x3: the same fused step on bf16 pairs (f32 tables, f32 memory K / V); the fp32 mode keeps the per-op kernels
+            if (p->precision == PARSEQ_BF16X3 && p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4) {
+                if (c.embed_dim == 384) { CHK((ar_loop_chains<384, true>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_chains<192, true>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
             }
         }
         for (int i = 0; !done && i < num_steps; ++i) {
@@ -2175,6 +2213,50 @@ extern "C" int parseq_op_enc_blocks(float* x, const void* const* block_ptrs, int
     HIPCHK(hipMemcpy(table_ws, host.data(), host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice));      // test hook: synchronous upload
     HIPCHK((launch_enc_blocks<384>((hipStream_t)stream, x, reinterpret_cast<const bf16_t*>(wlo), (size_t)(whi - wlo), reinterpret_cast<const float*>(plo),
                                    reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M)));
+    return 0;
+}
+
+// The head and the tail of the one-launch encoder with no blocks in between (encoder_blocks.h patch_head / kv_phase), for sharp
+// per-kernel tests.  images != NULL: x = patches(images) Wpe^T + posb is computed in the accumulators (else x is loaded);
+// kmem != NULL: the launch ends with K | V = LayerNorm(x; norm_w, norm_b) Wkv^T + bkv as bf16 head-split rows (else x is stored).
+extern "C" int parseq_op_enc_head_tail(float* x, const void* images, int images_dtype, const void* wpe, const float* posb,
+                                       const float* norm_w, const float* norm_b, const void* wkv, const float* bkv, void* kmem, void* vmem,
+                                       int M, void* stream) {
+    CHK(check_arch());
+    if (M <= 0 || (M % 128)) return fail(PARSEQ_E_INVALID, "M must be a multiple of 128 (whole images)");
+    const bool head = images != nullptr, tail = kmem != nullptr;
+    if (!head && !tail) return fail(PARSEQ_E_INVALID, "neither images (head) nor kmem (tail) given");
+    if (head && (!wpe || !posb || (images_dtype != PARSEQ_F32 && images_dtype != PARSEQ_BF16 && images_dtype != PARSEQ_U8)))
+        return fail(PARSEQ_E_INVALID, "head: wpe, posb and an image dtype of f32 / bf16 / u8 are required");
+    if (tail && (!vmem || !norm_w || !norm_b || !wkv || !bkv)) return fail(PARSEQ_E_INVALID, "tail: vmem, norm_w, norm_b, wkv, bkv are required");
+    if ((!head || !tail) && !x) return fail(PARSEQ_E_INVALID, "x is required unless both head and tail are given");
+    uintptr_t wlo = ~(uintptr_t)0, whi = 0, plo = ~(uintptr_t)0;
+    auto span_w = [&](const void* q, size_t elems) { const uintptr_t a = reinterpret_cast<uintptr_t>(q); wlo = std::min(wlo, a); whi = std::max(whi, a + elems * 2); };
+    if (head) span_w(wpe, (size_t)384 * 96);
+    if (tail) span_w(wkv, (size_t)768 * 384);
+    // the head's DMA pieces put "row offset - LDS immediate" into the scalar offset (StreamLane::issue_v): with the 192-byte rows of Wpe
+    // that is negative for a weight at the very start of the descriptor (EB_HEAD_MIN_WPE).  The product's pack has pos_embed ahead of
+    // it; here the descriptor simply starts 4 KiB below the lowest weight (addresses below it are never formed)
+    if (wlo >= 4096) wlo -= 4096;
+    if (tail) for (const float* q : {norm_w, norm_b, bkv}) plo = std::min(plo, reinterpret_cast<uintptr_t>(q));
+    if (whi - wlo >= ((uintptr_t)1 << 32) || (wlo & 1)) return fail(PARSEQ_E_INVALID, "weights are spread over more than 4 GiB of address space");
+    EncTailParams et{0, 0, 0, 0, nullptr, nullptr, 12};
+    if (tail) {
+        auto poff = [&](const float* q) { return (unsigned)((reinterpret_cast<uintptr_t>(q) - plo) / 4); };
+        for (const float* q : {norm_w, norm_b, bkv})
+            if ((reinterpret_cast<uintptr_t>(q) - plo) >= ((uintptr_t)1 << 34) || ((reinterpret_cast<uintptr_t>(q) - plo) & 3)) return fail(PARSEQ_E_INVALID, "tail vectors are spread too far apart");
+        et.norm_w = poff(norm_w); et.norm_b = poff(norm_b); et.bkv = poff(bkv);
+        et.wkv = (unsigned)((reinterpret_cast<uintptr_t>(wkv) - wlo) / 2);
+        et.kmem = reinterpret_cast<bf16_t*>(kmem); et.vmem = reinterpret_cast<bf16_t*>(vmem);
+    }
+    EncHeadParams eh{nullptr, 0, 0, nullptr};
+    if (head) {
+        eh.images = images;
+        eh.img_dtype = images_dtype == PARSEQ_U8 ? EB_IMG_U8 : (images_dtype == PARSEQ_BF16 ? EB_IMG_BF16 : EB_IMG_F32);
+        eh.wpe = (unsigned)((reinterpret_cast<uintptr_t>(wpe) - wlo) / 2); eh.posb = posb;
+    }
+    HIPCHK((launch_enc_blocks<384>((hipStream_t)stream, x, reinterpret_cast<const bf16_t*>(wlo), (size_t)(whi - wlo),
+                                   reinterpret_cast<const float*>(tail ? plo : reinterpret_cast<uintptr_t>(posb)), nullptr, 0, 1e-6f, M, et, eh)));
     return 0;
 }
 

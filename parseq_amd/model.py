@@ -168,6 +168,8 @@ class _NativeState:
         self.model = C.c_void_p(0)
         self.plans = {}            # (precision code, slot) -> (plan handle, max_batch)
         self.signature = None
+        self.epoch = 0             # bumped whenever a plan's device-side contents may have changed under an unchanged signature:
+                                   # plans created / destroyed / re-packed (re-upload, mark_dirty, an optimiser step on the device)
 
     def release(self):
         try:
@@ -181,6 +183,7 @@ class _NativeState:
             lib.parseq_model_destroy(self.model)
         self.model = C.c_void_p(0)
         self.signature = None
+        self.epoch += 1
 
     def __del__(self):
         self.release()
@@ -246,6 +249,12 @@ class _NativeBacked(nn.Module):
         params = list(self.parameters())
         return (str(self._device), tuple(p.data_ptr() for p in params), tuple(self._version_of(p) for p in params))
 
+    @staticmethod
+    def _trackable(sig) -> bool:
+        """False when a parameter keeps no version counter (a tensor created under torch.inference_mode): an in-place edit of it
+        could not be noticed, so such a signature never counts as "unchanged" and every call re-uploads (slow, never stale)."""
+        return sig is not None and all(v is not None for v in sig[2])
+
     def mark_dirty(self):
         """Force the next forward / encode / decode to re-upload every parameter.  Needed only after writes the signature cannot
         see: in-place edits through `param.data` (checkpoint averaging, EMA) do not bump a tensor's version counter."""
@@ -254,8 +263,13 @@ class _NativeBacked(nn.Module):
     def _sync_native(self):
         st: _NativeState = self._native_state
         sig = self._signature()
-        if st.signature == sig:
+        if st.signature == sig and self._trackable(sig):
             return st
+        if not self._trackable(sig) and not getattr(self, '_warned_untracked', False):
+            import warnings
+            warnings.warn('parseq_amd: a parameter was created under torch.inference_mode and keeps no version counter; in-place edits of it '
+                          'cannot be detected, so every call re-uploads the weights. Create / load the model outside inference_mode.')
+            self._warned_untracked = True
         lib = _native.lib()
         if self._device.type != 'cuda':
             raise RuntimeError('move the model to a ROCm device first: model.to("cuda")')
@@ -281,6 +295,7 @@ class _NativeBacked(nn.Module):
                 _native.check(lib.parseq_plan_refresh(plan, stream))
             torch.cuda.current_stream(self._device).synchronize()    # staging copies in `keep` must outlive the async D2D copies
         st.signature = sig
+        st.epoch += 1                     # every plan was re-packed (or released): cached K / V projections are stale
         return st
 
     def _adopt_native_weights(self):
@@ -295,6 +310,7 @@ class _NativeBacked(nn.Module):
             _native.check(lib.parseq_model_get_param(st.model, key.encode(), _native.ptr(t), t.numel(), stream))
         for plan, _ in st.plans.values():
             _native.check(lib.parseq_plan_refresh(plan, stream))
+        st.epoch += 1                     # same signature, new weights: a cached memory K / V projection is stale
 
     def _plan(self, batch: int, slot: int = 0):
         if self.precision not in _PRECISIONS:
@@ -308,6 +324,7 @@ class _NativeBacked(nn.Module):
                 torch.cuda.current_stream(self._device).synchronize()
                 lib.parseq_plan_destroy(plan)
                 del st.plans[(code, slot)]
+            st.epoch += 1                 # a fresh plan holds nobody's K / V (and a freed handle's address may be reused)
             cap = max(8, 1 << (batch - 1).bit_length())
             handle = C.c_void_p(0)
             with torch.cuda.device(self._device):
@@ -364,7 +381,7 @@ class PARSeq(_NativeBacked):
                              dtype=torch.float32, device=img.device)
         _native.check(_native.lib().parseq_encode(plan, _native.ptr(img), _native.dtype_code(img.dtype), img.shape[0],
                                                   _native.ptr(memory), _native.stream_ptr(self._device)))
-        self._remember_memory(memory)      # the K / V projection of THIS tensor object is what the plan now caches
+        self._remember_memory(memory, plan)      # the K / V projection of THIS tensor object is what THIS plan now caches
         return memory
 
     def _bind_memory(self, memory: Optional[Tensor], B: int, plan) -> None:
@@ -381,18 +398,19 @@ class PARSeq(_NativeBacked):
         if memory.device != self._device:
             raise RuntimeError(f'memory on {memory.device} but the model is on {self._device}')
         key = getattr(self, '_memory_key', None)
-        if key is not None and key[0]() is memory and key[1] is not None and key[1:] == (self._version_of(memory), self._native_state.signature):
+        if key is not None and key[0]() is memory and key[1] is not None and key[1:] == (self._version_of(memory), plan.value, self._native_state.epoch):
             return
         mem = memory.detach().to(torch.float32).contiguous()
         _native.check(_native.lib().parseq_set_memory(plan, _native.ptr(mem), B, _native.stream_ptr(self._device)))
         self._memory_keep = mem                 # stays alive until the asynchronous projection has read it
-        self._remember_memory(memory)
+        self._remember_memory(memory, plan)
 
-    def _remember_memory(self, memory: Tensor) -> None:
+    def _remember_memory(self, memory: Tensor, plan) -> None:
         # identity of the tensor OBJECT (a weak reference: a freed tensor whose storage address is reused by another one can
-        # never match), its in-place-modification counter, and the parameter signature the projection was made with
+        # never match), its in-place-modification counter, the PLAN that holds the projection (another precision or slot is another
+        # plan with its own K / V) and the state epoch (bumped by every re-upload, re-pack, optimiser step and plan creation)
         import weakref
-        self._memory_key = (weakref.ref(memory), self._version_of(memory), self._native_state.signature)
+        self._memory_key = (weakref.ref(memory), self._version_of(memory), plan.value, self._native_state.epoch)
 
 
     def decode(self, tgt: Tensor, memory: Optional[Tensor] = None, tgt_mask: Optional[Tensor] = None,
@@ -413,6 +431,8 @@ class PARSeq(_NativeBacked):
             q_start, q_len = 0, L
         else:
             pq = self.pos_queries
+            if not isinstance(tgt_query, Tensor) or tgt_query.dim() != 3 or tgt_query.shape[-1] != E:
+                raise RuntimeError(f'tgt_query must be [{B} or 1, Lq, {E}], got {list(getattr(tgt_query, "shape", []))}')
             off = (tgt_query.data_ptr() - pq.data_ptr()) // pq.element_size()
             q_len = tgt_query.shape[1]
             is_slice = (tgt_query.device == pq.device and tgt_query.dtype == pq.dtype and 0 <= off and off % E == 0 and
@@ -478,8 +498,9 @@ class PARSeq(_NativeBacked):
         images = self._check_images(images)
         B = images.shape[0]
         plan = self._plan(B, slot)
-        if slot == 0:
-            self._memory_key = None             # the plan's cached K / V now belong to these images, not to an encode() result
+        key = getattr(self, '_memory_key', None)
+        if key is not None and key[2] == plan.value:
+            self._memory_key = None             # this plan's cached K / V now belong to these images, not to an encode() result
         if (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id) != self._special_ids(tokenizer):
             raise RuntimeError('tokenizer special ids changed after the native model was built')
         logits = torch.empty(B, num_steps, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=images.device)

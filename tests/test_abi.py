@@ -59,3 +59,44 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setenv('PARSEQ_HIP_LIB', str(tmp_path / 'nope.so'))
     with pytest.raises(RuntimeError, match='no CPU/eager fallback'):
         _native.lib()
+
+
+def test_split_layernorm_loader_is_compiled_without_packed_f32(built_lib, tmp_path):
+    """gemm.h ln_apply4: the bf16x3 GEMMs with the LayerNorm-fused A-loader produced wrong values (two workgroups per CU) while the
+    loader's (x - mean) * rstd * gamma + beta was compiled to v_pk_mul_f32 / v_pk_fma_f32; empty-asm pins keep the SLP vectoriser
+    from forming them.  A compiler bump could undo that silently, so the shipped code object is checked: the
+    gemm_kernel<float, ..., ALayerNorm<float, E>, EpiStore / EpiGelu, SPLIT> instances (decoder q-projection / linear1 / head forms,
+    whose epilogues have no packed arithmetic of their own) must not contain a packed-f32 multiply / fma / add."""
+    import struct
+    import subprocess
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('llvm-objdump not found')
+    blob = open(built_lib, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    at = blob.find(magic)
+    assert at >= 0
+    n = struct.unpack_from('<Q', blob, at + len(magic))[0]
+    off, co = at + len(magic) + 8, None
+    for _ in range(n):
+        o, size, tlen = struct.unpack_from('<QQQ', blob, off)
+        triple = blob[off + 24:off + 24 + tlen].decode()
+        off += 24 + tlen
+        if 'gfx950' in triple:
+            co = blob[at + o:at + o + size]
+    assert co is not None, 'no gfx950 code object in the library'
+    path = tmp_path / 'lib.co'
+    path.write_bytes(co)
+    syms = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--symbols', '--wide', str(path)], capture_output=True, text=True, check=True).stdout
+    mangled = sorted({ln.split()[-1] for ln in syms.splitlines() if ' FUNC ' in ln and ln.split()[-1].startswith('_Z')})
+    names = subprocess.run(['/usr/bin/c++filt'], input='\n'.join(mangled), capture_output=True, text=True, check=True).stdout.splitlines()
+    want = [m for m, d in zip(mangled, names)
+            if 'gemm_kernel<float' in d and 'ALayerNorm<float' in d and ('EpiStore<float>' in d or 'EpiGelu<float>' in d)
+            and re.search(r'>, true, (false|true)>\(', d)]
+    assert len(want) >= 6, f'expected the SPLIT ALayerNorm GEMM instances in the code object, found {len(want)}'
+    for sym in want:
+        asm = subprocess.run([objdump, '-d', '--no-show-raw-insn', f'--disassemble-symbols={sym}', str(path)],
+                             capture_output=True, text=True, check=True).stdout
+        assert 'v_mfma' in asm, f'{sym}: disassembly is empty?'
+        bad = re.findall(r'v_pk_(?:mul|fma|add)_f32', asm)
+        assert not bad, f'{sym}: {len(bad)} packed-f32 VALU instructions — the ln_apply4 pins no longer hold'

@@ -366,3 +366,81 @@ def test_encoder_blocks_x3_one_launch(images, depth, tail):
         assert err <= tol, msg
         # and it must really be better than single bf16 products (a path that dropped the lo terms would sit at ~1e-2)
         assert err <= 1e-3
+
+
+def _patches(img):
+    """[B, 3, 32, 128] -> [B * 128, 96]: token = 16 gy + gx, k = 32 c + 8 ky + kx (timm PatchEmbed's Conv2d(3, E, (4, 8), stride (4, 8))
+    weight flattened)."""
+    B = img.shape[0]
+    return img.view(B, 3, 8, 4, 16, 8).permute(0, 2, 4, 1, 3, 5).reshape(B * 128, 96)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16', 'u8'])
+@pytest.mark.parametrize('images', [1, 5, 300])
+def test_patch_head(images, dtype):
+    """encoder_blocks.h patch_head alone (the head of the one-launch encoder, no blocks, x stored): x = patches W^T + (pos_embed + bias)
+    against fp64 on the SAME bf16 operands — f32 pixels are rounded to bf16 by the kernel, u8 pixels get ToTensor + Normalize(0.5, 0.5)
+    first (strhub/data/module.py:78-81).  Only the fp32 accumulation order differs: <= 2e-4 like test_linear."""
+    nat, lib = native()
+    E = 384
+    g = torch.Generator().manual_seed(50 + images)
+    if dtype == 'u8':
+        raw = torch.randint(0, 256, (images, 3, 32, 128), generator=g, dtype=torch.uint8)
+        pix = ((raw.float() / 255 - 0.5) / 0.5)
+        dev_img, code = raw.to(DEV), nat.PARSEQ_U8
+    else:
+        pix = torch.rand(images, 3, 32, 128, generator=g) * 2 - 1
+        if dtype == 'bf16':
+            dev_img, code = pix.bfloat16().to(DEV), nat.PARSEQ_BF16
+        else:
+            dev_img, code = pix.to(DEV), nat.PARSEQ_F32
+    W = (_gen(E, 96, seed=51) / 96 ** 0.5).bfloat16()
+    posb = _gen(128, E, seed=52, scale=0.5)
+    want = (_patches(pix.bfloat16().double()) @ W.double().T + posb.double().repeat(images, 1)).float()
+    Wd, pd = W.to(DEV), posb.to(DEV)
+    x = torch.full((images * 128, E), float('nan'), device=DEV)
+    nat.check(lib.parseq_op_enc_head_tail(nat.ptr(x), nat.ptr(dev_img), code, nat.ptr(Wd), nat.ptr(pd), None, None, None, None, None, None,
+                                          images * 128, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    err, msg = report(f'patch_head images={images} {dtype}', x, want)
+    assert err <= 2e-4, msg
+
+
+@pytest.mark.parametrize('images', [1, 5, 300])
+def test_kv_tail(images):
+    """encoder_blocks.h kv_phase alone (the tail of the one-launch encoder, no blocks): K | V = LayerNorm(x) Wkv^T + bkv as bf16
+    head-split rows, against fp64 with the same rounding points (LayerNorm output and weights bf16, result rounded to bf16).  A value
+    that sits on a bf16 rounding boundary may land on the neighbouring bf16 number: at most one ulp, and rarely."""
+    nat, lib = native()
+    E, M = 384, images * 128
+    x = _gen(M, E, seed=61, scale=1.5) + 0.2
+    gn, bn = 1 + 0.1 * _gen(E, seed=62), 0.1 * _gen(E, seed=63)
+    Wkv = (_gen(2 * E, E, seed=64) / E ** 0.5).bfloat16()
+    bkv = 0.1 * _gen(2 * E, seed=65)
+    ln = torch.nn.functional.layer_norm(x.double(), (E,), gn.double(), bn.double(), 1e-6).float().bfloat16().double()
+    kv = ln @ Wkv.double().T + bkv.double()
+    kw = kv[:, :E].reshape(images, 128, 12, 32).permute(0, 2, 1, 3).contiguous()
+    vw = kv[:, E:].reshape(images, 128, 12, 32).permute(0, 2, 1, 3).contiguous()
+    vec = torch.cat([gn, bn, bkv]).to(DEV)                       # one allocation: the kernel addresses the vectors relative to one base
+    xd, Wd = x.to(DEV), Wkv.to(DEV)
+    km = torch.zeros(images, 12, 128, 32, dtype=torch.bfloat16, device=DEV)
+    vm = torch.zeros_like(km)
+    nat.check(lib.parseq_op_enc_head_tail(nat.ptr(xd), None, 0, None, None, nat.ptr(vec), nat.ptr(vec[E:]), nat.ptr(Wd), nat.ptr(vec[2 * E:]),
+                                          nat.ptr(km), nat.ptr(vm), M, nat.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(xd.cpu(), x), 'the tail must not write x'
+    for tag, got, want in (('K', km, kw), ('V', vm, vw)):
+        got = got.float().cpu().double()
+        d = (got - want).abs()
+        ulp = torch.maximum(want.abs(), torch.tensor(2.0 ** -126, dtype=torch.float64)).log2().floor().exp2() * 2.0 ** -7      # bf16 spacing at |want|
+        print(f'[kv_tail {tag} images={images}] max|d| {d.max():.3e}, max |d| / ulp {float((d / ulp).max()):.3f}, '
+              f'exactly the rounded reference {(got == want.float().bfloat16().double()).float().mean():.4f}')
+        # Sharp bound (one bf16 ulp of the result + 2e-5 for the fp32 accumulation order) on nearly every TOKEN; a token whose LayerNorm
+        # output had one value land on the neighbouring bf16 number (fp32 vs fp64 statistics; a bf16 step of an O(4) value times a
+        # weight of O(0.1)) moves all of its outputs by up to ~3e-3: allowed for a few tokens, never more than that
+        sharp = (d <= 1.001 * ulp + 2e-5).all(-1)                         # [images, 12, 128]: per (head, token)
+        tok_ok = sharp.all(1)                                             # per token
+        print(f'[kv_tail {tag} images={images}] tokens inside the sharp bound {int(tok_ok.sum())}/{tok_ok.numel()}')
+        assert tok_ok.float().mean() >= 0.95, f'{tag}: too many tokens outside one bf16 ulp'
+        assert bool((d <= 1.001 * ulp + 4e-3).all()), f'{tag}: more than one bf16 ulp + 4e-3 from the fp64 reference'
+        assert (got == want.float().bfloat16().double()).float().mean() >= 0.97

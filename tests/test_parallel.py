@@ -210,3 +210,58 @@ def test_two_rank_nccl_real_model_matches_single_rank_bit_for_bit():
         assert all(shape_ok and equal for shape_ok, equal, _ in res), (rank, res)
     # the natural-exit run must really have exited early on these weights (synth.py lifts the EOS bias), or the test is vacuous
     assert results[0][1][1][2][1] < 26, results[0][1]
+
+
+def _bench_line(args, env_extra, timeout):
+    """Run bench.py as the driver does (a fresh interpreter) and return (the JSON lines it printed, the full stdout, stderr tail)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    lines = []
+    for ln in r.stdout.splitlines():
+        ln = ln.strip()
+        if ln.startswith('{') and ln.endswith('}'):
+            try:
+                lines.append(json.loads(ln))
+            except ValueError:
+                pass
+    return r.returncode, lines, r.stdout, r.stderr[-2000:]
+
+
+def test_bench_py_two_ranks_print_one_line_for_the_whole_job():
+    """bench.py's own multi-rank path on CPU (PARSEQ_BENCH_STUB=1: gloo, a shape-only stand-in for the model): `--gpus 2` from a plain
+    shell re-executes under torch.distributed.run on 127.0.0.1, both ranks run the timed loop with the uniform all-gather inside it,
+    and rank 0 alone prints ONE JSON line whose value / config describe the whole job (2 x 512 crops per step)."""
+    rc, lines, out, err = _bench_line(['--gpus', '2', '--steps', '3', '--warmup', '1', '--repeats', '2'], {'PARSEQ_BENCH_STUB': '1'}, 600)
+    assert rc == 0, err
+    assert len(lines) == 1, out
+    d = lines[0]
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['stub'] is True
+    assert d['config']['global_batch'] == 1024 and d['config']['parallelism'].startswith('dp2')
+    assert d['config']['output_shape'] == [1024, 26, 95]                 # every rank ends a step holding the logits of all 1024 crops
+    assert abs(d['value'] - 1024 * 3 / (d['ms_per_step'] * 3e-3)) <= 1e-3 * d['value']      # whole-job crops / max-over-ranks time
+    assert 'stub' in d['data']                                           # and the line cannot be mistaken for a measurement
+
+
+def test_bench_py_refuses_a_world_size_that_contradicts_gpus():
+    rc, lines, out, err = _bench_line(['--gpus', '1', '--steps', '1', '--warmup', '0'], {'PARSEQ_BENCH_STUB': '1', 'WORLD_SIZE': '2', 'RANK': '0'}, 300)
+    assert rc != 0 and not lines
+
+
+@pytest.mark.gpu
+def test_bench_py_force_dist_runs_the_rccl_path_on_one_gpu():
+    """The distributed path of bench.py on the one GPU a test box has: RCCL process group of one rank, the real all_gather_into_tensor
+    inside the timed step, two batches in flight on separate streams next to the communicator's streams (GPU_MAX_HW_QUEUES=8, DESIGN.md
+    section 6).  Short: 5 steps, no profile / CPU baseline / parity legs."""
+    rc, lines, out, err = _bench_line(['--force-dist', '--steps', '5', '--warmup', '2', '--repeats', '2', '--no-profile', '--no-cpu-baseline', '--no-parity'],
+                                      {}, 900)
+    assert rc == 0, err
+    assert len(lines) == 1, out
+    d = lines[0]
+    assert d['n_gpus'] == 1 and d['config']['output_shape'] == [512, 26, 95] and d['value'] > 0 and d['sequential_value'] > 0
