@@ -315,7 +315,7 @@ int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* strea
 int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                          int cfg, void* stream);
 /* out[M, N] (bf16) = gelu(LayerNorm(x[M, 384]; gamma, beta, eps 1e-6) W^T + bias) through the register-resident-A panel
- * kernel; W bf16 [N, 384], N a multiple of 128.  variant 0 = the product kernel; 1..4 = ablations (tools/panel_bench.py). */
+ * kernel; W bf16 [N, 384], N a multiple of 128.  variant must be 0 (the ablation variants of rounds 1-2 were removed; the parameter stays for ABI 4). */
 int parseq_op_ln_linear_gelu(const float* x, const float* gamma, const float* beta, const void* W, const float* bias,
                              void* out, int M, int N, int variant, void* stream);
 /* In place x[M, 384] (fp32) += fc2(gelu(fc1(LayerNorm(x; gamma, beta, eps 1e-6)))) through the fused MLP kernel:
@@ -325,7 +325,7 @@ int parseq_op_mlp(float* x, const float* gamma, const float* beta, const void* W
 /* In place x[M, 384] (fp32) += proj(attention(qkv(LayerNorm(x; gamma, beta, eps 1e-6)))) through the fused attention-branch kernel
  * (timm Block: x + attn(norm1(x)), 6 heads of 64, one image = 128 consecutive rows per workgroup; M a multiple of 128):
  * Wqkv bf16 [1152, 384] (q | k | v rows, head-major), bqkv fp32 [1152], Wproj bf16 [384, 384], bproj fp32 [384].
- * variant 0 = the product kernel; 6 = phase time stamps (tools/panel_bench.py). */
+ * variant 0 = encoder_attn_fused.h; 1 = the phase function the one-launch encoder is built from (encoder_blocks.h attn_branch_kernel). */
 int parseq_op_attn_fused(float* x, const float* gamma, const float* beta, const void* Wqkv, const float* bqkv, const void* Wproj,
                          const float* bproj, int M, int variant, void* stream);
 /* `depth` encoder blocks in one launch (encoder_blocks.h): in place on x[M, 384] (fp32), M a multiple of 128 (one image = 128
@@ -353,8 +353,8 @@ int parseq_op_enc_head_tail(float* x, const void* images, int images_dtype, cons
  * Test hook (the product path builds the tables once per plan); uploads the table synchronously. */
 int parseq_op_enc_blocks_x3(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
                             int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream);
-/* Ablation variants of parseq_op_mlp for tools/panel_bench.py (variant 0 = the product kernel; 10 = x resident in the fc2
- * accumulators, the form the encoder uses). */
+/* The forms of parseq_op_mlp: variant 0 = x re-read by the epilogue; 10 = x resident in the fc2 accumulators (the form the per-layer
+ * encoder path uses); 11 = the phase function the one-launch encoder is built from (encoder_blocks.h mlp_branch_kernel). */
 int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,
                           const float* b2, int M, int variant, void* stream);
 /* Encoder attention for `bh` (image, head) pairs: q, k [bh, 128, 64], vt [bh, 64, 128] in `dtype`;

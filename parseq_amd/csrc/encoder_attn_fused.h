@@ -47,12 +47,11 @@ constexpr size_t fused_attn_lds() {
     return (size_t)AF_NST * AF_STAGE_BYTES + 128 * AF_KROWB + 64 * AF_VROWB + (size_t)(6 * E) * sizeof(float);   // ring | K | V^T | bqkv | bproj | gamma | beta
 }
 
-// VARIANT (ablations, tools/panel_bench.py): 0 product; 6 phase time stamps.
-template <int E, int VARIANT = 0>
+template <int E>
 __global__ __launch_bounds__(256, 1)
 void fused_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                        const bf16_t* __restrict__ Wqkv, const float* __restrict__ bqkv, const bf16_t* __restrict__ Wproj,
-                       const float* __restrict__ bproj, int M, float scale, unsigned long long* __restrict__ dbg = nullptr) {
+                       const float* __restrict__ bproj, int M, float scale) {
     constexpr int H = E / 64;                 // heads
     constexpr int KSTEPS = E / 32;            // MFMA k-steps over E
     constexpr int KS1 = E / 128;              // ring slots per 64-row projection chunk (two 64-k stages per slot)
@@ -76,11 +75,6 @@ void fused_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma, c
     const int rr = lane & 15, g = lane >> 4;
     const bool lo_half = rr < 8;
     const int m0 = blockIdx.x * AF_BM;
-    const bool stamp = (VARIANT == 6) && dbg && (blockIdx.x == 0 || blockIdx.x == 300) && lane == 0;
-    unsigned long long* dslot = dbg + ((blockIdx.x == 0 ? 0 : 1) * 4 + wid) * 64;
-    int nstamp = 0;
-#define AF_STAMP() do { if (VARIANT == 6) { if (stamp) dslot[nstamp] = __builtin_amdgcn_s_memtime(); ++nstamp; } } while (0)
-    AF_STAMP();
 
     // ---- weight stream -----------------------------------------------------------------------------------------------
     // stage (head h, t), always 128 LDS rows x 128 bytes, one DMA instruction = 8 LDS rows, wave w issues rows 32 w .. 32 w + 31:
@@ -190,7 +184,6 @@ void fused_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma, c
             afrag[j][ks] = f;
         }
     }
-    AF_STAMP();      // 1: LayerNorm prologue done
 
     // ---- main loop over heads ----------------------------------------------------------------------------------------
     const int sx = rr & 7;
@@ -203,7 +196,6 @@ void fused_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma, c
     const float sc2 = scale * 1.44269504088896340736f;       // exp(scale (s - m)) = exp2(sc2 s - sc2 m)
 
     for (int h = 0; h < H; ++h) {
-        if (h == 1 || h == H - 1) AF_STAMP();      // 2: head 1 starts; 3: last head starts
         f32x4 acc1[4][2];
         bf16x8 qfrag[2][2], ofrag[2][2];
         static_for<0, SPH>([&](auto tc) {
@@ -387,7 +379,6 @@ void fused_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma, c
             }
         });
     }
-    AF_STAMP();      // 4: main loop done
 
     // ---- epilogue: x = accumulators + bproj (the accumulators already contain x), 8 lanes per row via the half-row swap ----
 #pragma unroll
@@ -413,19 +404,17 @@ void fused_attn_kernel(float* __restrict__ x, const float* __restrict__ gamma, c
             if (r_second < M) *reinterpret_cast<u32x4*>(x + (size_t)r_second * E + col) = second;
         }
     }
-    AF_STAMP();      // 5: epilogue done
-#undef AF_STAMP
 }
 
-template <int E, int VARIANT = 0>
+template <int E>
 inline hipError_t launch_fused_attn(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* Wqkv,
-                                    const float* bqkv, const bf16_t* Wproj, const float* bproj, int M, unsigned long long* dbg = nullptr) {
+                                    const float* bqkv, const bf16_t* Wproj, const float* bproj, int M) {
     constexpr size_t lds = fused_attn_lds<E>();
-    auto kern = fused_attn_kernel<E, VARIANT>;
+    auto kern = fused_attn_kernel<E>;
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((M + AF_BM - 1) / AF_BM), dim3(256), lds, s, x, gamma, beta, eps, Wqkv, bqkv, Wproj, bproj, M,
-                       0.125f, dbg);
+                       0.125f);
     return hipGetLastError();
 }
 

@@ -25,11 +25,8 @@
 
 namespace pq {
 
-// Timing ablations (results are WRONG with any bit set; tools/enc_ablate.sh builds and times them): 1 GELU -> identity, 2 no
-// soft-max core, 4 no LDS-DMA issue, 8 no triple barriers, 16 fragment reads only once per triple, 32 no waits for the LDS-DMA
-#ifndef EB_ABLATE
-#define EB_ABLATE 0
-#endif
+// (The timing ablations of this kernel — GELU / soft-max core / LDS-DMA issue / barriers / fragment reads / DMA waits removed one at
+// a time, profiles/r02_enc_ablation.log — and the rejected scheduling variants live on the branch `ablation-variants-r3`.)
 
 // Per-block parameters, one entry per encoder block: ELEMENT offsets relative to two bases the kernel receives once — the bf16
 // weights (wqkv, wproj, w1, w2) relative to `wbase`, the fp32 vectors relative to `pbase`.  32-bit offsets (instead of twelve
@@ -208,7 +205,6 @@ struct StreamLane {
     }
     // the same with the per-lane offset given (a row pitch other than E / 4E: the patch-embedding weights)
     static __device__ __forceinline__ void issue_v(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned origin, int pitch, unsigned char* dst, int q = -1) {
-        if constexpr ((EB_ABLATE & 4) != 0) return;
         auto* l = (__attribute__((address_space(3))) void*)dst;
         const unsigned rp = 2u * (unsigned)pitch;
         if (q < 0 || q == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin, 0, 0);
@@ -234,19 +230,9 @@ struct StreamLane {
 // triple's LDS-DMA pieces are issued at this triple's stage boundaries into a group whose last readers the triple's opening
 // barrier has already retired.
 constexpr int EB_GROUP_BYTES = 3 * 16384;
-template <int N> __device__ __forceinline__ void eb_wait_vmcnt() { if constexpr ((EB_ABLATE & 32) == 0) wait_vmcnt<N>(); }
-#ifndef EB_F1_EARLY
-#define EB_F1_EARLY 1            // the next chunk's fc1 triple is issued at this chunk's fc1 stage boundaries (two triples ahead) instead of in the GELU stretch (one)
-#endif
-#ifndef EB_ISSUE_SPLIT
-#define EB_ISSUE_SPLIT 1         // stages of the next triple issued at the three stage boundaries: 0 = 1/1/1, 1 = 2/1/0, 2 = 3/0/0
-#endif
-
-#ifndef EB_PIECEWISE
-#define EB_PIECEWISE 0           // the four LDS-DMA pieces of a stage boundary go out one per eight MFMAs instead of back to back
-#endif
+template <int N> __device__ __forceinline__ void eb_wait_vmcnt() { wait_vmcnt<N>(); }
 // mma(k, half, i, w): the two MFMAs (row tiles j = 0, 1) that consume weight fragment i of k-half `half` of stage k.
-// issue(k, q): the wave's LDS-DMA pieces due at stage k.  EB_PIECEWISE: q = 0..3, one call per eight MFMAs of the stage (the first
+// issue(k, q): the wave's LDS-DMA pieces due at stage k, one call per stage with q = -1 (all four pieces back to back) (the first
 // after the first eight fragment reads of the triple have been issued); otherwise one call per stage with q = -1 (all four).
 template <class Mma, class Issue>
 __device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, Issue&& issue) {
@@ -258,14 +244,11 @@ __device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, 
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, 6>([&](auto bc) {
         constexpr int b = decltype(bc)::value, k = b >> 1, half = b & 1, nb = b + 1;
-        constexpr bool reads = b < 5 && ((EB_ABLATE & 16) == 0 || b == 0);
+        constexpr bool reads = b < 5;
         const unsigned char* src = grp + (nb >> 1) * 16384 + ((nb & 1) ? fo1 : fo0);
         static_for<0, 2>([&](auto sc) {
             constexpr int sub = decltype(sc)::value;
-            if constexpr (EB_PIECEWISE) {
-                issue(k, 2 * half + sub);
-                __builtin_amdgcn_sched_barrier(0);
-            } else if constexpr (half == 0 && sub == 0) {
+            if constexpr (half == 0 && sub == 0) {
                 issue(k, -1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -291,16 +274,10 @@ __device__ __forceinline__ void run_triple(const unsigned char* grp, Mma&& mma, 
     });
 }
 
-// which stages of the NEXT triple go out at stage boundary k of this one (EB_ISSUE_SPLIT)
+// which stages of the NEXT triple go out at stage boundary k of this one: two, one, none (1 / 1 / 1 and 3 / 0 / 0 measured slower)
 template <class F>
 __device__ __forceinline__ void issue_split(int k, F&& one) {
-#if EB_ISSUE_SPLIT == 0
-    one(k);
-#elif EB_ISSUE_SPLIT == 1
     if (k == 0) { one(0); one(1); } else if (k == 1) one(2);
-#else
-    if (k == 0) { one(0); one(1); one(2); }
-#endif
 }
 
 // ---- attention phase: acc += proj(attention(qkv(afrag)))  (bias of proj NOT added) ------------------------------------------
@@ -336,7 +313,7 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
             constexpr int u = decltype(uc)::value;               // 0 q, 1 k, 2 v (operand roles swapped: V^T), 3 proj
             eb_wait_vmcnt<0>();                                  // this triple (issued during the previous one) has landed
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if constexpr (u < 3) {
 #pragma unroll
@@ -391,9 +368,7 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if constexpr ((EB_ABLATE & 2) != 0) {
-                    ofrag[0][0] = qfrag[0][0]; ofrag[0][1] = qfrag[0][1]; ofrag[1][0] = qfrag[1][0]; ofrag[1][1] = qfrag[1][1];
-                } else {
+                {
                 // S^T = K Q^T and the soft-max, one 16-query row tile at a time (32 score registers live instead of 64; the K
                 // fragments are read twice, 16 extra ds_read_b128 per head)
                 bf16x8 pfrag[2][4];
@@ -500,15 +475,13 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave)
         eb_wait_vmcnt<12>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
             acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);
             acc1[i & 3][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[1][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][1], 0, 0, 0);
         }, [&](int k, int q) {
-#if EB_F1_EARLY
             if (more) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, k, gcur == 0 ? 2 : gcur - 1, q);
-#endif
         });
         {
             const int g = opaque_lane() >> 4;                    // (shadows the argument: see opaque_lane)
@@ -524,12 +497,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                         xv[4 * pr + 2 + h2] = f32x2{acc1[2 * pr + 1][j][2 * h2] + bp[4 + 2 * h2], acc1[2 * pr + 1][j][2 * h2 + 1] + bp[4 + 2 * h2 + 1]};
                     }
                 }
-                if constexpr ((EB_ABLATE & 1) != 0) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) yv[e] = xv[e];
-                } else {
-                    gelu_poly_16(xv, yv);
-                }
+                gelu_poly_16(xv, yv);
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     bf16x8 f;
@@ -539,19 +507,11 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                 }
             }
         }
-        // the next chunk's fc1 triple goes into the group the fc1 barrier above has retired (two triples back), in the VALU-only gap
-        const int gnext2 = gcur == 0 ? 2 : gcur - 1;             // (gcur + 2) % 3
-#if !EB_F1_EARLY
-        if (more) {
-#pragma unroll
-            for (int tn = 0; tn < 3; ++tn) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, tn, gnext2);
-        }
-#endif
         gcur = gcur == 2 ? 0 : gcur + 1;
         // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
         if (more) eb_wait_vmcnt<12>(); else eb_wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const int gn2 = gcur == 0 ? 2 : gcur - 1;
         run_triple(ring + gcur * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
@@ -626,7 +586,7 @@ __device__ __forceinline__ void patch_head(const EncHeadParams& hp, unsigned cha
         constexpr int T = decltype(tc)::value;
         if constexpr (T == 0) eb_wait_vmcnt<12>(); else eb_wait_vmcnt<0>();       // (plain loads above were waited for by their uses)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         run_triple(ring + T * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
             const int st = 3 * T + k, ng = st >> 1, s32 = 2 * (st & 1) + half;       // constants after inlining
@@ -663,7 +623,7 @@ __device__ __forceinline__ void kv_phase(unsigned char* ring, const float* sbkv,
         for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         eb_wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr ((EB_ABLATE & 8) == 0) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         run_triple(ring + (c & 1) * EB_GROUP_BYTES, [&](int k, int half, int i, const bf16x8& w) {
             acc1[i & 3][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, afrag[0][(2 * k + (i >> 2)) * 2 + half], acc1[i & 3][0], 0, 0, 0);

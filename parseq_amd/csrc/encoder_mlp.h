@@ -39,18 +39,18 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 
 constexpr int MLP_BM = 128, MLP_NST = 8, MLP_DIST = 7, MLP_STAGE_BYTES = 128 * 128, MLP_HC = 64;
 
-// VARIANT (ablations, tools/panel_bench.py): 0 product; 1 no weight stream inside the loop (stale LDS); 2 no GELU (bias + convert
-// only); 3 no LDS reads / MFMAs; 4 no barriers and no vmcnt waits (garbage); 5 no LayerNorm prologue.
+// (The ablation variants of this kernel — no weight stream, no GELU, no MFMAs, no barriers, no LayerNorm prologue, phase time stamps —
+// that produced profiles/r01_panel_ablation.log live on the branch `ablation-variants-r3`.)
 // RESIDENT: the fp32 rows of x are loaded ONCE, straight into the fc2 accumulators (the pair-permuted W2 row order makes the
 // accumulator layout of a tile pair identical to the LayerNorm'd operand-fragment layout: lane (r16, g) holds columns
 // 32 q + 8 g + [0, 8) of row r16), LayerNorm statistics are taken from the accumulators, and the epilogue only stores:
 // x crosses HBM once in each direction (203 MB per launch at M = 65 536 instead of the 340 MB measured for the
 // load - LayerNorm - ... - reload - add - store form, profiles/r01_pmc_hbm_traffic.md).
-template <int E, int VARIANT = 0, bool RESIDENT = false>
+template <int E, bool RESIDENT = false>
 __global__ __launch_bounds__(256, 1)
 void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                       const bf16_t* __restrict__ W1, const float* __restrict__ b1, const bf16_t* __restrict__ W2,
-                      const float* __restrict__ b2, int M, unsigned long long* __restrict__ dbg = nullptr) {
+                      const float* __restrict__ b2, int M) {
     constexpr int F = 4 * E;                  // hidden width
     constexpr int KSTEPS = E / 32;            // MFMA k-steps over E
     constexpr int KS1 = E / 128;              // W1 ring slots per chunk: slot t holds k-stages 2t (LDS rows 0-63) and 2t+1 (rows 64-127)
@@ -72,12 +72,6 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     const int rr = lane & 15, g = lane >> 4;
     const bool lo_half = rr < 8;
     const int m0 = blockIdx.x * MLP_BM;
-    // VARIANT 6: phase time stamps (s_memtime) of workgroups 0 and 300, lane 0 of every wave -> dbg[(blk * 4 + wave) * 64 + k]
-    const bool stamp = (VARIANT == 6) && dbg && (blockIdx.x == 0 || blockIdx.x == 300) && lane == 0;
-    unsigned long long* dslot = dbg + ((blockIdx.x == 0 ? 0 : 1) * 4 + wid) * 64;
-    int nstamp = 0;
-#define MLP_STAMP() do { if (VARIANT == 6) { if (stamp) dslot[nstamp] = __builtin_amdgcn_s_memtime(); ++nstamp; } } while (0)
-    MLP_STAMP();
 
     // ---- weight stream -----------------------------------------------------------------------------------------------
     // ring slot contents for stage s = (chunk c = s / SPC, t = s % SPC), always 128 LDS rows x 128 bytes:
@@ -153,11 +147,6 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     // (coalesced 8-lanes-per-row loads + half-row swap, see encoder_panel.h)
     bf16x8 afrag[2][KSTEPS];
     f32x4 acc2[NG * 8][2];       // fc2 accumulators, 128 x E fp32 per workgroup; RESIDENT: initialised with x itself
-    if constexpr (VARIANT == 5) {
-        const bf16x8 f = *reinterpret_cast<const bf16x8*>(W1 + lane * 8);
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) { afrag[0][ks] = f; afrag[1][ks] = f; }
-    } else
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         float4 xa[KSTEPS], xb[KSTEPS];
@@ -203,9 +192,8 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
         }
     }
 
-    MLP_STAMP();      // 1: LayerNorm prologue done
     // ---- main loop ---------------------------------------------------------------------------------------------------
-    if constexpr (!RESIDENT || VARIANT == 5) {
+    if constexpr (!RESIDENT) {
 #pragma unroll
         for (int i = 0; i < NG * 8; ++i) { acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
@@ -214,7 +202,6 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     const int so0 = (g ^ sx) * 16, so1 = ((4 + g) ^ sx) * 16;
 
     for (int c = 0; c < NCH; ++c) {
-        if (c == 1 || c == 2 || c == NCH - 1) MLP_STAMP();     // 2,3: chunk boundaries; 4: start of last chunk
         f32x4 acc1[4][2];
         bf16x8 hfrag[2][2];
 #pragma unroll
@@ -222,9 +209,6 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
         static_for<0, SPC>([&](auto tc) {
             constexpr int t = decltype(tc)::value;
             const int s = c * SPC + t;
-#ifdef MLP_FINE_STAMPS
-            if (c < 2) MLP_STAMP();
-#endif
             // Issue schedule of the weight stream (per chunk c, for chunk c + 1's six stages; slot = stage index & 7):
             //   A: stages (c+1, 0..3) in the GELU gap of chunk c   (their slots held stages (c-1,4), (c-1,5), (c,0), (c,1))
             //   B: stage  (c+1, 4) at the start of stage (c, 4)    (slot of (c, 2))
@@ -233,7 +217,7 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
             // VALU-only gap (MI355X_MICROARCH.md, per-instruction table), so two thirds of them sit behind the GELU.
             // Stage s has landed for this wave once at most 4 x (stages issued after it) loads are outstanding:
             //   t = 0: 5   1: 4   2: 3   3: 6   4: 5   5: 5     (last chunk: 5 4 3 2 1 0, nothing is issued any more)
-            if constexpr (VARIANT != 4) {
+            {
                 const bool last = c == NCH - 1;
                 if constexpr (t == 0) wait_vmcnt<20>();
                 else if constexpr (t == 1) wait_vmcnt<16>();
@@ -243,13 +227,13 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
                 else { if (last) wait_vmcnt<0>(); else wait_vmcnt<20>(); }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if constexpr (VARIANT != 4) __builtin_amdgcn_s_barrier();   // stage s complete in LDS for everyone; the slot of stage s-1 is free
+            __builtin_amdgcn_s_barrier();   // stage s complete in LDS for everyone; the slot of stage s-1 is free
             asm volatile("" ::: "memory");
-            if constexpr (VARIANT != 1 && (t == 4 || t == 5)) {
+            if constexpr (t == 4 || t == 5) {
                 if (c + 1 < NCH) issue_stage(c + 1, t, (s + SPC) & (MLP_NST - 1));
             }
             const unsigned char* st = ring + (s & (MLP_NST - 1)) * MLP_STAGE_BYTES + frag_off;
-            if constexpr (VARIANT != 3) {
+            {
             bf16x8 wf0[8], wf1[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) wf0[i] = *reinterpret_cast<const bf16x8*>(st + i * 2048 + so0);
@@ -300,27 +284,19 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
                         bf16x8 f;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            if constexpr (VARIANT == 2) {
-                                f[r] = static_cast<bf16_t>(acc1[2 * pr][j][r] + bp[r]);
-                                f[4 + r] = static_cast<bf16_t>(acc1[2 * pr + 1][j][r] + bp[4 + r]);
-                            } else {
-                                f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
-                                f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
-                            }
+                            f[r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr][j][r] + bp[r]));
+                            f[4 + r] = static_cast<bf16_t>(gelu_poly(acc1[2 * pr + 1][j][r] + bp[4 + r]));
                         }
                         hfrag[j][pr] = f;
                     }
-                if constexpr (VARIANT != 1) {
-                    if (c + 1 < NCH) {
+                if (c + 1 < NCH) {
 #pragma unroll
-                        for (int tn = 0; tn < 4; ++tn) issue_stage(c + 1, tn, ((c + 1) * SPC + tn) & (MLP_NST - 1));
-                    }
+                    for (int tn = 0; tn < 4; ++tn) issue_stage(c + 1, tn, ((c + 1) * SPC + tn) & (MLP_NST - 1));
                 }
             }
         });
     }
 
-    MLP_STAMP();      // 5: main loop done
     // ---- epilogue: x += acc2 + b2  (fp32, in place; 8 lanes per row via the half-row swap) --------------------------
     // lane (r16, g), row tile j, 32-column group q32 (tile pair): columns cg = 32 q32 + 8 g + [0, 8) as piece A = [0,4), B = [4,8)
     // All old x values of a row tile are requested before the first store (the compiler cannot hoist a load above a store
@@ -328,7 +304,7 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
     // Row tile 1's old values are requested piece by piece while row tile 0 is being stored (each load right after the
     // piece of tile 0 whose registers it takes over): requested only after tile 0's 24 stores they would return behind all of
     // them (vector memory is in order), requested all up front they do not fit (44 spills, measured slower).
-    if constexpr (RESIDENT && VARIANT != 5) {
+    if constexpr (RESIDENT) {
         // the accumulators already contain x: add b2, regroup to 8 lanes per row (half-row swap) and store whole 128-byte lines
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -404,18 +380,16 @@ void fused_mlp_kernel(float* __restrict__ x, const float* __restrict__ gamma, co
         }
     }
     }
-    MLP_STAMP();      // 6: epilogue done
-#undef MLP_STAMP
 }
 
-template <int E, int VARIANT = 0, bool RESIDENT = false>
+template <int E, bool RESIDENT = false>
 inline hipError_t launch_fused_mlp(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1,
-                                   const float* b1, const bf16_t* W2, const float* b2, int M, unsigned long long* dbg = nullptr) {
+                                   const float* b1, const bf16_t* W2, const float* b2, int M) {
     const size_t lds = (size_t)MLP_NST * MLP_STAGE_BYTES + (size_t)(7 * E) * sizeof(float);     // ring | b1 | b2 | gamma | beta
-    auto kern = fused_mlp_kernel<E, VARIANT, RESIDENT>;
+    auto kern = fused_mlp_kernel<E, RESIDENT>;
     static LdsAttr attr;                // one per template instantiation
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((M + MLP_BM - 1) / MLP_BM), dim3(256), lds, s, x, gamma, beta, eps, W1, b1, W2, b2, M, dbg);
+    hipLaunchKernelGGL(kern, dim3((M + MLP_BM - 1) / MLP_BM), dim3(256), lds, s, x, gamma, beta, eps, W1, b1, W2, b2, M);
     return hipGetLastError();
 }
 

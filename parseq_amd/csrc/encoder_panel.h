@@ -91,9 +91,9 @@ __device__ __forceinline__ u32x4 swap_half_rows(const u32x4& v) {
 #endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// VARIANT (tools/panel_bench.py ablations): 0 full kernel; 1 no global stores; 2 no LayerNorm prologue (A fragments from
-// one load); 3 no MFMAs / LDS reads (stream + epilogue only); 4 no W stream waits (compute on whatever is in LDS).
-template <int E, typename Epi, int VARIANT = 0>
+// (Ablation variants — no stores, no LayerNorm prologue, no MFMAs, no stream waits: profiles/r01_panel_ablation.log — live on the
+// branch `ablation-variants-r3`.)
+template <int E, typename Epi>
 __global__ __launch_bounds__(256, 2)
 void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                           float eps, const bf16_t* __restrict__ W, const float* __restrict__ bias, int M, int N,
@@ -145,21 +145,11 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
     for (int i = tid; i < N; i += 256) sbias[i] = bias[i];     // before the DMA prefetch (ordinary loads behind it drain it)
     // the first three weight stages are requested right after row tile 0's activation loads (below): vector memory returns in
     // order, so activation rows queued behind twelve LDS-DMA copies would wait for all of them before the LayerNorm can start
-    if constexpr (VARIANT == 2) {
-        issue_stage(0);
-        if (S > 1) issue_stage(1);
-        if (S > 2) issue_stage(2);
-    }
 
     // ---- A panel: LayerNorm'd rows of this wave as MFMA fragments in registers --------------------------------------
     // lane (r16, g) of row tile j holds row m0 + 32 wid + 16 j + r16, elements [32 ks + 8 g, +8) for every k-step ks.
     bf16x8 afrag[2][KSTEPS];
     const bool lo_half = rr < 8;
-    if constexpr (VARIANT == 2) {
-        const bf16x8 f = *reinterpret_cast<const bf16x8*>(W + lane * 8);
-#pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) { afrag[0][ks] = f; afrag[1][ks] = f; }
-    }
     // ONE pass over x, fully coalesced: per k-step (128 bytes of a row) the 8 lanes {(r16 & 7, g), ((r16 & 7) + 8, g)}
     // read the 8 consecutive 16-byte pieces of ONE row — lanes r16 < 8 the even pieces 2g, lanes >= 8 the odd pieces
     // 2g+1 — first for rows 0-7, then for rows 8-15; a DPP half-row swap then gives every lane both pieces of its own
@@ -220,7 +210,7 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
             afrag[j][ks] = f;
         }
     };
-    if constexpr (VARIANT != 2) {
+    {
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using KE = std::integral_constant<int, PN_EARLY>; using KA = std::integral_constant<int, KSTEPS>;
         load_rows(I0{}, I0{}, KA{});
@@ -239,7 +229,7 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
     // ---- main loop over the W stream ---------------------------------------------------------------------------------
     f32x4 acc[8][2];
     // store instructions this wave issues per column tile (a row tile entirely past M issues none: exec == 0 is branched over)
-    const int st_per_tile = (VARIANT == 1) ? 0 : 2 * ((m0 + wid * 32 < M) + (m0 + wid * 32 + 8 < M) + (m0 + wid * 32 + 16 < M) + (m0 + wid * 32 + 24 < M));
+    const int st_per_tile = 2 * ((m0 + wid * 32 < M) + (m0 + wid * 32 + 8 < M) + (m0 + wid * 32 + 16 < M) + (m0 + wid * 32 + 24 < M));
     const int sx = rr & 7;
     const int frag_off = rr * 128;
     for (int nt = 0; nt < ntiles; ++nt) {
@@ -249,7 +239,7 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
         for (int kt = 0; kt < KS; ++kt) {
             const int s = nt * KS + kt;
             // stage s has landed for this wave once <= 4 * min(2, S-1-s) VMEM ops are outstanding (see header)
-            if constexpr (VARIANT != 4) {
+            {
                 // stores of the previous tile that are younger than stage s's loads: 4 per row tile this wave really stored
                 const int stp = ((kt <= 2) && (nt > 0)) ? st_per_tile : 0;
                 const int rem = S - 1 - s;
@@ -263,7 +253,7 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
             asm volatile("" ::: "memory");
             if (s + 3 < S) issue_stage(s + 3);
             const unsigned char* st = ring + (s & (PN_NST - 1)) * PN_STAGE_BYTES + frag_off;
-            if constexpr (VARIANT != 3) {
+            {
                 // all 16 W fragments of the stage: 8 requested up front, the 8 of the second k-step one per MFMA pair
                 // (pinned with sched_group_barrier: LLVM otherwise serialises 2 reads -> wait -> 4 MFMAs)
                 const int so0 = (g ^ sx) * 16, so1 = ((4 + g) ^ sx) * 16;
@@ -328,23 +318,18 @@ void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__
                 const int col = nq + (lo ? 8 * g : 32 + 8 * g);
                 const int r_first = mrow + (rr & 7), r_second = r_first + 8;
                 const u32x4 first = lo ? pa : got, second = lo ? got : pb;
-                if constexpr (VARIANT == 1) {
-                    asm volatile("" ::"v"(first[0]), "v"(first[3]), "v"(second[0]), "v"(second[3]));
-                    if (mrow < -5) epi.template store_piece<E>(r_first, col, first);
-                } else {
-                    if (r_first < M) epi.template store_piece<E>(r_first, col, first);
-                    if (r_second < M) epi.template store_piece<E>(r_second, col, second);
-                }
+                if (r_first < M) epi.template store_piece<E>(r_first, col, first);
+                if (r_second < M) epi.template store_piece<E>(r_second, col, second);
             }
         }
     }
 }
 
-template <int E, typename Epi, int VARIANT = 0>
+template <int E, typename Epi>
 inline hipError_t launch_ln_panel_gemm(hipStream_t s, const float* x, const float* gamma, const float* beta, float eps,
                                        const bf16_t* W, const float* bias, int M, int N, const Epi& epi) {
     const size_t lds = (size_t)PN_NST * PN_STAGE_BYTES + (size_t)N * sizeof(float);
-    auto kern = ln_panel_gemm_kernel<E, Epi, VARIANT>;
+    auto kern = ln_panel_gemm_kernel<E, Epi>;
     static LdsAttr attr;                // one per template instantiation
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((M + PN_BM - 1) / PN_BM), dim3(256), lds, s, x, gamma, beta, eps, W, bias, M, N, epi);

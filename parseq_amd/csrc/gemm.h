@@ -29,12 +29,9 @@
 
 #include "common.h"
 
-#ifndef PQ_DIAG_X3
-#define PQ_DIAG_X3 0     // bf16x3 co-residency defect hunt (tools/x3_diag2.py); see PQ_LSTORE
-#endif
-#ifndef PQ_PAIRS_RING
-#define PQ_PAIRS_RING 2   // LDS stages of the pre-split (PAIRS) GEMM loop: 2 = the two-buffer direct-to-LDS loop, two workgroups per CU (default); 4 = a counted-vmcnt ring, one workgroup per CU — measured slower (qkv 254 -> 305 us, fc1 347 -> 430, fc2 233 -> 261)
-#endif
+// (Removed, kept on the branch `ablation-variants-r3`: the four-stage counted-vmcnt ring of the pre-split (PAIRS) loop — one workgroup
+// per CU, measured slower than two buffers x two workgroups: qkv 254 -> 305 us, fc1 347 -> 430, fc2 233 -> 261 — and the diagnostic
+// builds of the bf16x3 co-residency defect hunt, tools/x3_diag2.py.)
 
 namespace pq {
 
@@ -496,65 +493,7 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
         }
         const int g4 = lane >> 4, sx = frow & 7;
         const int a_off = (wm * (BM / WM) + frow) * KB, w_off = (wn * (BN / WN) + frow) * KB;
-#ifndef PQ_PAIRS_RING
-#define PQ_PAIRS_RING 2
-#endif
-        if constexpr (PAIRS && PQ_PAIRS_RING > 2) {
-            // ---- pre-split operands: a ring of four 32 KiB stages, stage kt + 3 issued while stage kt is multiplied, counted vmcnt, one raw
-            // barrier per k-step.  One k-step is only 48 MFMAs per wave (0.35 us) against ~1 us from issue to landing: with two buffers every
-            // k-step waited for its own data (the second workgroup on the CU hid half of that); 128 KiB of LDS means one workgroup per CU.
-            constexpr int NB = PQ_PAIRS_RING, PCS = A_LI + W_LI;
-            unsigned char* As4 = smem;
-            unsigned char* Ws4 = smem + NB * BM * KB;
-#define PQ_DLOAD4(buf, k0)                                                                                                 \
-            {                                                                                                              \
-                _Pragma("unroll") for (int it = 0; it < A_LI; ++it)                                                        \
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[it] + (k0)),    \
-                        (__attribute__((address_space(3))) void*)(As4 + (buf) * BM * KB + (wu * A_LI + it) * 1024), 16, 0, 0); \
-                _Pragma("unroll") for (int it = 0; it < W_LI; ++it)                                                        \
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[it] + (k0)),    \
-                        (__attribute__((address_space(3))) void*)(Ws4 + (buf) * BN * KB + (wu * W_LI + it) * 1024), 16, 0, 0); \
-            }
-            for (int st = 0; st < NB - 1 && st < nk; ++st) PQ_DLOAD4(st, st * BK)
-            for (int kt = 0; kt < nk; ++kt) {
-                const int ahead = nk - 1 - kt;                       // stages issued beyond kt: min(ahead, NB - 2)
-                if (ahead >= NB - 2) wait_vmcnt<(NB - 2) * PCS>();
-                else if (ahead == 1) wait_vmcnt<PCS>();
-                else wait_vmcnt<0>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                        // stage kt landed for everyone; stage kt - 1's buffer retired
-                asm volatile("" ::: "memory");
-                if (kt + NB - 1 < nk) PQ_DLOAD4((kt + NB - 1) % NB, (kt + NB - 1) * BK)
-                const unsigned char* Ab = As4 + (kt % NB) * BM * KB + a_off;
-                const unsigned char* Wb = Ws4 + (kt % NB) * BN * KB + w_off;
-                const unsigned char* Pb = tr ? Ab : Wb;
-                const unsigned char* Qb = tr ? Wb : Ab;
-                const int so_h = (g4 ^ sx) * 16, so_l = ((4 + g4) ^ sx) * 16;
-                Frag<T> ph[TM], pl[TM], qh[TN], ql[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    ph[i].v = *reinterpret_cast<const decltype(ph[i].v)*>(Pb + i * 16 * KB + so_h);
-                    pl[i].v = *reinterpret_cast<const decltype(pl[i].v)*>(Pb + i * 16 * KB + so_l);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    qh[j].v = *reinterpret_cast<const decltype(qh[j].v)*>(Qb + j * 16 * KB + so_h);
-                    ql[j].v = *reinterpret_cast<const decltype(ql[j].v)*>(Qb + j * 16 * KB + so_l);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        mma16(acc[i][j], pl[i], qh[j]);          // small terms first
-                        mma16(acc[i][j], ph[i], ql[j]);
-                        mma16(acc[i][j], ph[i], qh[j]);
-                    }
-            }
-#undef PQ_DLOAD4
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                            // every wave has read the last stage: the ring becomes the epilogue's staging tile
-            asm volatile("" ::: "memory");
-        } else {
+        {
         PQ_DLOAD(0, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -640,12 +579,8 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
             rw[it] = *reinterpret_cast<const u32x4*>(W + (size_t)w_row[it] * ldw + (k_ < K ? k_ : klast)); \
         }                                                                                             \
     }
-#if 0
-#define PQ_DIAG_X3_DOC 0 /* bf16x3 co-residency defect hunt (tools/x3_diag2.py): 1 drain VMEM before the stage's LDS stores, 2 two volatile 8-byte stores instead of a mergeable pair, 4 wait states between the converts and the stores, 8 LayerNorm loader without packed f32 math */
-#endif
 #define PQ_LSTORE(buf, k0)                                                                                             \
     {                                                                                                                  \
-        if constexpr (SPLIT && PQ_DIAG_X3 == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       \
         _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                                          \
             const int c_ = it * NT + tid, k_ = (k0) + a_col[it];                                                       \
             const u32x4 v0_ = aload.finish(ra[it], a_row[it], k_ < K ? k_ : klast);                                    \
@@ -654,14 +589,8 @@ void gemm_kernel(const ALoad aload_, const T* __restrict__ W, int ldw, int M, in
                 uint2 hi_, lo_;                                                                                        \
                 split4(v_, hi_, lo_);                                                                                  \
                 unsigned char* d_ = As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + ((c_ % CPR) >> 3) * 128 + ((c_ % CPR) & 7) * 8; \
-                if constexpr (PQ_DIAG_X3 == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(hi_.x), "+v"(hi_.y), "+v"(lo_.x), "+v"(lo_.y)); \
-                if constexpr (PQ_DIAG_X3 == 2) {                                                                       \
-                    *reinterpret_cast<volatile unsigned long long*>(d_) = (unsigned long long)hi_.x | ((unsigned long long)hi_.y << 32);      \
-                    *reinterpret_cast<volatile unsigned long long*>(d_ + 64) = (unsigned long long)lo_.x | ((unsigned long long)lo_.y << 32); \
-                } else {                                                                                               \
-                    *reinterpret_cast<uint2*>(d_) = hi_;                                                               \
-                    *reinterpret_cast<uint2*>(d_ + 64) = lo_;                                                          \
-                }                                                                                                      \
+                *reinterpret_cast<uint2*>(d_) = hi_;                                                                   \
+                *reinterpret_cast<uint2*>(d_ + 64) = lo_;                                                              \
             } else {                                                                                                   \
                 *reinterpret_cast<u32x4*>(As + ((buf) * BM + c_ / CPR) * GEMM_ROWB + (c_ % CPR) * 16) = v_;             \
             }                                                                                                          \
@@ -807,9 +736,7 @@ template <int BM, int BN, int WM, int WN, typename Epi>
 inline hipError_t launch_gemm_pairs(hipStream_t s, const bf16_t* A, int lda, const bf16_t* W, int ldw, int M, int N, int K, const Epi& epi) {
     const int mtiles = (M + BM - 1) / BM, ntiles = (N + BN - 1) / BN;
     const int grid = ((mtiles + 7) / 8) * 8 * ntiles;
-    constexpr size_t ring = PQ_PAIRS_RING > 2 ? (size_t)PQ_PAIRS_RING * (BM + BN) * 128 : 0;
-    constexpr size_t lds2 = gemm_lds_bytes<BM, BN, 128, 2, 0, (int)sizeof(typename Epi::S)>();
-    constexpr size_t lds = ring > lds2 ? ring : lds2;
+    constexpr size_t lds = gemm_lds_bytes<BM, BN, 128, 2, 0, (int)sizeof(typename Epi::S)>();
     if (K % 64) return hipErrorInvalidValue;
     auto kd = gemm_kernel<bf16_t, BM, BN, WM, WN, 128, 2, true, ARowMajor<bf16_t>, Epi, false, true>;
     if (lds > 64 * 1024) {

@@ -314,7 +314,6 @@ __global__ void insert_cls_kernel(const float* __restrict__ xp, const float* __r
     reinterpret_cast<float4*>(x)[i4] = v;
 }
 
-constexpr int PQ_MAX_CHAINS = 8;
 struct parseq_plan {
     parseq_model* m = nullptr;
     int max_batch = 0;
@@ -340,16 +339,7 @@ struct parseq_plan {
     unsigned char* eos_seen = nullptr;
     unsigned char* cloze = nullptr;  // [npos][LDT]
     unsigned char* qmask_user = nullptr;  // [npos][LDT] staging for parseq_decode_logits
-    int* counters = nullptr;       // per AR chain k: [2k] eos_rows, [2k + 1] ar_len
-    // AR decoding in sub-batches ("chains"): the fused AR step kernels are latency-bound chains of small launches that use a few
-    // dozen CUs each, so several independent sub-batches of the images CAN run their 26-step loops concurrently on side streams
-    // (fork after the encoder, join before the refinement; PARSEQ_AR_CHAINS=n).  Measured on MI355X at batch 512 this is a loss —
-    // 88.1 / 86.5 / 70.0 / 56.2 k images/s one forward at a time with 1 / 2 / 4 / 8 chains (profiles/r02_ar_chains_sweep.log):
-    // launches from several HIP streams are not dispatched concurrently enough to overlap 20-microsecond kernels, they add
-    // cross-queue dependency latency to every one of them — so the default is ONE chain; the mechanism stays as a tested option.
-    int ar_chains = 1;
-    hipStream_t chain_stream[PQ_MAX_CHAINS - 1] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[PQ_MAX_CHAINS - 1] = {};
+    int* counters = nullptr;       // [0] rows that have seen an EOS, [1] step at which the reference would have stopped (ar_len)
     int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
     int num_cus = 256;             // compute units of the device (tail-round avoidance of the one- and two-workgroup-per-CU kernels)
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
@@ -675,12 +665,6 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->blocks_dev = reinterpret_cast<EncBlockParams*>(a + o_blocks);
     p->posb = reinterpret_cast<float*>(a + o_posb);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
-    if (const char* e_ = getenv("PARSEQ_AR_CHAINS")) p->ar_chains = std::min(std::max(atoi(e_), 1), PQ_MAX_CHAINS);
-    bool ok_ = hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; ok_ && k < PQ_MAX_CHAINS - 1; ++k)
-        ok_ = hipStreamCreateWithFlags(&p->chain_stream[k], hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming) == hipSuccess;
-    if (!ok_) p->ar_chains = 1;                  // no side streams: single chain on the caller's stream
     int r = pack_weights(p, (hipStream_t)stream);
     if (r != 0) { parseq_plan_destroy(p); return r; }
     *out = p;
@@ -696,11 +680,6 @@ extern "C" int parseq_plan_refresh(parseq_plan* p, void* stream) {
 extern "C" void parseq_plan_destroy(parseq_plan* p) {
     if (!p) return;
     DevGuard dg(p->m->device);
-    for (int k = 0; k < PQ_MAX_CHAINS - 1; ++k) {
-        if (p->chain_stream[k]) { (void)hipStreamSynchronize(p->chain_stream[k]); (void)hipStreamDestroy(p->chain_stream[k]); }
-        if (p->ev_join[k]) (void)hipEventDestroy(p->ev_join[k]);
-    }
-    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->arena) (void)hipFree(p->arena);
     delete p;
 }
@@ -936,7 +915,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             if constexpr (kBf16) {
                 ProfScope ps_(&p->prof, T_MLP, s);
                 if (p->mlp_resident)
-                    HIPCHK((launch_fused_mlp<384, 0, true>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
+                    HIPCHK((launch_fused_mlp<384, true>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
                                                            m->p(b + "mlp.fc1.bias"), W.w(b + "mlp.fc2.weight"), m->p(b + "mlp.fc2.bias"), Mm)));
                 else
                 HIPCHK((launch_fused_mlp<384>(s, p->x, m->p(b + "norm2.weight"), m->p(b + "norm2.bias"), c.enc_ln_eps, W.w(b + "mlp.fc1.weight"),
@@ -1029,11 +1008,10 @@ extern "C" int parseq_encode(parseq_plan* p, const void* images, int images_dtyp
 // Cross-attention of Lq queries per image against the plan's cached memory K / V: tuned kernels for 128 memory tokens
 // (streaming AR kernel, MFMA multi-query kernel), the key-count-generic kernel otherwise.
 template <typename T, int E>
-static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca, int b0 = 0) {
-    // b0: first image of a sub-batch (AR chains); `ca` is the caller's (already offset) output, q and the memory K / V are offset here
+static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca) {
     const int H = p->m->cfg.dec_heads, NK = p->m->tokens;
-    const T* kmem = reinterpret_cast<const T*>(p->kmem) + (size_t)b0 * NK * E; const T* vmem = reinterpret_cast<const T*>(p->vmem) + (size_t)b0 * NK * E;
-    const float* qc_ = p->qc + (size_t)b0 * Lq * E;
+    const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
+    const float* qc_ = p->qc;
     if (NK != 128) {
         if constexpr (sizeof(T) == 2) {
             const int nt16 = (NK + 15) / 16;
@@ -1189,22 +1167,19 @@ static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int
 // storage; E <= 384): step i's logits are produced by the mid kernel of step i + 1 (and by one trailing finish-only launch after
 // the last step).
 template <int E, bool X3 = false>
-static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chain, int num_steps, float* logits_all, bool testing) {
-    // images [b0, b0 + Bc) of the batch: every per-row buffer is offset to the sub-batch, the counters are the chain's own
+static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing) {
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
-    const int M = Bc, C = m->classes, npos = c.max_label_length + 1;
+    const int M = B, C = m->classes, npos = c.max_label_length + 1;
     const std::string d = "decoder.layers.0.";
-    int* eos_rows = p->counters + 2 * chain; int* ar_len = p->counters + 2 * chain + 1;
+    int* eos_rows = p->counters; int* ar_len = p->counters + 1;
     using TS = typename std::conditional<X3, float, bf16_t>::type;      // storage type of kvtab, the memory K / V and ca
-    TS* ca = reinterpret_cast<TS*>(p->ca) + (size_t)b0 * E;
-    // linear2 partial sums [ds_split][M][E] f32 (the generic path's MLP hidden buffer is idle here): one region per chain
-    float* partial = reinterpret_cast<float*>(p->hdn) + (size_t)ds_split<E>() * b0 * E;
-    float* tq = p->qc + (size_t)b0 * E;                                   // t' lives in the q-projection buffer once the cross-attention has consumed it
-    float* t = p->t + (size_t)b0 * E;
-    int* tok = p->tok + (size_t)b0 * LDT;
-    unsigned char* eos_seen = p->eos_seen + b0;
-    float* logits = logits_all + (size_t)b0 * num_steps * C;
+    TS* ca = reinterpret_cast<TS*>(p->ca);
+    float* partial = reinterpret_cast<float*>(p->hdn);                    // linear2 partial sums [ds_split][M][E] f32 (the generic path's MLP hidden buffer is idle here)
+    float* tq = p->qc;                                                    // t' lives in the q-projection buffer once the cross-attention has consumed it
+    float* t = p->t;
+    int* tok = p->tok;
+    unsigned char* eos_seen = p->eos_seen;
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
     static LdsAttr attr_mid, attr_mlp;
@@ -1227,7 +1202,7 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chai
         if (!do_start) break;
         {
             ProfScope ps_(&p->prof, T_DEC_CA, s);
-            CHK((run_cross_attention<TS, E>(p, s, Bc, 1, scale, ca, b0)));
+            CHK((run_cross_attention<TS, E>(p, s, B, 1, scale, ca)));
         }
         {
             ProfScope ps_(&p->prof, T_DEC_POST, s);
@@ -1240,30 +1215,6 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int b0, int Bc, int chai
     return 0;
 }
 
-// The fused AR loop over the whole batch as `chains` concurrent sub-batch loops: chain 0 on the caller's stream, the others on the
-// plan's side streams between a fork event (the encoder and the memory K / V projection are done) and join events.
-template <int E, bool X3 = false>
-static int ar_loop_chains(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing, int* chains_used) {
-    int chains = std::min(p->ar_chains, std::max(1, B / 64));                 // at least 64 images (4 row tiles) per chain
-    if (p->prof.enabled) chains = 1;                                          // per-family event timing brackets one stream
-    const int tiles = (B + DS_ROWS - 1) / DS_ROWS, per = (tiles + chains - 1) / chains * DS_ROWS;
-    chains = (B + per - 1) / per;
-    *chains_used = chains;
-    if (chains > 1) {
-        HIPCHK(hipEventRecord(p->ev_fork, s));
-        for (int k = 1; k < chains; ++k) HIPCHK(hipStreamWaitEvent(p->chain_stream[k - 1], p->ev_fork, 0));
-    }
-    for (int k = 0; k < chains; ++k) {
-        const int b0 = k * per, bc = std::min(per, B - b0);
-        CHK((ar_loop_fused<E, X3>(p, k == 0 ? s : p->chain_stream[k - 1], b0, bc, k, num_steps, logits, testing)));
-    }
-    for (int k = 1; k < chains; ++k) {
-        HIPCHK(hipEventRecord(p->ev_join[k - 1], p->chain_stream[k - 1]));
-        HIPCHK(hipStreamWaitEvent(s, p->ev_join[k - 1], 0));
-    }
-    return 0;
-}
-
 template <typename T>
 static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int num_steps, float* logits, int* out_len, hipStream_t s) {
     const parseq_model* m = p->m;
@@ -1271,23 +1222,22 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     const int C = m->classes;
     const bool ar = flags & PARSEQ_FLAG_DECODE_AR, testing = flags & PARSEQ_FLAG_TESTING;
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
-    int chains_used = 1;
-    hipLaunchKernelGGL(ar_init_kernel, dim3((B * LDT + 255) / 256), dim3(256), 0, s, p->tok, LDT, B, c.bos_id, c.pad_id, p->eos_seen, p->counters, 2 * PQ_MAX_CHAINS, num_steps);
+    hipLaunchKernelGGL(ar_init_kernel, dim3((B * LDT + 255) / 256), dim3(256), 0, s, p->tok, LDT, B, c.bos_id, c.pad_id, p->eos_seen, p->counters, 2, num_steps);
     HIPCHK(hipGetLastError());
     if (ar) {
         // model.py:119-147.  All num_steps steps are always run (no per-step host sync); the step at which the reference
         // would have stopped is recorded on the device and only truncates the returned view.
         bool done = false;
         if constexpr (sizeof(T) == 2) {
-            if (p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4 && !getenv("PARSEQ_STEP_PREPOST")) {
-                if (c.embed_dim == 384) { CHK((ar_loop_chains<384>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
-                else if (c.embed_dim == 192) { CHK((ar_loop_chains<192>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
+            if (p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4) {
+                if (c.embed_dim == 384) { CHK((ar_loop_fused<384>(p, s, B, num_steps, logits, testing))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192>(p, s, B, num_steps, logits, testing))); done = true; }
             }
         } else {
             // bf16x3: the same fused step on bf16 pairs (f32 tables, f32 memory K / V); the fp32 mode keeps the per-op kernels
             if (p->precision == PARSEQ_BF16X3 && p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4) {
-                if (c.embed_dim == 384) { CHK((ar_loop_chains<384, true>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
-                else if (c.embed_dim == 192) { CHK((ar_loop_chains<192, true>(p, s, B, num_steps, logits, testing, &chains_used))); done = true; }
+                if (c.embed_dim == 384) { CHK((ar_loop_fused<384, true>(p, s, B, num_steps, logits, testing))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192, true>(p, s, B, num_steps, logits, testing))); done = true; }
             }
         }
         for (int i = 0; !done && i < num_steps; ++i) {
@@ -1309,13 +1259,12 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     }
     int L = num_steps;
     if (ar && testing && refine_iters == 0) {
-        // the reference stops after the first step at which EVERY row holds an EOS: each chain recorded that step for its own rows
-        // (num_steps if it never happened), the batch-level length is the maximum (the condition is monotone in the step)
-        int cnt[2 * PQ_MAX_CHAINS];
-        HIPCHK(hipMemcpyAsync(cnt, p->counters, sizeof(int) * 2 * chains_used, hipMemcpyDeviceToHost, s));
+        // the reference stops after the first step at which EVERY row holds an EOS: the device recorded that step (num_steps if it
+        // never happened)
+        int cnt[2];
+        HIPCHK(hipMemcpyAsync(cnt, p->counters, sizeof(cnt), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        L = 0;
-        for (int k = 0; k < chains_used; ++k) L = std::max(L, cnt[2 * k + 1]);
+        L = cnt[1];
     }
     if (out_len) *out_len = L;
     return 0;
@@ -2140,20 +2089,9 @@ extern "C" int parseq_op_mlp_variant(float* x, const float* gamma, const float* 
     CHK(check_arch());
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
-        case 0: HIPCHK((launch_fused_mlp<384, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
-        case 1: HIPCHK((launch_fused_mlp<384, 1>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
-        case 2: HIPCHK((launch_fused_mlp<384, 2>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
-        case 3: HIPCHK((launch_fused_mlp<384, 3>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
-        case 4: HIPCHK((launch_fused_mlp<384, 4>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
-        case 5: HIPCHK((launch_fused_mlp<384, 5>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;
-        case 10: HIPCHK((launch_fused_mlp<384, 0, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;   // x resident in the accumulators
-        case 11: HIPCHK((launch_mlp_branch<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;            // shared-phase form (encoder_blocks.h)
-        case 16: {  // stamps of the resident form
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
-            HIPCHK((launch_fused_mlp<384, 6, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }
-        case 6: {   // phase time stamps: the LAST 4096 bytes of x's allocation are not touched (caller passes M smaller than the buffer)
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
-            HIPCHK((launch_fused_mlp<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M, dbg))); break; }
+        case 0: HIPCHK((launch_fused_mlp<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;             // x re-read by the epilogue
+        case 10: HIPCHK((launch_fused_mlp<384, true>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;      // x resident in the accumulators
+        case 11: HIPCHK((launch_mlp_branch<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W1, b1, (const bf16_t*)W2, b2, M))); break;           // shared-phase form (encoder_blocks.h)
         default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
     }
     return 0;
@@ -2165,11 +2103,8 @@ extern "C" int parseq_op_attn_fused(float* x, const float* gamma, const float* b
     if (!x || !gamma || !beta || !Wqkv || !bqkv || !Wproj || !bproj || M <= 0 || (M % 128)) return fail(PARSEQ_E_INVALID, "bad argument (M must be a multiple of 128: whole images)");
     hipStream_t s = (hipStream_t)stream;
     switch (variant) {
-        case 0: HIPCHK((launch_fused_attn<384, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M))); break;
+        case 0: HIPCHK((launch_fused_attn<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M))); break;
         case 1: HIPCHK((launch_attn_branch<384>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M))); break;   // shared-phase form (encoder_blocks.h)
-        case 6: {   // phase time stamps behind the matrix (see parseq_op_mlp_variant)
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(x + (size_t)M * 384);
-            HIPCHK((launch_fused_attn<384, 6>(s, x, gamma, beta, 1e-6f, (const bf16_t*)Wqkv, bqkv, (const bf16_t*)Wproj, bproj, M, dbg))); break; }
         default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
     }
     return 0;
@@ -2287,21 +2222,15 @@ extern "C" int parseq_op_enc_blocks_x3(float* x, const float* master, const void
     return 0;
 }
 
-// LayerNorm + Linear + GELU through the panel kernel (E = 384), with ablation variants for tools/panel_bench.py.
+// LayerNorm + Linear + GELU through the panel kernel (E = 384); `variant` must be 0 (kept in the signature: ABI 4).
 extern "C" int parseq_op_ln_linear_gelu(const float* x, const float* gamma, const float* beta, const void* W, const float* bias,
                                         void* out, int M, int N, int variant, void* stream) {
     CHK(check_arch());
     if (!x || !gamma || !beta || !W || !bias || !out || M <= 0 || N <= 0 || (N % PN_BN)) return fail(PARSEQ_E_INVALID, "bad argument (N must be a multiple of 128)");
     PanelGelu pg; pg.out = (bf16_t*)out; pg.ldo = N;
     hipStream_t s = (hipStream_t)stream;
-    switch (variant) {
-        case 0: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 0>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
-        case 1: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 1>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
-        case 2: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 2>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
-        case 3: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 3>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
-        case 4: HIPCHK((launch_ln_panel_gemm<384, PanelGelu, 4>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg))); break;
-        default: return fail(PARSEQ_E_INVALID, "variant %d", variant);
-    }
+    if (variant != 0) return fail(PARSEQ_E_INVALID, "variant %d (the ablation variants were removed)", variant);
+    HIPCHK((launch_ln_panel_gemm<384, PanelGelu>(s, x, gamma, beta, 1e-6f, (const bf16_t*)W, bias, M, N, pg)));
     return 0;
 }
 

@@ -562,29 +562,27 @@ def test_baseline_configs_distinct_crops(batch, refine):
     assert e16[agree16].median() <= 3e-2 and e32[agree32].median() <= 6e-2
 
 
-def test_ar_chains_early_exit_length(golden, monkeypatch):
-    """The fused AR loop can run as concurrent sub-batch chains (PARSEQ_AR_CHAINS, 64+ images each; off by default: slower).  With the natural early exit (AR, no refinement,
-    max_length=None) the returned length is the step at which EVERY row of the batch holds an EOS (model.py:144-145): the
-    maximum over the chains' own exit steps.  A batch whose chains exit at different steps must return exactly the
-    single-chain length, and every image the values of its solo run."""
+@pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
+def test_early_exit_length_is_the_batch_maximum(golden, precision):
+    """With the natural early exit (AR, no refinement, max_length=None) the returned length is the step at which EVERY row of the
+    batch holds an EOS (model.py:144-145) — counted on the device by the fused AR step, read back once.  A batch whose images exit at
+    different steps must return the maximum of their solo lengths, and every image the values of its solo run over its own length."""
     g, _ = golden('parseq')
-    monkeypatch.setenv('PARSEQ_AR_CHAINS', '4')               # read when a plan is created: this model's plans are created below
-    m = make_model('parseq', 'bf16', decode_ar=True, refine_iters=0)
+    m = make_model('parseq', precision, decode_ar=True, refine_iters=0)
     imgs = g['images'].to(DEV)
     with torch.inference_mode():
         solo = [m(imgs[i:i + 1]).float().cpu() for i in range(8)]
     lens = [int(s.shape[1]) for s in solo]
     order = sorted(range(8), key=lambda i: lens[i])
     assert lens[order[0]] < lens[order[-1]], f'golden crops all exit at the same step {lens}: the test would be vacuous'
-    # 4 chains of 64 images: chain k holds copies of one crop, so the chains exit at different steps
     pick = [order[0], order[2], order[5], order[-1]]
-    idx = torch.tensor([p for p in pick for _ in range(64)])
+    idx = torch.tensor([p for p in pick for _ in range(64)])      # 256 images = 16 row tiles of the step kernels
     with torch.inference_mode():
         got = m(imgs[idx]).float().cpu()
     assert got.shape[1] == max(lens[p] for p in pick), (got.shape, [lens[p] for p in pick])
     for k, p in enumerate(pick):
         L = lens[p]
-        assert torch.equal(got[64 * k:64 * k + 64, :L], solo[p].expand(64, -1, -1)), f'chain {k} (crop {p}) differs from its solo run'
+        assert torch.equal(got[64 * k:64 * k + 64, :L], solo[p].expand(64, -1, -1)), f'group {k} (crop {p}) differs from its solo run'
 
 
 def test_bf16x3_fused_ar_step_vs_per_op_kernels(monkeypatch):
