@@ -1548,7 +1548,21 @@ static int train_attn_mfma(const TrainCtx& cx, const TrainAttnArgs& a, int B, bo
     HIPCHK(hipGetLastError());
     return 0;
 }
+// encoder shape in the bf16-operand mode (train_attn_bf16_kernel): 128 tokens, head width 64, per-image queries, no masks, no dropout
+static int train_attn_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
+    hipStream_t s = cx.s;
+    static LdsAttr attr_f, attr_b;
+    HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_bf16_kernel<false>), train_attn_bf16_lds(false)));
+    HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_bf16_kernel<true>), train_attn_bf16_lds(true)));
+    if (backward) hipLaunchKernelGGL((train_attn_bf16_kernel<true>), dim3(B * a.H), dim3(256), train_attn_bf16_lds(true), s, a);
+    else hipLaunchKernelGGL((train_attn_bf16_kernel<false>), dim3(B * a.H), dim3(256), train_attn_bf16_lds(false), s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward, int hd) {
+    if (cx.bf16_ops && hd == TB_HD && a.Lq == TB_N && a.Lk == TB_N && !a.qmask && !a.kmask && !a.drop.thresh && a.q_bstride == (long)a.Lq * a.ldq &&
+        a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
+        return train_attn_bf16(cx, a, B, backward);
     if (hd == 64 && a.Lq % 32 == 0 && a.Lk % 16 == 0 && a.Lk <= 128 && !a.qmask && !a.kmask && !a.drop.thresh && !getenv("PARSEQ_TRAIN_VALU_ATTN"))
         return train_attn_mfma(cx, a, B, backward);
     if (hd == 32) return train_attn_hd<32>(cx, a, B, backward);

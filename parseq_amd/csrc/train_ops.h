@@ -835,6 +835,229 @@ void train_attn_mfma_kernel(const TrainAttnArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Encoder attention of the training step in the bf16-operand mode (train_precision = bf16): 128 tokens, head width 64, no masks, no
+// dropout — the five products S = Q K^T, O = P V, dP = dO V^T, dQ = dS K, dK = dS^T Q, dV = P^T dO on v_mfma_f32_16x16x32_bf16 with
+// fp32 accumulation, soft-max and its backward in fp32 registers (the fp32 mode keeps train_attn_mfma_kernel: exact 16x16x4 products).
+// One workgroup of four waves per (image, head); the queries are walked in two blocks of 64, wave w owns the block's query tile w.
+//   S^T = K Q^T is computed (A = K rows, B = Q rows): lane (r16, g) then holds, for ITS query l = r16, the scores of keys
+//   16 jt + 4 g + r — the soft-max over the keys is a reduction over the lane's registers and the four lane groups (rows4_max / sum),
+//   and the probabilities are already the B operand (k-slots = keys) of O^T = V^T P^T and, backward, dS^T of dQ^T = K^T dS^T: no LDS
+//   round trip between the score product and the products that contract over the keys (the inference kernel's trick,
+//   encoder_attn.h).  The products that contract over the QUERIES (dK, dV) need P^T / dS^T with lanes indexed by key: those go
+//   through LDS as bf16 [key][query] images, written two bytes at a time; the operands indexed by head column with a token k-axis
+//   (V^T, K^T, Q^T, dO^T) are staged transposed once.
+// Rounding points of the mode: q, k, v, dO (operands), p and dS (operands of the second-level products) are rounded to bf16;
+// everything else is fp32.  MFMA conventions as everywhere (common.h mma16): result lane (r16, g) holds D[row 4 g + r][col r16].
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int TB_N = 128, TB_HD = 64, TB_QB = 64;
+constexpr int TB_RP = TB_HD + 8;          // pitch (elements) of [token][d] images: 144 B rows, conflict-free ds_read_b128
+constexpr int TB_TP = TB_N + 8;           // pitch of [d][key] images (V^T, K^T)
+constexpr int TB_PP = TB_QB + 8;          // pitch of [key][query in block] / [d][query in block] images
+constexpr size_t train_attn_bf16_lds(bool backward) {
+    return sizeof(bf16_t) * (backward ? (size_t)2 * TB_N * TB_RP + (size_t)TB_HD * TB_TP + (size_t)2 * TB_QB * TB_RP + (size_t)2 * TB_HD * TB_PP + (size_t)2 * TB_N * TB_PP
+                                      : (size_t)TB_N * TB_RP + (size_t)TB_HD * TB_TP + (size_t)TB_QB * TB_RP);
+}
+
+// rows [r0, r0 + NR) of a [*, 64] fp32 matrix (row stride ld) -> bf16 row-major image (pitch TB_RP) and / or transposed image
+// (dst_t[d][row - r0], pitch tp); all 256 threads, 16-byte global loads
+template <bool ROWS, bool TRANS>
+__device__ __forceinline__ void tb_stage(const float* __restrict__ src, long ld, int NR, bf16_t* dst_r, bf16_t* dst_t, int tp, int tid) {
+    for (int idx = tid; idx < NR * (TB_HD / 4); idx += 256) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c4);
+        const bf16_t e0 = static_cast<bf16_t>(v.x), e1 = static_cast<bf16_t>(v.y), e2 = static_cast<bf16_t>(v.z), e3 = static_cast<bf16_t>(v.w);
+        if constexpr (ROWS) {
+            bf16x4 o; o[0] = e0; o[1] = e1; o[2] = e2; o[3] = e3;
+            *reinterpret_cast<bf16x4*>(dst_r + row * TB_RP + c4) = o;
+        }
+        if constexpr (TRANS) {
+            dst_t[(c4 + 0) * tp + row] = e0; dst_t[(c4 + 1) * tp + row] = e1;
+            dst_t[(c4 + 2) * tp + row] = e2; dst_t[(c4 + 3) * tp + row] = e3;
+        }
+    }
+}
+
+// A fragment of a [d][key] image for the key k-slot order of the S^T accumulators: lane (d = row0 + r16, g), k-step kk (32 keys):
+// slots 0-3 = keys 32 kk + 4 g + [0, 4), slots 4-7 = keys 32 kk + 16 + 4 g + [0, 4)
+__device__ __forceinline__ Frag<bf16_t> tb_keyslot_frag(const bf16_t* img, int row, int kk, int g) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(img + row * TB_TP + 32 * kk + 4 * g);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(img + row * TB_TP + 32 * kk + 16 + 4 * g);
+    Frag<bf16_t> f;
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3]; f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+    return f;
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(256)
+void train_attn_bf16_kernel(const TrainAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tb_smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(tb_smem);               // [128][TB_RP]  K
+    bf16_t* Vs = Ks + TB_N * TB_RP;                                 // backward: [128][TB_RP] V
+    bf16_t* XT = BACKWARD ? Vs + TB_N * TB_RP : Ks + TB_N * TB_RP;  // [64][TB_TP]  forward: V^T; backward: K^T
+    bf16_t* Qs = XT + TB_HD * TB_TP;                                // [64][TB_RP]  Q block
+    bf16_t* dOs = Qs + TB_QB * TB_RP;                               // backward: [64][TB_RP] dO block
+    bf16_t* Qt = dOs + TB_QB * TB_RP;                               // backward: [64 d][TB_PP] Q^T block
+    bf16_t* dOt = Qt + TB_HD * TB_PP;                               // backward: [64 d][TB_PP] dO^T block
+    bf16_t* Pt = dOt + TB_HD * TB_PP;                               // backward: [128 key][TB_PP] P^T
+    bf16_t* dSt = Pt + TB_N * TB_PP;                                // backward: [128 key][TB_PP] dS^T
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const float sl2 = a.scale * 1.44269504088896340736f;           // scale * log2(e): p = exp2((s - max) * sl2)
+
+    const float* kg = a.k + (size_t)b * TB_N * a.ldkv + h * TB_HD;
+    const float* vg = a.v + (size_t)b * TB_N * a.ldkv + h * TB_HD;
+    if constexpr (BACKWARD) {
+        tb_stage<true, true>(kg, a.ldkv, TB_N, Ks, XT, TB_TP, tid);
+        tb_stage<true, false>(vg, a.ldkv, TB_N, Vs, nullptr, 0, tid);
+    } else {
+        tb_stage<true, false>(kg, a.ldkv, TB_N, Ks, nullptr, 0, tid);
+        tb_stage<false, true>(vg, a.ldkv, TB_N, nullptr, XT, TB_TP, tid);
+    }
+    f32x4 gk[2][4], gv[2][4];                    // backward: dK / dV of key tiles 2 wave + {0, 1}, head-column tiles 0..3
+    if constexpr (BACKWARD) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { gk[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; gv[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    }
+
+    for (int q0 = 0; q0 < TB_N; q0 += TB_QB) {
+        __syncthreads();                         // the previous block's readers of Qs / dOs / Qt / dOt / Pt / dSt are done
+        const float* qg = a.q + (size_t)b * a.q_bstride + (size_t)q0 * a.ldq + h * TB_HD;
+        if constexpr (BACKWARD) {
+            tb_stage<true, true>(qg, a.ldq, TB_QB, Qs, Qt, TB_PP, tid);
+            tb_stage<true, true>(a.d_o + ((size_t)b * TB_N + q0) * a.ldo + h * TB_HD, a.ldo, TB_QB, dOs, dOt, TB_PP, tid);
+        } else {
+            tb_stage<true, false>(qg, a.ldq, TB_QB, Qs, nullptr, 0, tid);
+        }
+        __syncthreads();
+        // ---- S^T (and dP^T) of this wave's 16 queries against all 128 keys
+        Frag<bf16_t> qf[2], of[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks].v = *reinterpret_cast<const bf16x8*>(Qs + (16 * wave + r16) * TB_RP + 32 * ks + 8 * g);
+            if constexpr (BACKWARD) of[ks].v = *reinterpret_cast<const bf16x8*>(dOs + (16 * wave + r16) * TB_RP + 32 * ks + 8 * g);
+        }
+        f32x4 sacc[8], pacc[8];
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+            sacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (BACKWARD) pacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<bf16_t> kf;
+                kf.v = *reinterpret_cast<const bf16x8*>(Ks + (16 * jt + r16) * TB_RP + 32 * ks + 8 * g);
+                mma16(sacc[jt], kf, qf[ks]);
+                if constexpr (BACKWARD) {
+                    Frag<bf16_t> vf;
+                    vf.v = *reinterpret_cast<const bf16x8*>(Vs + (16 * jt + r16) * TB_RP + 32 * ks + 8 * g);
+                    mma16(pacc[jt], vf, of[ks]);
+                }
+            }
+        }
+        // ---- soft-max over the keys of query l = r16: registers, then the four lane groups
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sacc[jt][r]);
+        mx = rows4_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f((sacc[jt][r] - mx) * sl2); sacc[jt][r] = e; sum += e; }
+        sum = rows4_sum(sum);
+        const float inv = 1.0f / sum;
+        if constexpr (!BACKWARD) {
+            // ---- O^T = V^T P^T with the un-normalised probabilities as the B operand; 1 / sum applied to the result
+            Frag<bf16_t> pf[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) pf[kk].v[s8] = static_cast<bf16_t>(sacc[2 * kk + (s8 >> 2)][s8 & 3]);
+            float* og = a.o + ((size_t)b * TB_N + q0 + 16 * wave + r16) * a.ldo + h * TB_HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) mma16(oacc, tb_keyslot_frag(XT, 16 * dt + r16, kk, g), pf[kk]);
+                // oacc[r] = O[query r16][d = 16 dt + 4 g + r]
+                *reinterpret_cast<f32x4*>(og + 16 * dt + 4 * g) = oacc * inv;
+            }
+        } else {
+            // ---- dS^T = P^T * (dP^T - sum_j P dP) * scale; P^T and dS^T to LDS ([key][query]) for the products over the queries
+            float dot = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sacc[jt][r] *= inv; dot += sacc[jt][r] * pacc[jt][r]; }
+            dot = rows4_sum(dot);
+#pragma unroll
+            for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = sacc[jt][r];
+                    const float ds = p * (pacc[jt][r] - dot) * a.scale;
+                    pacc[jt][r] = ds;
+                    Pt[(16 * jt + 4 * g + r) * TB_PP + 16 * wave + r16] = static_cast<bf16_t>(p);
+                    dSt[(16 * jt + 4 * g + r) * TB_PP + 16 * wave + r16] = static_cast<bf16_t>(ds);
+                }
+            // ---- dQ^T = K^T dS^T with dS^T straight from the registers (k-slots = keys)
+            Frag<bf16_t> df[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8) df[kk].v[s8] = static_cast<bf16_t>(pacc[2 * kk + (s8 >> 2)][s8 & 3]);
+            float* dqg = a.dq + ((size_t)b * TB_N + q0 + 16 * wave + r16) * a.lddq + h * TB_HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 qacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) mma16(qacc, tb_keyslot_frag(XT, 16 * dt + r16, kk, g), df[kk]);
+                *reinterpret_cast<f32x4*>(dqg + 16 * dt + 4 * g) = qacc;
+            }
+            __syncthreads();                     // P^T / dS^T of all 64 queries of the block are in LDS
+            // ---- dV += P^T dO, dK += dS^T Q over the block's 64 queries: key tiles 2 wave + jj, every head-column tile
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<bf16_t> pa[2], sa[2];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    pa[jj].v = *reinterpret_cast<const bf16x8*>(Pt + (16 * (2 * wave + jj) + r16) * TB_PP + 32 * ks + 8 * g);
+                    sa[jj].v = *reinterpret_cast<const bf16x8*>(dSt + (16 * (2 * wave + jj) + r16) * TB_PP + 32 * ks + 8 * g);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    Frag<bf16_t> ob, qb;
+                    ob.v = *reinterpret_cast<const bf16x8*>(dOt + (16 * dt + r16) * TB_PP + 32 * ks + 8 * g);
+                    qb.v = *reinterpret_cast<const bf16x8*>(Qt + (16 * dt + r16) * TB_PP + 32 * ks + 8 * g);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        mma16(gv[jj][dt], pa[jj], ob);       // gv[r] = dV[key 16 jt + 4 g + r][d = 16 dt + r16]
+                        mma16(gk[jj][dt], sa[jj], qb);
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (BACKWARD) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const size_t gi = ((size_t)b * TB_N + 16 * (2 * wave + jj) + 4 * g + r) * a.lddkv + h * TB_HD + 16 * dt + r16;
+                    a.dk[gi] = a.kv_accumulate ? a.dk[gi] + gk[jj][dt][r] : gk[jj][dt][r];
+                    a.dv[gi] = a.kv_accumulate ? a.dv[gi] + gv[jj][dt][r] : gv[jj][dt][r];
+                }
+    }
+}
+
 // im2col of the patch embedding: row (b, gy, gx), column (c, ky, kx) = img[b][c][gy * ph + ky][gx * pw + kx]   (fp32)
 __global__ __launch_bounds__(256)
 void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw, float* __restrict__ out) {
