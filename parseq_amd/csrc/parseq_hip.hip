@@ -1559,7 +1559,21 @@ static int train_attn_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B, bo
     HIPCHK(hipGetLastError());
     return 0;
 }
+// decoder shapes in the bf16-operand mode (train_attn_dec_bf16_kernel): head width 32, <= 32 queries, <= 128 keys, masks, dropout
+static int train_attn_dec_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
+    hipStream_t s = cx.s;
+    static LdsAttr attr_f, attr_b;
+    HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<false>), train_attn_dec_lds(false)));
+    HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<true>), train_attn_dec_lds(true)));
+    if (backward) hipLaunchKernelGGL((train_attn_dec_bf16_kernel<true>), dim3(B * a.H), dim3(128), train_attn_dec_lds(true), s, a);
+    else hipLaunchKernelGGL((train_attn_dec_bf16_kernel<false>), dim3(B * a.H), dim3(128), train_attn_dec_lds(false), s, a);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward, int hd) {
+    if (cx.bf16_ops && hd == TD_HD && a.Lq <= TD_Q && a.Lk <= TD_K && a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && a.q_bstride % 4 == 0 &&
+        (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
+        return train_attn_dec_bf16(cx, a, B, backward);
     if (cx.bf16_ops && hd == TB_HD && a.Lq == TB_N && a.Lk == TB_N && !a.qmask && !a.kmask && !a.drop.thresh && a.q_bstride == (long)a.Lq * a.ldq &&
         a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
         return train_attn_bf16(cx, a, B, backward);

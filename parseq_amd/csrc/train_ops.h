@@ -1058,6 +1058,219 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
     }
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Decoder attention of the training step in the bf16-operand mode: head width 32, <= 32 queries (one block), <= 128 keys, torch-style
+// boolean masks (query x key and per-image key padding) and dropout on the probabilities — the same arrangement as
+// train_attn_bf16_kernel (S^T = K Q^T, lane = query; probabilities as the B operand of the key-contracting products; P^T / dS^T
+// through LDS for dK / dV) at the decoder's shapes: one workgroup of TWO waves per (image, head), wave w owns query tile w and the
+// key tiles jt = w (mod 2) of dK / dV.  Queries past Lq and keys past Lk are zero rows (keys additionally masked), so they
+// contribute nothing and are never stored.  Dropout: the counter-based generator of train_attn_kernel, same element index
+// ((b H + h) Lq + l) Lk + j, so the two kernels drop the same probabilities.
+// -------------------------------------------------------------------------------------------------------------------
+constexpr int TD_HD = 32, TD_Q = 32, TD_K = 128;
+constexpr int TD_RP = TD_HD + 8;          // pitch of [token][d] images (80-byte rows: conflict-free ds_read_b128)
+constexpr int TD_TP = TD_K + 8;           // pitch of [d][key] images
+constexpr int TD_PP = TD_Q + 8;           // pitch of [key][query] and [d][query] images
+constexpr size_t train_attn_dec_lds(bool backward) {
+    return sizeof(bf16_t) * (backward ? (size_t)2 * TD_K * TD_RP + (size_t)TD_HD * TD_TP + (size_t)2 * TD_Q * TD_RP + (size_t)2 * TD_HD * TD_PP + (size_t)2 * TD_K * TD_PP
+                                      : (size_t)TD_K * TD_RP + (size_t)TD_HD * TD_TP + (size_t)TD_Q * TD_RP);
+}
+
+// rows [0, NRP) of the images; rows >= nr are zero.  src row r at src + r * ld (32 floats used).  128 threads.
+template <bool ROWS, bool TRANS>
+__device__ __forceinline__ void td_stage(const float* __restrict__ src, long ld, int nr, int NRP, bf16_t* dst_r, bf16_t* dst_t, int tp, int tid) {
+    for (int idx = tid; idx < NRP * (TD_HD / 4); idx += 128) {
+        const int row = idx >> 3, c4 = (idx & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nr) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c4);
+        const bf16_t e0 = static_cast<bf16_t>(v.x), e1 = static_cast<bf16_t>(v.y), e2 = static_cast<bf16_t>(v.z), e3 = static_cast<bf16_t>(v.w);
+        if constexpr (ROWS) {
+            bf16x4 o; o[0] = e0; o[1] = e1; o[2] = e2; o[3] = e3;
+            *reinterpret_cast<bf16x4*>(dst_r + row * TD_RP + c4) = o;
+        }
+        if constexpr (TRANS) {
+            dst_t[(c4 + 0) * tp + row] = e0; dst_t[(c4 + 1) * tp + row] = e1;
+            dst_t[(c4 + 2) * tp + row] = e2; dst_t[(c4 + 3) * tp + row] = e3;
+        }
+    }
+}
+__device__ __forceinline__ Frag<bf16_t> td_keyslot_frag(const bf16_t* img, int row, int kk, int g) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(img + row * TD_TP + 32 * kk + 4 * g);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(img + row * TD_TP + 32 * kk + 16 + 4 * g);
+    Frag<bf16_t> f;
+    f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3]; f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+    return f;
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(128)
+void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char td_smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(td_smem);               // [128][TD_RP]  K
+    bf16_t* Vs = Ks + TD_K * TD_RP;                                 // backward: [128][TD_RP] V
+    bf16_t* XT = BACKWARD ? Vs + TD_K * TD_RP : Ks + TD_K * TD_RP;  // [32][TD_TP]  forward: V^T; backward: K^T
+    bf16_t* Qs = XT + TD_HD * TD_TP;                                // [32][TD_RP]  Q
+    bf16_t* dOs = Qs + TD_Q * TD_RP;                                // backward: [32][TD_RP] dO
+    bf16_t* Qt = dOs + TD_Q * TD_RP;                                // backward: [32 d][TD_PP] Q^T
+    bf16_t* dOt = Qt + TD_HD * TD_PP;                               // backward: [32 d][TD_PP] dO^T
+    bf16_t* Pt = dOt + TD_HD * TD_PP;                               // backward: [128 key][TD_PP] (P * dropout factor)^T
+    bf16_t* dSt = Pt + TD_K * TD_PP;                                // backward: [128 key][TD_PP] dS^T
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const int Lq = a.Lq, Lk = a.Lk;
+    const int njt = (Lk + 15) >> 4, nkk = (njt + 1) >> 1, NKP = 32 * nkk;      // key tiles, 32-key k-steps, padded key count
+    const float sl2 = a.scale * 1.44269504088896340736f;
+
+    const float* kg = a.k + (size_t)b * Lk * a.ldkv + h * TD_HD;
+    const float* vg = a.v + (size_t)b * Lk * a.ldkv + h * TD_HD;
+    const float* qg = a.q + (size_t)b * a.q_bstride + h * TD_HD;
+    if constexpr (BACKWARD) {
+        td_stage<true, true>(kg, a.ldkv, Lk, NKP, Ks, XT, TD_TP, tid);
+        td_stage<true, false>(vg, a.ldkv, Lk, NKP, Vs, nullptr, 0, tid);
+        td_stage<true, true>(qg, a.ldq, Lq, TD_Q, Qs, Qt, TD_PP, tid);
+        td_stage<true, true>(a.d_o + (size_t)b * Lq * a.ldo + h * TD_HD, a.ldo, Lq, TD_Q, dOs, dOt, TD_PP, tid);
+    } else {
+        td_stage<true, false>(kg, a.ldkv, Lk, NKP, Ks, nullptr, 0, tid);
+        td_stage<false, true>(vg, a.ldkv, Lk, NKP, nullptr, XT, TD_TP, tid);
+        td_stage<true, false>(qg, a.ldq, Lq, TD_Q, Qs, nullptr, 0, tid);
+    }
+    __syncthreads();
+
+    // ---- S^T (and dP^T) of this wave's 16 queries; one 32-wide k-step over the head width
+    const int l = 16 * wave + r16;                                  // this lane's query
+    Frag<bf16_t> qf, of;
+    qf.v = *reinterpret_cast<const bf16x8*>(Qs + l * TD_RP + 8 * g);
+    if constexpr (BACKWARD) of.v = *reinterpret_cast<const bf16x8*>(dOs + l * TD_RP + 8 * g);
+    f32x4 sacc[8], pacc[8];
+    float fdrop[8][4];                                              // backward: dropout factor of (query l, key)
+    const unsigned long long drow = ((unsigned long long)blockIdx.x * Lq + l) * Lk;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+        sacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BACKWARD) pacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (jt < 2 * nkk) {
+            Frag<bf16_t> kf;
+            kf.v = *reinterpret_cast<const bf16x8*>(Ks + (16 * jt + r16) * TD_RP + 8 * g);
+            mma16(sacc[jt], kf, qf);
+            if constexpr (BACKWARD) {
+                Frag<bf16_t> vf;
+                vf.v = *reinterpret_cast<const bf16x8*>(Vs + (16 * jt + r16) * TD_RP + 8 * g);
+                mma16(pacc[jt], vf, of);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * g + r;
+            bool masked = j >= Lk;
+            if (!masked && l < Lq) masked = (a.qmask && a.qmask[(size_t)l * Lk + j]) || (a.kmask && a.kmask[(size_t)b * a.ldkm + j]);
+            if (masked) sacc[jt][r] = -INFINITY;
+            mx = fmaxf(mx, sacc[jt][r]);
+        }
+    }
+    mx = rows4_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f((sacc[jt][r] - mx) * sl2); sacc[jt][r] = e; sum += e; }
+    sum = rows4_sum(sum);
+    const float inv = 1.0f / sum;
+    if constexpr (!BACKWARD) {
+        // ---- O^T = V^T (P f)^T: un-normalised probabilities times the dropout factor as the B operand, 1 / sum on the result
+        Frag<bf16_t> pf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int jt = 2 * kk + (s8 >> 2), r = s8 & 3, j = 16 * jt + 4 * g + r;
+                float e = sacc[jt][r];
+                if (a.drop.thresh && j < Lk && l < Lq) e *= drop_factor(a.drop, a.drop_site, drow + j);
+                pf[kk].v[s8] = static_cast<bf16_t>(e);
+            }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (kk < nkk) mma16(oacc, td_keyslot_frag(XT, 16 * dt + r16, kk, g), pf[kk]);
+            if (l < Lq) *reinterpret_cast<f32x4*>(a.o + ((size_t)b * Lq + l) * a.ldo + h * TD_HD + 16 * dt + 4 * g) = oacc * inv;
+        }
+    } else {
+        // ---- P = e / sum;  PD = P f (what multiplied V);  dp = dP f;  dS = P (dp - sum_j dp P) scale
+        float dot = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * g + r;
+                const float f = (a.drop.thresh && j < Lk && l < Lq) ? drop_factor(a.drop, a.drop_site, drow + j) : 1.0f;
+                fdrop[jt][r] = f;
+                sacc[jt][r] *= inv;
+                pacc[jt][r] *= f;
+                dot += sacc[jt][r] * pacc[jt][r];
+            }
+        dot = rows4_sum(dot);
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = sacc[jt][r];
+                const float ds = p * (pacc[jt][r] - dot) * a.scale;
+                pacc[jt][r] = ds;
+                if (jt < 2 * nkk) {
+                    Pt[(16 * jt + 4 * g + r) * TD_PP + l] = static_cast<bf16_t>(p * fdrop[jt][r]);
+                    dSt[(16 * jt + 4 * g + r) * TD_PP + l] = static_cast<bf16_t>(ds);
+                }
+            }
+        // ---- dQ^T = K^T dS^T, dS^T from the registers
+        Frag<bf16_t> df[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) df[kk].v[s8] = static_cast<bf16_t>(pacc[2 * kk + (s8 >> 2)][s8 & 3]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            f32x4 qacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                if (kk < nkk) mma16(qacc, td_keyslot_frag(XT, 16 * dt + r16, kk, g), df[kk]);
+            if (l < Lq) *reinterpret_cast<f32x4*>(a.dq + ((size_t)b * Lq + l) * a.lddq + h * TD_HD + 16 * dt + 4 * g) = qacc;
+        }
+        __syncthreads();                         // (P f)^T and dS^T of all 32 queries are in LDS
+        // ---- dV = (P f)^T dO, dK = dS^T Q over the 32 queries (one k-step): key tiles jt = wave, wave + 2, ...
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int jt = wave + 2 * jj;
+            if (jt < njt) {
+                Frag<bf16_t> pa, sa;
+                pa.v = *reinterpret_cast<const bf16x8*>(Pt + (16 * jt + r16) * TD_PP + 8 * g);
+                sa.v = *reinterpret_cast<const bf16x8*>(dSt + (16 * jt + r16) * TD_PP + 8 * g);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    Frag<bf16_t> ob, qb;
+                    ob.v = *reinterpret_cast<const bf16x8*>(dOt + (16 * dt + r16) * TD_PP + 8 * g);
+                    qb.v = *reinterpret_cast<const bf16x8*>(Qt + (16 * dt + r16) * TD_PP + 8 * g);
+                    f32x4 gv = f32x4{0.f, 0.f, 0.f, 0.f}, gk = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma16(gv, pa, ob);               // gv[r] = dV[key 16 jt + 4 g + r][d = 16 dt + r16]
+                    mma16(gk, sa, qb);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * jt + 4 * g + r;
+                        if (j < Lk) {
+                            const size_t gi = ((size_t)b * Lk + j) * a.lddkv + h * TD_HD + 16 * dt + r16;
+                            a.dk[gi] = a.kv_accumulate ? a.dk[gi] + gk[r] : gk[r];
+                            a.dv[gi] = a.kv_accumulate ? a.dv[gi] + gv[r] : gv[r];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // im2col of the patch embedding: row (b, gy, gx), column (c, ky, kx) = img[b][c][gy * ph + ky][gx * pw + kx]   (fp32)
 __global__ __launch_bounds__(256)
 void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw, float* __restrict__ out) {

@@ -9,4 +9,5 @@ PARSEQ_TRAIN_F32_ATTN=1 timeout 600 python tools/train_bench.py --steps 5 --warm
 rm -rf gpurun_out/prof_train
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_train -o t -- python tools/train_bench.py --steps 3 --warmup 1 > gpurun_out/train_prof.log 2>&1
 S=$(find gpurun_out/prof_train -name "*results.db" | head -1); python tools/rocprof_summary.py $S > gpurun_out/train_step_rocprof.md; head -24 gpurun_out/train_step_rocprof.md
+python tools/rocprof_by_grid.py $S mfma_bgemm 24 > gpurun_out/train_gemm_by_grid.md; cat gpurun_out/train_gemm_by_grid.md
 rm -rf gpurun_out/prof_train
