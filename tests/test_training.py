@@ -455,6 +455,50 @@ def test_decoder_backward_matches_reference_gradients(train_golden, p_drop):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('p_drop', [0.0, 0.1])
+def test_decoder_backward_bf16_operands_with_dropout(train_golden, p_drop):
+    """`parseq_train_decoder` in the bf16-operand mode (every Linear product AND the attention products of
+    train_attn_dec_bf16_kernel on bf16 operands), with and without dropout: the masks come from the same counter-based generator as
+    the fp32 kernels', so the CPU backward with the SAME masks and exact fp32 arithmetic is the reference and the only difference
+    is operand rounding — held to the budget test_bf16_operand_rounding_budget measured (per-tensor L2 error <= 6e-2, cosine >= 0.998,
+    loss 5e-4), memory gradient included.  The encoder output is taken from the CPU oracle so that the comparison is the decoder's alone."""
+    from gpu_util import DEV, make_model
+    from oracle import decoder_backward as DB
+    from parseq_amd.train import decoder_backward
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    m = make_model('parseq', 'fp32')
+    m.train_precision = 'bf16'
+    perms = g['perms'].long()
+    seed = 0x0FEDCBA987654321
+    with torch.no_grad():
+        memory = O.encode(sd, cfg, g['images'])
+        trace = {}
+        want_loss, _, want_grads, want_dmem = DB.loss_and_grads(sd, cfg, memory, m.tokenizer.encode(meta['labels']), perms,
+                                                                O.attn_masks_from_perm, trace, DB.Dropout(p_drop, seed))
+    res = decoder_backward(m, g['images'].to(DEV), meta['labels'], perms, memory=memory.to(DEV), dropout=p_drop, seed=seed)
+    torch.cuda.synchronize()
+    assert abs(float(res.loss) - float(want_loss)) <= 5e-4 * float(want_loss)
+    if p_drop:      # the same probabilities were dropped: the cross-attention output's zero pattern is the masks' (a dropped hidden unit is exactly 0)
+        got_h = res.intermediate('hact', trace['hact'].numel()).cpu().view(trace['hact'].shape)
+        assert torch.equal(got_h == 0, trace['hact'] == 0)
+    rel, cos = [], []
+    for key, ref in list(want_grads.items()) + [('d memory', want_dmem)]:
+        if key.startswith('encoder.'):
+            continue
+        got = res.dmemory if key == 'd memory' else res.grads[key]
+        a, b = ref.double().flatten(), got.cpu().double().flatten()
+        if float(a.norm()) < 1e-7:
+            continue
+        rel.append((float((a - b).norm() / a.norm()), key))
+        cos.append(float(a @ b / (a.norm() * b.norm())))
+    rel.sort()
+    print(f'bf16 decoder backward, dropout {p_drop}: per-tensor L2 error median {rel[len(rel) // 2][0]:.2e}, worst {rel[-1][0]:.2e} ({rel[-1][1]}), min cosine {min(cos):.5f}')
+    assert 1e-4 < rel[len(rel) // 2][0] < 2e-2 and rel[-1][0] < 6e-2 and min(cos) > 0.998
+
+
+@pytest.mark.gpu
 def test_full_step_gradients_match_reference(train_golden):
     """Encoder forward (fp32, activations kept) -> decoder forward / backward -> encoder backward: the loss and the gradient of
     all 175 parameters against the reference's `training_step` + `loss.backward()` (tests/golden/parseq_train.*; every tensor
