@@ -161,6 +161,43 @@ class _StubModel(torch.nn.Module):
         return x.float().mean(dim=(1, 2, 3))[:, None, None].expand(x.shape[0], 26, 95).contiguous()
 
 
+def train_leg(dev, batch=384, steps=3, warmup=1):
+    """tools/train_bench.py's measurement, short: images/s of the training step (strhub/models/parseq/system.py:168-199 + loss.backward()
+    + gradient_clip_val 20 + AdamW under OneCycleLR, train.py:62-71 / base.py:98-110) with synthetic crops and labels resident on the device."""
+    from parseq_amd import create_model
+    from parseq_amd.train import TrainStep
+    torch.manual_seed(0)
+    system = create_model('parseq', precision='bf16').to(dev)
+    system.train_precision = 'bf16'
+    g = torch.Generator().manual_seed(4321)
+    ih, iw = system.hparams.img_size
+    images = (torch.rand(batch, 3, ih, iw, generator=g) * 2 - 1).to(dev)
+    charset = system.hparams.charset_train
+    lengths = torch.randint(1, 26, (batch,), generator=g).tolist()
+    lengths[0] = 25
+    labels = [''.join(charset[int(i)] for i in torch.randint(0, len(charset), (n,), generator=g)) for n in lengths]
+    step = TrainStep(system, total_steps=steps + warmup + 1, num_devices=1)
+    for _ in range(warmup):
+        step(images, labels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step(images, labels)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # algorithmic FLOPs of one step (2 x MAC; forward + dX + dW = 3 x the forward products): encoder 12 x 239.08 + 4.72 MMAC per image,
+    # decoder per image 6 passes x 26 rows x (14 E^2 + 95 E) MAC + the memory K / V projection once (128 x 2 E^2), E = 384
+    E = 384
+    mmac_img = 12 * 239.08 + 4.72 + (6 * 26 * (14 * E * E + 95 * E) + 128 * 2 * E * E) / 1e6
+    tflop = 3 * 2 * mmac_img * 1e6 * batch / 1e12
+    ms = 1e3 * el / steps
+    return {'metric': 'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], one GPU)',
+            'value': round(batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
+            'dtype': 'bf16 operands (Linear and attention products), fp32 accumulate / master weights / LayerNorm / soft-max / loss / AdamW',
+            'dropout': float(system.hparams.dropout), 'final_loss': round(float(loss), 4), 'algorithmic_tflop_per_step': round(tflop, 3),
+            'achieved_tflops': round(tflop / (ms * 1e-3), 1), 'frac_of_bf16_mfma_peak': round(tflop / (ms * 1e-3) / PEAK['bf16'], 4)}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` from a plain shell: check the box, then re-exec under torch.distributed.run."""
     have = torch.cuda.device_count()
@@ -191,6 +228,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--no-train', action='store_true', help='skip the short training-step leg (SURVEY.md section 8f row N3 / BASELINE.json configs[4]) reported as "train"')
     ap.add_argument('--force-dist', action='store_true', help='self-test: initialise the RCCL process group and run the collectives even with one rank')
     ap.add_argument('--repeats', type=int, default=5, help='repetitions of the K-step timed region; the median is reported, min / max alongside')
     ap.add_argument('--streams', type=int, default=2, help='batches in flight for `value` (independent workspaces on separate HIP streams); '
@@ -206,7 +244,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if STUB:
         dev = torch.device('cpu')
-        args.no_profile = args.no_cpu_baseline = args.no_parity = True
+        args.no_profile = args.no_cpu_baseline = args.no_parity = args.no_train = True
         torch.cuda.synchronize = lambda *a, **k: None          # this process only: the timed-region code below runs unchanged
     else:
         if torch.cuda.device_count() <= local_rank:
@@ -384,6 +422,13 @@ def main():
                 result['repeats']['exact_sequential_value'] = xspread1
         except Exception as e:      # parity evidence must never take the throughput line down with it; say what happened
             result['parity'] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0 and world == 1 and not args.no_train and args.model == 'parseq':
+        # Row N3 on the driver's record (never part of `value`): the training step of BASELINE.json configs[4] on this GPU — 384 crops,
+        # K = 6 permutations, dropout 0.1, forward + backward + clip + AdamW in the bf16-operand mode — one warm-up step, three timed.
+        try:
+            result['train'] = train_leg(dev)
+        except Exception as e:
+            result['train'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
         # the headline, unambiguous: `value` is the timed dtype's throughput; whether that dtype meets the north star's 1e-3 / argmax bar
         # on the timed weights and inputs is stated next to it, with the throughput of the mode that does
