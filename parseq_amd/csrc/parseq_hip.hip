@@ -1452,8 +1452,13 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         }
         const int k_chunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
         splits = (K + k_chunk - 1) / k_chunk;
-        if (bf16) hipLaunchKernelGGL(mfma_bgemm_kernel, dim3(gn_, gm_, splits), dim3(256), 0, s, a, k_chunk, cx.scratch);
-        else
+        if (bf16) {
+            const dim3 grid_((unsigned)(gn_ * gm_), 1, splits);      // one-dimensional tile index: the kernel orders the tiles XCD-aware
+            if (sak == 1 && sbk == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, true>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
+            else if (sak == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, false>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
+            else if (sbk == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<false, true>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
+            else hipLaunchKernelGGL((mfma_bgemm_kernel<false, false>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
+        } else
         hipLaunchKernelGGL(mfma_sgemm_kernel, dim3(N / MG_BN, M / MG_BM, splits), dim3(256), 0, s, a, k_chunk, cx.scratch);
         HIPCHK(hipGetLastError());
         if (splits > 1) {

@@ -175,70 +175,97 @@ void mfma_sgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
 // current stage's MFMAs and converted / stored after them (one barrier per stage).  Split-K and epilogue exactly as mfma_sgemm_kernel.
 constexpr int BG_BK = 32, BG_LD = 40;       // elements
 
-// `limit`: number of valid outer indices (rows of A / columns of B): tiles may hang over the edge — over-the-edge lanes re-read the last
-// valid row (k-contiguous operand) or the last valid group of four (outer-contiguous operand; limit % 4 == 0 there) and their products
-// land in accumulator rows / columns the epilogue does not store.
-__device__ __forceinline__ void bg_fetch(const float* __restrict__ base, long s_outer, long s_k, int outer0, int limit, int k0, bool k_fast, float4 (&r)[4], int tid) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = tid + 256 * it;
-        if (k_fast) { const int o = min(outer0 + (idx >> 3), limit - 1), k4 = idx & 7; r[it] = *reinterpret_cast<const float4*>(base + (size_t)o * s_outer + k0 + 4 * k4); }
-        else { const int k = 4 * (tid >> 5) + it, o = min(outer0 + 4 * (tid & 31), limit - 4); r[it] = *reinterpret_cast<const float4*>(base + (size_t)(k0 + k) * s_k + o); }      // four CONSECUTIVE k of the same four outer indices per thread
-    }
-}
-__device__ __forceinline__ void bg_park(bf16_t (*tile)[BG_LD], bool k_fast, const float4 (&r)[4], int tid) {
-    if (k_fast) {
+// Tiles may hang over the edge of the matrix: over-the-edge lanes re-read the last valid row (k-contiguous operand) or the last valid
+// group of four (outer-contiguous operand; the outer extent is a multiple of 4 there) and their products land in accumulator rows /
+// columns the epilogue does not store.
+// Round 3 (profiles/r03_train_gemm_counters_v0.md: 60 % of the wave cycles parked at s_waitcnt, 10 VALU instructions per MFMA, L2 hit
+// rate 42 % with 1.4-3x the algorithmic bytes fetched from HBM):
+//   * the kernel is a template on the two operand orientations and every thread's four source pointers per operand are computed ONCE
+//     — the loop body used to redo 64-bit index arithmetic with clamps per load behind a run-time orientation branch, and the
+//     register shuffling that came with it made the compiler wait for five of the eight loads of stage k + 1 BEFORE the MFMAs of stage
+//     k (the disassembly showed `s_waitcnt vmcnt(7)`, `vmcnt(3)` ahead of the first MFMA): the prefetch hid nothing;
+//   * XCD-aware tile order: the hardware deals consecutive workgroup ids to the eight XCDs (private L2s) round-robin, so the N-tiles
+//     that share an A row panel all landed on different XCDs and each fetched the panel from HBM for itself.  Workgroup id L now maps to
+//     logical id (L % 8) * (total / 8) + L / 8 and logical ids walk the N-tiles of one row panel first: a panel's consumers share an L2.
+template <bool KFAST>
+struct BgOperand {
+    const float* p[4];            // this thread's four 16-byte loads of the current stage
+    long step;                    // pointer increment per 32-deep stage
+    __device__ __forceinline__ void init(const float* __restrict__ base, long s_outer, long s_k, int outer0, int limit, int k0, int tid) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = tid + 256 * it, o = idx >> 3, k4 = idx & 7;
-            union { uint2 u; bf16_t e[4]; } h;
-            h.e[0] = static_cast<bf16_t>(r[it].x); h.e[1] = static_cast<bf16_t>(r[it].y); h.e[2] = static_cast<bf16_t>(r[it].z); h.e[3] = static_cast<bf16_t>(r[it].w);
-            *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
+            if constexpr (KFAST) {                  // rows of 32 consecutive k: thread = (row idx >> 3, 4 consecutive k at 4 (idx & 7))
+                const int idx = tid + 256 * it, o = min(outer0 + (idx >> 3), limit - 1);
+                p[it] = base + (size_t)o * s_outer + k0 + 4 * (idx & 7);
+            } else {                                 // four CONSECUTIVE k of the same four outer indices per thread
+                const int k = 4 * (tid >> 5) + it, o = min(outer0 + 4 * (tid & 31), limit - 4);
+                p[it] = base + (size_t)(k0 + k) * s_k + o;
+            }
         }
-    } else {
-        // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index
-        const int kq = tid >> 5, o4 = tid & 31;
-        const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+        step = KFAST ? (long)BG_BK : (long)BG_BK * s_k;
+    }
+    __device__ __forceinline__ void fetch(float4 (&r)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            union { uint2 u; bf16_t e[4]; } h;
+        for (int it = 0; it < 4; ++it) { r[it] = *reinterpret_cast<const float4*>(p[it]); p[it] += step; }
+    }
+    static __device__ __forceinline__ void park(bf16_t (*tile)[BG_LD], const float4 (&r)[4], int tid) {
+        if constexpr (KFAST) {
 #pragma unroll
-            for (int it = 0; it < 4; ++it) h.e[it] = static_cast<bf16_t>(v[it][i]);
-            *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = h.u;
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + 256 * it, o = idx >> 3, k4 = idx & 7;
+                union { uint2 u; bf16_t e[4]; } h;
+                h.e[0] = static_cast<bf16_t>(r[it].x); h.e[1] = static_cast<bf16_t>(r[it].y); h.e[2] = static_cast<bf16_t>(r[it].z); h.e[3] = static_cast<bf16_t>(r[it].w);
+                *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
+            }
+        } else {
+            // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index
+            const int kq = tid >> 5, o4 = tid & 31;
+            const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                union { uint2 u; bf16_t e[4]; } h;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) h.e[it] = static_cast<bf16_t>(v[it][i]);
+                *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = h.u;
+            }
         }
     }
-}
+};
 
+// grid: (tiles_n * tiles_m, 1, splits) workgroups; gn, gm = the tile counts
+template <bool AKF, bool BKF>
 __global__ __launch_bounds__(256)
-void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial) {
+void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
     __shared__ __attribute__((aligned(16))) bf16_t As[2][MG_BM][BG_LD];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[2][MG_BN][BG_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * MG_BM, n0 = blockIdx.x * MG_BN;
+    // XCD-aware tile order (see above); the tail that does not fill a whole group of eight keeps its id
+    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
+    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
+    const int tn_ = logical % gn, tm_ = logical / gn;
+    const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int r16 = lane & 15, g = lane >> 4;
-    const bool a_kfast = a.sak == 1, b_kfast = a.sbk == 1;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    BgOperand<AKF> oa; BgOperand<BKF> ob;
+    oa.init(a.A, a.sam, a.sak, m0, a.M, kbeg, tid);
+    ob.init(a.B, a.sbn, a.sbk, n0, a.N, kbeg, tid);
     float4 ra[4], rb[4];
     if (kbeg < kend) {
-        bg_fetch(a.A, a.sam, a.sak, m0, a.M, kbeg, a_kfast, ra, tid);
-        bg_fetch(a.B, a.sbn, a.sbk, n0, a.N, kbeg, b_kfast, rb, tid);
-        bg_park(As[0], a_kfast, ra, tid);
-        bg_park(Bs[0], b_kfast, rb, tid);
+        oa.fetch(ra); ob.fetch(rb);
+        BgOperand<AKF>::park(As[0], ra, tid);
+        BgOperand<BKF>::park(Bs[0], rb, tid);
     }
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BG_BK) {
         const bool more = k0 + BG_BK < kend;
-        if (more) {
-            bg_fetch(a.A, a.sam, a.sak, m0, a.M, k0 + BG_BK, a_kfast, ra, tid);
-            bg_fetch(a.B, a.sbn, a.sbk, n0, a.N, k0 + BG_BK, b_kfast, rb, tid);
-        }
+        if (more) { oa.fetch(ra); ob.fetch(rb); }       // in flight under this stage's MFMAs; first touched by park() below
         bf16x8 av[4], bv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -249,9 +276,10 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);              // nothing of park() (its waits for the loads) moves above the MFMAs
         if (more) {
-            bg_park(As[cur ^ 1], a_kfast, ra, tid);
-            bg_park(Bs[cur ^ 1], b_kfast, rb, tid);
+            BgOperand<AKF>::park(As[cur ^ 1], ra, tid);
+            BgOperand<BKF>::park(Bs[cur ^ 1], rb, tid);
         }
         __syncthreads();
         cur ^= 1;
@@ -264,18 +292,18 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int gm = m0 + wm + 16 * i + 4 * g + r;
-            if (gm >= a.M) continue;
+            const int gm_ = m0 + wm + 16 * i + 4 * g + r;
+            if (gm_ >= a.M) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int gn = n0 + wn + 16 * j + r16;
-                if (gn >= a.N) continue;
+                const int gn_ = n0 + wn + 16 * j + r16;
+                if (gn_ >= a.N) continue;
                 float v = acc[i][j][r];
-                float* c = out + (size_t)gm * ldo + gn;
+                float* c = out + (size_t)gm_ * ldo + gn_;
                 if (direct) {
                     v *= a.alpha;
-                    if (a.bias) v += a.bias[gn];
-                    if (a.R) v += a.R[(size_t)(gm % a.rper) * a.ldr + gn];
+                    if (a.bias) v += a.bias[gn_];
+                    if (a.R) v += a.R[(size_t)(gm_ % a.rper) * a.ldr + gn_];
                     if (a.accumulate) v += *c;
                 }
                 *c = v;
