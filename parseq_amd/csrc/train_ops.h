@@ -218,15 +218,25 @@ struct BgOperand {
                 *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
             }
         } else {
-            // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index
-            const int kq = tid >> 5, o4 = tid & 31;
+            // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index.
+            // Store s of lane o4 writes row 4 o4 + ((s + (o4 >> 2)) & 3): with every lane on row 4 o4 + s the 32 lanes of a store hit
+            // only four bank groups (rows four apart are 320 bytes = 16 banks mod 64 apart: 8-way conflicts, 80 % of the LDS cycles of
+            // the dW products); rotating the row by o4 / 4 spreads a store over sixteen groups (2-way).
+            const int kq = tid >> 5, o4 = tid & 31, rot = (o4 >> 2) & 3;
             const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
+            uint2 packed[4];                       // packed[i] = the four k of outer index 4 o4 + i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 union { uint2 u; bf16_t e[4]; } h;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) h.e[it] = static_cast<bf16_t>(v[it][i]);
-                *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = h.u;
+                packed[i] = h.u;
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const int i = (s_ + rot) & 3;
+                const uint2 u = i == 0 ? packed[0] : (i == 1 ? packed[1] : (i == 2 ? packed[2] : packed[3]));
+                *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = u;
             }
         }
     }
@@ -284,30 +294,50 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
         __syncthreads();
         cur ^= 1;
     }
-    // lane holds D[row = 16 i + 4 g + r][col = 16 j + r16]
+    // lane holds D[row = 16 i + 4 g + r][col = 16 j + r16].  Epilogue per row: ONE row base for C (and for the residual row), the four
+    // columns at constant offsets; bias once per column; the residual / old-C values of a row are all requested before the row's first
+    // store (the element-at-a-time form spent 64-bit index arithmetic and a modulo per element and waited for every load on its own:
+    // as many VALU instructions as 2.5 main loops at K = 384).  R never aliases C on this path (C itself is re-read only by accumulate).
     const bool direct = gridDim.z == 1;
-    float* out = direct ? a.C : partial + (size_t)blockIdx.z * a.M * a.N;
+    float* __restrict__ out = direct ? a.C : partial + (size_t)blockIdx.z * a.M * a.N;
     const long ldo = direct ? a.ldc : a.N;
+    const int gn0 = n0 + wn + r16;
+    bool cok[4];
+    float bj[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cok[j] = gn0 + 16 * j < a.N;
+        bj[j] = (direct && a.bias && cok[j]) ? a.bias[gn0 + 16 * j] : 0.f;
+    }
+    const float* __restrict__ Rb = direct ? a.R : nullptr;
+    const bool acc_c = direct && a.accumulate;
+    const float alpha = direct ? a.alpha : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int gm_ = m0 + wm + 16 * i + 4 * g + r;
             if (gm_ >= a.M) continue;
+            float* __restrict__ crow = out + (size_t)gm_ * ldo + gn0;
+            float add[4] = {bj[0], bj[1], bj[2], bj[3]};
+            if (Rb) {
+                const float* __restrict__ rrow = Rb + (size_t)(gm_ < a.rper ? gm_ : gm_ % a.rper) * a.ldr + gn0;
+                float rv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gn_ = n0 + wn + 16 * j + r16;
-                if (gn_ >= a.N) continue;
-                float v = acc[i][j][r];
-                float* c = out + (size_t)gm_ * ldo + gn_;
-                if (direct) {
-                    v *= a.alpha;
-                    if (a.bias) v += a.bias[gn_];
-                    if (a.R) v += a.R[(size_t)(gm_ % a.rper) * a.ldr + gn_];
-                    if (a.accumulate) v += *c;
-                }
-                *c = v;
+                for (int j = 0; j < 4; ++j) rv[j] = cok[j] ? rrow[16 * j] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add[j] += rv[j];
             }
+            if (acc_c) {
+                float cv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cv[j] = cok[j] ? crow[16 * j] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) add[j] += cv[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (cok[j]) crow[16 * j] = alpha * acc[i][j][r] + add[j];
         }
 }
 
