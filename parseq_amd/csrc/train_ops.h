@@ -218,25 +218,17 @@ struct BgOperand {
                 *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
             }
         } else {
-            // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index.
-            // Store s of lane o4 writes row 4 o4 + ((s + (o4 >> 2)) & 3): with every lane on row 4 o4 + s the 32 lanes of a store hit
-            // only four bank groups (rows four apart are 320 bytes = 16 banks mod 64 apart: 8-way conflicts, 80 % of the LDS cycles of
-            // the dW products); rotating the row by o4 / 4 spreads a store over sixteen groups (2-way).
-            const int kq = tid >> 5, o4 = tid & 31, rot = (o4 >> 2) & 3;
+            // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index
+            // (these stores conflict 8-way in LDS — rows four apart are 16 banks apart; rotating each lane's row order made them 2-way and
+            // changed nothing measurable: the dW products are not bound by it)
+            const int kq = tid >> 5, o4 = tid & 31;
             const float v[4][4] = {{r[0].x, r[0].y, r[0].z, r[0].w}, {r[1].x, r[1].y, r[1].z, r[1].w}, {r[2].x, r[2].y, r[2].z, r[2].w}, {r[3].x, r[3].y, r[3].z, r[3].w}};
-            uint2 packed[4];                       // packed[i] = the four k of outer index 4 o4 + i
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 union { uint2 u; bf16_t e[4]; } h;
 #pragma unroll
                 for (int it = 0; it < 4; ++it) h.e[it] = static_cast<bf16_t>(v[it][i]);
-                packed[i] = h.u;
-            }
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                const int i = (s_ + rot) & 3;
-                const uint2 u = i == 0 ? packed[0] : (i == 1 ? packed[1] : (i == 2 ? packed[2] : packed[3]));
-                *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = u;
+                *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = h.u;
             }
         }
     }
