@@ -1428,11 +1428,14 @@ struct TrainCtx {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// asum (optional): [M] += row sums of A over k, folded into the product when it takes the bf16 matrix-core kernel; returns through
+// *asum_done whether it did (the caller runs the column-sum kernel otherwise)
 static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
-                 long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate) {
+                 long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate, float* asum = nullptr, bool* asum_done = nullptr) {
     hipStream_t s = cx.s;
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
-    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0};
+    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr};
+    if (asum_done) *asum_done = false;
     // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
     const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
     const bool b_ok = aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0));
@@ -1447,12 +1450,13 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         int splits = 1;
         if (tiles < 256) {
             splits = std::min((512 + tiles - 1) / tiles, K / (4 * bk));
-            splits = (int)std::min<size_t>((size_t)std::max(splits, 1), cx.scratch_floats / ((size_t)M * N));
+            splits = (int)std::min<size_t>((size_t)std::max(splits, 1), cx.scratch_floats / ((size_t)M * N + (size_t)M));      // + the row-sum slots
             splits = std::max(splits, 1);
         }
         const int k_chunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
         splits = (K + k_chunk - 1) / k_chunk;
         if (bf16) {
+            if (asum) { a.asum = asum; if (asum_done) *asum_done = true; }
             const dim3 grid_((unsigned)(gn_ * gm_), 1, splits);      // one-dimensional tile index: the kernel orders the tiles XCD-aware
             if (sak == 1 && sbk == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, true>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
             else if (sak == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, false>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
@@ -1512,8 +1516,10 @@ static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const flo
         if (dx) CHK(sgemm(c2, dyp, Np, 1, Wp, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, Np, 1.f, false));
         return 0;
     }
-    CHK(sgemm(cx, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true));
-    CHK(colsum(cx, dy, N, M, N, db, true));
+    // dW += dY^T X; the bias gradient (column sums of dY = row sums of the product's A operand) rides on it in the bf16-operand mode
+    bool db_done = false;
+    CHK(sgemm(cx, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true, db, &db_done));
+    if (!db_done) CHK(colsum(cx, dy, N, M, N, db, true));
     if (dx) CHK(sgemm(cx, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false));
     return 0;
 }
@@ -1522,10 +1528,16 @@ static int ln_bwd(const TrainCtx& cx, const float* x, const float* gamma, const 
                   float* tmp, int rows, int E, float eps) {
     hipStream_t s = cx.s;
     if (E > 768) return fail(PARSEQ_E_INVALID, "layernorm backward: E=%d > 768", E);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, dy, add, dx, tmp, rows, E, eps);
+    // per-chunk partial sums of dy * xhat and dy land in the scratch ([chunks][2E]); two small column sums fold them (`tmp` is no longer used)
+    (void)tmp;
+    const int chunks = (rows + LNB_ROWS - 1) / LNB_ROWS;
+    if (!cx.scratch || (size_t)chunks * 2 * E + (size_t)64 * E > cx.scratch_floats) return fail(PARSEQ_E_INVALID, "layernorm backward: %d rows do not fit the scratch", rows);
+    float* part = cx.scratch + (cx.scratch_floats - (size_t)chunks * 2 * E);      // the END of the scratch: colsum's own partials use its start
+    TrainCtx c2 = cx; c2.scratch_floats = cx.scratch_floats - (size_t)chunks * 2 * E;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(chunks), dim3(256), 0, s, x, gamma, dy, add, dx, part, rows, E, eps);
     HIPCHK(hipGetLastError());
-    CHK(colsum(cx, tmp, E, rows, E, dgamma, true));
-    return colsum(cx, dy, E, rows, E, dbeta, true);
+    CHK(colsum(c2, part, 2L * E, chunks, E, dgamma, true));
+    return colsum(c2, part + E, 2L * E, chunks, E, dbeta, true);
 }
 template <int HD>
 static int train_attn_hd(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {

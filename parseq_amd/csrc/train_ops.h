@@ -26,6 +26,8 @@ struct SgemmArgs {
     int M, N, K;
     float alpha;
     int accumulate;                      // C += ... instead of C = ...
+    float* asum;                         // [M] += sum_k A(m, k) (fp32, before any rounding) or nullptr: the bias gradient riding on the dW
+                                         // product dY^T X (A = dY^T), which streams dY anyway — mfma_bgemm_kernel only
 };
 
 constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16;
@@ -258,8 +260,22 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
     oa.init(a.A, a.sam, a.sak, m0, a.M, kbeg, tid);
     ob.init(a.B, a.sbn, a.sbk, n0, a.N, kbeg, tid);
     float4 ra[4], rb[4];
+    // row sums of A over this workgroup's k range (a.asum; only the first N-tile of a row panel adds them up): rs[i] belongs to outer
+    // index 4 (tid & 31) + i (outer-contiguous A) or to row (tid >> 3) + 32 i (k-contiguous A: eight lanes per row)
+    const bool do_sum = a.asum != nullptr && tn_ == 0;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto add_rows = [&]() {
+        if constexpr (AKF) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rs[it] += (ra[it].x + ra[it].y) + (ra[it].z + ra[it].w);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { rs[0] += ra[it].x; rs[1] += ra[it].y; rs[2] += ra[it].z; rs[3] += ra[it].w; }
+        }
+    };
     if (kbeg < kend) {
         oa.fetch(ra); ob.fetch(rb);
+        if (do_sum) add_rows();
         BgOperand<AKF>::park(As[0], ra, tid);
         BgOperand<BKF>::park(Bs[0], rb, tid);
     }
@@ -280,11 +296,37 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);              // nothing of park() (its waits for the loads) moves above the MFMAs
         if (more) {
+            if (do_sum) add_rows();
             BgOperand<AKF>::park(As[cur ^ 1], ra, tid);
             BgOperand<BKF>::park(Bs[cur ^ 1], rb, tid);
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if (do_sum) {
+        // fold the threads' partial row sums in a fixed order through LDS (the operand tiles are dead) and add them to a.asum
+        // (split-K: to this split's slot behind the product's partials; splitk_reduce_kernel adds the slots up)
+        float* red = reinterpret_cast<float*>(&As[0][0][0]);          // [8][128]
+        if constexpr (AKF) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float v = rs[it];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                if ((tid & 7) == 0) red[(tid >> 3) + 32 * it] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(tid >> 5) * 128 + 4 * (tid & 31) + i] = rs[i];
+        }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < a.M) {
+            float v;
+            if constexpr (AKF) v = red[tid];
+            else v = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) + ((red[512 + tid] + red[640 + tid]) + (red[768 + tid] + red[896 + tid]));
+            if (gridDim.z == 1) a.asum[m0 + tid] += v;
+            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)blockIdx.z * a.M + m0 + tid] = v;
+        }
+        __syncthreads();
     }
     // lane holds D[row = 16 i + 4 g + r][col = 16 j + r16].  Epilogue per row: ONE row base for C (and for the residual row), the four
     // columns at constant offsets; bias once per column; the residual / old-C values of a row are all requested before the row's first
@@ -350,6 +392,11 @@ void add_into_kernel(const float* __restrict__ src, float* __restrict__ dst, siz
 __global__ __launch_bounds__(256)
 void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, int splits) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)a.M * a.N;
+    if (a.asum && idx < (size_t)a.M) {       // row sums of A: partials behind the product's, [splits][M]
+        float t = 0.f;
+        for (int z = 0; z < splits; ++z) t += partial[(size_t)splits * total + (size_t)z * a.M + idx];
+        a.asum[idx] += t;
+    }
     if (idx >= total) return;
     const int gm = (int)(idx / a.N), gn = (int)(idx % a.N);
     float v = 0.f;
@@ -385,54 +432,91 @@ void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* _
     }
 }
 
-// LayerNorm backward, one wave per row, statistics recomputed from x (E <= 768):
+// LayerNorm backward, statistics recomputed from x (E <= 768); a workgroup owns LNB_ROWS consecutive rows, one wave per row at a time:
 //   dx_out = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
-//   dyxhat = dy * xhat        (column sums of it are the weight gradient; column sums of dy the bias gradient)
+//   partial[chunk][0 .. E)   = sum over the chunk's rows of dy * xhat   (weight gradient)
+//   partial[chunk][E .. 2E)  = sum over the chunk's rows of dy          (bias gradient)
+// summed per lane over the wave's rows in ascending order, then over the four waves in wave order: deterministic.  The host folds the
+// chunks with colsum_kernel.  (Round 3: the first form wrote dy * xhat as a [rows, E] matrix and ran two column-sum passes over it and
+// over dy — 225 MB of extra traffic and two more launches per LayerNorm at 49 152 rows.)
+constexpr int LNB_ROWS = 32;
 __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ add,
-                   float* __restrict__ dx_out, float* __restrict__ dyxhat, int rows, int E, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const size_t base = (size_t)r * E;
-    float xv[12], gv[12], dv[12];
-    float s = 0.f;
+                   float* __restrict__ dx_out, float* __restrict__ partial, int rows, int E, float eps) {
+    __shared__ float red[4][2][768];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pg[12], pb[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int c = lane + 64 * i;
-        xv[i] = c < E ? x[base + c] : 0.f;
-        s += xv[i];
-    }
+    for (int i = 0; i < 12; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
     const float inv = 1.0f / (float)E;
-    const float mean = wave_sum(s) * inv;
-    float ss = 0.f;
+    const int r_first = blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
+    // the next row's x and dy are requested before the current row is worked on (the row loop is a chain of wave reductions: without
+    // the prefetch every row paid its own memory round trip)
+    float nx[12], nd[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const int c = lane + 64 * i;
-        const float d = c < E ? xv[i] - mean : 0.f;
-        ss += d * d;
+        const bool ok = c < E && r_first < rows;
+        nx[i] = ok ? x[(size_t)r_first * E + c] : 0.f;
+        nd[i] = ok ? dy[(size_t)r_first * E + c] : 0.f;
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv + eps);
-    float s1 = 0.f, s2 = 0.f;
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const int r = r_first + rr;
+        if (r >= rows) break;
+        const size_t base = (size_t)r * E;
+        float xv[12], gv[12], dv[12];
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int c = lane + 64 * i;
-        xv[i] = c < E ? (xv[i] - mean) * rstd : 0.f;          // xhat
-        dv[i] = c < E ? dy[base + c] : 0.f;
-        gv[i] = c < E ? dv[i] * w[c] : 0.f;
-        s1 += gv[i];
-        s2 += gv[i] * xv[i];
-    }
-    const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+        for (int i = 0; i < 12; ++i) { xv[i] = nx[i]; dv[i] = nd[i]; s += xv[i]; }
+        if (rr + 1 < LNB_ROWS / 4 && r + 1 < rows) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const int c = lane + 64 * i;
-        if (c < E) {
-            float d = rstd * (gv[i] - m1 - xv[i] * m2);
-            if (add) d += add[base + c];
-            dx_out[base + c] = d;
-            dyxhat[base + c] = dv[i] * xv[i];
+            for (int i = 0; i < 12; ++i) {
+                const int c = lane + 64 * i;
+                nx[i] = c < E ? x[base + E + c] : 0.f;
+                nd[i] = c < E ? dy[base + E + c] : 0.f;
+            }
         }
+        const float mean = wave_sum(s) * inv;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = lane + 64 * i;
+            const float d = c < E ? xv[i] - mean : 0.f;
+            ss += d * d;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = lane + 64 * i;
+            xv[i] = c < E ? (xv[i] - mean) * rstd : 0.f;          // xhat
+            gv[i] = c < E ? dv[i] * w[c] : 0.f;
+            s1 += gv[i];
+            s2 += gv[i] * xv[i];
+        }
+        const float m1 = wave_sum(s1) * inv, m2 = wave_sum(s2) * inv;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = lane + 64 * i;
+            if (c < E) {
+                float d = rstd * (gv[i] - m1 - xv[i] * m2);
+                if (add) d += add[base + c];
+                dx_out[base + c] = d;
+                pg[i] += dv[i] * xv[i];
+                pb[i] += dv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int c = lane + 64 * i;
+        if (c < E) { red[wave][0][c] = pg[i]; red[wave][1][c] = pb[i]; }
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * 2 * E;
+    for (int c = threadIdx.x; c < 2 * E; c += 256) {
+        const int which = c >= E, cc = which ? c - E : c;
+        out[c] = ((red[0][which][cc] + red[1][which][cc]) + red[2][which][cc]) + red[3][which][cc];
     }
 }
 
