@@ -1466,7 +1466,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         hipLaunchKernelGGL(mfma_sgemm_kernel, dim3(N / MG_BN, M / MG_BM, splits), dim3(256), 0, s, a, k_chunk, cx.scratch);
         HIPCHK(hipGetLastError());
         if (splits > 1) {
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + 255) / 256)), dim3(256), 0, s, a, cx.scratch, splits);
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + (a.asum ? (size_t)M : 0) + 255) / 256)), dim3(256), 0, s, a, cx.scratch, splits);
             HIPCHK(hipGetLastError());
         }
         return 0;

@@ -392,12 +392,15 @@ void add_into_kernel(const float* __restrict__ src, float* __restrict__ dst, siz
 __global__ __launch_bounds__(256)
 void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, int splits) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)a.M * a.N;
-    if (a.asum && idx < (size_t)a.M) {       // row sums of A: partials behind the product's, [splits][M]
-        float t = 0.f;
-        for (int z = 0; z < splits; ++z) t += partial[(size_t)splits * total + (size_t)z * a.M + idx];
-        a.asum[idx] += t;
+    if (idx >= total) {                       // the threads past the product fold the row sums of A (partials behind the product's, [splits][M])
+        const size_t m = idx - total;
+        if (a.asum && m < (size_t)a.M) {
+            float t = 0.f;
+            for (int z = 0; z < splits; ++z) t += partial[(size_t)splits * total + (size_t)z * a.M + m];
+            a.asum[m] += t;
+        }
+        return;
     }
-    if (idx >= total) return;
     const int gm = (int)(idx / a.N), gn = (int)(idx % a.N);
     float v = 0.f;
     for (int z = 0; z < splits; ++z) v += partial[(size_t)z * total + idx];
@@ -439,7 +442,7 @@ void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* _
 // summed per lane over the wave's rows in ascending order, then over the four waves in wave order: deterministic.  The host folds the
 // chunks with colsum_kernel.  (Round 3: the first form wrote dy * xhat as a [rows, E] matrix and ran two column-sum passes over it and
 // over dy — 225 MB of extra traffic and two more launches per LayerNorm at 49 152 rows.)
-constexpr int LNB_ROWS = 32;
+constexpr int LNB_ROWS = 4;       // one row per wave: 64 and 32 rows per workgroup (a serial row loop per wave, even with the next row prefetched) ran the kernel at 68-75 us where one row per wave runs it at HBM speed
 __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ add,
                    float* __restrict__ dx_out, float* __restrict__ partial, int rows, int E, float eps) {
