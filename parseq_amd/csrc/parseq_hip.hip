@@ -1431,10 +1431,11 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // asum (optional): [M] += row sums of A over k, folded into the product when it takes the bf16 matrix-core kernel; returns through
 // *asum_done whether it did (the caller runs the column-sum kernel otherwise)
 static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
-                 long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate, float* asum = nullptr, bool* asum_done = nullptr) {
+                 long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate, float* asum = nullptr, bool* asum_done = nullptr,
+                 const float* gelu_pre = nullptr) {      // gelu_pre: same contract as asum (folded on the bf16 matrix-core kernel, reported through asum_done)
     hipStream_t s = cx.s;
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
-    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr};
+    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr, nullptr};
     if (asum_done) *asum_done = false;
     // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
     const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
@@ -1457,6 +1458,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         splits = (K + k_chunk - 1) / k_chunk;
         if (bf16) {
             if (asum) { a.asum = asum; if (asum_done) *asum_done = true; }
+            if (gelu_pre) { a.gelu_pre = gelu_pre; if (asum_done) *asum_done = true; }
             const dim3 grid_((unsigned)(gn_ * gm_), 1, splits);      // one-dimensional tile index: the kernel orders the tiles XCD-aware
             if (sak == 1 && sbk == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, true>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
             else if (sak == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, false>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
@@ -1495,7 +1497,10 @@ static int lin_fwd(const TrainCtx& cx, const float* x, const float* W, const flo
     return sgemm(cx, x, K, 1, W, 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false);
 }
 // dW[N, K] += dy[M, N]^T x[M, K];  db[N] += column sums of dy;  dx[M, K] = dy W   (dx may be null)
-static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const float* dy, float* dW, float* db, float* dx, int M, int N, int K) {
+// dx_gelu_pre (optional, [M, K]): dx is additionally multiplied by gelu'(dx_gelu_pre) — the GELU backward of the layer below, folded
+// into the dX product's epilogue when it takes the bf16 matrix-core kernel and run as gelu_bwd_kernel otherwise
+static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const float* dy, float* dW, float* db, float* dx, int M, int N, int K,
+                   const float* dx_gelu_pre = nullptr) {
     // bf16-operand mode, output width not a multiple of 4 (the 95-class head): rows of dy are not 16-byte aligned and N is no multiple of
     // the 32-deep k-step, so both products would fall to the VALU kernel (10 % of the step).  Instead dy and W are copied into zero-padded
     // [M, Np] / [Np, K] buffers (Np = N rounded up to 32) carved off the end of the scratch, both products run on the matrix cores, and the
@@ -1514,13 +1519,21 @@ static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const flo
         HIPCHK(hipGetLastError());
         CHK(colsum(c2, dy, N, M, N, db, true));
         if (dx) CHK(sgemm(c2, dyp, Np, 1, Wp, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, Np, 1.f, false));
+        if (dx && dx_gelu_pre) { hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)(((size_t)M * K + 1023) / 1024)), dim3(256), 0, s, dx_gelu_pre, dx, dx, (size_t)M * K); HIPCHK(hipGetLastError()); }
         return 0;
     }
     // dW += dY^T X; the bias gradient (column sums of dY = row sums of the product's A operand) rides on it in the bf16-operand mode
     bool db_done = false;
     CHK(sgemm(cx, dy, 1, N, x, K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true, db, &db_done));
     if (!db_done) CHK(colsum(cx, dy, N, M, N, db, true));
-    if (dx) CHK(sgemm(cx, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false));
+    if (dx) {
+        bool fused = false;
+        CHK(sgemm(cx, dy, N, 1, W, K, 1, nullptr, nullptr, 0, 0, dx, K, M, K, N, 1.f, false, nullptr, &fused, dx_gelu_pre));
+        if (dx_gelu_pre && !fused) {
+            hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)(((size_t)M * K + 1023) / 1024)), dim3(256), 0, cx.s, dx_gelu_pre, dx, dx, (size_t)M * K);
+            HIPCHK(hipGetLastError());
+        }
+    }
     return 0;
 }
 // dx = add + LayerNorm backward; dgamma += column sums of dy * xhat; dbeta += column sums of dy.  `tmp` is [rows, E] scratch.
@@ -1897,9 +1910,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
         hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, hact, elems);
         HIPCHK(hipGetLastError());
-        CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F));
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, elems);
-        HIPCHK(hipGetLastError());
+        CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F, hpre));      // d_h = d hpre (GELU backward folded in)
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n, nullptr, MS, E, eps)));
         CHK(lin_bwd(cx, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));
         CHK(ln_bwd(cx, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps));   // d_x = d x_mid

@@ -28,7 +28,10 @@ struct SgemmArgs {
     int accumulate;                      // C += ... instead of C = ...
     float* asum;                         // [M] += sum_k A(m, k) (fp32, before any rounding) or nullptr: the bias gradient riding on the dW
                                          // product dY^T X (A = dY^T), which streams dY anyway — mfma_bgemm_kernel only
+    const float* gelu_pre;               // [M][ldc] or nullptr: the stored value is multiplied by gelu'(gelu_pre[m][n]) — the GELU backward
+                                         // riding on the dX product through fc2 (d hpre = (dY W2) * gelu'(hpre)) — mfma_bgemm_kernel only
 };
+__device__ __forceinline__ float gelu_grad(float v);
 
 constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16;
 
@@ -369,9 +372,18 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
 #pragma unroll
                 for (int j = 0; j < 4; ++j) add[j] += cv[j];
             }
+            float mul[4] = {1.f, 1.f, 1.f, 1.f};
+            if (direct && a.gelu_pre) {
+                const float* __restrict__ prow = a.gelu_pre + (size_t)gm_ * a.ldc + gn0;
+                float pv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[j] = cok[j] ? prow[16 * j] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mul[j] = gelu_grad(pv[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (cok[j]) crow[16 * j] = alpha * acc[i][j][r] + add[j];
+                if (cok[j]) crow[16 * j] = (alpha * acc[i][j][r] + add[j]) * mul[j];
         }
 }
 
@@ -408,7 +420,9 @@ void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, 
     if (a.bias) v += a.bias[gn];
     if (a.R) v += a.R[(size_t)(gm % a.rper) * a.ldr + gn];
     float* c = a.C + (size_t)gm * a.ldc + gn;
-    *c = a.accumulate ? *c + v : v;
+    if (a.accumulate) v += *c;
+    if (a.gelu_pre) v *= gelu_grad(a.gelu_pre[(size_t)gm * a.ldc + gn]);
+    *c = v;
 }
 
 // out[n] (+)= sum_m A[m * lda + n]: bias gradients, LayerNorm affine gradients, sums over the batch ([B, L * E] views).
