@@ -1432,10 +1432,10 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // *asum_done whether it did (the caller runs the column-sum kernel otherwise)
 static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
                  long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate, float* asum = nullptr, bool* asum_done = nullptr,
-                 const float* gelu_pre = nullptr) {      // gelu_pre: same contract as asum (folded on the bf16 matrix-core kernel, reported through asum_done)
+                 const float* gelu_pre = nullptr, float* gelu_out = nullptr) {      // gelu_pre / gelu_out: same contract as asum (folded on the bf16 matrix-core kernel, reported through asum_done)
     hipStream_t s = cx.s;
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
-    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr, nullptr};
+    SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr, nullptr, nullptr};
     if (asum_done) *asum_done = false;
     // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
     const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
@@ -1459,6 +1459,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         if (bf16) {
             if (asum) { a.asum = asum; if (asum_done) *asum_done = true; }
             if (gelu_pre) { a.gelu_pre = gelu_pre; if (asum_done) *asum_done = true; }
+            if (gelu_out) { a.gelu_out = gelu_out; if (asum_done) *asum_done = true; }
             const dim3 grid_((unsigned)(gn_ * gm_), 1, splits);      // one-dimensional tile index: the kernel orders the tiles XCD-aware
             if (sak == 1 && sbk == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, true>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
             else if (sak == 1) hipLaunchKernelGGL((mfma_bgemm_kernel<true, false>), grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
@@ -1493,8 +1494,16 @@ static int colsum(const TrainCtx& cx, const float* A, long lda, int M, int N, fl
     return 0;
 }
 // y[M, N] = x[M, K] W[N, K]^T + bias + R[m % rper]
-static int lin_fwd(const TrainCtx& cx, const float* x, const float* W, const float* bias, const float* R, int rper, float* y, int M, int N, int K) {
-    return sgemm(cx, x, K, 1, W, 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false);
+// gelu_out (optional, [M, N]): gelu(y) as a second output — from the product's epilogue on the bf16 matrix-core kernel, by gelu_fwd_kernel otherwise
+static int lin_fwd(const TrainCtx& cx, const float* x, const float* W, const float* bias, const float* R, int rper, float* y, int M, int N, int K,
+                   float* gelu_out = nullptr) {
+    bool fused = false;
+    CHK(sgemm(cx, x, K, 1, W, 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false, nullptr, &fused, nullptr, gelu_out));
+    if (gelu_out && !fused) {
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)(((size_t)M * N + 1023) / 1024)), dim3(256), 0, cx.s, y, gelu_out, (size_t)M * N);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
 }
 // dW[N, K] += dy[M, N]^T x[M, K];  db[N] += column sums of dy;  dx[M, K] = dy W   (dx may be null)
 // dx_gelu_pre (optional, [M, K]): dx is additionally multiplied by gelu'(dx_gelu_pre) — the GELU backward of the layer below, folded
@@ -1811,7 +1820,8 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
 struct TrainEncoderLayout {          // offsets in floats
     size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, total;
     size_t x(int i) const { return layer0 + i * layer_stride; }
-    size_t qkv, ao, x_mid, hpre;     // offsets inside one layer's record (x at 0)
+    size_t qkv, ao, x_mid, hpre, hact_l;     // offsets inside one layer's record (x at 0); hact_l: the GELU output, kept for the backward (round 3:
+                                             // it used to be recomputed there — one more 600 MB pass per block; +4 E floats per token per block)
 };
 static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     const size_t E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, MS = (size_t)B * m->tokens, PK = m->patch_k;
@@ -1822,6 +1832,7 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     o.layer0 = off;
     take(MS * E); o.qkv = off - o.layer0; take(MS * 3 * E); o.ao = off - o.layer0; take(MS * E); o.x_mid = off - o.layer0; take(MS * E);
     o.hpre = off - o.layer0; take(MS * F);
+    o.hact_l = off - o.layer0; take(MS * F);
     o.layer_stride = off - o.layer0;
     off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
     o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
@@ -1879,10 +1890,9 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
         CHK(train_attn(cx, enc_attn_args(m, qkv, ao, nullptr, nullptr), batch, false, ATT_HD));
         CHK(lin_fwd(cx, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), w + o.n, nullptr, MS, E, eps)));
-        CHK(lin_fwd(cx, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E));
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, w + o.hact, elems);
-        HIPCHK(hipGetLastError());
-        CHK(lin_fwd(cx, w + o.hact, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
+        float* hact_l = x + o.hact_l;
+        CHK(lin_fwd(cx, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact_l));      // hpre and gelu(hpre), one epilogue
+        CHK(lin_fwd(cx, hact_l, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
     }
     return run_layernorm<float>(s, w + o.x_last, P("norm.weight"), P("norm.bias"), memory_out, nullptr, MS, E, eps);
 }
@@ -1899,7 +1909,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* w = reinterpret_cast<float*>(workspace);
     auto P = [&](const std::string& key) { return m->p(m->enc + key); };
     auto G = [&](const std::string& key) { return grads + m->params[m->index.at(m->enc + key)].offset; };
-    float* n = w + o.n; float* hact = w + o.hact; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
+    float* n = w + o.n; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
     const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
@@ -1908,8 +1918,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((elems + 1023) / 1024)), dim3(256), 0, s, hpre, hact, elems);
-        HIPCHK(hipGetLastError());
+        const float* hact = x + o.hact_l;                        // kept by the forward
         CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F, hpre));      // d_h = d hpre (GELU backward folded in)
         CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n, nullptr, MS, E, eps)));
         CHK(lin_bwd(cx, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));

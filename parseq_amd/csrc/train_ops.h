@@ -30,6 +30,8 @@ struct SgemmArgs {
                                          // product dY^T X (A = dY^T), which streams dY anyway — mfma_bgemm_kernel only
     const float* gelu_pre;               // [M][ldc] or nullptr: the stored value is multiplied by gelu'(gelu_pre[m][n]) — the GELU backward
                                          // riding on the dX product through fc2 (d hpre = (dY W2) * gelu'(hpre)) — mfma_bgemm_kernel only
+    float* gelu_out;                     // [M][ldc] or nullptr: gelu(stored value) is written here as well (fc1: pre-activation AND activation from one
+                                         // epilogue) — mfma_bgemm_kernel only
 };
 __device__ __forceinline__ float gelu_grad(float v);
 
@@ -381,9 +383,14 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mul[j] = gelu_grad(pv[j]);
             }
+            float* __restrict__ grow = (direct && a.gelu_out) ? a.gelu_out + (size_t)gm_ * a.ldc + gn0 : nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (cok[j]) crow[16 * j] = (alpha * acc[i][j][r] + add[j]) * mul[j];
+                if (cok[j]) {
+                    const float v = (alpha * acc[i][j][r] + add[j]) * mul[j];
+                    crow[16 * j] = v;
+                    if (grow) grow[16 * j] = gelu_erf(v);
+                }
         }
 }
 
@@ -423,6 +430,7 @@ void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, 
     if (a.accumulate) v += *c;
     if (a.gelu_pre) v *= gelu_grad(a.gelu_pre[(size_t)gm * a.ldc + gn]);
     *c = v;
+    if (a.gelu_out) a.gelu_out[(size_t)gm * a.ldc + gn] = gelu_erf(v);
 }
 
 // out[n] (+)= sum_m A[m * lda + n]: bias gradients, LayerNorm affine gradients, sums over the batch ([B, L * E] views).
