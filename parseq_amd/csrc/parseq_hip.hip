@@ -1820,8 +1820,9 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
 struct TrainEncoderLayout {          // offsets in floats
     size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, total;
     size_t x(int i) const { return layer0 + i * layer_stride; }
-    size_t qkv, ao, x_mid, hpre, hact_l;     // offsets inside one layer's record (x at 0); hact_l: the GELU output, kept for the backward (round 3:
-                                             // it used to be recomputed there — one more 600 MB pass per block; +4 E floats per token per block)
+    size_t qkv, ao, x_mid, hpre, hact_l, n1, n2;     // offsets inside one layer's record (x at 0); hact_l, n1, n2: the GELU output and the two
+                                             // LayerNorm outputs, kept for the backward (round 3: they used to be recomputed there — a 600 MB and two
+                                             // 150 MB passes per block; the record grows from 10 E to 16 E floats per token per block)
 };
 static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     const size_t E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio, MS = (size_t)B * m->tokens, PK = m->patch_k;
@@ -1833,6 +1834,7 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     take(MS * E); o.qkv = off - o.layer0; take(MS * 3 * E); o.ao = off - o.layer0; take(MS * E); o.x_mid = off - o.layer0; take(MS * E);
     o.hpre = off - o.layer0; take(MS * F);
     o.hact_l = off - o.layer0; take(MS * F);
+    o.n1 = off - o.layer0; take(MS * E); o.n2 = off - o.layer0; take(MS * E);
     o.layer_stride = off - o.layer0;
     off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
     o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
@@ -1885,13 +1887,13 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         float* x_out = i + 1 < m->cfg.enc_depth ? w + o.x(i + 1) : w + o.x_last;
-        CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), w + o.n, nullptr, MS, E, eps)));
-        CHK(lin_fwd(cx, w + o.n, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
+        CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), x + o.n1, nullptr, MS, E, eps)));
+        CHK(lin_fwd(cx, x + o.n1, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
         CHK(train_attn(cx, enc_attn_args(m, qkv, ao, nullptr, nullptr), batch, false, ATT_HD));
         CHK(lin_fwd(cx, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
-        CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), w + o.n, nullptr, MS, E, eps)));
+        CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), x + o.n2, nullptr, MS, E, eps)));
         float* hact_l = x + o.hact_l;
-        CHK(lin_fwd(cx, w + o.n, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact_l));      // hpre and gelu(hpre), one epilogue
+        CHK(lin_fwd(cx, x + o.n2, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact_l));      // hpre and gelu(hpre), one epilogue
         CHK(lin_fwd(cx, hact_l, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
     }
     return run_layernorm<float>(s, w + o.x_last, P("norm.weight"), P("norm.bias"), memory_out, nullptr, MS, E, eps);
@@ -1909,7 +1911,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* w = reinterpret_cast<float*>(workspace);
     auto P = [&](const std::string& key) { return m->p(m->enc + key); };
     auto G = [&](const std::string& key) { return grads + m->params[m->index.at(m->enc + key)].offset; };
-    float* n = w + o.n; float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
+    float* d_x = w + o.d_x; float* d_a = w + o.d_a; float* d_h = w + o.d_h; float* dqkv = w + o.dqkv;
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
     const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
@@ -1920,14 +1922,12 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
         const float* hact = x + o.hact_l;                        // kept by the forward
         CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F, hpre));      // d_h = d hpre (GELU backward folded in)
-        CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n, nullptr, MS, E, eps)));
-        CHK(lin_bwd(cx, n, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));
+        CHK(lin_bwd(cx, x + o.n2, P(p + "mlp.fc1.weight"), d_h, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, MS, F, E));
         CHK(ln_bwd(cx, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps));   // d_x = d x_mid
         // x_mid = x + proj(attention(qkv(norm1(x))))
         CHK(lin_bwd(cx, ao, P(p + "attn.proj.weight"), d_x, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, MS, E, E));        // d_a = d ao
         CHK(train_attn(cx, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
-        CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), n, nullptr, MS, E, eps)));
-        CHK(lin_bwd(cx, n, P(p + "attn.qkv.weight"), dqkv, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, MS, 3 * E, E));
+        CHK(lin_bwd(cx, x + o.n1, P(p + "attn.qkv.weight"), dqkv, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, MS, 3 * E, E));
         CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps));          // d_x = d x
     }
     CHK(colsum(cx, d_x, (long)S * E, batch, S * E, G("pos_embed"), true));
