@@ -1037,11 +1037,21 @@ constexpr size_t train_attn_bf16_lds(bool backward) {
 
 // rows [r0, r0 + NR) of a [*, 64] fp32 matrix (row stride ld) -> bf16 row-major image (pitch TB_RP) and / or transposed image
 // (dst_t[d][row - r0], pitch tp); all 256 threads, 16-byte global loads
-template <bool ROWS, bool TRANS>
-__device__ __forceinline__ void tb_stage(const float* __restrict__ src, long ld, int NR, bf16_t* dst_r, bf16_t* dst_t, int tp, int tid) {
-    for (int idx = tid; idx < NR * (TB_HD / 4); idx += 256) {
-        const int row = idx >> 4, c4 = (idx & 15) * 4;
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c4);
+// All of a call's loads are issued before the first conversion (NR is a compile-time row count: the loop form was compiled to one load,
+// `s_waitcnt vmcnt(0)`, its LDS stores, next load ... — a full memory round trip per 16 bytes and thread, most of the first version's time).
+template <bool ROWS, bool TRANS, int NR>
+__device__ __forceinline__ void tb_stage(const float* __restrict__ src, long ld, bf16_t* dst_r, bf16_t* dst_t, int tp, int tid) {
+    constexpr int IT = NR * (TB_HD / 4) / 256;
+    float4 ld4[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + 256 * it;
+        ld4[it] = *reinterpret_cast<const float4*>(src + (size_t)(idx >> 4) * ld + (idx & 15) * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + 256 * it, row = idx >> 4, c4 = (idx & 15) * 4;
+        const float4 v = ld4[it];
         const bf16_t e0 = static_cast<bf16_t>(v.x), e1 = static_cast<bf16_t>(v.y), e2 = static_cast<bf16_t>(v.z), e3 = static_cast<bf16_t>(v.w);
         if constexpr (ROWS) {
             bf16x4 o; o[0] = e0; o[1] = e1; o[2] = e2; o[3] = e3;
@@ -1086,11 +1096,11 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
     const float* kg = a.k + (size_t)b * TB_N * a.ldkv + h * TB_HD;
     const float* vg = a.v + (size_t)b * TB_N * a.ldkv + h * TB_HD;
     if constexpr (BACKWARD) {
-        tb_stage<true, true>(kg, a.ldkv, TB_N, Ks, XT, TB_TP, tid);
-        tb_stage<true, false>(vg, a.ldkv, TB_N, Vs, nullptr, 0, tid);
+        tb_stage<true, true, TB_N>(kg, a.ldkv, Ks, XT, TB_TP, tid);
+        tb_stage<true, false, TB_N>(vg, a.ldkv, Vs, nullptr, 0, tid);
     } else {
-        tb_stage<true, false>(kg, a.ldkv, TB_N, Ks, nullptr, 0, tid);
-        tb_stage<false, true>(vg, a.ldkv, TB_N, nullptr, XT, TB_TP, tid);
+        tb_stage<true, false, TB_N>(kg, a.ldkv, Ks, nullptr, 0, tid);
+        tb_stage<false, true, TB_N>(vg, a.ldkv, nullptr, XT, TB_TP, tid);
     }
     f32x4 gk[2][4], gv[2][4];                    // backward: dK / dV of key tiles 2 wave + {0, 1}, head-column tiles 0..3
     if constexpr (BACKWARD) {
@@ -1104,10 +1114,10 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
         __syncthreads();                         // the previous block's readers of Qs / dOs / Qt / dOt / Pt / dSt are done
         const float* qg = a.q + (size_t)b * a.q_bstride + (size_t)q0 * a.ldq + h * TB_HD;
         if constexpr (BACKWARD) {
-            tb_stage<true, true>(qg, a.ldq, TB_QB, Qs, Qt, TB_PP, tid);
-            tb_stage<true, true>(a.d_o + ((size_t)b * TB_N + q0) * a.ldo + h * TB_HD, a.ldo, TB_QB, dOs, dOt, TB_PP, tid);
+            tb_stage<true, true, TB_QB>(qg, a.ldq, Qs, Qt, TB_PP, tid);
+            tb_stage<true, true, TB_QB>(a.d_o + ((size_t)b * TB_N + q0) * a.ldo + h * TB_HD, a.ldo, dOs, dOt, TB_PP, tid);
         } else {
-            tb_stage<true, false>(qg, a.ldq, TB_QB, Qs, nullptr, 0, tid);
+            tb_stage<true, false, TB_QB>(qg, a.ldq, Qs, nullptr, 0, tid);
         }
         __syncthreads();
         // ---- S^T (and dP^T) of this wave's 16 queries against all 128 keys
@@ -1253,12 +1263,22 @@ constexpr size_t train_attn_dec_lds(bool backward) {
 }
 
 // rows [0, NRP) of the images; rows >= nr are zero.  src row r at src + r * ld (32 floats used).  128 threads.
-template <bool ROWS, bool TRANS>
+// MAXR: compile-time bound of NRP; all loads of a call are issued before the first conversion (see tb_stage)
+template <bool ROWS, bool TRANS, int MAXR>
 __device__ __forceinline__ void td_stage(const float* __restrict__ src, long ld, int nr, int NRP, bf16_t* dst_r, bf16_t* dst_t, int tp, int tid) {
-    for (int idx = tid; idx < NRP * (TD_HD / 4); idx += 128) {
-        const int row = idx >> 3, c4 = (idx & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nr) v = *reinterpret_cast<const float4*>(src + (size_t)row * ld + c4);
+    constexpr int IT = MAXR * (TD_HD / 4) / 128;
+    float4 ld4[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + 128 * it, row = idx >> 3;
+        ld4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nr) ld4[it] = *reinterpret_cast<const float4*>(src + (size_t)row * ld + (idx & 7) * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = tid + 128 * it, row = idx >> 3, c4 = (idx & 7) * 4;
+        if (row >= NRP) continue;
+        const float4 v = ld4[it];
         const bf16_t e0 = static_cast<bf16_t>(v.x), e1 = static_cast<bf16_t>(v.y), e2 = static_cast<bf16_t>(v.z), e3 = static_cast<bf16_t>(v.w);
         if constexpr (ROWS) {
             bf16x4 o; o[0] = e0; o[1] = e1; o[2] = e2; o[3] = e3;
@@ -1303,14 +1323,14 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
     const float* vg = a.v + (size_t)b * Lk * a.ldkv + h * TD_HD;
     const float* qg = a.q + (size_t)b * a.q_bstride + h * TD_HD;
     if constexpr (BACKWARD) {
-        td_stage<true, true>(kg, a.ldkv, Lk, NKP, Ks, XT, TD_TP, tid);
-        td_stage<true, false>(vg, a.ldkv, Lk, NKP, Vs, nullptr, 0, tid);
-        td_stage<true, true>(qg, a.ldq, Lq, TD_Q, Qs, Qt, TD_PP, tid);
-        td_stage<true, true>(a.d_o + (size_t)b * Lq * a.ldo + h * TD_HD, a.ldo, Lq, TD_Q, dOs, dOt, TD_PP, tid);
+        td_stage<true, true, TD_K>(kg, a.ldkv, Lk, NKP, Ks, XT, TD_TP, tid);
+        td_stage<true, false, TD_K>(vg, a.ldkv, Lk, NKP, Vs, nullptr, 0, tid);
+        td_stage<true, true, TD_Q>(qg, a.ldq, Lq, TD_Q, Qs, Qt, TD_PP, tid);
+        td_stage<true, true, TD_Q>(a.d_o + (size_t)b * Lq * a.ldo + h * TD_HD, a.ldo, Lq, TD_Q, dOs, dOt, TD_PP, tid);
     } else {
-        td_stage<true, false>(kg, a.ldkv, Lk, NKP, Ks, nullptr, 0, tid);
-        td_stage<false, true>(vg, a.ldkv, Lk, NKP, nullptr, XT, TD_TP, tid);
-        td_stage<true, false>(qg, a.ldq, Lq, TD_Q, Qs, nullptr, 0, tid);
+        td_stage<true, false, TD_K>(kg, a.ldkv, Lk, NKP, Ks, nullptr, 0, tid);
+        td_stage<false, true, TD_K>(vg, a.ldkv, Lk, NKP, nullptr, XT, TD_TP, tid);
+        td_stage<true, false, TD_Q>(qg, a.ldq, Lq, TD_Q, Qs, nullptr, 0, tid);
     }
     __syncthreads();
 
@@ -1432,13 +1452,21 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
                     f32x4 gv = f32x4{0.f, 0.f, 0.f, 0.f}, gk = f32x4{0.f, 0.f, 0.f, 0.f};
                     mma16(gv, pa, ob);               // gv[r] = dV[key 16 jt + 4 g + r][d = 16 dt + r16]
                     mma16(gk, sa, qb);
+                    float ok_[4], ov_[4];            // old values (accumulate): all eight requested before the first store
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * jt + 4 * g + r;
+                        const size_t gi = ((size_t)b * Lk + (j < Lk ? j : 0)) * a.lddkv + h * TD_HD + 16 * dt + r16;
+                        ok_[r] = (a.kv_accumulate && j < Lk) ? a.dk[gi] : 0.f;
+                        ov_[r] = (a.kv_accumulate && j < Lk) ? a.dv[gi] : 0.f;
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = 16 * jt + 4 * g + r;
                         if (j < Lk) {
                             const size_t gi = ((size_t)b * Lk + j) * a.lddkv + h * TD_HD + 16 * dt + r16;
-                            a.dk[gi] = a.kv_accumulate ? a.dk[gi] + gk[r] : gk[r];
-                            a.dv[gi] = a.kv_accumulate ? a.dv[gi] + gv[r] : gv[r];
+                            a.dk[gi] = ok_[r] + gk[r];
+                            a.dv[gi] = ov_[r] + gv[r];
                         }
                     }
                 }
