@@ -1430,13 +1430,60 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // asum (optional): [M] += row sums of A over k, folded into the product when it takes the bf16 matrix-core kernel; returns through
 // *asum_done whether it did (the caller runs the column-sum kernel otherwise)
+// bf16 shadow operands and outputs of a product (train_ops.h SgemmArgs a16 / b16 / c16 / gelu_out16): only on the matrix-core kernels of
+// the bf16-operand mode; a product that asks for them and cannot take those kernels is an error, never a silent fp32 read of bf16 data
+struct GemmExt {
+    bool a16 = false, b16 = false;
+    bf16_t* c16 = nullptr;
+    bf16_t* gelu_out16 = nullptr;
+};
 static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
                  long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate, float* asum = nullptr, bool* asum_done = nullptr,
-                 const float* gelu_pre = nullptr, float* gelu_out = nullptr) {      // gelu_pre / gelu_out: same contract as asum (folded on the bf16 matrix-core kernel, reported through asum_done)
+                 const float* gelu_pre = nullptr, float* gelu_out = nullptr,      // gelu_pre / gelu_out: same contract as asum (folded on the bf16 matrix-core kernel, reported through asum_done)
+                 const GemmExt* ext = nullptr) {
     hipStream_t s = cx.s;
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
     SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr, nullptr, nullptr};
     if (asum_done) *asum_done = false;
+    if (ext && (ext->a16 || ext->b16 || ext->c16 || ext->gelu_out16)) {
+        if (!cx.bf16_ops || !cx.scratch || M < 16 || N < 16) return fail(PARSEQ_E_STATE, "sgemm: bf16 shadow operands outside the bf16-operand mode");
+        a.a16 = ext->a16; a.b16 = ext->b16; a.c16 = ext->c16; a.gelu_out16 = ext->gelu_out16;
+        const int gm_ = (M + MG_BM - 1) / MG_BM, gn_ = (N + MG_BN - 1) / MG_BN, tiles = gm_ * gn_;
+        const bool both = ext->a16 && ext->b16;
+        const int bk = both ? BH_BK : BG_BK;
+        // alignment of the 16-byte (k-contiguous) / 8-byte (outer-contiguous) pieces the loaders read
+        const bool a_ok16 = !ext->a16 ? (aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0 && M % 4 == 0)))
+                                      : (both && aligned16(A) && sak == 1 && sam % 8 == 0);
+        const bool b_ok16 = !ext->b16 ? (aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0)))
+                                      : (aligned16(B) && (sbk == 1 ? sbn % 8 == 0 : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0)));
+        if (!a_ok16 || !b_ok16 || K % bk != 0 || (ext->a16 && !ext->b16) || (both && sbk != 1))
+            return fail(PARSEQ_E_INVALID, "sgemm: shadow operands of a %d x %d x %d product are not laid out for the matrix-core kernels", M, N, K);
+        int splits = 1;
+        if (tiles < 256) {      // the same split as the fp32-in-memory path takes (32-deep stages), so that the two stay bit-identical
+            splits = std::min((512 + tiles - 1) / tiles, K / (4 * BG_BK));
+            splits = (int)std::min<size_t>((size_t)std::max(splits, 1), cx.scratch_floats / ((size_t)M * N + (size_t)M));
+            splits = std::max(splits, 1);
+        }
+        const int k_chunk = ((K + splits - 1) / splits + bk - 1) / bk * bk;
+        splits = (K + k_chunk - 1) / k_chunk;
+        if (asum) { if (both) return fail(PARSEQ_E_INVALID, "sgemm: row sums of a bf16 shadow"); a.asum = asum; }
+        a.gelu_pre = gelu_pre; a.gelu_out = gelu_out;
+        if (asum_done) *asum_done = true;
+        const dim3 grid_((unsigned)tiles, 1, splits);
+        void (*kern)(const SgemmArgs, int, float*, int, int);
+        if (both) kern = mfma_bgemm16_kernel;
+        else if (ext->b16) kern = sak == 1 ? (sbk == 1 ? mfma_bgemm_kernel<true, true, true> : mfma_bgemm_kernel<true, false, true>)
+                                           : (sbk == 1 ? mfma_bgemm_kernel<false, true, true> : mfma_bgemm_kernel<false, false, true>);
+        else kern = sak == 1 ? (sbk == 1 ? mfma_bgemm_kernel<true, true, false> : mfma_bgemm_kernel<true, false, false>)
+                             : (sbk == 1 ? mfma_bgemm_kernel<false, true, false> : mfma_bgemm_kernel<false, false, false>);
+        hipLaunchKernelGGL(kern, grid_, dim3(256), 0, s, a, k_chunk, cx.scratch, gn_, gm_);
+        HIPCHK(hipGetLastError());
+        if (splits > 1) {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)M * N + (a.asum ? (size_t)M : 0) + 255) / 256)), dim3(256), 0, s, a, cx.scratch, splits);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     // matrix-core path: whole 128 x 128 tiles, whole 16-deep stages, 16-byte aligned rows along whichever axis is contiguous
     const bool a_ok = aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
     const bool b_ok = aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0));
@@ -1545,9 +1592,29 @@ static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const flo
     }
     return 0;
 }
+// The same three products on bf16 SHADOW operands (encoder, bf16-operand mode; train_ops.h SgemmArgs): x16 [M, K] and the weight shadows W16 [N, K] /
+// Wt16 [K, N] are bfloat16 in memory; dy stays fp32 where it is the A operand of the dW product (the bias gradient is summed from the
+// unrounded values there) and is read through its shadow dy16 (when the producer wrote one) by the dX product; dx16 / gelu_out16: the
+// result again as bf16 for the next product.  Bit-identical to lin_fwd / lin_bwd on the fp32 copies: the rounding moved, nothing else.
+static int lin_fwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* W16, const float* bias, const float* R, int rper, float* y, int M, int N, int K,
+                     bf16_t* gelu_out16 = nullptr) {
+    GemmExt e; e.a16 = e.b16 = true; e.gelu_out16 = gelu_out16;
+    return sgemm(cx, reinterpret_cast<const float*>(x16), K, 1, reinterpret_cast<const float*>(W16), 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false,
+                 nullptr, nullptr, nullptr, nullptr, &e);
+}
+static int lin_bwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* Wt16, const float* dy, const bf16_t* dy16, float* dW, float* db, float* dx,
+                     bf16_t* dx16, int M, int N, int K, const float* dx_gelu_pre = nullptr) {
+    GemmExt ew; ew.b16 = true;
+    CHK(sgemm(cx, dy, 1, N, reinterpret_cast<const float*>(x16), K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true, db, nullptr, nullptr, nullptr, &ew));
+    if (!dx) return 0;
+    GemmExt ex; ex.b16 = true; ex.a16 = dy16 != nullptr; ex.c16 = dx16;
+    return sgemm(cx, dy16 ? reinterpret_cast<const float*>(dy16) : dy, N, 1, reinterpret_cast<const float*>(Wt16), 1, N, nullptr, nullptr, 0, 0, dx, K, M, K, N,
+                 1.f, false, nullptr, nullptr, dx_gelu_pre, nullptr, &ex);
+}
 // dx = add + LayerNorm backward; dgamma += column sums of dy * xhat; dbeta += column sums of dy.  `tmp` is [rows, E] scratch.
+// dx16 (optional): dx again as bf16, the operand shadow of the dX product that follows.
 static int ln_bwd(const TrainCtx& cx, const float* x, const float* gamma, const float* dy, const float* add, float* dx, float* dgamma, float* dbeta,
-                  float* tmp, int rows, int E, float eps) {
+                  float* tmp, int rows, int E, float eps, bf16_t* dx16 = nullptr) {
     hipStream_t s = cx.s;
     if (E > 768) return fail(PARSEQ_E_INVALID, "layernorm backward: E=%d > 768", E);
     // per-chunk partial sums of dy * xhat and dy land in the scratch ([chunks][2E]); two small column sums fold them (`tmp` is no longer used)
@@ -1556,7 +1623,7 @@ static int ln_bwd(const TrainCtx& cx, const float* x, const float* gamma, const 
     if (!cx.scratch || (size_t)chunks * 2 * E + (size_t)64 * E > cx.scratch_floats) return fail(PARSEQ_E_INVALID, "layernorm backward: %d rows do not fit the scratch", rows);
     float* part = cx.scratch + (cx.scratch_floats - (size_t)chunks * 2 * E);      // the END of the scratch: colsum's own partials use its start
     TrainCtx c2 = cx; c2.scratch_floats = cx.scratch_floats - (size_t)chunks * 2 * E;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(chunks), dim3(256), 0, s, x, gamma, dy, add, dx, part, rows, E, eps);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(chunks), dim3(256), 0, s, x, gamma, dy, add, dx, part, rows, E, eps, dx16);
     HIPCHK(hipGetLastError());
     CHK(colsum(c2, part, 2L * E, chunks, E, dgamma, true));
     return colsum(c2, part + E, 2L * E, chunks, E, dbeta, true);
@@ -1616,6 +1683,7 @@ static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool ba
     if (cx.bf16_ops && hd == TB_HD && a.Lq == TB_N && a.Lk == TB_N && !a.qmask && !a.kmask && !a.drop.thresh && a.q_bstride == (long)a.Lq * a.ldq &&
         a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
         return train_attn_bf16(cx, a, B, backward);
+    if (a.o16) return fail(PARSEQ_E_INVALID, "training attention: a bf16 output is only written by the encoder-shaped bf16 kernel");
     if (hd == 64 && a.Lq % 32 == 0 && a.Lk % 16 == 0 && a.Lk <= 128 && !a.qmask && !a.kmask && !a.drop.thresh && !getenv("PARSEQ_TRAIN_VALU_ATTN"))
         return train_attn_mfma(cx, a, B, backward);
     if (hd == 32) return train_attn_hd<32>(cx, a, B, backward);
@@ -1819,6 +1887,8 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
 // ---- training step, encoder side: forward that keeps what the backward needs, and the backward ------------------------------
 struct TrainEncoderLayout {          // offsets in floats
     size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, total;
+    size_t w16, w16_layer, d_x16, d_h16;      // bf16 shadows (train_enc_shadows): the Linear weights and their transposes ([layer][qkv, proj, fc1, fc2][W16 | Wt16]),
+                                              // the residual-stream gradient and the fc1-output gradient
     size_t x(int i) const { return layer0 + i * layer_stride; }
     size_t qkv, ao, x_mid, hpre, hact_l, n1, n2;     // offsets inside one layer's record (x at 0); hact_l, n1, n2: the GELU output and the two
                                              // LayerNorm outputs, kept for the backward (round 3: they used to be recomputed there — a 600 MB and two
@@ -1839,6 +1909,8 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
     o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
     o.dqkv = take(MS * 3 * E); o.tmp = take(MS * E); o.scratch = take(TRAIN_SCRATCH_FLOATS);
+    o.w16_layer = 4 * E * E + 2 * E * F;      // floats = 2 bf16 each: W16 and Wt16 of the block's four Linear weights
+    o.w16 = take(o.w16_layer * (size_t)m->cfg.enc_depth); o.d_x16 = take(MS * E / 2 + 8); o.d_h16 = take(MS * F / 2 + 8);
     o.total = off;
     return o;
 }
@@ -1856,6 +1928,29 @@ static int train_encoder_check(const parseq_model* m, int batch, const void* wor
     const size_t need = train_encoder_layout(m, batch).total * sizeof(float);
     if (workspace_bytes < need) return fail(PARSEQ_E_INVALID, "workspace: %zu bytes given, %zu needed", workspace_bytes, need);
     return 0;
+}
+
+template <typename TO>
+static int train_ln_fwd(hipStream_t s, const float* x, const float* w, const float* b, TO* out, int rows, int E, float eps) {
+    if (E > 768 || E % 2) return fail(PARSEQ_E_INVALID, "training layernorm: E=%d", E);
+    hipLaunchKernelGGL((ln_fwd_kernel<TO>), dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, out, rows, E, eps);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+// bf16 shadow operands for the encoder's products (train_ops.h SgemmArgs): the bf16-operand mode at the shapes the bf16 attention kernel
+// and the 64-deep GEMM take.  In that mode the record's n1 / n2 / ao / hact_l slots hold bf16 (in the first half of the fp32 slot).
+// PARSEQ_TRAIN_NO_SHADOWS=1 keeps every operand fp32 in memory (the A/B and the bit-identity test).
+static bool train_enc_shadows(const parseq_model* m) {
+    const int E = m->cfg.embed_dim, F = E * m->cfg.enc_mlp_ratio;
+    return m->train_precision == PARSEQ_BF16 && E % 64 == 0 && F % 64 == 0 && m->tokens == TB_N && E == m->cfg.enc_heads * TB_HD &&
+           !getenv("PARSEQ_TRAIN_F32_ATTN") && !getenv("PARSEQ_TRAIN_NO_SHADOWS");
+}
+struct EncShadowW { bf16_t* w; bf16_t* wt; };
+// which: 0 attn.qkv [3E, E], 1 attn.proj [E, E], 2 mlp.fc1 [F, E], 3 mlp.fc2 [E, F]
+static EncShadowW enc_shadow_w(const TrainEncoderLayout& o, float* ws, int layer, int which, size_t E, size_t F) {
+    bf16_t* base = reinterpret_cast<bf16_t*>(ws + o.w16 + o.w16_layer * (size_t)layer);
+    const size_t at[4] = {0, 6 * E * E, 8 * E * E, 8 * E * E + 2 * E * F}, n[4] = {3 * E * E, E * E, E * F, E * F};
+    return EncShadowW{base + at[which], base + at[which] + n[which]};
 }
 
 static TrainAttnArgs enc_attn_args(const parseq_model* m, float* qkv, float* ao, const float* d_ao, float* dqkv) {
@@ -1883,15 +1978,41 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     HIPCHK(hipGetLastError());
     CHK(lin_fwd(cx, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
     const size_t elems = (size_t)MS * F;
+    const bool shadows = train_enc_shadows(m);
+    if (shadows) {
+        // this step's weights as bf16, both ways round (the backward entry reads the transposes from the same workspace)
+        const char* names[4] = {"attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"};
+        const int wn[4] = {3 * E, E, F, E}, wk[4] = {E, E, E, F};
+        for (int i = 0; i < m->cfg.enc_depth; ++i)
+            for (int j = 0; j < 4; ++j) {
+                const EncShadowW sw = enc_shadow_w(o, w, i, j, E, F);
+                hipLaunchKernelGGL(weight_shadow_kernel, dim3(wk[j] / 32, wn[j] / 32), dim3(256), 0, s, P("blocks." + std::to_string(i) + "." + names[j]), wn[j], wk[j], sw.w, sw.wt);
+            }
+        HIPCHK(hipGetLastError());
+    }
     for (int i = 0; i < m->cfg.enc_depth; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         float* x_out = i + 1 < m->cfg.enc_depth ? w + o.x(i + 1) : w + o.x_last;
-        CHK((run_layernorm<float>(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), x + o.n1, nullptr, MS, E, eps)));
+        if (shadows) {
+            bf16_t* n1 = reinterpret_cast<bf16_t*>(x + o.n1); bf16_t* n2 = reinterpret_cast<bf16_t*>(x + o.n2);
+            bf16_t* ao16 = reinterpret_cast<bf16_t*>(ao); bf16_t* hact16 = reinterpret_cast<bf16_t*>(x + o.hact_l);
+            CHK(train_ln_fwd(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, MS, E, eps));
+            CHK(lin_fwd16(cx, n1, enc_shadow_w(o, w, i, 0, E, F).w, P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
+            TrainAttnArgs aa = enc_attn_args(m, qkv, ao, nullptr, nullptr);
+            aa.o16 = ao16;
+            CHK(train_attn(cx, aa, batch, false, ATT_HD));
+            CHK(lin_fwd16(cx, ao16, enc_shadow_w(o, w, i, 1, E, F).w, P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
+            CHK(train_ln_fwd(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, MS, E, eps));
+            CHK(lin_fwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).w, P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact16));
+            CHK(lin_fwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).w, P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
+            continue;
+        }
+        CHK(train_ln_fwd(s, x, P(p + "norm1.weight"), P(p + "norm1.bias"), x + o.n1, MS, E, eps));
         CHK(lin_fwd(cx, x + o.n1, P(p + "attn.qkv.weight"), P(p + "attn.qkv.bias"), nullptr, 0, qkv, MS, 3 * E, E));
         CHK(train_attn(cx, enc_attn_args(m, qkv, ao, nullptr, nullptr), batch, false, ATT_HD));
         CHK(lin_fwd(cx, ao, P(p + "attn.proj.weight"), P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
-        CHK((run_layernorm<float>(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), x + o.n2, nullptr, MS, E, eps)));
+        CHK(train_ln_fwd(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), x + o.n2, MS, E, eps));
         float* hact_l = x + o.hact_l;
         CHK(lin_fwd(cx, x + o.n2, P(p + "mlp.fc1.weight"), P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact_l));      // hpre and gelu(hpre), one epilogue
         CHK(lin_fwd(cx, hact_l, P(p + "mlp.fc2.weight"), P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
@@ -1915,10 +2036,25 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
     const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
-    CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps));
+    const bool shadows = train_enc_shadows(m);
+    bf16_t* d_x16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_x16) : nullptr;
+    bf16_t* d_h16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_h16) : nullptr;
+    CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps, d_x16));
     for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
+        if (shadows) {
+            const bf16_t* n1 = reinterpret_cast<const bf16_t*>(x + o.n1); const bf16_t* n2 = reinterpret_cast<const bf16_t*>(x + o.n2);
+            const bf16_t* ao16 = reinterpret_cast<const bf16_t*>(ao); const bf16_t* hact16 = reinterpret_cast<const bf16_t*>(x + o.hact_l);
+            CHK(lin_bwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).wt, d_x, d_x16, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, d_h16, MS, E, F, hpre));
+            CHK(lin_bwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).wt, d_h, d_h16, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, nullptr, MS, F, E));
+            CHK(ln_bwd(cx, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps, d_x16));
+            CHK(lin_bwd16(cx, ao16, enc_shadow_w(o, w, i, 1, E, F).wt, d_x, d_x16, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, nullptr, MS, E, E));
+            CHK(train_attn(cx, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
+            CHK(lin_bwd16(cx, n1, enc_shadow_w(o, w, i, 0, E, F).wt, dqkv, nullptr, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, nullptr, MS, 3 * E, E));
+            CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps, d_x16));
+            continue;
+        }
         // x_out = x_mid + fc2(gelu(fc1(norm2(x_mid))))        d_x = d x_out
         const float* hact = x + o.hact_l;                        // kept by the forward
         CHK(lin_bwd(cx, hact, P(p + "mlp.fc2.weight"), d_x, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, MS, E, F, hpre));      // d_h = d hpre (GELU backward folded in)

@@ -10,6 +10,7 @@
 // All tensors are fp32, row-major.  Kernels that accumulate say so; everything is deterministic (no atomics).
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 namespace pq {
 
@@ -32,6 +33,12 @@ struct SgemmArgs {
                                          // riding on the dX product through fc2 (d hpre = (dY W2) * gelu'(hpre)) — mfma_bgemm_kernel only
     float* gelu_out;                     // [M][ldc] or nullptr: gelu(stored value) is written here as well (fc1: pre-activation AND activation from one
                                          // epilogue) — mfma_bgemm_kernel only
+    // bf16 SHADOW operands (round 3; the matrix-core kernels of the bf16-operand mode only): the producer of an activation writes it as
+    // bfloat16 — the same round-to-nearest-even the operand loaders applied on the way into LDS, so the products are bit-identical — and
+    // the GEMM reads half the bytes with nothing to convert.  a16 / b16: A / B point at bf16_t data (strides in elements).
+    int a16, b16;
+    bf16_t* c16;                         // [M][ldc] or nullptr: the stored value again, rounded to bf16 (the next product's operand)
+    bf16_t* gelu_out16;                  // [M][ldc] or nullptr: gelu(stored value) as bf16 (instead of gelu_out)
 };
 __device__ __forceinline__ float gelu_grad(float v);
 
@@ -194,16 +201,22 @@ constexpr int BG_BK = 32, BG_LD = 40;       // elements
 //   * XCD-aware tile order: the hardware deals consecutive workgroup ids to the eight XCDs (private L2s) round-robin, so the N-tiles
 //     that share an A row panel all landed on different XCDs and each fetched the panel from HBM for itself.  Workgroup id L now maps to
 //     logical id (L % 8) * (total / 8) + L / 8 and logical ids walk the N-tiles of one row panel first: a panel's consumers share an L2.
-template <bool KFAST>
+template <bool KFAST, typename T = float>
 struct BgOperand {
-    const float* p[4];            // this thread's four 16-byte loads of the current stage
+    static constexpr bool HALF = sizeof(T) == 2;                 // bf16 shadow operand: loaded and parked as it is
+    static constexpr int NL = (KFAST && HALF) ? 2 : 4;           // loads per thread and stage
+    using V = std::conditional_t<!HALF, float4, std::conditional_t<KFAST, u32x4, u32x2>>;      // native vectors: HIP's uint4 / uint2 structs in an array end up in scratch
+    const T* p[NL];               // this thread's loads of the current stage
     long step;                    // pointer increment per 32-deep stage
-    __device__ __forceinline__ void init(const float* __restrict__ base, long s_outer, long s_k, int outer0, int limit, int k0, int tid) {
+    __device__ __forceinline__ void init(const T* __restrict__ base, long s_outer, long s_k, int outer0, int limit, int k0, int tid) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            if constexpr (KFAST) {                  // rows of 32 consecutive k: thread = (row idx >> 3, 4 consecutive k at 4 (idx & 7))
+        for (int it = 0; it < NL; ++it) {
+            if constexpr (KFAST && !HALF) {         // rows of 32 consecutive k: thread = (row idx >> 3, 4 consecutive k at 4 (idx & 7))
                 const int idx = tid + 256 * it, o = min(outer0 + (idx >> 3), limit - 1);
                 p[it] = base + (size_t)o * s_outer + k0 + 4 * (idx & 7);
+            } else if constexpr (KFAST) {           // bf16 rows of 32 k = 64 bytes: thread = (row idx >> 2, 8 consecutive k at 8 (idx & 3))
+                const int idx = tid + 256 * it, o = min(outer0 + (idx >> 2), limit - 1);
+                p[it] = base + (size_t)o * s_outer + k0 + 8 * (idx & 3);
             } else {                                 // four CONSECUTIVE k of the same four outer indices per thread
                 const int k = 4 * (tid >> 5) + it, o = min(outer0 + 4 * (tid & 31), limit - 4);
                 p[it] = base + (size_t)(k0 + k) * s_k + o;
@@ -211,12 +224,12 @@ struct BgOperand {
         }
         step = KFAST ? (long)BG_BK : (long)BG_BK * s_k;
     }
-    __device__ __forceinline__ void fetch(float4 (&r)[4]) {
+    __device__ __forceinline__ void fetch(V (&r)[NL]) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { r[it] = *reinterpret_cast<const float4*>(p[it]); p[it] += step; }
+        for (int it = 0; it < NL; ++it) { r[it] = *reinterpret_cast<const V*>(p[it]); p[it] += step; }
     }
-    static __device__ __forceinline__ void park(bf16_t (*tile)[BG_LD], const float4 (&r)[4], int tid) {
-        if constexpr (KFAST) {
+    static __device__ __forceinline__ void park(bf16_t (*tile)[BG_LD], const V (&r)[NL], int tid) {
+        if constexpr (KFAST && !HALF) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int idx = tid + 256 * it, o = idx >> 3, k4 = idx & 7;
@@ -224,7 +237,13 @@ struct BgOperand {
                 h.e[0] = static_cast<bf16_t>(r[it].x); h.e[1] = static_cast<bf16_t>(r[it].y); h.e[2] = static_cast<bf16_t>(r[it].z); h.e[3] = static_cast<bf16_t>(r[it].w);
                 *reinterpret_cast<uint2*>(&tile[o][4 * k4]) = h.u;
             }
-        } else {
+        } else if constexpr (KFAST) {
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int idx = tid + 256 * it;
+                *reinterpret_cast<u32x4*>(&tile[idx >> 2][8 * (idx & 3)]) = r[it];
+            }
+        } else if constexpr (!HALF) {
             // r[it] = four outer indices (4 o4 .. 4 o4 + 3) at k = 4 kq + it: transposed in registers, one 8-byte store per outer index
             // (these stores conflict 8-way in LDS — rows four apart are 16 banks apart; rotating each lane's row order made them 2-way and
             // changed nothing measurable: the dW products are not bound by it)
@@ -237,109 +256,121 @@ struct BgOperand {
                 for (int it = 0; it < 4; ++it) h.e[it] = static_cast<bf16_t>(v[it][i]);
                 *reinterpret_cast<uint2*>(&tile[4 * o4 + i][4 * kq]) = h.u;
             }
+        } else {
+            // the same 4 x 4 transposition on 16-bit values: r[it] = {lo 16 bits of .x: outer 0, hi: outer 1, .y: outer 2, 3} at k = 4 kq + it
+            const int kq = tid >> 5, o4 = tid & 31;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned e[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { const unsigned w = (i & 2) ? r[it].y : r[it].x; e[it] = (i & 1) ? (w >> 16) : (w & 0xffffu); }
+                *reinterpret_cast<u32x2*>(&tile[4 * o4 + i][4 * kq]) = u32x2{e[0] | (e[1] << 16), e[2] | (e[3] << 16)};
+            }
         }
     }
 };
 
-// grid: (tiles_n * tiles_m, 1, splits) workgroups; gn, gm = the tile counts
-template <bool AKF, bool BKF>
-__global__ __launch_bounds__(256)
-void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[2][MG_BM][BG_LD];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][MG_BN][BG_LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order (see above); the tail that does not fill a whole group of eight keeps its id
-    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
-    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
-    const int tn_ = logical % gn, tm_ = logical / gn;
-    const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
+// Epilogue of the bf16-operand kernels.  Lane holds D[row = 16 i + 4 g + r][col = 16 j + r16] of its wave's 64 x 64 quarter.
+//
+// Staged form (round 3, the usual case): the accumulators go through LDS — the operand tiles are dead — 64 rows at a time, and come back
+// as 16-byte row pieces: 32 lanes write 512 contiguous bytes of a row of C (and read the residual / old-C / GELU rows the same way),
+// the bf16 shadows leave as 8-byte pieces.  The direct form below it (one 4-byte access per lane and element, 16 lanes = 64 bytes per row
+// and instruction, 64 store instructions per lane and output) ran the products whose output is large at 1-2 TB/s of C — the stores, not
+// the operand traffic, were what bounded them (49 152 x 1536: 302 MB of C in 169 us; with a second, 2-byte shadow store per element
+// 229 us).  Same arithmetic in the same order: (alpha acc + ((bias + residual) + old C)) * gelu'(pre).
+// The direct form remains for outputs that are not 16-byte addressable (the 95-class head) and for edge tiles in N.
+constexpr int EP_LD = 132;       // floats per staged row: 128 + 4 (the four row groups of a store land on distinct banks)
+constexpr int EP_STAGE_BYTES = 64 * EP_LD * 4;
+__device__ __forceinline__ bool ep_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+__device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&acc)[4][4], float* __restrict__ partial, float* __restrict__ stage,
+                                            int m0, int n0, int tid) {
+    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int r16 = lane & 15, g = lane >> 4;
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
-    BgOperand<AKF> oa; BgOperand<BKF> ob;
-    oa.init(a.A, a.sam, a.sak, m0, a.M, kbeg, tid);
-    ob.init(a.B, a.sbn, a.sbk, n0, a.N, kbeg, tid);
-    float4 ra[4], rb[4];
-    // row sums of A over this workgroup's k range (a.asum; only the first N-tile of a row panel adds them up): rs[i] belongs to outer
-    // index 4 (tid & 31) + i (outer-contiguous A) or to row (tid >> 3) + 32 i (k-contiguous A: eight lanes per row)
-    const bool do_sum = a.asum != nullptr && tn_ == 0;
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    auto add_rows = [&]() {
-        if constexpr (AKF) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) rs[it] += (ra[it].x + ra[it].y) + (ra[it].z + ra[it].w);
-        } else {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) { rs[0] += ra[it].x; rs[1] += ra[it].y; rs[2] += ra[it].z; rs[3] += ra[it].w; }
-        }
-    };
-    if (kbeg < kend) {
-        oa.fetch(ra); ob.fetch(rb);
-        if (do_sum) add_rows();
-        BgOperand<AKF>::park(As[0], ra, tid);
-        BgOperand<BKF>::park(Bs[0], rb, tid);
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BG_BK) {
-        const bool more = k0 + BG_BK < kend;
-        if (more) { oa.fetch(ra); ob.fetch(rb); }       // in flight under this stage's MFMAs; first touched by park() below
-        bf16x8 av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            av[i] = *reinterpret_cast<const bf16x8*>(&As[cur][wm + 16 * i + r16][8 * g]);
-            bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn + 16 * i + r16][8 * g]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);              // nothing of park() (its waits for the loads) moves above the MFMAs
-        if (more) {
-            if (do_sum) add_rows();
-            BgOperand<AKF>::park(As[cur ^ 1], ra, tid);
-            BgOperand<BKF>::park(Bs[cur ^ 1], rb, tid);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (do_sum) {
-        // fold the threads' partial row sums in a fixed order through LDS (the operand tiles are dead) and add them to a.asum
-        // (split-K: to this split's slot behind the product's partials; splitk_reduce_kernel adds the slots up)
-        float* red = reinterpret_cast<float*>(&As[0][0][0]);          // [8][128]
-        if constexpr (AKF) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                float v = rs[it];
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-                if ((tid & 7) == 0) red[(tid >> 3) + 32 * it] = v;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) red[(tid >> 5) * 128 + 4 * (tid & 31) + i] = rs[i];
-        }
-        __syncthreads();
-        if (tid < 128 && m0 + tid < a.M) {
-            float v;
-            if constexpr (AKF) v = red[tid];
-            else v = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) + ((red[512 + tid] + red[640 + tid]) + (red[768 + tid] + red[896 + tid]));
-            if (gridDim.z == 1) a.asum[m0 + tid] += v;
-            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)blockIdx.z * a.M + m0 + tid] = v;
-        }
-        __syncthreads();
-    }
-    // lane holds D[row = 16 i + 4 g + r][col = 16 j + r16].  Epilogue per row: ONE row base for C (and for the residual row), the four
-    // columns at constant offsets; bias once per column; the residual / old-C values of a row are all requested before the row's first
-    // store (the element-at-a-time form spent 64-bit index arithmetic and a modulo per element and waited for every load on its own:
-    // as many VALU instructions as 2.5 main loops at K = 384).  R never aliases C on this path (C itself is re-read only by accumulate).
     const bool direct = gridDim.z == 1;
     float* __restrict__ out = direct ? a.C : partial + (size_t)blockIdx.z * a.M * a.N;
     const long ldo = direct ? a.ldc : a.N;
+    const float* __restrict__ Rb = direct ? a.R : nullptr;
+    const bool acc_c = direct && a.accumulate;
+    const float alpha = direct ? a.alpha : 1.f;
+    bool vec = n0 + MG_BN <= a.N && ldo % 4 == 0 && ep_al16(out);
+    if (direct)
+        vec = vec && ep_al16(a.bias) && ep_al16(a.R) && a.ldr % 4 == 0 && ep_al16(a.gelu_pre) && ep_al16(a.gelu_out) && ep_al16(a.c16) && ep_al16(a.gelu_out16);
+    if (vec) {
+        const int c4 = tid & 31, gn = n0 + 4 * c4;
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (direct && a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + gn);
+        const float* __restrict__ pre = direct ? a.gelu_pre : nullptr;
+        float* __restrict__ gout = direct ? a.gelu_out : nullptr;
+        bf16_t* __restrict__ c16 = direct ? a.c16 : nullptr;
+        bf16_t* __restrict__ g16 = direct ? a.gelu_out16 : nullptr;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if ((wave >> 1) == h) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) stage[(16 * i + 4 * g + r) * EP_LD + wn + 16 * j + r16] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                // two row pieces per thread and round (four would spill at three waves per SIMD): everything they read is requested
+                // before the first of them is stored
+                constexpr int NQ = 2;
+                f32x4 v[NQ], rv[NQ], cv[NQ], pv[NQ];
+                bool ok[NQ];
+                size_t at[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int row = (tid >> 5) + 8 * (NQ * qq + q), gm_ = m0 + 64 * h + row;
+                    ok[q] = gm_ < a.M;
+                    at[q] = (size_t)gm_ * ldo + gn;
+                    v[q] = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + 4 * c4);
+                    rv[q] = cv[q] = pv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (Rb && ok[q]) rv[q] = *reinterpret_cast<const f32x4*>(Rb + (size_t)(gm_ < a.rper ? gm_ : gm_ % a.rper) * a.ldr + gn);
+                    if (acc_c && ok[q]) cv[q] = *reinterpret_cast<const f32x4*>(out + at[q]);
+                    if (pre && ok[q]) pv[q] = *reinterpret_cast<const f32x4*>(pre + at[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (!ok[q]) continue;
+                    f32x4 add = b4;
+                    if (Rb) add += rv[q];
+                    if (acc_c) add += cv[q];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf(alpha, v[q][e], add[e]);      // spelled out: both forms and every instantiation round alike
+                    if (pre) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] *= gelu_grad(pv[q][e]);
+                    }
+                    *reinterpret_cast<f32x4*>(out + at[q]) = o;
+                    if (c16) {
+                        union { u32x2 u; bf16_t e[4]; } hh;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) hh.e[e] = static_cast<bf16_t>(o[e]);
+                        *reinterpret_cast<u32x2*>(c16 + at[q]) = hh.u;
+                    }
+                    if (gout || g16) {
+                        f32x4 ge;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ge[e] = gelu_erf(o[e]);
+                        if (gout) *reinterpret_cast<f32x4*>(gout + at[q]) = ge;
+                        if (g16) {
+                            union { u32x2 u; bf16_t e[4]; } hh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) hh.e[e] = static_cast<bf16_t>(ge[e]);
+                            *reinterpret_cast<u32x2*>(g16 + at[q]) = hh.u;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int gn0 = n0 + wn + r16;
     bool cok[4];
     float bj[4];
@@ -348,9 +379,6 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
         cok[j] = gn0 + 16 * j < a.N;
         bj[j] = (direct && a.bias && cok[j]) ? a.bias[gn0 + 16 * j] : 0.f;
     }
-    const float* __restrict__ Rb = direct ? a.R : nullptr;
-    const bool acc_c = direct && a.accumulate;
-    const float alpha = direct ? a.alpha : 1.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -384,14 +412,209 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
                 for (int j = 0; j < 4; ++j) mul[j] = gelu_grad(pv[j]);
             }
             float* __restrict__ grow = (direct && a.gelu_out) ? a.gelu_out + (size_t)gm_ * a.ldc + gn0 : nullptr;
+            bf16_t* __restrict__ c16row = (direct && a.c16) ? a.c16 + (size_t)gm_ * a.ldc + gn0 : nullptr;
+            bf16_t* __restrict__ g16row = (direct && a.gelu_out16) ? a.gelu_out16 + (size_t)gm_ * a.ldc + gn0 : nullptr;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (cok[j]) {
-                    const float v = (alpha * acc[i][j][r] + add[j]) * mul[j];
+                    const float v = fmaf(alpha, acc[i][j][r], add[j]) * mul[j];
                     crow[16 * j] = v;
+                    if (c16row) c16row[16 * j] = static_cast<bf16_t>(v);
                     if (grow) grow[16 * j] = gelu_erf(v);
+                    if (g16row) g16row[16 * j] = static_cast<bf16_t>(gelu_erf(v));
                 }
         }
+}
+
+// grid: (tiles_n * tiles_m, 1, splits) workgroups; gn, gm = the tile counts.  B16: the B operand is a bf16 shadow (a.b16).
+template <bool AKF, bool BKF, bool B16 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    using TB = std::conditional_t<B16, bf16_t, float>;
+    using OpB = BgOperand<BKF, TB>;
+    // one LDS block: the two operands' two stages, then (all of it) the epilogue's staging tile
+    constexpr int TILE_BYTES = 2 * MG_BM * BG_LD * 2;
+    static_assert(2 * TILE_BYTES >= EP_STAGE_BYTES && 2 * TILE_BYTES >= 8 * 128 * 4, "LDS block too small for the epilogue");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    bf16_t (*As)[MG_BM][BG_LD] = reinterpret_cast<bf16_t (*)[MG_BM][BG_LD]>(smem);
+    bf16_t (*Bs)[MG_BN][BG_LD] = reinterpret_cast<bf16_t (*)[MG_BN][BG_LD]>(smem + TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order (see above); the tail that does not fill a whole group of eight keeps its id
+    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
+    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
+    const int tn_ = logical % gn, tm_ = logical / gn;
+    const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    BgOperand<AKF> oa; OpB ob;
+    oa.init(a.A, a.sam, a.sak, m0, a.M, kbeg, tid);
+    ob.init(reinterpret_cast<const TB*>(a.B), a.sbn, a.sbk, n0, a.N, kbeg, tid);
+    float4 ra[4];
+    typename OpB::V rb[OpB::NL];
+    // row sums of A over this workgroup's k range (a.asum; only the first N-tile of a row panel adds them up): rs[i] belongs to outer
+    // index 4 (tid & 31) + i (outer-contiguous A) or to row (tid >> 3) + 32 i (k-contiguous A: eight lanes per row)
+    const bool do_sum = a.asum != nullptr && tn_ == 0;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    auto add_rows = [&]() {
+        if constexpr (AKF) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rs[it] += (ra[it].x + ra[it].y) + (ra[it].z + ra[it].w);
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { rs[0] += ra[it].x; rs[1] += ra[it].y; rs[2] += ra[it].z; rs[3] += ra[it].w; }
+        }
+    };
+    if (kbeg < kend) {
+        oa.fetch(ra); ob.fetch(rb);
+        if (do_sum) add_rows();
+        BgOperand<AKF>::park(As[0], ra, tid);
+        OpB::park(Bs[0], rb, tid);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BG_BK) {
+        const bool more = k0 + BG_BK < kend;
+        if (more) { oa.fetch(ra); ob.fetch(rb); }       // in flight under this stage's MFMAs; first touched by park() below
+        bf16x8 av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            av[i] = *reinterpret_cast<const bf16x8*>(&As[cur][wm + 16 * i + r16][8 * g]);
+            bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn + 16 * i + r16][8 * g]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);              // nothing of park() (its waits for the loads) moves above the MFMAs
+        if (more) {
+            if (do_sum) add_rows();
+            BgOperand<AKF>::park(As[cur ^ 1], ra, tid);
+            OpB::park(Bs[cur ^ 1], rb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (do_sum) {
+        // fold the threads' partial row sums in a fixed order through LDS (the operand tiles are dead) and add them to a.asum
+        // (split-K: to this split's slot behind the product's partials; splitk_reduce_kernel adds the slots up)
+        float* red = reinterpret_cast<float*>(smem);                   // [8][128]
+        if constexpr (AKF) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                float v = rs[it];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                if ((tid & 7) == 0) red[(tid >> 3) + 32 * it] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(tid >> 5) * 128 + 4 * (tid & 31) + i] = rs[i];
+        }
+        __syncthreads();
+        if (tid < 128 && m0 + tid < a.M) {
+            float v;
+            if constexpr (AKF) v = red[tid];
+            else v = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) + ((red[512 + tid] + red[640 + tid]) + (red[768 + tid] + red[896 + tid]));
+            if (gridDim.z == 1) a.asum[m0 + tid] += v;
+            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)blockIdx.z * a.M + m0 + tid] = v;
+        }
+        __syncthreads();
+    }
+    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
+}
+
+// Both operands bf16 shadows with k contiguous (the forward products x W^T of the encoder, and dX = dY W through the transposed
+// weight shadow): 64 of K per stage — a row of a stage is 128 bytes, one whole cache line per row and request, where a 32-deep stage of
+// bf16 would use half of every line it pulls into the CU's L1 — loaded as 16-byte pieces and parked in LDS as they are (no conversion,
+// no VALU work between the load and the ds_write_b128).  One LDS buffer of 128 x (64 + 8) per operand (36 KiB: three workgroups per CU
+// as before), the next stage waits in registers under the current stage's 32 MFMAs per wave.  Same tile order, accumulation order
+// (ascending k in steps of 32), split-K and epilogue as mfma_bgemm_kernel: bit-identical results.  K % 64 == 0.
+constexpr int BH_BK = 64, BH_LD = 72;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
+    static_assert(2 * TILE_BYTES >= EP_STAGE_BYTES, "LDS block too small for the epilogue");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
+    bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
+    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
+    const int tn_ = logical % gn, tm_ = logical / gn;
+    const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    // thread = (row idx >> 3, 8 consecutive k at 8 (idx & 7)), idx = tid + 256 it; rows past the edge re-read the last valid row
+    const bf16_t* pa[4];
+    const bf16_t* pb[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = tid + 256 * it;
+        pa[it] = reinterpret_cast<const bf16_t*>(a.A) + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.sam + kbeg + 8 * (idx & 7);
+        pb[it] = reinterpret_cast<const bf16_t*>(a.B) + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.sbn + kbeg + 8 * (idx & 7);
+    }
+    u32x4 ra[4], rb[4];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { ra[it] = *reinterpret_cast<const u32x4*>(pa[it]); pa[it] += BH_BK; }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { rb[it] = *reinterpret_cast<const u32x4*>(pb[it]); pb[it] += BH_BK; }
+    };
+    if (kbeg < kend) fetch();
+    for (int k0 = kbeg; k0 < kend; k0 += BH_BK) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;
+            *reinterpret_cast<u32x4*>(&As[idx >> 3][8 * (idx & 7)]) = ra[it];
+            *reinterpret_cast<u32x4*>(&Bs[idx >> 3][8 * (idx & 7)]) = rb[it];
+        }
+        __syncthreads();
+        if (k0 + BH_BK < kend) fetch();                 // in flight under this stage's MFMAs; first touched by the stores above, next round
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
+                bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * i + r16][32 * kk + 8 * g]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);              // the waits for the loads stay below the MFMAs
+        __syncthreads();
+    }
+    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
+}
+
+// bf16 shadows of a Linear weight W [N, K] (fp32 master): W16 [N, K] and its transpose Wt16 [K, N], once per step.  N, K multiples of 32.
+__global__ __launch_bounds__(256)
+void weight_shadow_kernel(const float* __restrict__ W, int N, int K, bf16_t* __restrict__ W16, bf16_t* __restrict__ Wt16) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const float v = W[(size_t)(n0 + r) * K + k0 + tx];
+        t[r][tx] = v;
+        W16[(size_t)(n0 + r) * K + k0 + tx] = static_cast<bf16_t>(v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) Wt16[(size_t)(k0 + r) * N + n0 + tx] = static_cast<bf16_t>(t[tx][r]);
 }
 
 // dst[Rd, Cd] = src[Rs, Cs] in its top-left corner, zeros elsewhere (Rd >= Rs, Cd >= Cs)
@@ -430,7 +653,9 @@ void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, 
     if (a.accumulate) v += *c;
     if (a.gelu_pre) v *= gelu_grad(a.gelu_pre[(size_t)gm * a.ldc + gn]);
     *c = v;
+    if (a.c16) a.c16[(size_t)gm * a.ldc + gn] = static_cast<bf16_t>(v);
     if (a.gelu_out) a.gelu_out[(size_t)gm * a.ldc + gn] = gelu_erf(v);
+    if (a.gelu_out16) a.gelu_out16[(size_t)gm * a.ldc + gn] = static_cast<bf16_t>(gelu_erf(v));
 }
 
 // out[n] (+)= sum_m A[m * lda + n]: bias gradients, LayerNorm affine gradients, sums over the batch ([B, L * E] views).
@@ -457,6 +682,48 @@ void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* _
     }
 }
 
+// LayerNorm forward of the training encoder, E <= 768 and even; one row per wave, a lane owns column pairs (2 lane + 128 i).  Two-pass
+// statistics like rowops.h layernorm_kernel; the affine step is ONE explicit fma, so that the fp32 output and the bf16 output (the
+// operand shadow of the products that follow, two elements per 4-byte store) are roundings of the same value whatever the compiler
+// does with each instantiation (layernorm_kernel<float> and <bf16> contract it differently: 5 of 1.5 M elements a bf16 ulp apart).
+template <typename TO>
+__global__ __launch_bounds__(256)
+void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, TO* __restrict__ out, int rows, int E, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* __restrict__ xr = x + (size_t)row * E;
+    f32x2 v[6];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = 2 * lane + 128 * i;
+        v[i] = c < E ? *reinterpret_cast<const f32x2*>(xr + c) : f32x2{0.f, 0.f};
+        s += v[i][0] + v[i][1];
+    }
+    const float inv = 1.0f / (float)E;
+    const float mean = wave_sum(s) * inv;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (2 * lane + 128 * i < E) { const float d0 = v[i][0] - mean, d1 = v[i][1] - mean; ss += d0 * d0 + d1 * d1; }
+    const float rstd = 1.0f / sqrtf(wave_sum(ss) * inv + eps);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int c = 2 * lane + 128 * i;
+        if (c < E) {
+            const f32x2 wv = *reinterpret_cast<const f32x2*>(w + c), bv = *reinterpret_cast<const f32x2*>(b + c);
+            const float y0 = fmaf((v[i][0] - mean) * rstd, wv[0], bv[0]), y1 = fmaf((v[i][1] - mean) * rstd, wv[1], bv[1]);
+            if constexpr (sizeof(TO) == 2) {
+                union { unsigned u; bf16_t e[2]; } h;
+                h.e[0] = static_cast<bf16_t>(y0); h.e[1] = static_cast<bf16_t>(y1);
+                *reinterpret_cast<unsigned*>(out + (size_t)row * E + c) = h.u;
+            } else {
+                *reinterpret_cast<f32x2*>(out + (size_t)row * E + c) = f32x2{y0, y1};
+            }
+        }
+    }
+}
+
 // LayerNorm backward, statistics recomputed from x (E <= 768); a workgroup owns LNB_ROWS consecutive rows, one wave per row at a time:
 //   dx_out = (add ? add : 0) + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
 //   partial[chunk][0 .. E)   = sum over the chunk's rows of dy * xhat   (weight gradient)
@@ -467,7 +734,7 @@ void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* _
 constexpr int LNB_ROWS = 4;       // one row per wave: 64 and 32 rows per workgroup (a serial row loop per wave, even with the next row prefetched) ran the kernel at 68-75 us where one row per wave runs it at HBM speed
 __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ add,
-                   float* __restrict__ dx_out, float* __restrict__ partial, int rows, int E, float eps) {
+                   float* __restrict__ dx_out, float* __restrict__ partial, int rows, int E, float eps, bf16_t* __restrict__ dx16) {
     __shared__ float red[4][2][768];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float pg[12], pb[12];
@@ -527,6 +794,7 @@ void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
                 float d = rstd * (gv[i] - m1 - xv[i] * m2);
                 if (add) d += add[base + c];
                 dx_out[base + c] = d;
+                if (dx16) dx16[base + c] = static_cast<bf16_t>(d);      // the shadow the next dX product reads
                 pg[i] += dv[i] * xv[i];
                 pb[i] += dv[i];
             }
@@ -731,6 +999,7 @@ struct TrainAttnArgs {
     const float* k; const float* v; int ldkv;
     const unsigned char* qmask; const unsigned char* kmask; int ldkm;
     float* o; int ldo;                                           // forward output, row (b, l): o + (b * Lq + l) * ldo + HD h
+    bf16_t* o16 = nullptr;                                       // train_attn_bf16_kernel forward: write o here as bf16 INSTEAD (same layout)
     const float* d_o;                                            // backward: gradient of o (same layout as o)
     float* dq; int lddq;                                         // backward: stored, row (b, l) even when q is shared
     float* dk; float* dv; int lddkv;                             // backward: layout of k / v; accumulated into if kv_accumulate
@@ -1172,6 +1441,12 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) mma16(oacc, tb_keyslot_frag(XT, 16 * dt + r16, kk, g), pf[kk]);
                 // oacc[r] = O[query r16][d = 16 dt + 4 g + r]
+                if (a.o16) {
+                    union { uint2 u; bf16_t e[4]; } h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h.e[r] = static_cast<bf16_t>(oacc[r] * inv);
+                    *reinterpret_cast<uint2*>(a.o16 + (og - a.o) + 16 * dt + 4 * g) = h.u;
+                } else
                 *reinterpret_cast<f32x4*>(og + 16 * dt + 4 * g) = oacc * inv;
             }
         } else {

@@ -679,3 +679,41 @@ def test_bf16_operand_step_within_the_rounding_budget():
     res32 = loss_and_grads(m, images.to(DEV), labels, res.perms)
     key = 'encoder.blocks.0.mlp.fc1.weight'
     assert float((res32.grads[key].cpu() - want[key]).abs().max()) <= 3e-4 * float(want[key].abs().max()) + 1e-7
+
+
+@pytest.mark.gpu
+def test_bf16_shadow_operands_change_no_bit():
+    """Round 3: in the bf16-operand mode the encoder's activations that only feed Linear products (LayerNorm outputs, attention output,
+    GELU output), the Linear weights and the gradients on the dX side are WRITTEN as bfloat16 by their producers and read by the
+    64-deep matrix-core GEMM (train_ops.h mfma_bgemm16_kernel / the B16 forms of mfma_bgemm_kernel).  That is the same
+    round-to-nearest-even the fp32-in-memory path applies on the way into LDS, in the same accumulation order: loss and every one of
+    the 175 gradients must be bit-identical with PARSEQ_TRAIN_NO_SHADOWS=1 (every operand fp32 in memory)."""
+    import os
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import loss_and_grads
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    gen = torch.Generator().manual_seed(5)
+    images = synth_images(32, cfg, seed=21).to(DEV)
+    lengths = torch.randint(1, 26, (32,), generator=gen).tolist()
+    lengths[3] = 25
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+
+    def run():
+        m.rng = np.random.default_rng(8)
+        torch.manual_seed(9)
+        r = loss_and_grads(m, images, labels)
+        torch.cuda.synchronize()
+        return float(r.loss), {k: v.clone() for k, v in r.grads.items()}
+
+    assert 'PARSEQ_TRAIN_NO_SHADOWS' not in os.environ
+    loss_a, grads_a = run()
+    os.environ['PARSEQ_TRAIN_NO_SHADOWS'] = '1'
+    try:
+        loss_b, grads_b = run()
+    finally:
+        del os.environ['PARSEQ_TRAIN_NO_SHADOWS']
+    assert loss_a == loss_b
+    diff = [k for k in grads_a if not torch.equal(grads_a[k], grads_b[k])]
+    assert not diff, diff
