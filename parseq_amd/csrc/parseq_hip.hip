@@ -1436,6 +1436,7 @@ struct GemmExt {
     bool a16 = false, b16 = false;
     bf16_t* c16 = nullptr;
     bf16_t* gelu_out16 = nullptr;
+    const bf16_t* gelu_pre16 = nullptr;
 };
 static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const float* B, long sbk, long sbn, const float* bias, const float* R,
                  long ldr, int rper, float* C, long ldc, int M, int N, int K, float alpha, bool accumulate, float* asum = nullptr, bool* asum_done = nullptr,
@@ -1445,18 +1446,21 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
     if (M <= 0 || N <= 0 || K <= 0) return fail(PARSEQ_E_INVALID, "sgemm: bad shape %d x %d x %d", M, N, K);
     SgemmArgs a{A, sam, sak, B, sbk, sbn, bias, R, ldr, rper > 0 ? rper : 1, C, ldc, M, N, K, alpha, accumulate ? 1 : 0, nullptr, nullptr, nullptr};
     if (asum_done) *asum_done = false;
-    if (ext && (ext->a16 || ext->b16 || ext->c16 || ext->gelu_out16)) {
+    if (ext && (ext->a16 || ext->b16 || ext->c16 || ext->gelu_out16 || ext->gelu_pre16)) {
         if (!cx.bf16_ops || !cx.scratch || M < 16 || N < 16) return fail(PARSEQ_E_STATE, "sgemm: bf16 shadow operands outside the bf16-operand mode");
-        a.a16 = ext->a16; a.b16 = ext->b16; a.c16 = ext->c16; a.gelu_out16 = ext->gelu_out16;
+        if (!C && !ext->c16) return fail(PARSEQ_E_INVALID, "sgemm: no output");
+        a.a16 = ext->a16; a.b16 = ext->b16; a.c16 = ext->c16; a.gelu_out16 = ext->gelu_out16; a.gelu_pre16 = ext->gelu_pre16;
         const int gm_ = (M + MG_BM - 1) / MG_BM, gn_ = (N + MG_BN - 1) / MG_BN, tiles = gm_ * gn_;
-        const bool both = ext->a16 && ext->b16;
-        const int bk = both ? BH_BK : BG_BK;
+        const bool both = ext->a16 && ext->b16 && sak == 1 && sbk == 1;       // the 64-deep kernel
+        const bool both_t = ext->a16 && ext->b16 && sam == 1 && sbn == 1;     // dW with a bf16 dY: both operands outer-contiguous
+        const bool deep_t = both_t && K % BH_BK == 0;                       // ... at 64 rows of the contraction per stage
+        const int bk = (both || deep_t) ? BH_BK : BG_BK;
         // alignment of the 16-byte (k-contiguous) / 8-byte (outer-contiguous) pieces the loaders read
         const bool a_ok16 = !ext->a16 ? (aligned16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0 && M % 4 == 0)))
-                                      : (both && aligned16(A) && sak == 1 && sam % 8 == 0);
+                                      : (aligned16(A) && (both ? sam % 8 == 0 : (both_t && sak % 4 == 0 && M % 4 == 0)));
         const bool b_ok16 = !ext->b16 ? (aligned16(B) && (sbk == 1 ? sbn % 4 == 0 : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0)))
                                       : (aligned16(B) && (sbk == 1 ? sbn % 8 == 0 : (sbn == 1 && sbk % 4 == 0 && N % 4 == 0)));
-        if (!a_ok16 || !b_ok16 || K % bk != 0 || (ext->a16 && !ext->b16) || (both && sbk != 1))
+        if (!a_ok16 || !b_ok16 || K % bk != 0 || (ext->a16 && !both && !both_t))
             return fail(PARSEQ_E_INVALID, "sgemm: shadow operands of a %d x %d x %d product are not laid out for the matrix-core kernels", M, N, K);
         int splits = 1;
         if (tiles < 256) {      // the same split as the fp32-in-memory path takes (32-deep stages), so that the two stay bit-identical
@@ -1472,6 +1476,8 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         const dim3 grid_((unsigned)tiles, 1, splits);
         void (*kern)(const SgemmArgs, int, float*, int, int);
         if (both) kern = mfma_bgemm16_kernel;
+        else if (deep_t) kern = mfma_bgemm16t_kernel;
+        else if (both_t) kern = mfma_bgemm_kernel<false, false, true, true>;
         else if (ext->b16) kern = sak == 1 ? (sbk == 1 ? mfma_bgemm_kernel<true, true, true> : mfma_bgemm_kernel<true, false, true>)
                                            : (sbk == 1 ? mfma_bgemm_kernel<false, true, true> : mfma_bgemm_kernel<false, false, true>);
         else kern = sak == 1 ? (sbk == 1 ? mfma_bgemm_kernel<true, true, false> : mfma_bgemm_kernel<true, false, false>)
@@ -1596,18 +1602,23 @@ static int lin_bwd(const TrainCtx& cx, const float* x, const float* W, const flo
 // Wt16 [K, N] are bfloat16 in memory; dy stays fp32 where it is the A operand of the dW product (the bias gradient is summed from the
 // unrounded values there) and is read through its shadow dy16 (when the producer wrote one) by the dX product; dx16 / gelu_out16: the
 // result again as bf16 for the next product.  Bit-identical to lin_fwd / lin_bwd on the fp32 copies: the rounding moved, nothing else.
+// y may be nullptr when y16 is given (bf16-only storage of the result)
 static int lin_fwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* W16, const float* bias, const float* R, int rper, float* y, int M, int N, int K,
-                     bf16_t* gelu_out16 = nullptr) {
-    GemmExt e; e.a16 = e.b16 = true; e.gelu_out16 = gelu_out16;
+                     bf16_t* gelu_out16 = nullptr, bf16_t* y16 = nullptr) {
+    GemmExt e; e.a16 = e.b16 = true; e.gelu_out16 = gelu_out16; e.c16 = y16;
     return sgemm(cx, reinterpret_cast<const float*>(x16), K, 1, reinterpret_cast<const float*>(W16), 1, K, bias, R, N, rper, y, N, M, N, K, 1.f, false,
                  nullptr, nullptr, nullptr, nullptr, &e);
 }
+// dy may be nullptr when dy16 is given (the gradient exists as bf16 only: both products read it, the bias gradient sums the bf16 values);
+// dx may be nullptr when dx16 is given; dx_gelu_pre16: the pre-activation as bf16
 static int lin_bwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* Wt16, const float* dy, const bf16_t* dy16, float* dW, float* db, float* dx,
-                     bf16_t* dx16, int M, int N, int K, const float* dx_gelu_pre = nullptr) {
-    GemmExt ew; ew.b16 = true;
-    CHK(sgemm(cx, dy, 1, N, reinterpret_cast<const float*>(x16), K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true, db, nullptr, nullptr, nullptr, &ew));
-    if (!dx) return 0;
-    GemmExt ex; ex.b16 = true; ex.a16 = dy16 != nullptr; ex.c16 = dx16;
+                     bf16_t* dx16, int M, int N, int K, const float* dx_gelu_pre = nullptr, const bf16_t* dx_gelu_pre16 = nullptr) {
+    if (!dy && !dy16) return fail(PARSEQ_E_INVALID, "lin_bwd16: no gradient");
+    GemmExt ew; ew.b16 = true; ew.a16 = dy == nullptr;
+    CHK(sgemm(cx, dy ? dy : reinterpret_cast<const float*>(dy16), 1, N, reinterpret_cast<const float*>(x16), K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true,
+              db, nullptr, nullptr, nullptr, &ew));
+    if (!dx && !dx16) return 0;
+    GemmExt ex; ex.b16 = true; ex.a16 = dy16 != nullptr; ex.c16 = dx16; ex.gelu_pre16 = dx_gelu_pre16;
     return sgemm(cx, dy16 ? reinterpret_cast<const float*>(dy16) : dy, N, 1, reinterpret_cast<const float*>(Wt16), 1, N, nullptr, nullptr, 0, 0, dx, K, M, K, N,
                  1.f, false, nullptr, nullptr, dx_gelu_pre, nullptr, &ex);
 }
@@ -1683,7 +1694,7 @@ static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool ba
     if (cx.bf16_ops && hd == TB_HD && a.Lq == TB_N && a.Lk == TB_N && !a.qmask && !a.kmask && !a.drop.thresh && a.q_bstride == (long)a.Lq * a.ldq &&
         a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
         return train_attn_bf16(cx, a, B, backward);
-    if (a.o16) return fail(PARSEQ_E_INVALID, "training attention: a bf16 output is only written by the encoder-shaped bf16 kernel");
+    if (a.o16 || a.dq16) return fail(PARSEQ_E_INVALID, "training attention: a bf16 output is only written by the encoder-shaped bf16 kernel");
     if (hd == 64 && a.Lq % 32 == 0 && a.Lk % 16 == 0 && a.Lk <= 128 && !a.qmask && !a.kmask && !a.drop.thresh && !getenv("PARSEQ_TRAIN_VALU_ATTN"))
         return train_attn_mfma(cx, a, B, backward);
     if (hd == 32) return train_attn_hd<32>(cx, a, B, backward);
@@ -1945,6 +1956,16 @@ static bool train_enc_shadows(const parseq_model* m) {
     return m->train_precision == PARSEQ_BF16 && E % 64 == 0 && F % 64 == 0 && m->tokens == TB_N && E == m->cfg.enc_heads * TB_HD &&
            !getenv("PARSEQ_TRAIN_F32_ATTN") && !getenv("PARSEQ_TRAIN_NO_SHADOWS");
 }
+// Level 2 (the default with shadows on): tensors that exist ONLY to be rounded to bf16 by their consumers or to feed a GELU derivative are
+// stored as bf16 and nothing else — the fc1 pre-activation (its GELU derivative is taken at the bf16 value), the gradient of the fc1
+// output and the gradient of q | k | v (the dW products read them as bf16 too; the bias gradients are sums of the bf16 values) — and the
+// fc2 / proj dW products read the residual-stream gradient through its bf16 shadow (the fp32 copy stays: LayerNorm backward adds to it).  That is
+// what bf16-mixed autocast keeps of these tensors (BASELINE configs[4]); it is no longer bit-identical to the fp32-in-memory path — the
+// oracle gates of the bf16-operand mode hold it.  PARSEQ_TRAIN_SHADOW_LEVEL=1: shadows beside the fp32 copies only (bit-identical).
+static bool train_enc_bf16_only(const parseq_model* m) {
+    const char* lv = getenv("PARSEQ_TRAIN_SHADOW_LEVEL");
+    return train_enc_shadows(m) && !(lv && lv[0] == '1');
+}
 struct EncShadowW { bf16_t* w; bf16_t* wt; };
 // which: 0 attn.qkv [3E, E], 1 attn.proj [E, E], 2 mlp.fc1 [F, E], 3 mlp.fc2 [E, F]
 static EncShadowW enc_shadow_w(const TrainEncoderLayout& o, float* ws, int layer, int which, size_t E, size_t F) {
@@ -1978,7 +1999,7 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     HIPCHK(hipGetLastError());
     CHK(lin_fwd(cx, w + o.patches, P("patch_embed.proj.weight"), P("patch_embed.proj.bias"), P("pos_embed"), S, w + o.x(0), MS, E, PK));
     const size_t elems = (size_t)MS * F;
-    const bool shadows = train_enc_shadows(m);
+    const bool shadows = train_enc_shadows(m), only16 = train_enc_bf16_only(m);
     if (shadows) {
         // this step's weights as bf16, both ways round (the backward entry reads the transposes from the same workspace)
         const char* names[4] = {"attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"};
@@ -2004,7 +2025,8 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
             CHK(train_attn(cx, aa, batch, false, ATT_HD));
             CHK(lin_fwd16(cx, ao16, enc_shadow_w(o, w, i, 1, E, F).w, P(p + "attn.proj.bias"), x, MS, x_mid, MS, E, E));
             CHK(train_ln_fwd(s, x_mid, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, MS, E, eps));
-            CHK(lin_fwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).w, P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact16));
+            if (only16) CHK(lin_fwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).w, P(p + "mlp.fc1.bias"), nullptr, 0, nullptr, MS, F, E, hact16, reinterpret_cast<bf16_t*>(hpre)));
+            else CHK(lin_fwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).w, P(p + "mlp.fc1.bias"), nullptr, 0, hpre, MS, F, E, hact16));
             CHK(lin_fwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).w, P(p + "mlp.fc2.bias"), x_mid, MS, x_out, MS, E, F));
             continue;
         }
@@ -2036,7 +2058,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     float* tmp = w + o.tmp;
     const size_t elems = (size_t)MS * F;
     const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
-    const bool shadows = train_enc_shadows(m);
+    const bool shadows = train_enc_shadows(m), only16 = train_enc_bf16_only(m);
     bf16_t* d_x16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_x16) : nullptr;
     bf16_t* d_h16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_h16) : nullptr;
     CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps, d_x16));
@@ -2046,12 +2068,26 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         if (shadows) {
             const bf16_t* n1 = reinterpret_cast<const bf16_t*>(x + o.n1); const bf16_t* n2 = reinterpret_cast<const bf16_t*>(x + o.n2);
             const bf16_t* ao16 = reinterpret_cast<const bf16_t*>(ao); const bf16_t* hact16 = reinterpret_cast<const bf16_t*>(x + o.hact_l);
-            CHK(lin_bwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).wt, d_x, d_x16, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, d_h16, MS, E, F, hpre));
-            CHK(lin_bwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).wt, d_h, d_h16, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, nullptr, MS, F, E));
+            if (only16) {
+                CHK(lin_bwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).wt, nullptr, d_x16, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), nullptr, d_h16, MS, E, F,
+                              nullptr, reinterpret_cast<const bf16_t*>(hpre)));
+                CHK(lin_bwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).wt, nullptr, d_h16, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, nullptr, MS, F, E));
+            } else {
+                CHK(lin_bwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).wt, d_x, d_x16, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), d_h, d_h16, MS, E, F, hpre));
+                CHK(lin_bwd16(cx, n2, enc_shadow_w(o, w, i, 2, E, F).wt, d_h, d_h16, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), d_a, nullptr, MS, F, E));
+            }
             CHK(ln_bwd(cx, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps, d_x16));
-            CHK(lin_bwd16(cx, ao16, enc_shadow_w(o, w, i, 1, E, F).wt, d_x, d_x16, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, nullptr, MS, E, E));
-            CHK(train_attn(cx, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
-            CHK(lin_bwd16(cx, n1, enc_shadow_w(o, w, i, 0, E, F).wt, dqkv, nullptr, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, nullptr, MS, 3 * E, E));
+            CHK(lin_bwd16(cx, ao16, enc_shadow_w(o, w, i, 1, E, F).wt, only16 ? nullptr : d_x, d_x16, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), d_a, nullptr, MS, E, E));
+            if (only16) {
+                TrainAttnArgs ab = enc_attn_args(m, qkv, ao, d_a, dqkv);
+                bf16_t* dqkv16 = reinterpret_cast<bf16_t*>(dqkv);
+                ab.dq16 = dqkv16; ab.dk16 = dqkv16 + E; ab.dv16 = dqkv16 + 2 * E;
+                CHK(train_attn(cx, ab, batch, true, ATT_HD));
+                CHK(lin_bwd16(cx, n1, enc_shadow_w(o, w, i, 0, E, F).wt, nullptr, dqkv16, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, nullptr, MS, 3 * E, E));
+            } else {
+                CHK(train_attn(cx, enc_attn_args(m, qkv, ao, d_a, dqkv), batch, true, ATT_HD));
+                CHK(lin_bwd16(cx, n1, enc_shadow_w(o, w, i, 0, E, F).wt, dqkv, nullptr, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), d_a, nullptr, MS, 3 * E, E));
+            }
             CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps, d_x16));
             continue;
         }

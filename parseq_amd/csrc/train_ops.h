@@ -39,7 +39,12 @@ struct SgemmArgs {
     int a16, b16;
     bf16_t* c16;                         // [M][ldc] or nullptr: the stored value again, rounded to bf16 (the next product's operand)
     bf16_t* gelu_out16;                  // [M][ldc] or nullptr: gelu(stored value) as bf16 (instead of gelu_out)
+    // bf16-ONLY storage (the step's default in the bf16-operand mode, what bf16-mixed autocast keeps of a Linear output): C may be nullptr
+    // when c16 is given — the fp32 copy of the result is not written at all — and the GELU backward can read its pre-activation as bf16
+    const bf16_t* gelu_pre16;            // [M][ldc] or nullptr: as gelu_pre, from the bf16 copy of the pre-activation
 };
+__device__ __forceinline__ float bf16_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
 __device__ __forceinline__ float gelu_grad(float v);
 
 constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16;
@@ -294,12 +299,14 @@ __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&ac
     const float alpha = direct ? a.alpha : 1.f;
     bool vec = n0 + MG_BN <= a.N && ldo % 4 == 0 && ep_al16(out);
     if (direct)
-        vec = vec && ep_al16(a.bias) && ep_al16(a.R) && a.ldr % 4 == 0 && ep_al16(a.gelu_pre) && ep_al16(a.gelu_out) && ep_al16(a.c16) && ep_al16(a.gelu_out16);
+        vec = vec && ep_al16(a.gelu_pre16) && ep_al16(a.bias) && ep_al16(a.R) && a.ldr % 4 == 0 && ep_al16(a.gelu_pre) && ep_al16(a.gelu_out) && ep_al16(a.c16) && ep_al16(a.gelu_out16);
     if (vec) {
         const int c4 = tid & 31, gn = n0 + 4 * c4;
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (direct && a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + gn);
         const float* __restrict__ pre = direct ? a.gelu_pre : nullptr;
+        const bf16_t* __restrict__ pre16 = direct ? a.gelu_pre16 : nullptr;
+        const bool store32 = out != nullptr;
         float* __restrict__ gout = direct ? a.gelu_out : nullptr;
         bf16_t* __restrict__ c16 = direct ? a.c16 : nullptr;
         bf16_t* __restrict__ g16 = direct ? a.gelu_out16 : nullptr;
@@ -332,6 +339,10 @@ __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&ac
                     if (Rb && ok[q]) rv[q] = *reinterpret_cast<const f32x4*>(Rb + (size_t)(gm_ < a.rper ? gm_ : gm_ % a.rper) * a.ldr + gn);
                     if (acc_c && ok[q]) cv[q] = *reinterpret_cast<const f32x4*>(out + at[q]);
                     if (pre && ok[q]) pv[q] = *reinterpret_cast<const f32x4*>(pre + at[q]);
+                    if (pre16 && ok[q]) {
+                        const u32x2 w = *reinterpret_cast<const u32x2*>(pre16 + at[q]);
+                        pv[q] = f32x4{bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y)};
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -342,11 +353,11 @@ __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&ac
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = fmaf(alpha, v[q][e], add[e]);      // spelled out: both forms and every instantiation round alike
-                    if (pre) {
+                    if (pre || pre16) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] *= gelu_grad(pv[q][e]);
                     }
-                    *reinterpret_cast<f32x4*>(out + at[q]) = o;
+                    if (store32) *reinterpret_cast<f32x4*>(out + at[q]) = o;
                     if (c16) {
                         union { u32x2 u; bf16_t e[4]; } hh;
 #pragma unroll
@@ -403,6 +414,11 @@ __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&ac
                 for (int j = 0; j < 4; ++j) add[j] += cv[j];
             }
             float mul[4] = {1.f, 1.f, 1.f, 1.f};
+            if (direct && a.gelu_pre16) {
+                const bf16_t* __restrict__ prow = a.gelu_pre16 + (size_t)gm_ * a.ldc + gn0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mul[j] = gelu_grad(cok[j] ? static_cast<float>(prow[16 * j]) : 0.f);
+            }
             if (direct && a.gelu_pre) {
                 const float* __restrict__ prow = a.gelu_pre + (size_t)gm_ * a.ldc + gn0;
                 float pv[4];
@@ -418,7 +434,7 @@ __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&ac
             for (int j = 0; j < 4; ++j)
                 if (cok[j]) {
                     const float v = fmaf(alpha, acc[i][j][r], add[j]) * mul[j];
-                    crow[16 * j] = v;
+                    if (out) crow[16 * j] = v;
                     if (c16row) c16row[16 * j] = static_cast<bf16_t>(v);
                     if (grow) grow[16 * j] = gelu_erf(v);
                     if (g16row) g16row[16 * j] = static_cast<bf16_t>(gelu_erf(v));
@@ -427,11 +443,16 @@ __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&ac
 }
 
 // grid: (tiles_n * tiles_m, 1, splits) workgroups; gn, gm = the tile counts.  B16: the B operand is a bf16 shadow (a.b16).
-template <bool AKF, bool BKF, bool B16 = false>
+// A16: so is the A operand (a.a16; outer-contiguous only: the dW products' dY^T, whose row sums — the bias gradient — are then the sums
+// of the bf16 values)
+template <bool AKF, bool BKF, bool B16 = false, bool A16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    static_assert(!(A16 && AKF), "a k-contiguous bf16 A goes to mfma_bgemm16_kernel");
     using TB = std::conditional_t<B16, bf16_t, float>;
     using OpB = BgOperand<BKF, TB>;
+    using TA = std::conditional_t<A16, bf16_t, float>;
+    using OpA = BgOperand<AKF, TA>;
     // one LDS block: the two operands' two stages, then (all of it) the epilogue's staging tile
     constexpr int TILE_BYTES = 2 * MG_BM * BG_LD * 2;
     static_assert(2 * TILE_BYTES >= EP_STAGE_BYTES && 2 * TILE_BYTES >= 8 * 128 * 4, "LDS block too small for the epilogue");
@@ -452,17 +473,20 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
-    BgOperand<AKF> oa; OpB ob;
-    oa.init(a.A, a.sam, a.sak, m0, a.M, kbeg, tid);
+    OpA oa; OpB ob;
+    oa.init(reinterpret_cast<const TA*>(a.A), a.sam, a.sak, m0, a.M, kbeg, tid);
     ob.init(reinterpret_cast<const TB*>(a.B), a.sbn, a.sbk, n0, a.N, kbeg, tid);
-    float4 ra[4];
+    typename OpA::V ra[OpA::NL];
     typename OpB::V rb[OpB::NL];
     // row sums of A over this workgroup's k range (a.asum; only the first N-tile of a row panel adds them up): rs[i] belongs to outer
     // index 4 (tid & 31) + i (outer-contiguous A) or to row (tid >> 3) + 32 i (k-contiguous A: eight lanes per row)
     const bool do_sum = a.asum != nullptr && tn_ == 0;
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     auto add_rows = [&]() {
-        if constexpr (AKF) {
+        if constexpr (A16) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { rs[0] += bf16_lo(ra[it].x); rs[1] += bf16_hi(ra[it].x); rs[2] += bf16_lo(ra[it].y); rs[3] += bf16_hi(ra[it].y); }
+        } else if constexpr (AKF) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) rs[it] += (ra[it].x + ra[it].y) + (ra[it].z + ra[it].w);
         } else {
@@ -473,7 +497,7 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
     if (kbeg < kend) {
         oa.fetch(ra); ob.fetch(rb);
         if (do_sum) add_rows();
-        BgOperand<AKF>::park(As[0], ra, tid);
+        OpA::park(As[0], ra, tid);
         OpB::park(Bs[0], rb, tid);
     }
     __syncthreads();
@@ -494,7 +518,7 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
         __builtin_amdgcn_sched_barrier(0);              // nothing of park() (its waits for the loads) moves above the MFMAs
         if (more) {
             if (do_sum) add_rows();
-            BgOperand<AKF>::park(As[cur ^ 1], ra, tid);
+            OpA::park(As[cur ^ 1], ra, tid);
             OpB::park(Bs[cur ^ 1], rb, tid);
         }
         __syncthreads();
@@ -600,6 +624,103 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
     bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
 }
 
+// The dW products dY^T X with BOTH operands bf16 in memory and outer-contiguous (the contraction index m is the row index of dY [m, n]
+// and of X [m, k']): 64 rows of m per stage.  A thread loads 8-byte pieces (four outer indices at one m), eight of them per operand
+// and stage, and parks them transposed: for each of its four outer indices the eight m values as ONE 16-byte LDS store.  One LDS buffer
+// + the next stage in registers, as mfma_bgemm16_kernel; with 32-deep stages the kernel paid one exposed memory round trip per 16
+// MFMAs per wave (49 152-deep contractions in 15 splits: 102 stages of 1.9 us) — at 64 deep it pays one per 32.  Row sums of A (the bias
+// gradient, a.asum) are sums of the bf16 values.  K % 64 == 0, M % 4 == 0, N % 4 == 0.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
+    static_assert(2 * TILE_BYTES >= EP_STAGE_BYTES && 2 * TILE_BYTES >= 8 * 128 * 4, "LDS block too small for the epilogue");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
+    bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
+    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
+    const int tn_ = logical % gn, tm_ = logical / gn;
+    const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    // thread = (outer group o4 = tid & 31: outer indices 4 o4 .. 4 o4 + 3, k octet kq = tid >> 5: k = 8 kq + it); groups past the edge
+    // re-read the last valid group of four
+    const int o4 = tid & 31, kq = tid >> 5;
+    const bf16_t* pa = reinterpret_cast<const bf16_t*>(a.A) + (size_t)(kbeg + 8 * kq) * a.sak + min(m0 + 4 * o4, a.M - 4);
+    const bf16_t* pb = reinterpret_cast<const bf16_t*>(a.B) + (size_t)(kbeg + 8 * kq) * a.sbk + min(n0 + 4 * o4, a.N - 4);
+    const long sa = a.sak, sb = a.sbk;
+    u32x2 ra[8], rb[8];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) ra[it] = *reinterpret_cast<const u32x2*>(pa + it * sa);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) rb[it] = *reinterpret_cast<const u32x2*>(pb + it * sb);
+        pa += BH_BK * sa; pb += BH_BK * sb;
+    };
+    // r[it] = {outer 0 | outer 1 << 16, outer 2 | outer 3 << 16} at k = 8 kq + it  ->  row (4 o4 + i): k = 8 kq .. 8 kq + 7 as four dwords
+    auto park = [&](bf16_t (*tile)[BH_LD], const u32x2 (&r)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned w0 = (i & 2) ? r[2 * d].y : r[2 * d].x, w1 = (i & 2) ? r[2 * d + 1].y : r[2 * d + 1].x;
+                o[d] = (i & 1) ? ((w0 >> 16) | (w1 & 0xffff0000u)) : ((w0 & 0xffffu) | (w1 << 16));
+            }
+            *reinterpret_cast<u32x4*>(&tile[4 * o4 + i][8 * kq]) = o;
+        }
+    };
+    const bool do_sum = a.asum != nullptr && tn_ == 0;
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kbeg < kend) fetch();
+    for (int k0 = kbeg; k0 < kend; k0 += BH_BK) {
+        if (do_sum) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) { rs[0] += bf16_lo(ra[it].x); rs[1] += bf16_hi(ra[it].x); rs[2] += bf16_lo(ra[it].y); rs[3] += bf16_hi(ra[it].y); }
+        }
+        park(As, ra);
+        park(Bs, rb);
+        __syncthreads();
+        if (k0 + BH_BK < kend) fetch();                 // in flight under this stage's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
+                bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * i + r16][32 * kk + 8 * g]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    if (do_sum) {
+        // as mfma_bgemm_kernel: the eight k octets' partial sums of every row through LDS in a fixed order
+        float* red = reinterpret_cast<float*>(smem);                   // [8][128]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[kq * 128 + 4 * o4 + i] = rs[i];
+        __syncthreads();
+        if (tid < 128 && m0 + tid < a.M) {
+            const float v = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) + ((red[512 + tid] + red[640 + tid]) + (red[768 + tid] + red[896 + tid]));
+            if (gridDim.z == 1) a.asum[m0 + tid] += v;
+            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)blockIdx.z * a.M + m0 + tid] = v;
+        }
+        __syncthreads();
+    }
+    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
+}
+
 // bf16 shadows of a Linear weight W [N, K] (fp32 master): W16 [N, K] and its transpose Wt16 [K, N], once per step.  N, K multiples of 32.
 __global__ __launch_bounds__(256)
 void weight_shadow_kernel(const float* __restrict__ W, int N, int K, bf16_t* __restrict__ W16, bf16_t* __restrict__ Wt16) {
@@ -652,7 +773,8 @@ void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, 
     float* c = a.C + (size_t)gm * a.ldc + gn;
     if (a.accumulate) v += *c;
     if (a.gelu_pre) v *= gelu_grad(a.gelu_pre[(size_t)gm * a.ldc + gn]);
-    *c = v;
+    if (a.gelu_pre16) v *= gelu_grad(static_cast<float>(a.gelu_pre16[(size_t)gm * a.ldc + gn]));
+    if (a.C) *c = v;
     if (a.c16) a.c16[(size_t)gm * a.ldc + gn] = static_cast<bf16_t>(v);
     if (a.gelu_out) a.gelu_out[(size_t)gm * a.ldc + gn] = gelu_erf(v);
     if (a.gelu_out16) a.gelu_out16[(size_t)gm * a.ldc + gn] = static_cast<bf16_t>(gelu_erf(v));
@@ -1000,6 +1122,8 @@ struct TrainAttnArgs {
     const unsigned char* qmask; const unsigned char* kmask; int ldkm;
     float* o; int ldo;                                           // forward output, row (b, l): o + (b * Lq + l) * ldo + HD h
     bf16_t* o16 = nullptr;                                       // train_attn_bf16_kernel forward: write o here as bf16 INSTEAD (same layout)
+    bf16_t* dq16 = nullptr; bf16_t* dk16 = nullptr; bf16_t* dv16 = nullptr;      // train_attn_bf16_kernel backward: write dq / dk / dv here as bf16
+                                                                 // INSTEAD (layouts of dq / dk / dv; no kv_accumulate)
     const float* d_o;                                            // backward: gradient of o (same layout as o)
     float* dq; int lddq;                                         // backward: stored, row (b, l) even when q is shared
     float* dk; float* dv; int lddkv;                             // backward: layout of k / v; accumulated into if kv_accumulate
@@ -1479,6 +1603,12 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
                 f32x4 qacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) mma16(qacc, tb_keyslot_frag(XT, 16 * dt + r16, kk, g), df[kk]);
+                if (a.dq16) {
+                    union { u32x2 u; bf16_t e[4]; } hq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hq.e[r] = static_cast<bf16_t>(qacc[r]);
+                    *reinterpret_cast<u32x2*>(a.dq16 + (dqg - a.dq) + 16 * dt + 4 * g) = hq.u;
+                } else
                 *reinterpret_cast<f32x4*>(dqg + 16 * dt + 4 * g) = qacc;
             }
             __syncthreads();                     // P^T / dS^T of all 64 queries of the block are in LDS
@@ -1513,6 +1643,11 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const size_t gi = ((size_t)b * TB_N + 16 * (2 * wave + jj) + 4 * g + r) * a.lddkv + h * TB_HD + 16 * dt + r16;
+                    if (a.dk16) {
+                        a.dk16[gi] = static_cast<bf16_t>(gk[jj][dt][r]);
+                        a.dv16[gi] = static_cast<bf16_t>(gv[jj][dt][r]);
+                        continue;
+                    }
                     a.dk[gi] = a.kv_accumulate ? a.dk[gi] + gk[jj][dt][r] : gk[jj][dt][r];
                     a.dv[gi] = a.kv_accumulate ? a.dv[gi] + gv[jj][dt][r] : gv[jj][dt][r];
                 }

@@ -707,8 +707,12 @@ def test_bf16_shadow_operands_change_no_bit():
         torch.cuda.synchronize()
         return float(r.loss), {k: v.clone() for k, v in r.grads.items()}
 
-    assert 'PARSEQ_TRAIN_NO_SHADOWS' not in os.environ
-    loss_a, grads_a = run()
+    assert 'PARSEQ_TRAIN_NO_SHADOWS' not in os.environ and 'PARSEQ_TRAIN_SHADOW_LEVEL' not in os.environ
+    os.environ['PARSEQ_TRAIN_SHADOW_LEVEL'] = '1'      # shadows BESIDE the fp32 copies; the default (bf16-only storage of the fc1 pre-activation
+    try:                                               # and of two gradients) is a different rounding, gated by the oracle tests above
+        loss_a, grads_a = run()
+    finally:
+        del os.environ['PARSEQ_TRAIN_SHADOW_LEVEL']
     os.environ['PARSEQ_TRAIN_NO_SHADOWS'] = '1'
     try:
         loss_b, grads_b = run()
