@@ -1536,13 +1536,13 @@ static int colsum(const TrainCtx& cx, const float* A, long lda, int M, int N, fl
     constexpr int CHUNKS = 64;
     if (M >= 2048 && cx.scratch && (size_t)CHUNKS * N <= cx.scratch_floats) {
         const int rows_per = (M + CHUNKS - 1) / CHUNKS;
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, CHUNKS), dim3(1024), 0, s, A, lda, M, N, cx.scratch, 0, rows_per);
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, CHUNKS), dim3(1024), 0, s, A, lda, M, N, cx.scratch, 0, rows_per, (float*)nullptr, 0);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, cx.scratch, (long)N, CHUNKS, N, out, accumulate ? 1 : 0, CHUNKS);
+        hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, cx.scratch, (long)N, CHUNKS, N, out, accumulate ? 1 : 0, CHUNKS, (float*)nullptr, 0);
         HIPCHK(hipGetLastError());
         return 0;
     }
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, A, lda, M, N, out, accumulate ? 1 : 0, M);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, 1), dim3(1024), 0, s, A, lda, M, N, out, accumulate ? 1 : 0, M, (float*)nullptr, 0);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1636,8 +1636,18 @@ static int ln_bwd(const TrainCtx& cx, const float* x, const float* gamma, const 
     TrainCtx c2 = cx; c2.scratch_floats = cx.scratch_floats - (size_t)chunks * 2 * E;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(chunks), dim3(256), 0, s, x, gamma, dy, add, dx, part, rows, E, eps, dx16);
     HIPCHK(hipGetLastError());
-    CHK(colsum(c2, part, 2L * E, chunks, E, dgamma, true));
-    return colsum(c2, part + E, 2L * E, chunks, E, dbeta, true);
+    // both column sums in one pair of launches: [chunks][2E] -> 64 row chunks -> dgamma (columns < E) and dbeta (the rest)
+    constexpr int CHUNKS = 64;
+    if (chunks >= 2048 && (size_t)CHUNKS * 2 * E <= c2.scratch_floats) {
+        const int rows_per = (chunks + CHUNKS - 1) / CHUNKS;
+        hipLaunchKernelGGL(colsum_kernel, dim3((2 * E + 63) / 64, CHUNKS), dim3(1024), 0, s, part, 2L * E, chunks, 2 * E, c2.scratch, 0, rows_per, (float*)nullptr, 0);
+        hipLaunchKernelGGL(colsum_kernel, dim3((2 * E + 63) / 64, 1), dim3(1024), 0, s, c2.scratch, 2L * E, CHUNKS, 2 * E, dgamma, 1, CHUNKS, dbeta, E);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3((2 * E + 63) / 64, 1), dim3(1024), 0, s, part, 2L * E, chunks, 2 * E, dgamma, 1, chunks, dbeta, E);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 template <int HD>
 static int train_attn_hd(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
@@ -1689,10 +1699,11 @@ static int train_attn_dec_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B
 }
 static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward, int hd) {
     if (cx.bf16_ops && hd == TD_HD && a.Lq <= TD_Q && a.Lk <= TD_K && a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && a.q_bstride % 4 == 0 &&
-        (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
+        (!backward || (a.lddq % 4 == 0 && a.lddkv % 4 == 0 && aligned16(a.dk) && aligned16(a.dv))) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
         return train_attn_dec_bf16(cx, a, B, backward);
     if (cx.bf16_ops && hd == TB_HD && a.Lq == TB_N && a.Lk == TB_N && !a.qmask && !a.kmask && !a.drop.thresh && a.q_bstride == (long)a.Lq * a.ldq &&
-        a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || a.lddq % 4 == 0) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
+        a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || (a.lddq % 4 == 0 && a.lddkv % 4 == 0 && aligned16(a.dk) && aligned16(a.dv))) &&
+        !getenv("PARSEQ_TRAIN_F32_ATTN"))
         return train_attn_bf16(cx, a, B, backward);
     if (a.o16 || a.dq16) return fail(PARSEQ_E_INVALID, "training attention: a bf16 output is only written by the encoder-shaped bf16 kernel");
     if (hd == 64 && a.Lq % 32 == 0 && a.Lk % 16 == 0 && a.Lk <= 128 && !a.qmask && !a.kmask && !a.drop.thresh && !getenv("PARSEQ_TRAIN_VALU_ATTN"))

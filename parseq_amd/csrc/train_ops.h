@@ -785,7 +785,8 @@ void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, 
 // 16 row groups x 64 columns per workgroup, rows added in a fixed order.  blockIdx.y = row chunk of `rows_per` rows; with more
 // than one chunk the kernel writes out[chunk][n] (a partial, never accumulated into).
 __global__ __launch_bounds__(1024)
-void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* __restrict__ out, int accumulate, int rows_per) {
+void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* __restrict__ out, int accumulate, int rows_per,
+                   float* __restrict__ out2 = nullptr, int split = 0) {      // out2 (single-chunk form only): columns >= split go to out2[n - split]
     __shared__ float part[16][64];
     const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -799,7 +800,7 @@ void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* _
         float t = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) t += part[i][c];
-        float* o = out + (size_t)blockIdx.y * N + n;
+        float* o = (out2 && n >= split) ? out2 + (n - split) : out + (size_t)blockIdx.y * N + n;
         *o = (accumulate && gridDim.y == 1) ? *o + t : t;
     }
 }
@@ -1628,8 +1629,8 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
                     qb.v = *reinterpret_cast<const bf16x8*>(Qt + (16 * dt + r16) * TB_PP + 32 * ks + 8 * g);
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
-                        mma16(gv[jj][dt], pa[jj], ob);       // gv[r] = dV[key 16 jt + 4 g + r][d = 16 dt + r16]
-                        mma16(gk[jj][dt], sa[jj], qb);
+                        mma16(gv[jj][dt], ob, pa[jj]);       // transposed tiles: gv[r] = dV[key 16 jt + r16][d = 16 dt + 4 g + r] (16-byte stores below)
+                        mma16(gk[jj][dt], qb, sa[jj]);
                     }
                 }
             }
@@ -1639,18 +1640,21 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt) {
+                const size_t gi = ((size_t)b * TB_N + 16 * (2 * wave + jj) + r16) * a.lddkv + h * TB_HD + 16 * dt + 4 * g;
+                if (a.dk16) {
+                    union { u32x2 u; bf16_t e[4]; } hk, hv;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const size_t gi = ((size_t)b * TB_N + 16 * (2 * wave + jj) + 4 * g + r) * a.lddkv + h * TB_HD + 16 * dt + r16;
-                    if (a.dk16) {
-                        a.dk16[gi] = static_cast<bf16_t>(gk[jj][dt][r]);
-                        a.dv16[gi] = static_cast<bf16_t>(gv[jj][dt][r]);
-                        continue;
-                    }
-                    a.dk[gi] = a.kv_accumulate ? a.dk[gi] + gk[jj][dt][r] : gk[jj][dt][r];
-                    a.dv[gi] = a.kv_accumulate ? a.dv[gi] + gv[jj][dt][r] : gv[jj][dt][r];
+                    for (int r = 0; r < 4; ++r) { hk.e[r] = static_cast<bf16_t>(gk[jj][dt][r]); hv.e[r] = static_cast<bf16_t>(gv[jj][dt][r]); }
+                    *reinterpret_cast<u32x2*>(a.dk16 + gi) = hk.u;
+                    *reinterpret_cast<u32x2*>(a.dv16 + gi) = hv.u;
+                    continue;
                 }
+                f32x4 ok_ = f32x4{0.f, 0.f, 0.f, 0.f}, ov_ = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (a.kv_accumulate) { ok_ = *reinterpret_cast<const f32x4*>(a.dk + gi); ov_ = *reinterpret_cast<const f32x4*>(a.dv + gi); }
+                *reinterpret_cast<f32x4*>(a.dk + gi) = ok_ + gk[jj][dt];
+                *reinterpret_cast<f32x4*>(a.dv + gi) = ov_ + gv[jj][dt];
+            }
     }
 }
 
@@ -1859,25 +1863,20 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
                     Frag<bf16_t> ob, qb;
                     ob.v = *reinterpret_cast<const bf16x8*>(dOt + (16 * dt + r16) * TD_PP + 8 * g);
                     qb.v = *reinterpret_cast<const bf16x8*>(Qt + (16 * dt + r16) * TD_PP + 8 * g);
+                    // the TRANSPOSED tiles (operands swapped: the same products in the same order): a lane holds four consecutive head
+                    // columns of ONE key — gv[r] = dV[key 16 jt + r16][d = 16 dt + 4 g + r] — so the read-modify-write of dK / dV is one
+                    // 16-byte access per lane and tile instead of four 4-byte ones (the cross-attention pass moves 300 MB of dK | dV
+                    // per launch through this epilogue)
                     f32x4 gv = f32x4{0.f, 0.f, 0.f, 0.f}, gk = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma16(gv, pa, ob);               // gv[r] = dV[key 16 jt + 4 g + r][d = 16 dt + r16]
-                    mma16(gk, sa, qb);
-                    float ok_[4], ov_[4];            // old values (accumulate): all eight requested before the first store
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * jt + 4 * g + r;
-                        const size_t gi = ((size_t)b * Lk + (j < Lk ? j : 0)) * a.lddkv + h * TD_HD + 16 * dt + r16;
-                        ok_[r] = (a.kv_accumulate && j < Lk) ? a.dk[gi] : 0.f;
-                        ov_[r] = (a.kv_accumulate && j < Lk) ? a.dv[gi] : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int j = 16 * jt + 4 * g + r;
-                        if (j < Lk) {
-                            const size_t gi = ((size_t)b * Lk + j) * a.lddkv + h * TD_HD + 16 * dt + r16;
-                            a.dk[gi] = ok_[r] + gk[r];
-                            a.dv[gi] = ov_[r] + gv[r];
-                        }
+                    mma16(gv, ob, pa);
+                    mma16(gk, qb, sa);
+                    const int j = 16 * jt + r16;
+                    if (j < Lk) {
+                        const size_t gi = ((size_t)b * Lk + j) * a.lddkv + h * TD_HD + 16 * dt + 4 * g;
+                        f32x4 ok_ = f32x4{0.f, 0.f, 0.f, 0.f}, ov_ = f32x4{0.f, 0.f, 0.f, 0.f};      // old values (accumulate): both requested before the first store
+                        if (a.kv_accumulate) { ok_ = *reinterpret_cast<const f32x4*>(a.dk + gi); ov_ = *reinterpret_cast<const f32x4*>(a.dv + gi); }
+                        *reinterpret_cast<f32x4*>(a.dk + gi) = ok_ + gk;
+                        *reinterpret_cast<f32x4*>(a.dv + gi) = ov_ + gv;
                     }
                 }
             }
