@@ -281,12 +281,16 @@ int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int bat
  *                      grad_norm: device scalar from parseq_grad_norm or NULL — when given the gradient is scaled by
  *                      min(1, max_norm / (norm + 1e-6)) on the fly (no host round trip).  Plans built on the model must be
  *                      refreshed (parseq_plan_refresh) before the next inference call.
- *   parseq_model_get_param  copies one parameter of the master weights out (device fp32), the inverse of parseq_model_set_param */
+ *   parseq_model_get_param  copies one parameter of the master weights out (device fp32), the inverse of parseq_model_set_param
+ *   parseq_model_get_params copies EVERY parameter out in one launch: device_ptrs is a HOST array of `count` = parseq_model_num_params
+ *                      device pointers in parseq_model_param_info order, each to that parameter's numel floats (what the reference's
+ *                      optimizer.step() leaves in the module's tensors, strhub/models/base.py:98-107) */
 int parseq_grad_norm(const float* grads, int64_t n, float* norm_out, float* workspace, void* stream);
 int parseq_adamw_step(parseq_model* m, const float* grads, float* exp_avg, float* exp_avg_sq, const int32_t* decay_flags, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, const float* grad_norm, float max_norm,
                       void* stream);
 int parseq_model_get_param(const parseq_model* m, const char* key, float* device_ptr, int64_t numel, void* stream);
+int parseq_model_get_params(parseq_model* m, float* const* device_ptrs, int count, void* stream);
 
 /* ---- single operators, exported so each kernel is parity-tested through the C ABI ------------------------------- */
 

@@ -80,6 +80,7 @@ SIGNATURES = {
     'parseq_adamw_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     'parseq_model_get_param': (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'parseq_model_get_params': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
     'parseq_op_layernorm': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                       C.c_float, C.c_void_p]),
     'parseq_op_linear': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

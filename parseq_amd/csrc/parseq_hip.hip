@@ -146,6 +146,10 @@ struct parseq_model {
     float* master = nullptr;  // device, all parameters fp32 back to back (each 16-byte aligned)
     size_t master_elems = 0;
     uint64_t version = 0;
+    // parseq_model_get_params: the caller's destination pointers of the last call and the device table of copy pieces built from them
+    std::vector<float*> out_ptrs;
+    void* out_chunks = nullptr;
+    int out_chunk_count = 0;
 
     const float* p(const std::string& key) const { return master + params[index.at(key)].offset; }
 };
@@ -239,6 +243,7 @@ extern "C" void parseq_model_destroy(parseq_model* m) {
     if (!m) return;
     DevGuard dg(m->device);
     if (m->master) (void)hipFree(m->master);
+    if (m->out_chunks) (void)hipFree(m->out_chunks);
     delete m;
 }
 
@@ -1692,15 +1697,25 @@ static int train_attn_dec_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B
     static LdsAttr attr_f, attr_b;
     HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<false>), train_attn_dec_lds(false)));
     HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<true>), train_attn_dec_lds(true)));
-    if (backward) hipLaunchKernelGGL((train_attn_dec_bf16_kernel<true>), dim3(B * a.H), dim3(128), train_attn_dec_lds(true), s, a);
-    else hipLaunchKernelGGL((train_attn_dec_bf16_kernel<false>), dim3(B * a.H), dim3(128), train_attn_dec_lds(false), s, a);
+    if (a.pass_loop > 1 && !(a.pass_B > 0 && a.kv_shared && B == a.pass_B * a.pass_loop))
+        return fail(PARSEQ_E_INVALID, "training attention: pass_loop needs pass_B, shared K / V and a batch of pass_B * pass_loop images");
+    const int blocks = (a.pass_loop > 1 ? a.pass_B : B) * a.H;      // pass_loop: one workgroup per (image, head) walks the passes
+    if (backward) hipLaunchKernelGGL((train_attn_dec_bf16_kernel<true>), dim3(blocks), dim3(128), train_attn_dec_lds(true), s, a);
+    else hipLaunchKernelGGL((train_attn_dec_bf16_kernel<false>), dim3(blocks), dim3(128), train_attn_dec_lds(false), s, a);
     HIPCHK(hipGetLastError());
     return 0;
+}
+// whether a decoder-shaped attention call (forward and backward) runs on train_attn_dec_bf16_kernel
+static bool train_attn_is_dec_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int hd) {
+    return cx.bf16_ops && hd == TD_HD && a.Lq <= TD_Q && a.Lk <= TD_K && a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && a.q_bstride % 4 == 0 &&
+           a.lddq % 4 == 0 && a.lddkv % 4 == 0 && aligned16(a.dk) && aligned16(a.dv) && !getenv("PARSEQ_TRAIN_F32_ATTN");
 }
 static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward, int hd) {
     if (cx.bf16_ops && hd == TD_HD && a.Lq <= TD_Q && a.Lk <= TD_K && a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && a.q_bstride % 4 == 0 &&
         (!backward || (a.lddq % 4 == 0 && a.lddkv % 4 == 0 && aligned16(a.dk) && aligned16(a.dv))) && !getenv("PARSEQ_TRAIN_F32_ATTN"))
         return train_attn_dec_bf16(cx, a, B, backward);
+    if (a.pass_loop > 1) return fail(PARSEQ_E_INVALID, "training attention: pass_loop is train_attn_dec_bf16_kernel's alone");
+    if (a.pass_B && hd != TD_HD) return fail(PARSEQ_E_INVALID, "training attention: several passes per launch only at the decoder's head width");
     if (cx.bf16_ops && hd == TB_HD && a.Lq == TB_N && a.Lk == TB_N && !a.qmask && !a.kmask && !a.drop.thresh && a.q_bstride == (long)a.Lq * a.ldq &&
         a.ldq % 4 == 0 && a.ldkv % 4 == 0 && a.ldo % 4 == 0 && (!backward || (a.lddq % 4 == 0 && a.lddkv % 4 == 0 && aligned16(a.dk) && aligned16(a.dv))) &&
         !getenv("PARSEQ_TRAIN_F32_ATTN"))
@@ -1713,22 +1728,37 @@ static int train_attn(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool ba
     return fail(PARSEQ_E_INVALID, "training attention: head width %d not in {32, 64}", hd);
 }
 
+// The K permutation passes of a step share every weight and differ in their masks, dropout sites and (after two passes) targets only
+// (system.py:175-196), so the decoder runs them as ONE batch of KP * B images (KP = K by default): every Linear product, LayerNorm,
+// attention launch and column sum once per step instead of once per pass — 6 x the rows per launch, a sixth of the launches and of the
+// split-K folds, the dW products contracted over all passes at once.  PARSEQ_TRAIN_PERM_GROUP=g runs the passes g at a time (1 = one after
+// the other, the arrangement of rounds 1-2: same masks, same per-pass losses, gradients equal up to fp32 summation order).
+static int train_perm_group(int K) {
+    int g = K;
+    if (const char* e = getenv("PARSEQ_TRAIN_PERM_GROUP")) { const int v = atoi(e); if (v >= 1) g = v; }
+    return std::min(std::max(g, 1), K);
+}
 struct TrainDecoderLayout {          // offsets in floats into the caller's workspace
     size_t content0, content, cn, kvc, qd, qn, qsa, kvm, sa_o, t1, n1, q2, ca_o, t2, n2, hpre, hact, t3, out, logits;
-    size_t d_a, d_b, d_c, d_h, pm, tmp, d_kvc, d_kvm, d_content, d_pq, d_qb, row_loss, losses, counts, scratch, total;
+    size_t d_a, d_b, d_c, d_h, pm, d_kvc, d_kvm, d_kvm_p, d_content, d_pq, d_qb, row_loss, tgt_all, losses, counts, scratch, total;
+    int KP;                          // passes per batch
 };
 static TrainDecoderLayout train_decoder_layout(const parseq_model* m, int B, int L, int K) {
     const size_t E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, S = m->tokens, C = m->classes, M = (size_t)B * L, MS = (size_t)B * S;
     TrainDecoderLayout o;
+    o.KP = train_perm_group(K);
+    const size_t P = (size_t)o.KP, MP = P * M;      // rows of a per-pass buffer
     size_t off = 0;
     auto take = [&](size_t n) { const size_t at = off; off += (n + 63) / 64 * 64; return at; };
-    o.content0 = take(M * E); o.content = take(M * E); o.cn = take(M * E); o.kvc = take(M * 2 * E); o.qd = take(M * E); o.qn = take(M * E);
-    o.qsa = take(M * E); o.kvm = take(MS * 2 * E);
-    o.sa_o = take(M * E); o.t1 = take(M * E); o.n1 = take(M * E); o.q2 = take(M * E); o.ca_o = take(M * E); o.t2 = take(M * E); o.n2 = take(M * E);
-    o.hpre = take(M * F); o.hact = take(M * F); o.t3 = take(M * E); o.out = take(M * E); o.logits = take(M * C);
-    o.d_a = take(M * E); o.d_b = take(M * E); o.d_c = take(M * E); o.d_h = take(M * F); o.pm = take(M * E); o.tmp = take(M * E);
-    o.d_kvc = take(M * 2 * E); o.d_kvm = take(MS * 2 * E); o.d_content = take(M * E); o.d_pq = take(L * E); o.d_qb = take(M * E);
-    o.row_loss = take(M); o.losses = take(K + 1); o.counts = take(K + 1); o.scratch = take(TRAIN_SCRATCH_FLOATS);
+    o.content0 = take(M * E); o.content = take(MP * E); o.cn = take(MP * E); o.kvc = take(MP * 2 * E); o.qd = take(MP * E); o.qn = take(MP * E);
+    o.qsa = take(MP * E); o.kvm = take(MS * 2 * E);
+    o.sa_o = take(MP * E); o.t1 = take(MP * E); o.n1 = take(MP * E); o.q2 = take(MP * E); o.ca_o = take(MP * E); o.t2 = take(MP * E); o.n2 = take(MP * E);
+    o.hpre = take(MP * F); o.hact = take(MP * F); o.t3 = take(MP * E); o.out = take(MP * E); o.logits = take(MP * C);
+    o.d_a = take(MP * E); o.d_b = take(MP * E); o.d_c = take(MP * E); o.d_h = take(MP * F); o.pm = take(MP * E);
+    o.d_kvc = take(MP * 2 * E); o.d_kvm = take(MS * 2 * E);
+    o.d_kvm_p = o.KP > 1 ? take(P * MS * 2 * E) : o.d_kvm;      // each pass's own d K | d V of the memory, folded into d_kvm after the batch
+    o.d_content = take(M * E); o.d_pq = take(L * E); o.d_qb = take(MP * E);
+    o.row_loss = take(MP); o.tgt_all = take((size_t)K * M); o.losses = take(K + 1); o.counts = take(K + 1); o.scratch = take(TRAIN_SCRATCH_FLOATS);
     o.total = off;
     return o;
 }
@@ -1749,11 +1779,15 @@ extern "C" int parseq_model_set_train_precision(parseq_model* m, int precision) 
 extern "C" int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, int batch, int ctx_len, int num_perms, const char* name) {
     if (!m || !name || batch <= 0 || ctx_len <= 0 || num_perms <= 0) return -1;
     const TrainDecoderLayout o = train_decoder_layout(m, batch, ctx_len, num_perms);
-    const std::pair<const char*, size_t> table[] = {
-        {"content", o.content}, {"cn", o.cn}, {"kvc", o.kvc}, {"qd", o.qd}, {"qn", o.qn}, {"qsa", o.qsa}, {"kvm", o.kvm}, {"sa_o", o.sa_o}, {"t1", o.t1},
-        {"n1", o.n1}, {"q2", o.q2}, {"ca_o", o.ca_o}, {"t2", o.t2}, {"n2", o.n2}, {"hpre", o.hpre}, {"hact", o.hact}, {"t3", o.t3}, {"out", o.out},
-        {"dlogits", o.logits}, {"d_kvc", o.d_kvc}, {"d_kvm", o.d_kvm}, {"d_content", o.d_content}, {"d_pq", o.d_pq}};
-    for (const auto& e : table) if (!strcmp(e.first, name)) return (int64_t)e.second;
+    const size_t E = m->cfg.embed_dim, F = E * m->cfg.dec_mlp_ratio, C = m->classes, M = (size_t)batch * ctx_len;
+    const size_t last = (size_t)((num_perms - 1) % o.KP);      // the last pass's slot in its batch of KP passes
+    struct Entry { const char* name; size_t off, width; };      // width: floats per row of a per-pass buffer; 0 = shared by the passes
+    const Entry table[] = {
+        {"content", o.content, E}, {"cn", o.cn, E}, {"kvc", o.kvc, 2 * E}, {"qd", o.qd, E}, {"qn", o.qn, E}, {"qsa", o.qsa, E}, {"kvm", o.kvm, 0},
+        {"sa_o", o.sa_o, E}, {"t1", o.t1, E}, {"n1", o.n1, E}, {"q2", o.q2, E}, {"ca_o", o.ca_o, E}, {"t2", o.t2, E}, {"n2", o.n2, E},
+        {"hpre", o.hpre, F}, {"hact", o.hact, F}, {"t3", o.t3, E}, {"out", o.out, E}, {"dlogits", o.logits, C}, {"d_kvc", o.d_kvc, 2 * E},
+        {"d_kvm", o.d_kvm, 0}, {"d_content", o.d_content, 0}, {"d_pq", o.d_pq, 0}};
+    for (const Entry& e : table) if (!strcmp(e.name, name)) return (int64_t)(e.off + last * M * e.width);
     return -1;
 }
 
@@ -1762,10 +1796,11 @@ extern "C" size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, in
     return train_decoder_layout(m, batch, ctx_len, num_perms).total * sizeof(float);
 }
 
-// y = R + dropout(x) over n elements (R may be null, x == y allowed); with dropout off a plain add / copy
-static int dropout_add(const TrainCtx& cx, const float* x, const float* R, float* y, size_t n, const DropSpec& d, unsigned site) {
+// y = R + dropout(x) over `passes` passes of n_pass elements each (train_ops.h dropout_passes_kernel: R may be null, x == y allowed,
+// x_shared: one pass of x read by every pass); with dropout off a plain add / copy
+static int dropout_add(const TrainCtx& cx, const float* x, bool x_shared, const float* R, float* y, size_t n_pass, int passes, const DropSpec& d, unsigned site) {
     hipStream_t s = cx.s;
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, R, y, n, d, site);
+    hipLaunchKernelGGL(dropout_passes_kernel, dim3((unsigned)((n_pass + 255) / 256), (unsigned)passes), dim3(256), 0, s, x, x_shared ? 1 : 0, R, y, n_pass, d, site);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1800,95 +1835,120 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
     float* qn = w + o.qn; float* qsa = w + o.qsa; float* kvm = w + o.kvm;
     float* sa_o = w + o.sa_o; float* t1 = w + o.t1; float* n1 = w + o.n1; float* q2 = w + o.q2; float* ca_o = w + o.ca_o; float* t2 = w + o.t2;
     float* n2 = w + o.n2; float* hpre = w + o.hpre; float* hact = w + o.hact; float* t3 = w + o.t3; float* out = w + o.out; float* logits = w + o.logits;
-    float* d_a = w + o.d_a; float* d_b = w + o.d_b; float* d_c = w + o.d_c; float* d_h = w + o.d_h; float* pm = w + o.pm; float* tmp = w + o.tmp;
-    float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_content = w + o.d_content; float* d_pq = w + o.d_pq; float* d_qb = w + o.d_qb;
-    float* row_loss = w + o.row_loss; float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
+    float* d_a = w + o.d_a; float* d_b = w + o.d_b; float* d_c = w + o.d_c; float* d_h = w + o.d_h; float* pm = w + o.pm;
+    float* d_kvc = w + o.d_kvc; float* d_kvm = w + o.d_kvm; float* d_kvm_p = w + o.d_kvm_p; float* d_content = w + o.d_content; float* d_pq = w + o.d_pq;
+    float* d_qb = w + o.d_qb;
+    float* row_loss = w + o.row_loss; int* tgt_all = reinterpret_cast<int*>(w + o.tgt_all); float* losses = w + o.losses; int* counts = reinterpret_cast<int*>(w + o.counts);
     const size_t ME = (size_t)M * E, MF = (size_t)M * F;
+    const int KP = o.KP;                           // passes per batch (train_perm_group)
     const TrainCtx cx{s, w + o.scratch, m->train_precision == PARSEQ_BF16};
 
     // ---- shared by all permutations: the content rows before dropout, and the memory's K / V (model.py:95-98, modules.py:74) ----
     hipLaunchKernelGGL(train_content_kernel, dim3(M), dim3(256), 0, s, P("text_embed.embedding.weight"), pq, tokens, L, L, E, sqrtE, content0);
     HIPCHK(hipGetLastError());
     CHK(lin_fwd(cx, memory, ca_w + (size_t)E * E, ca_b + E, nullptr, 0, kvm, MS, 2 * E, E));
-    HIPCHK(hipMemsetAsync(d_kvm, 0, (size_t)MS * 2 * E * sizeof(float), s));
-    HIPCHK(hipMemsetAsync(d_content, 0, ME * sizeof(float), s));
+    if (KP == 1) HIPCHK(hipMemsetAsync(d_kvm, 0, (size_t)MS * 2 * E * sizeof(float), s));      // the passes accumulate into it one after the other
     HIPCHK(hipMemsetAsync(d_pq, 0, (size_t)L * E * sizeof(float), s));
+    // the targets of pass i, one row per pass: <eos> targets are dropped after two permutations (system.py:191-195)
+    for (int i = 0; i < K; ++i)
+        HIPCHK(hipMemcpyAsync(tgt_all + (size_t)i * M, targets + (size_t)(i < 2 ? 0 : 1) * M, (size_t)M * sizeof(int), hipMemcpyDeviceToDevice, s));
 
     TrainAttnArgs sa{};      // self-attention of the query stream over the content stream (modules.py:70-72)
     sa.q = qsa; sa.q_bstride = (long)L * E; sa.ldq = E; sa.k = kvc; sa.v = kvc + E; sa.ldkv = 2 * E; sa.kmask = key_padding_mask; sa.ldkm = L;
     sa.o = sa_o; sa.ldo = E; sa.d_o = d_b; sa.dq = d_qb; sa.lddq = E; sa.dk = d_kvc; sa.dv = d_kvc + E; sa.lddkv = 2 * E;
     sa.Lq = L; sa.Lk = L; sa.H = H; sa.scale = scale; sa.kv_accumulate = 0; sa.drop = drop;
+    sa.pass_B = B; sa.qmask_pstride = (long)L * L; sa.site_pstride = 8; sa.kv_shared = 0;
     TrainAttnArgs ca{};      // cross-attention over the encoder memory (modules.py:74-75)
     ca.q = q2; ca.q_bstride = (long)L * E; ca.ldq = E; ca.k = kvm; ca.v = kvm + E; ca.ldkv = 2 * E; ca.o = ca_o; ca.ldo = E; ca.d_o = d_c;
-    ca.dq = d_a; ca.lddq = E; ca.dk = d_kvm; ca.dv = d_kvm + E; ca.lddkv = 2 * E; ca.Lq = L; ca.Lk = S; ca.H = H; ca.scale = scale; ca.kv_accumulate = 1;
+    ca.dq = d_a; ca.lddq = E; ca.dk = d_kvm_p; ca.dv = d_kvm_p + E; ca.lddkv = 2 * E; ca.Lq = L; ca.Lk = S; ca.H = H; ca.scale = scale;
+    ca.kv_accumulate = KP == 1 ? 1 : 0;      // KP == 1: d_kvm_p IS d_kvm; otherwise each pass of the batch writes its own copy
     ca.drop = drop;
+    ca.pass_B = B; ca.qmask_pstride = 0; ca.site_pstride = 8; ca.kv_shared = 1;
+    // bf16-operand mode: one workgroup per (image, head) walks the batch's passes (train_ops.h TrainAttnArgs::pass_loop) — the memory's K | V
+    // are staged once per batch instead of once per pass and d K | d V go straight into d_kvm, summed over the passes in the accumulators
+    const bool ca_loop = KP > 1 && train_attn_is_dec_bf16(cx, ca, 32) && !getenv("PARSEQ_TRAIN_NO_PASS_LOOP");
+    if (ca_loop) { ca.dk = d_kvm; ca.dv = d_kvm + E; }
     enum { S_CONTENT, S_QUERY, S_SA_PROB, S_SA_OUT, S_CA_PROB, S_CA_OUT, S_FF_HIDDEN, S_FF_OUT };      // dropout sites of one pass
 
-    for (int i = 0; i < K; ++i) {
-        const int32_t* tgt = targets + (size_t)(i < 2 ? 0 : 1) * M;      // <eos> targets are dropped after two permutations (system.py:191-195)
-        auto site = [&](int k) { return (unsigned)(8 * i + k); };
+    for (int i0 = 0; i0 < K; i0 += KP) {
+        const int kp = std::min(KP, K - i0);       // passes i0 .. i0 + kp - 1 as one batch of kp * B images
+        const int R = kp * M;                      // rows of this batch
+        const size_t RF = (size_t)R * F;
+        const int32_t* tgt = tgt_all + (size_t)i0 * M;
+        auto site = [&](int k) { return (unsigned)(8 * i0 + k); };      // of the batch's first pass; pass p draws site + 8 p
         // ---- forward: model.decode (model.py:86-103) — the embeddings and the queries are dropped afresh in every pass -----------
-        CHK(dropout_add(cx, content0, nullptr, content, ME, drop, site(S_CONTENT)));
-        CHK((run_layernorm<float>(s, content, P(p + "norm_c.weight"), P(p + "norm_c.bias"), cn, nullptr, M, E, eps)));
-        CHK(lin_fwd(cx, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, M, 2 * E, E));
-        hipLaunchKernelGGL(dropout_rows_kernel, dim3((unsigned)((ME + 255) / 256)), dim3(256), 0, s, pq, L, E, qd, ME, drop, site(S_QUERY));
+        CHK(dropout_add(cx, content0, true, nullptr, content, ME, kp, drop, site(S_CONTENT)));
+        CHK((run_layernorm<float>(s, content, P(p + "norm_c.weight"), P(p + "norm_c.bias"), cn, nullptr, R, E, eps)));
+        CHK(lin_fwd(cx, cn, sa_w + (size_t)E * E, sa_b + E, nullptr, 0, kvc, R, 2 * E, E));
+        hipLaunchKernelGGL(dropout_rows_passes_kernel, dim3((unsigned)((ME + 255) / 256), (unsigned)kp), dim3(256), 0, s, pq, L, E, qd, ME, drop, site(S_QUERY));
         HIPCHK(hipGetLastError());
-        CHK((run_layernorm<float>(s, qd, P(p + "norm_q.weight"), P(p + "norm_q.bias"), qn, nullptr, M, E, eps)));
-        CHK(lin_fwd(cx, qn, sa_w, sa_b, nullptr, 0, qsa, M, E, E));
+        CHK((run_layernorm<float>(s, qd, P(p + "norm_q.weight"), P(p + "norm_q.bias"), qn, nullptr, R, E, eps)));
+        CHK(lin_fwd(cx, qn, sa_w, sa_b, nullptr, 0, qsa, R, E, E));
         // ---- DecoderLayer.forward_stream (modules.py:55-79), Decoder.norm (:124), head (model.py:63) -----------------------------
-        sa.qmask = query_masks + (size_t)i * L * L; sa.drop_site = site(S_SA_PROB);
-        CHK(train_attn(cx, sa, B, false, 32));
-        CHK(lin_fwd(cx, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
-        CHK(dropout_add(cx, pm, qd, t1, ME, drop, site(S_SA_OUT)));
-        CHK((run_layernorm<float>(s, t1, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, nullptr, M, E, eps)));
-        CHK(lin_fwd(cx, n1, ca_w, ca_b, nullptr, 0, q2, M, E, E));
+        sa.qmask = query_masks + (size_t)i0 * L * L; sa.drop_site = site(S_SA_PROB);
+        CHK(train_attn(cx, sa, kp * B, false, 32));
+        CHK(lin_fwd(cx, sa_o, P(p + "self_attn.out_proj.weight"), P(p + "self_attn.out_proj.bias"), nullptr, 0, pm, R, E, E));
+        CHK(dropout_add(cx, pm, false, qd, t1, ME, kp, drop, site(S_SA_OUT)));
+        CHK((run_layernorm<float>(s, t1, P(p + "norm1.weight"), P(p + "norm1.bias"), n1, nullptr, R, E, eps)));
+        CHK(lin_fwd(cx, n1, ca_w, ca_b, nullptr, 0, q2, R, E, E));
         ca.drop_site = site(S_CA_PROB);
-        CHK(train_attn(cx, ca, B, false, 32));
-        CHK(lin_fwd(cx, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), nullptr, 0, pm, M, E, E));
-        CHK(dropout_add(cx, pm, t1, t2, ME, drop, site(S_CA_OUT)));
-        CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, M, E, eps)));
-        CHK(lin_fwd(cx, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, M, F, E));
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((MF + 1023) / 1024)), dim3(256), 0, s, hpre, hact, MF);
+        if (ca_loop) { ca.pass_loop = kp; ca.kv_accumulate = i0 > 0 ? 1 : 0; }
+        CHK(train_attn(cx, ca, kp * B, false, 32));
+        CHK(lin_fwd(cx, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), nullptr, 0, pm, R, E, E));
+        CHK(dropout_add(cx, pm, false, t1, t2, ME, kp, drop, site(S_CA_OUT)));
+        CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, R, E, eps)));
+        CHK(lin_fwd(cx, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, R, F, E));
+        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((RF + 1023) / 1024)), dim3(256), 0, s, hpre, hact, RF);
         HIPCHK(hipGetLastError());
-        if (drop.thresh) CHK(dropout_add(cx, hact, nullptr, hact, MF, drop, site(S_FF_HIDDEN)));
-        CHK(lin_fwd(cx, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, M, E, F));
-        CHK(dropout_add(cx, pm, t2, t3, ME, drop, site(S_FF_OUT)));
-        CHK((run_layernorm<float>(s, t3, P("decoder.norm.weight"), P("decoder.norm.bias"), out, nullptr, M, E, eps)));
-        CHK(lin_fwd(cx, out, P("head.weight"), P("head.bias"), nullptr, 0, logits, M, C, E));
-        hipLaunchKernelGGL(ce_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, row_loss);
+        if (drop.thresh) CHK(dropout_add(cx, hact, false, nullptr, hact, MF, kp, drop, site(S_FF_HIDDEN)));
+        CHK(lin_fwd(cx, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, R, E, F));
+        CHK(dropout_add(cx, pm, false, t2, t3, ME, kp, drop, site(S_FF_OUT)));
+        CHK((run_layernorm<float>(s, t3, P("decoder.norm.weight"), P("decoder.norm.bias"), out, nullptr, R, E, eps)));
+        CHK(lin_fwd(cx, out, P("head.weight"), P("head.bias"), nullptr, 0, logits, R, C, E));
+        hipLaunchKernelGGL(ce_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, s, logits, tgt, R, C, m->cfg.pad_id, row_loss);
         HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss, tgt, M, m->cfg.pad_id, losses + i, counts + i);
-        HIPCHK(hipGetLastError());
+        for (int q = 0; q < kp; ++q) {             // each pass's own mean (system.py:189-190), rows summed in the order its own launch would
+            hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(256), 0, s, row_loss + (size_t)q * M, tgt + (size_t)q * M, M, m->cfg.pad_id, losses + i0 + q,
+                               counts + i0 + q);
+            HIPCHK(hipGetLastError());
+        }
         // ---- backward ------------------------------------------------------------------------------------------------------------
-        hipLaunchKernelGGL(ce_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, logits, tgt, M, C, m->cfg.pad_id, 1.0f / (float)total_targets);
+        hipLaunchKernelGGL(ce_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, s, logits, tgt, R, C, m->cfg.pad_id, 1.0f / (float)total_targets);
         HIPCHK(hipGetLastError());
-        CHK(lin_bwd(cx, out, P("head.weight"), logits, G("head.weight"), G("head.bias"), d_a, M, C, E));                                    // d_a = d out
-        CHK(ln_bwd(cx, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), tmp, M, E, eps));  // d_b = d t3
-        CHK(dropout_add(cx, d_b, nullptr, pm, ME, drop, site(S_FF_OUT)));
-        CHK(lin_bwd(cx, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, M, E, F));                  // d_h = d hact
-        if (drop.thresh) CHK(dropout_add(cx, d_h, nullptr, d_h, MF, drop, site(S_FF_HIDDEN)));
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((MF + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, MF);                      // d_h = d hpre
+        CHK(lin_bwd(cx, out, P("head.weight"), logits, G("head.weight"), G("head.bias"), d_a, R, C, E));                                    // d_a = d out
+        CHK(ln_bwd(cx, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), nullptr, R, E, eps));  // d_b = d t3
+        CHK(dropout_add(cx, d_b, false, nullptr, pm, ME, kp, drop, site(S_FF_OUT)));
+        CHK(lin_bwd(cx, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, R, E, F));                  // d_h = d hact
+        if (drop.thresh) CHK(dropout_add(cx, d_h, false, nullptr, d_h, MF, kp, drop, site(S_FF_HIDDEN)));
+        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((RF + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, RF);                      // d_h = d hpre
         HIPCHK(hipGetLastError());
-        CHK(lin_bwd(cx, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, M, F, E));                   // d_a = d n2
-        CHK(ln_bwd(cx, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, M, E, eps));              // d_b = d t2
-        CHK(dropout_add(cx, d_b, nullptr, pm, ME, drop, site(S_CA_OUT)));
+        CHK(lin_bwd(cx, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, R, F, E));                   // d_a = d n2
+        CHK(ln_bwd(cx, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), nullptr, R, E, eps));          // d_b = d t2
+        CHK(dropout_add(cx, d_b, false, nullptr, pm, ME, kp, drop, site(S_CA_OUT)));
         CHK(lin_bwd(cx, ca_o, P(p + "cross_attn.out_proj.weight"), pm, G(p + "cross_attn.out_proj.weight"), G(p + "cross_attn.out_proj.bias"),
-                    d_c, M, E, E));                                                                                                        // d_c = d ca_o
-        CHK(train_attn(cx, ca, B, true, 32));                                                                                               // d_a = d q2; d_kvm +=
-        CHK(lin_bwd(cx, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, M, E, E));                // d_c = d n1
-        CHK(ln_bwd(cx, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, M, E, eps));              // d_a = d t1
-        CHK(dropout_add(cx, d_a, nullptr, pm, ME, drop, site(S_SA_OUT)));
+                    d_c, R, E, E));                                                                                                        // d_c = d ca_o
+        CHK(train_attn(cx, ca, kp * B, true, 32));                                                                                          // d_a = d q2; d_kvm_p[pass] = (KP == 1: d_kvm +=)
+        if (KP > 1 && !ca_loop) {                  // d_kvm (+)= the batch's passes, in ascending order
+            hipLaunchKernelGGL(sum_passes_kernel, dim3((unsigned)(((size_t)MS * 2 * E / 4 + 255) / 256)), dim3(256), 0, s, d_kvm_p, d_kvm, (size_t)MS * 2 * E, kp,
+                               i0 > 0 ? 1 : 0);
+            HIPCHK(hipGetLastError());
+        }
+        CHK(lin_bwd(cx, n1, ca_w, d_a, G(p + "cross_attn.in_proj_weight"), G(p + "cross_attn.in_proj_bias"), d_c, R, E, E));                // d_c = d n1
+        CHK(ln_bwd(cx, t1, P(p + "norm1.weight"), d_c, d_b, d_a, G(p + "norm1.weight"), G(p + "norm1.bias"), nullptr, R, E, eps));          // d_a = d t1
+        CHK(dropout_add(cx, d_a, false, nullptr, pm, ME, kp, drop, site(S_SA_OUT)));
         CHK(lin_bwd(cx, sa_o, P(p + "self_attn.out_proj.weight"), pm, G(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.bias"),
-                    d_b, M, E, E));                                                                                                        // d_b = d sa_o
-        CHK(train_attn(cx, sa, B, true, 32));                                                                                               // d_qb = d q; d_kvc =
-        CHK(lin_bwd(cx, qn, sa_w, d_qb, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_c, M, E, E));                 // d_c = d qn
-        CHK(ln_bwd(cx, qd, P(p + "norm_q.weight"), d_c, d_a, d_b, G(p + "norm_q.weight"), G(p + "norm_q.bias"), tmp, M, E, eps));           // d_b = d qd
-        CHK(dropout_add(cx, d_b, nullptr, d_b, ME, drop, site(S_QUERY)));
-        CHK(colsum(cx, d_b, (long)L * E, B, L * E, d_pq, true));                                // every image's query rows are pos_queries[l]
+                    d_b, R, E, E));                                                                                                        // d_b = d sa_o
+        CHK(train_attn(cx, sa, kp * B, true, 32));                                                                                          // d_qb = d q; d_kvc =
+        CHK(lin_bwd(cx, qn, sa_w, d_qb, G(p + "self_attn.in_proj_weight"), G(p + "self_attn.in_proj_bias"), d_c, R, E, E));                 // d_c = d qn
+        CHK(ln_bwd(cx, qd, P(p + "norm_q.weight"), d_c, d_a, d_b, G(p + "norm_q.weight"), G(p + "norm_q.bias"), nullptr, R, E, eps));       // d_b = d qd
+        CHK(dropout_add(cx, d_b, false, nullptr, d_b, ME, kp, drop, site(S_QUERY)));
+        CHK(colsum(cx, d_b, (long)L * E, kp * B, L * E, d_pq, true));                           // every image's query rows are pos_queries[l]
         CHK(lin_bwd(cx, cn, sa_w + (size_t)E * E, d_kvc, G(p + "self_attn.in_proj_weight") + (size_t)E * E, G(p + "self_attn.in_proj_bias") + E,
-                    d_c, M, 2 * E, E));                                                                                                    // d_c = d cn
-        CHK(ln_bwd(cx, content, P(p + "norm_c.weight"), d_c, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), tmp, M, E, eps));  // d_b = d content
-        CHK(dropout_add(cx, d_b, d_content, d_content, ME, drop, site(S_CONTENT)));             // d_content += through this pass's mask
+                    d_c, R, 2 * E, E));                                                                                                    // d_c = d cn
+        CHK(ln_bwd(cx, content, P(p + "norm_c.weight"), d_c, nullptr, d_b, G(p + "norm_c.weight"), G(p + "norm_c.bias"), nullptr, R, E, eps));  // d_b = d content
+        // d_content (+)= every pass's d content through that pass's mask (the passes in ascending order)
+        hipLaunchKernelGGL(dropout_sum_passes_kernel, dim3((unsigned)((ME + 255) / 256)), dim3(256), 0, s, d_b, d_content, ME, kp, drop, site(S_CONTENT), i0 > 0 ? 1 : 0);
+        HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, s, losses, counts, K, losses + K);
     HIPCHK(hipGetLastError());
@@ -2163,6 +2223,33 @@ extern "C" int parseq_model_get_param(const parseq_model* m, const char* key, fl
     if (ps.numel != numel) return fail(PARSEQ_E_INVALID, "parameter %s: numel %lld, expected %lld", key, (long long)numel, (long long)ps.numel);
     DevGuard dg(m->device);
     HIPCHK(hipMemcpyAsync(device_ptr, m->master + ps.offset, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// Every parameter out in ONE launch (the per-tensor form above is ~170 small device copies per optimiser step: 0.6 ms of a 34 ms step).
+// The table of copy pieces is rebuilt only when the destination pointers change (never, in a training loop).
+extern "C" int parseq_model_get_params(parseq_model* m, float* const* device_ptrs, int count, void* stream) {
+    if (!m || !device_ptrs) return fail(PARSEQ_E_INVALID, "null argument");
+    if (count != (int)m->params.size()) return fail(PARSEQ_E_INVALID, "%d destination pointers for %d parameters", count, (int)m->params.size());
+    for (int i = 0; i < count; ++i) if (!device_ptrs[i]) return fail(PARSEQ_E_INVALID, "parameter %s: null destination", m->params[i].key.c_str());
+    DevGuard dg(m->device);
+    hipStream_t s = (hipStream_t)stream;
+    if (!m->out_chunks || m->out_ptrs.size() != (size_t)count || !std::equal(m->out_ptrs.begin(), m->out_ptrs.end(), device_ptrs)) {
+        std::vector<CopyPiece> pieces;
+        for (int i = 0; i < count; ++i) {
+            const ParamSpec& ps = m->params[i];
+            for (int64_t at = 0; at < ps.numel; at += COPY_PIECE_ELEMS)
+                pieces.push_back(CopyPiece{m->master + ps.offset + at, device_ptrs[i] + at, (int)std::min<int64_t>(COPY_PIECE_ELEMS, ps.numel - at)});
+        }
+        HIPCHK(hipStreamSynchronize(s));      // a launch that still reads the old table
+        if (m->out_chunks) { (void)hipFree(m->out_chunks); m->out_chunks = nullptr; }
+        HIPCHK(hipMalloc(&m->out_chunks, pieces.size() * sizeof(CopyPiece)));
+        HIPCHK(hipMemcpy(m->out_chunks, pieces.data(), pieces.size() * sizeof(CopyPiece), hipMemcpyHostToDevice));
+        m->out_chunk_count = (int)pieces.size();
+        m->out_ptrs.assign(device_ptrs, device_ptrs + count);
+    }
+    hipLaunchKernelGGL(copy_pieces_kernel, dim3((unsigned)m->out_chunk_count), dim3(256), 0, s, reinterpret_cast<const CopyPiece*>(m->out_chunks));
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -963,6 +963,15 @@ void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ da
     }
 }
 
+// dst[i] = src[i] over a table of pieces, one workgroup per piece (parseq_model_get_params: the master weights back into the caller's tensors)
+struct CopyPiece { const float* src; float* dst; int n; };
+constexpr int COPY_PIECE_ELEMS = 8192;
+__global__ __launch_bounds__(256)
+void copy_pieces_kernel(const CopyPiece* __restrict__ pieces) {
+    const CopyPiece c = pieces[blockIdx.x];
+    for (int i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
+}
+
 // y = a + b (elementwise)
 __global__ __launch_bounds__(256)
 void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
@@ -1092,21 +1101,46 @@ __host__ __device__ __forceinline__ float drop_factor(const DropSpec& d, unsigne
     return h >= d.thresh ? d.scale : 0.0f;
 }
 
-// y[i] = (R ? R[i] : 0) + drop(x[i])      (x == y allowed)
+// y[i] = (R ? R[i] : 0) + drop(x[i]) (x == y allowed) and y[m][e] = drop(table[m % L][e]) (element index m * E + e: the decoder queries
+// pos_queries[:, :L] expanded over the batch), over `passes` permutation passes laid out one after the other ([passes][n_pass] elements):
+// pass p draws site `site + 8 p` on the element index WITHIN the pass — what a launch of its own per pass would draw — so that a step may
+// run its K passes as one batch of K * B images without changing a single mask bit.  x_shared: x holds one pass ([n_pass]) that every pass reads.
+// grid: (ceil(n_pass / 256), passes)
 __global__ __launch_bounds__(256)
-void dropout_kernel(const float* x, const float* R, float* y, size_t n, DropSpec d, unsigned site) {      // x / R may alias y
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float v = x[i] * drop_factor(d, site, i);
+void dropout_passes_kernel(const float* x, int x_shared, const float* R, float* y, size_t n_pass, DropSpec d, unsigned site) {
+    const size_t li = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= n_pass) return;
+    const size_t i = (size_t)blockIdx.y * n_pass + li;
+    const float v = x[x_shared ? li : i] * drop_factor(d, site + 8u * blockIdx.y, li);
     y[i] = R ? R[i] + v : v;
 }
-// y[m][e] = drop(table[m % L][e]), element index m * E + e: the decoder queries pos_queries[:, :L] expanded over the batch
 __global__ __launch_bounds__(256)
-void dropout_rows_kernel(const float* __restrict__ table, int L, int E, float* __restrict__ y, size_t n, DropSpec d, unsigned site) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const size_t m = i / E, e = i % E;
-    y[i] = table[(m % L) * E + e] * drop_factor(d, site, i);
+void dropout_rows_passes_kernel(const float* __restrict__ table, int L, int E, float* __restrict__ y, size_t n_pass, DropSpec d, unsigned site) {
+    const size_t li = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= n_pass) return;
+    const size_t m = li / E, e = li % E;
+    y[(size_t)blockIdx.y * n_pass + li] = table[(m % L) * E + e] * drop_factor(d, site + 8u * blockIdx.y, li);
+}
+// y[li] (+)= sum over the passes, in ascending order, of drop(x[p][li]) (d.thresh == 0: a plain sum of the passes)
+__global__ __launch_bounds__(256)
+void dropout_sum_passes_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n_pass, int passes, DropSpec d, unsigned site, int accumulate) {
+    const size_t li = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (li >= n_pass) return;
+    float t = accumulate ? y[li] : 0.f;
+    for (int p = 0; p < passes; ++p) t += x[(size_t)p * n_pass + li] * drop_factor(d, site + 8u * (unsigned)p, li);
+    y[li] = t;
+}
+// y[i] (+)= sum over the passes of x[p][i], four elements per thread (n_pass a multiple of 4, 16-byte aligned)
+__global__ __launch_bounds__(256)
+void sum_passes_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n_pass, int passes, int accumulate) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n_pass) return;
+    float4 t = accumulate ? *reinterpret_cast<const float4*>(y + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < passes; ++p) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (size_t)p * n_pass + i);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(y + i) = t;
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -1132,7 +1166,28 @@ struct TrainAttnArgs {
     int Lq, Lk, H;
     float scale;
     DropSpec drop; unsigned drop_site;                           // dropout on the probabilities, element ((b H + h) Lq + l) Lk + j
+    // Several permutation passes in one launch (train_attn_kernel and train_attn_dec_bf16_kernel; 0 = off): the batch is [passes][pass_B]
+    // images, image index b = p * pass_B + bl.  q / o / d_o / dq / dk / dv rows are indexed by b; the key-padding mask and the dropout
+    // element index by bl (what pass p's own launch would use), the query mask is qmask + p * qmask_pstride, the dropout site
+    // drop_site + p * site_pstride; kv_shared: k / v rows are image bl's for every pass (cross-attention over the encoder memory).
+    int pass_B = 0; long qmask_pstride = 0; unsigned site_pstride = 0; int kv_shared = 0;
+    // train_attn_dec_bf16_kernel only, with pass_B and kv_shared: the launch has pass_B * H workgroups and each walks pass_loop passes of its
+    // image (K / V staged once, dK / dV summed over the passes in the accumulators and stored once, rows of image bl)
+    int pass_loop = 0;
 };
+// (image over all passes, head) of a workgroup -> what the pass-batched launch indexes with; pass_B == 0 reduces to the plain launch
+struct TrainAttnIdx { int bf, bl, bkv, h; const unsigned char* qmask; unsigned site; unsigned long long dblock; };
+__device__ __forceinline__ TrainAttnIdx train_attn_idx(const TrainAttnArgs& a) {
+    TrainAttnIdx x;
+    x.bf = blockIdx.x / a.H; x.h = blockIdx.x % a.H;
+    const int p = a.pass_B ? x.bf / a.pass_B : 0;
+    x.bl = a.pass_B ? x.bf - p * a.pass_B : x.bf;
+    x.bkv = a.kv_shared ? x.bl : x.bf;
+    x.qmask = a.qmask ? a.qmask + (size_t)p * a.qmask_pstride : nullptr;
+    x.site = a.drop_site + (unsigned)p * a.site_pstride;
+    x.dblock = (unsigned long long)x.bl * a.H + x.h;
+    return x;
+}
 
 constexpr int TA_QB = 32, TA_NACC = 32;
 
@@ -1156,11 +1211,12 @@ void train_attn_kernel(const TrainAttnArgs a) {
     float* dS = dOs + (size_t)nqmax * PAD;        // [nq][Lk + 1]   (backward only)
     float* PD = dS + (size_t)nqmax * ldp;         // [nq][Lk + 1]   (backward only) probabilities after dropout
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const TrainAttnIdx ix = train_attn_idx(a);
+    const int b = ix.bf, h = ix.h;      // b: the image over all passes (rows of q / o / d_o / dq / dk / dv)
 
     for (int idx = tid; idx < Lk * HD; idx += 256) {
         const int j = idx / HD, d = idx % HD;
-        const size_t g = ((size_t)b * Lk + j) * a.ldkv + h * HD + d;
+        const size_t g = ((size_t)ix.bkv * Lk + j) * a.ldkv + h * HD + d;
         Ks[j * PAD + d] = a.k[g];
         Vs[j * PAD + d] = a.v[g];
     }
@@ -1186,7 +1242,7 @@ void train_attn_kernel(const TrainAttnArgs a) {
                 s = fmaf(Qs[l * PAD + d], Ks[j * PAD + d], s);
                 if (BACKWARD) dp = fmaf(dOs[l * PAD + d], Vs[j * PAD + d], dp);
             }
-            const bool masked = (a.qmask && a.qmask[(size_t)(q0 + l) * Lk + j]) || (a.kmask && a.kmask[(size_t)b * a.ldkm + j]);
+            const bool masked = (ix.qmask && ix.qmask[(size_t)(q0 + l) * Lk + j]) || (a.kmask && a.kmask[(size_t)ix.bl * a.ldkm + j]);
             P[l * ldp + j] = masked ? -INFINITY : s * a.scale;
             if (BACKWARD) dS[l * ldp + j] = dp;
         }
@@ -1199,11 +1255,11 @@ void train_attn_kernel(const TrainAttnArgs a) {
             float sum = 0.f;
             for (int j = lane; j < Lk; j += 64) { const float e = expf(P[l * ldp + j] - mx); P[l * ldp + j] = e; sum += e; }
             const float inv = 1.0f / wave_sum(sum);
-            const unsigned long long row = ((unsigned long long)blockIdx.x * Lq + q0 + l) * Lk;
+            const unsigned long long row = (ix.dblock * Lq + q0 + l) * Lk;
             float dot = 0.f;
             for (int j = lane; j < Lk; j += 64) {
                 const float p = P[l * ldp + j] * inv;
-                const float f = drop_factor(a.drop, a.drop_site, row + j);
+                const float f = drop_factor(a.drop, ix.site, row + j);
                 if (BACKWARD) {
                     P[l * ldp + j] = p;                       // soft-max output
                     PD[l * ldp + j] = p * f;                  // what multiplied V
@@ -1728,22 +1784,42 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+    const TrainAttnIdx ix = train_attn_idx(a);
+    const int h = ix.h;
     const int Lq = a.Lq, Lk = a.Lk;
     const int njt = (Lk + 15) >> 4, nkk = (njt + 1) >> 1, NKP = 32 * nkk;      // key tiles, 32-key k-steps, padded key count
     const float sl2 = a.scale * 1.44269504088896340736f;
+    // pass_loop (> 1, with pass_B and kv_shared): ONE workgroup per (image bl, head) walks that image's pass_loop permutation passes — K / V
+    // are staged once for all of them and dK / dV accumulate in the matrix-core accumulators across the passes, one store at the end
+    // (the cross-attention over the encoder memory: its K | V and their gradients are 300 MB per pass otherwise).  Else one pass: p0.
+    const int npass = a.pass_loop > 1 ? a.pass_loop : 1;
 
-    const float* kg = a.k + (size_t)b * Lk * a.ldkv + h * TD_HD;
-    const float* vg = a.v + (size_t)b * Lk * a.ldkv + h * TD_HD;
-    const float* qg = a.q + (size_t)b * a.q_bstride + h * TD_HD;
+    const float* kg = a.k + (size_t)ix.bkv * Lk * a.ldkv + h * TD_HD;
+    const float* vg = a.v + (size_t)ix.bkv * Lk * a.ldkv + h * TD_HD;
     if constexpr (BACKWARD) {
         td_stage<true, true, TD_K>(kg, a.ldkv, Lk, NKP, Ks, XT, TD_TP, tid);
         td_stage<true, false, TD_K>(vg, a.ldkv, Lk, NKP, Vs, nullptr, 0, tid);
-        td_stage<true, true, TD_Q>(qg, a.ldq, Lq, TD_Q, Qs, Qt, TD_PP, tid);
-        td_stage<true, true, TD_Q>(a.d_o + (size_t)b * Lq * a.ldo + h * TD_HD, a.ldo, Lq, TD_Q, dOs, dOt, TD_PP, tid);
     } else {
         td_stage<true, false, TD_K>(kg, a.ldkv, Lk, NKP, Ks, nullptr, 0, tid);
         td_stage<false, true, TD_K>(vg, a.ldkv, Lk, NKP, nullptr, XT, TD_TP, tid);
+    }
+    f32x4 gkacc[4][2], gvacc[4][2];                                  // backward: dK / dV tiles (jj, dt) of this wave, over the passes
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { gkacc[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; gvacc[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    for (int pp = 0; pp < npass; ++pp) {
+    // b: the image over all passes (rows of q / o / d_o / dq); with pass_loop the launch's images are bl and the passes come from the loop
+    const int b = a.pass_loop > 1 ? pp * a.pass_B + ix.bl : ix.bf;
+    const unsigned char* qmask = a.pass_loop > 1 ? (a.qmask ? a.qmask + (size_t)pp * a.qmask_pstride : nullptr) : ix.qmask;
+    const unsigned site = a.pass_loop > 1 ? a.drop_site + (unsigned)pp * a.site_pstride : ix.site;
+    const float* qg = a.q + (size_t)b * a.q_bstride + h * TD_HD;
+    if (pp) __syncthreads();                     // the previous pass's readers are done with Q / dO / P^T / dS^T
+    if constexpr (BACKWARD) {
+        td_stage<true, true, TD_Q>(qg, a.ldq, Lq, TD_Q, Qs, Qt, TD_PP, tid);
+        td_stage<true, true, TD_Q>(a.d_o + (size_t)b * Lq * a.ldo + h * TD_HD, a.ldo, Lq, TD_Q, dOs, dOt, TD_PP, tid);
+    } else {
         td_stage<true, false, TD_Q>(qg, a.ldq, Lq, TD_Q, Qs, nullptr, 0, tid);
     }
     __syncthreads();
@@ -1755,7 +1831,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
     if constexpr (BACKWARD) of.v = *reinterpret_cast<const bf16x8*>(dOs + l * TD_RP + 8 * g);
     f32x4 sacc[8], pacc[8];
     float fdrop[8][4];                                              // backward: dropout factor of (query l, key)
-    const unsigned long long drow = ((unsigned long long)blockIdx.x * Lq + l) * Lk;
+    const unsigned long long drow = (ix.dblock * Lq + l) * Lk;
     float mx = -INFINITY;
 #pragma unroll
     for (int jt = 0; jt < 8; ++jt) {
@@ -1775,7 +1851,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + 4 * g + r;
             bool masked = j >= Lk;
-            if (!masked && l < Lq) masked = (a.qmask && a.qmask[(size_t)l * Lk + j]) || (a.kmask && a.kmask[(size_t)b * a.ldkm + j]);
+            if (!masked && l < Lq) masked = (qmask && qmask[(size_t)l * Lk + j]) || (a.kmask && a.kmask[(size_t)ix.bl * a.ldkm + j]);
             if (masked) sacc[jt][r] = -INFINITY;
             mx = fmaxf(mx, sacc[jt][r]);
         }
@@ -1797,7 +1873,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
             for (int s8 = 0; s8 < 8; ++s8) {
                 const int jt = 2 * kk + (s8 >> 2), r = s8 & 3, j = 16 * jt + 4 * g + r;
                 float e = sacc[jt][r];
-                if (a.drop.thresh && j < Lk && l < Lq) e *= drop_factor(a.drop, a.drop_site, drow + j);
+                if (a.drop.thresh && j < Lk && l < Lq) e *= drop_factor(a.drop, site, drow + j);
                 pf[kk].v[s8] = static_cast<bf16_t>(e);
             }
 #pragma unroll
@@ -1816,7 +1892,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * g + r;
-                const float f = (a.drop.thresh && j < Lk && l < Lq) ? drop_factor(a.drop, a.drop_site, drow + j) : 1.0f;
+                const float f = (a.drop.thresh && j < Lk && l < Lq) ? drop_factor(a.drop, site, drow + j) : 1.0f;
                 fdrop[jt][r] = f;
                 sacc[jt][r] *= inv;
                 pacc[jt][r] *= f;
@@ -1850,7 +1926,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
             if (l < Lq) *reinterpret_cast<f32x4*>(a.dq + ((size_t)b * Lq + l) * a.lddq + h * TD_HD + 16 * dt + 4 * g) = qacc;
         }
         __syncthreads();                         // (P f)^T and dS^T of all 32 queries are in LDS
-        // ---- dV = (P f)^T dO, dK = dS^T Q over the 32 queries (one k-step): key tiles jt = wave, wave + 2, ...
+        // ---- dV += (P f)^T dO, dK += dS^T Q over the 32 queries (one k-step): key tiles jt = wave, wave + 2, ...
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int jt = wave + 2 * jj;
@@ -1865,19 +1941,28 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
                     qb.v = *reinterpret_cast<const bf16x8*>(Qt + (16 * dt + r16) * TD_PP + 8 * g);
                     // the TRANSPOSED tiles (operands swapped: the same products in the same order): a lane holds four consecutive head
                     // columns of ONE key — gv[r] = dV[key 16 jt + r16][d = 16 dt + 4 g + r] — so the read-modify-write of dK / dV is one
-                    // 16-byte access per lane and tile instead of four 4-byte ones (the cross-attention pass moves 300 MB of dK | dV
-                    // per launch through this epilogue)
-                    f32x4 gv = f32x4{0.f, 0.f, 0.f, 0.f}, gk = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma16(gv, ob, pa);
-                    mma16(gk, qb, sa);
-                    const int j = 16 * jt + r16;
-                    if (j < Lk) {
-                        const size_t gi = ((size_t)b * Lk + j) * a.lddkv + h * TD_HD + 16 * dt + 4 * g;
-                        f32x4 ok_ = f32x4{0.f, 0.f, 0.f, 0.f}, ov_ = f32x4{0.f, 0.f, 0.f, 0.f};      // old values (accumulate): both requested before the first store
-                        if (a.kv_accumulate) { ok_ = *reinterpret_cast<const f32x4*>(a.dk + gi); ov_ = *reinterpret_cast<const f32x4*>(a.dv + gi); }
-                        *reinterpret_cast<f32x4*>(a.dk + gi) = ok_ + gk;
-                        *reinterpret_cast<f32x4*>(a.dv + gi) = ov_ + gv;
-                    }
+                    // 16-byte access per lane and tile instead of four 4-byte ones
+                    mma16(gvacc[jj][dt], ob, pa);
+                    mma16(gkacc[jj][dt], qb, sa);
+                }
+            }
+        }
+    }
+    }      // passes
+    if constexpr (BACKWARD) {
+        // dK / dV leave once: rows of image ix.bf (pass_loop: ix.bl — one copy for all the passes), added to the old values if kv_accumulate
+        const int bo = a.pass_loop > 1 ? ix.bl : ix.bf;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int jt = wave + 2 * jj, j = 16 * jt + r16;
+            if (jt < njt && j < Lk) {
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const size_t gi = ((size_t)bo * Lk + j) * a.lddkv + h * TD_HD + 16 * dt + 4 * g;
+                    f32x4 ok_ = f32x4{0.f, 0.f, 0.f, 0.f}, ov_ = f32x4{0.f, 0.f, 0.f, 0.f};      // old values (accumulate): both requested before the first store
+                    if (a.kv_accumulate) { ok_ = *reinterpret_cast<const f32x4*>(a.dk + gi); ov_ = *reinterpret_cast<const f32x4*>(a.dv + gi); }
+                    *reinterpret_cast<f32x4*>(a.dk + gi) = ok_ + gkacc[jj][dt];
+                    *reinterpret_cast<f32x4*>(a.dv + gi) = ov_ + gvacc[jj][dt];
                 }
             }
         }

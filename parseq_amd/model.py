@@ -168,6 +168,7 @@ class _NativeState:
         self.model = C.c_void_p(0)
         self.plans = {}            # (precision code, slot) -> (plan handle, max_batch)
         self.signature = None
+        self.param_order = None    # (native model handle, [(state_dict key, numel)] in the library's parameter order)
         self.epoch = 0             # bumped whenever a plan's device-side contents may have changed under an unchanged signature:
                                    # plans created / destroyed / re-packed (re-upload, mark_dirty, an optimiser step on the device)
 
@@ -304,10 +305,22 @@ class _NativeBacked(nn.Module):
         signature, do not change and nothing is uploaded again — and re-pack the plans' bf16 copies / decoder tables."""
         st: _NativeState = self._native_state
         lib, stream = _native.lib(), _native.stream_ptr(self._device)
-        for key, t in self.state_dict().items():
-            if t.dtype != torch.float32 or not t.is_contiguous():
-                raise RuntimeError(f'parameter {key}: training needs contiguous fp32 parameters')
-            _native.check(lib.parseq_model_get_param(st.model, key.encode(), _native.ptr(t), t.numel(), stream))
+        sd = self.state_dict()
+        n = lib.parseq_model_num_params(st.model)
+        if st.param_order is None or st.param_order[0] != st.model.value:      # the library's own parameter order, asked for once per native model
+            order = []
+            for i in range(n):
+                key, numel = C.c_char_p(), C.c_int64()
+                _native.check(lib.parseq_model_param_info(st.model, i, C.byref(key), C.byref(numel)))
+                order.append((key.value.decode(), numel.value))
+            st.param_order = (st.model.value, order)
+        ptrs = (C.c_void_p * n)()
+        for i, (key, numel) in enumerate(st.param_order[1]):
+            t = sd[key]
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != numel:
+                raise RuntimeError(f'parameter {key}: training needs contiguous fp32 parameters of the model\'s shape')
+            ptrs[i] = t.data_ptr()
+        _native.check(lib.parseq_model_get_params(st.model, ptrs, n, stream))      # one launch for all of them
         for plan, _ in st.plans.values():
             _native.check(lib.parseq_plan_refresh(plan, stream))
         st.epoch += 1                     # same signature, new weights: a cached memory K / V projection is stale

@@ -721,3 +721,83 @@ def test_bf16_shadow_operands_change_no_bit():
     assert loss_a == loss_b
     diff = [k for k in grads_a if not torch.equal(grads_a[k], grads_b[k])]
     assert not diff, diff
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_permutation_passes_as_one_batch_equal_one_after_the_other(train_golden, precision, monkeypatch):
+    """Round 3: the decoder runs the K permutation passes of a step as ONE batch of K * B images (parseq_train_decoder,
+    PARSEQ_TRAIN_PERM_GROUP).  Against the passes one after the other (group 1, the arrangement every earlier gate was measured on), with
+    dropout on: the SAME masks (the zero pattern of the dropped hidden units of the last pass is identical), the same per-pass losses
+    and every decoder-side gradient and d loss / d memory equal up to the summation order of fp32 (and, in the bf16-operand mode, the
+    operand roundings that order can flip).  Also the uneven grouping 4 + 2 and, in the bf16 mode, the cross-attention with and without
+    the in-kernel walk over the passes (TrainAttnArgs::pass_loop)."""
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import decoder_backward
+    g, meta = train_golden
+    m = make_model('parseq', 'fp32')
+    m.train_precision = precision
+    perms = g['perms'].long()
+    assert len(perms) == 6
+    with torch.no_grad():
+        memory = O.encode(synth_state_dict(CONFIGS['parseq'], 0), CONFIGS['parseq'], g['images']).to(DEV)
+    seed = 0x00C0FFEE12345678
+
+    def run(group, no_loop=False):
+        if group is None:
+            monkeypatch.delenv('PARSEQ_TRAIN_PERM_GROUP', raising=False)
+        else:
+            monkeypatch.setenv('PARSEQ_TRAIN_PERM_GROUP', str(group))
+        if no_loop:
+            monkeypatch.setenv('PARSEQ_TRAIN_NO_PASS_LOOP', '1')
+        else:
+            monkeypatch.delenv('PARSEQ_TRAIN_NO_PASS_LOOP', raising=False)
+        r = decoder_backward(m, g['images'].to(DEV), meta['labels'], perms, memory=memory, dropout=0.1, seed=seed)
+        torch.cuda.synchronize()
+        B, L, K = r._shape
+        hact = r.intermediate('hact', B * L * 4 * 384).clone()
+        out = (float(r.loss), r.perm_losses.clone(), {k: v.clone() for k, v in r.grads.items()}, r.dmemory.clone(), hact)
+        del r
+        return out
+
+    base = run(1)
+    tol = 2e-5 if precision == 'fp32' else 5e-3
+    variants = [('all at once', run(None)), ('4 + 2', run(4))]
+    if precision == 'bf16':
+        variants.append(('all at once, per-pass d K | d V', run(None, no_loop=True)))
+    for what, (loss, pp, grads, dmem, hact) in variants:
+        assert torch.equal(hact == 0, base[4] == 0), what
+        assert abs(loss - base[0]) <= tol * abs(base[0]), (what, loss, base[0])
+        assert (pp - base[1]).abs().max() <= tol * float(base[1].abs().max()), what
+        worst = []
+        for key, ref in list(base[2].items()) + [('d memory', base[3])]:
+            got = dmem if key == 'd memory' else grads[key]
+            a, b = ref.double().flatten(), got.double().flatten()
+            if float(a.norm()) < 1e-9:
+                assert float(b.norm()) < 1e-9, (what, key)
+                continue
+            worst.append((float((a - b).norm() / a.norm()), key))
+        worst.sort()
+        print(f'{precision}, {what}: worst per-tensor L2 difference {worst[-1][0]:.2e} ({worst[-1][1]})')
+        assert worst[-1][0] <= tol, (what, worst[-3:])
+
+
+@pytest.mark.gpu
+def test_optimiser_step_hands_every_weight_back_in_one_launch(train_golden):
+    """`parseq_model_get_params` (one launch over a table of copy pieces) leaves in the module's tensors exactly what the per-tensor
+    `parseq_model_get_param` copies do."""
+    import ctypes as C
+    from gpu_util import DEV, make_model
+    from parseq_amd import _native
+    from parseq_amd.train import TrainStep
+    g, meta = train_golden
+    m = make_model('parseq', 'fp32')
+    step = TrainStep(m, total_steps=10)
+    step(g['images'].to(DEV), meta['labels'], g['perms'].long())
+    torch.cuda.synchronize()
+    lib, st = _native.lib(), m.model._native_state
+    for key, t in m.model.state_dict().items():
+        one = torch.empty_like(t)
+        _native.check(lib.parseq_model_get_param(st.model, key.encode(), _native.ptr(one), one.numel(), _native.stream_ptr(one)))
+        torch.cuda.synchronize()
+        assert torch.equal(one, t), key
