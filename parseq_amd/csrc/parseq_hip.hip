@@ -1694,14 +1694,22 @@ static int train_attn_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B, bo
 // decoder shapes in the bf16-operand mode (train_attn_dec_bf16_kernel): head width 32, <= 32 queries, <= 128 keys, masks, dropout
 static int train_attn_dec_bf16(const TrainCtx& cx, const TrainAttnArgs& a, int B, bool backward) {
     hipStream_t s = cx.s;
-    static LdsAttr attr_f, attr_b;
-    HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<false>), train_attn_dec_lds(false)));
-    HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<true>), train_attn_dec_lds(true)));
+    static LdsAttr attr_f, attr_b, attr_f2, attr_b2;
+    HIPCHK(attr_f.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<false, 8>), train_attn_dec_lds(false, 8)));
+    HIPCHK(attr_b.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<true, 8>), train_attn_dec_lds(true, 8)));
+    HIPCHK(attr_f2.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<false, 2>), train_attn_dec_lds(false, 2)));
+    HIPCHK(attr_b2.ensure(reinterpret_cast<const void*>(train_attn_dec_bf16_kernel<true, 2>), train_attn_dec_lds(true, 2)));
     if (a.pass_loop > 1 && !(a.pass_B > 0 && a.kv_shared && B == a.pass_B * a.pass_loop))
         return fail(PARSEQ_E_INVALID, "training attention: pass_loop needs pass_B, shared K / V and a batch of pass_B * pass_loop images");
     const int blocks = (a.pass_loop > 1 ? a.pass_B : B) * a.H;      // pass_loop: one workgroup per (image, head) walks the passes
-    if (backward) hipLaunchKernelGGL((train_attn_dec_bf16_kernel<true>), dim3(blocks), dim3(128), train_attn_dec_lds(true), s, a);
-    else hipLaunchKernelGGL((train_attn_dec_bf16_kernel<false>), dim3(blocks), dim3(128), train_attn_dec_lds(false), s, a);
+    const bool small = a.Lk <= 32 && !getenv("PARSEQ_TRAIN_ATTN_KT8");      // the self-attention: the 32-key instantiation (a quarter of the LDS, a third of the registers)
+    if (small) {
+        if (backward) hipLaunchKernelGGL((train_attn_dec_bf16_kernel<true, 2>), dim3(blocks), dim3(128), train_attn_dec_lds(true, 2), s, a);
+        else hipLaunchKernelGGL((train_attn_dec_bf16_kernel<false, 2>), dim3(blocks), dim3(128), train_attn_dec_lds(false, 2), s, a);
+    } else {
+        if (backward) hipLaunchKernelGGL((train_attn_dec_bf16_kernel<true, 8>), dim3(blocks), dim3(128), train_attn_dec_lds(true, 8), s, a);
+        else hipLaunchKernelGGL((train_attn_dec_bf16_kernel<false, 8>), dim3(blocks), dim3(128), train_attn_dec_lds(false, 8), s, a);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1897,9 +1905,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         CHK(lin_fwd(cx, ca_o, P(p + "cross_attn.out_proj.weight"), P(p + "cross_attn.out_proj.bias"), nullptr, 0, pm, R, E, E));
         CHK(dropout_add(cx, pm, false, t1, t2, ME, kp, drop, site(S_CA_OUT)));
         CHK((run_layernorm<float>(s, t2, P(p + "norm2.weight"), P(p + "norm2.bias"), n2, nullptr, R, E, eps)));
-        CHK(lin_fwd(cx, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, R, F, E));
-        hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((RF + 1023) / 1024)), dim3(256), 0, s, hpre, hact, RF);
-        HIPCHK(hipGetLastError());
+        CHK(lin_fwd(cx, n2, P(p + "linear1.weight"), P(p + "linear1.bias"), nullptr, 0, hpre, R, F, E, hact));      // hact = gelu(hpre): the product's epilogue (bf16-operand mode) or gelu_fwd_kernel
         if (drop.thresh) CHK(dropout_add(cx, hact, false, nullptr, hact, MF, kp, drop, site(S_FF_HIDDEN)));
         CHK(lin_fwd(cx, hact, P(p + "linear2.weight"), P(p + "linear2.bias"), nullptr, 0, pm, R, E, F));
         CHK(dropout_add(cx, pm, false, t2, t3, ME, kp, drop, site(S_FF_OUT)));
@@ -1919,8 +1925,12 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         CHK(ln_bwd(cx, t3, P("decoder.norm.weight"), d_a, nullptr, d_b, G("decoder.norm.weight"), G("decoder.norm.bias"), nullptr, R, E, eps));  // d_b = d t3
         CHK(dropout_add(cx, d_b, false, nullptr, pm, ME, kp, drop, site(S_FF_OUT)));
         CHK(lin_bwd(cx, hact, P(p + "linear2.weight"), pm, G(p + "linear2.weight"), G(p + "linear2.bias"), d_h, R, E, F));                  // d_h = d hact
-        if (drop.thresh) CHK(dropout_add(cx, d_h, false, nullptr, d_h, MF, kp, drop, site(S_FF_HIDDEN)));
-        hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((RF + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, RF);                      // d_h = d hpre
+        if (drop.thresh && MF % 4 == 0)            // d_h = d hpre: the MLP's inner dropout and the GELU backward in one pass
+            hipLaunchKernelGGL(gelu_bwd_drop_passes_kernel, dim3((unsigned)((MF + 1023) / 1024), (unsigned)kp), dim3(256), 0, s, hpre, d_h, d_h, MF, drop, site(S_FF_HIDDEN));
+        else {
+            if (drop.thresh) CHK(dropout_add(cx, d_h, false, nullptr, d_h, MF, kp, drop, site(S_FF_HIDDEN)));
+            hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((RF + 1023) / 1024)), dim3(256), 0, s, hpre, d_h, d_h, RF);
+        }
         HIPCHK(hipGetLastError());
         CHK(lin_bwd(cx, n2, P(p + "linear1.weight"), d_h, G(p + "linear1.weight"), G(p + "linear1.bias"), d_a, R, F, E));                   // d_a = d n2
         CHK(ln_bwd(cx, t2, P(p + "norm2.weight"), d_a, d_b, d_b, G(p + "norm2.weight"), G(p + "norm2.bias"), nullptr, R, E, eps));          // d_b = d t2
@@ -1957,8 +1967,18 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
 
     // ---- what every permutation shares, once ---------------------------------------------------------------------------------------
     if (L > 1) CHK(colsum(cx, d_content + E, (long)L * E, B, (L - 1) * E, d_pq, true));       // content row j carries pos_queries[j - 1]
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens), dim3(256), 0, s, d_content, tokens, L, B, L, E, sqrtE, G("text_embed.embedding.weight"));
-    HIPCHK(hipGetLastError());
+    {   // token-embedding gradient: the B * L rows in chunks of 768, one workgroup per (token id, chunk), then the chunks folded in order
+        const int rows_per = 768, chunks = (M + rows_per - 1) / rows_per;
+        if (chunks > 1 && (size_t)m->cfg.num_tokens * chunks * E <= cx.scratch_floats) {
+            hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens, chunks), dim3(256), 0, s, d_content, tokens, L, B, L, E, sqrtE,
+                               G("text_embed.embedding.weight"), cx.scratch, rows_per);
+            hipLaunchKernelGGL(embed_bwd_fold_kernel, dim3(m->cfg.num_tokens), dim3(256), 0, s, cx.scratch, chunks, E, sqrtE, G("text_embed.embedding.weight"));
+        } else {
+            hipLaunchKernelGGL(embed_bwd_kernel, dim3(m->cfg.num_tokens, 1), dim3(256), 0, s, d_content, tokens, L, B, L, E, sqrtE,
+                               G("text_embed.embedding.weight"), (float*)nullptr, M);
+        }
+        HIPCHK(hipGetLastError());
+    }
     CHK(lin_bwd(cx, memory, ca_w + (size_t)E * E, d_kvm, G(p + "cross_attn.in_proj_weight") + (size_t)E * E, G(p + "cross_attn.in_proj_bias") + E,
                 dmemory, MS, 2 * E, E));
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)(((size_t)L * E + 255) / 256)), dim3(256), 0, s, G("pos_queries"), d_pq, G("pos_queries"), (size_t)L * E);

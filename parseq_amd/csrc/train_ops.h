@@ -992,14 +992,17 @@ void train_content_kernel(const float* __restrict__ emb, const float* __restrict
 // d emb[v] += scale * sum over the rows whose token is v, rows visited in ascending order (deterministic; one workgroup per token id).
 // The B * L token ids are scanned 256 at a time (one compare per thread, the four waves' ballots through LDS) instead of one after the
 // other by the whole workgroup — the first form spent 2.4 ms per step on 9 984 dependent loads; the summation order is unchanged.
+// Round 3: the rows are cut into gridDim.y chunks of rows_per (a multiple of 256) rows, workgroup (v, c) writes the unscaled sum of ITS rows
+// to partial[v][c][E] and embed_bwd_fold_kernel adds the chunks up in ascending order — <pad> is ~45 % of a batch, and ONE workgroup
+// walking its 4 500 rows was 0.58 ms of the step.  partial == nullptr (gridDim.y == 1): the single-stage form, straight into demb.
 __global__ __launch_bounds__(256)
 void embed_bwd_kernel(const float* __restrict__ dcontent, const int* __restrict__ tok, int ldt, int B, int L, int E, float scale,
-                      float* __restrict__ demb) {
+                      float* __restrict__ demb, float* __restrict__ partial, int rows_per) {
     __shared__ unsigned long long hits[4];
     const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = B * L;
+    const int n = min(B * L, (int)(blockIdx.y + 1) * rows_per);
     float acc[3] = {0.f, 0.f, 0.f};                              // E <= 768
-    for (int base = 0; base < n; base += 256) {
+    for (int base = blockIdx.y * rows_per; base < n; base += 256) {
         const int i = base + tid;
         bool hit = false;
         if (i < n) { const int b = i / L, j = i - b * L; hit = tok[b * ldt + j] == v; }
@@ -1042,7 +1045,19 @@ void embed_bwd_kernel(const float* __restrict__ dcontent, const int* __restrict_
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int c = tid + 256 * k;
-        if (c < E) demb[(size_t)v * E + c] += scale * acc[k];
+        if (c >= E) continue;
+        if (partial) partial[((size_t)v * gridDim.y + blockIdx.y) * E + c] = acc[k];
+        else demb[(size_t)v * E + c] += scale * acc[k];
+    }
+}
+// d emb[v] += scale * (the chunks of embed_bwd_kernel in ascending order); one workgroup per token id
+__global__ __launch_bounds__(256)
+void embed_bwd_fold_kernel(const float* __restrict__ partial, int chunks, int E, float scale, float* __restrict__ demb) {
+    const int v = blockIdx.x;
+    for (int c = threadIdx.x; c < E; c += 256) {
+        float t = 0.f;
+        for (int q = 0; q < chunks; ++q) t += partial[((size_t)v * chunks + q) * E + c];
+        demb[(size_t)v * E + c] += scale * t;
     }
 }
 
@@ -1120,6 +1135,18 @@ void dropout_rows_passes_kernel(const float* __restrict__ table, int L, int E, f
     if (li >= n_pass) return;
     const size_t m = li / E, e = li % E;
     y[(size_t)blockIdx.y * n_pass + li] = table[(m % L) * E + e] * drop_factor(d, site + 8u * blockIdx.y, li);
+}
+// dpre = drop(dact) * gelu'(pre) over [passes][n_pass] elements (grid (ceil(n_pass / 1024), passes), n_pass % 4 == 0): the dropout inside the MLP
+// (site `site + 8 p`, element index within the pass — the mask dropout_passes_kernel drew in the forward) and the GELU backward in one pass
+__global__ __launch_bounds__(256)
+void gelu_bwd_drop_passes_kernel(const float* __restrict__ pre, const float* dact, float* dpre, size_t n_pass, DropSpec d, unsigned site) {
+    const size_t li = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (li >= n_pass) return;
+    const size_t i = (size_t)blockIdx.y * n_pass + li;
+    const unsigned st = site + 8u * blockIdx.y;
+    const float4 v = *reinterpret_cast<const float4*>(pre + i), g = *reinterpret_cast<const float4*>(dact + i);
+    *reinterpret_cast<float4*>(dpre + i) = make_float4(g.x * drop_factor(d, st, li) * gelu_grad(v.x), g.y * drop_factor(d, st, li + 1) * gelu_grad(v.y),
+                                                       g.z * drop_factor(d, st, li + 2) * gelu_grad(v.z), g.w * drop_factor(d, st, li + 3) * gelu_grad(v.w));
 }
 // y[li] (+)= sum over the passes, in ascending order, of drop(x[p][li]) (d.thresh == 0: a plain sum of the passes)
 __global__ __launch_bounds__(256)
@@ -1725,11 +1752,15 @@ void train_attn_bf16_kernel(const TrainAttnArgs a) {
 // -------------------------------------------------------------------------------------------------------------------
 constexpr int TD_HD = 32, TD_Q = 32, TD_K = 128;
 constexpr int TD_RP = TD_HD + 8;          // pitch of [token][d] images (80-byte rows: conflict-free ds_read_b128)
-constexpr int TD_TP = TD_K + 8;           // pitch of [d][key] images
+constexpr int TD_TP = TD_K + 8;           // pitch of [d][key] images at 128 keys (KT 16-key tiles: 16 KT + 8)
 constexpr int TD_PP = TD_Q + 8;           // pitch of [key][query] and [d][query] images
-constexpr size_t train_attn_dec_lds(bool backward) {
-    return sizeof(bf16_t) * (backward ? (size_t)2 * TD_K * TD_RP + (size_t)TD_HD * TD_TP + (size_t)2 * TD_Q * TD_RP + (size_t)2 * TD_HD * TD_PP + (size_t)2 * TD_K * TD_PP
-                                      : (size_t)TD_K * TD_RP + (size_t)TD_HD * TD_TP + (size_t)TD_Q * TD_RP);
+// KT: the 16-key tiles the instantiation holds — 8 (128 keys: the cross-attention over the encoder memory) or 2 (32 keys: the self-attention
+// over <= 26 context positions, whose workgroups then take a quarter of the LDS and a third of the registers: 27 648 of them per step
+// batch, each a chain of dependent memory round trips, so what the launch needs is more of them resident)
+constexpr size_t train_attn_dec_lds(bool backward, int KT = 8) {
+    const size_t K_ = 16 * (size_t)KT, TP_ = K_ + 8;
+    return sizeof(bf16_t) * (backward ? 2 * K_ * TD_RP + (size_t)TD_HD * TP_ + (size_t)2 * TD_Q * TD_RP + (size_t)2 * TD_HD * TD_PP + 2 * K_ * TD_PP
+                                      : K_ * TD_RP + (size_t)TD_HD * TP_ + (size_t)TD_Q * TD_RP);
 }
 
 // rows [0, NRP) of the images; rows >= nr are zero.  src row r at src + r * ld (32 floats used).  128 threads.
@@ -1760,27 +1791,30 @@ __device__ __forceinline__ void td_stage(const float* __restrict__ src, long ld,
         }
     }
 }
+template <int TP>
 __device__ __forceinline__ Frag<bf16_t> td_keyslot_frag(const bf16_t* img, int row, int kk, int g) {
-    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(img + row * TD_TP + 32 * kk + 4 * g);
-    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(img + row * TD_TP + 32 * kk + 16 + 4 * g);
+    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(img + row * TP + 32 * kk + 4 * g);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4*>(img + row * TP + 32 * kk + 16 + 4 * g);
     Frag<bf16_t> f;
     f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3]; f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
     return f;
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, int KT = 8>
 __global__ __launch_bounds__(128)
 void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
+    static_assert(KT == 2 || KT == 8, "key tiles per instantiation");
+    constexpr int KMAX = 16 * KT, TP = KMAX + 8, KK = KT / 2, JJ = KT / 2;      // keys held, pitch of the [d][key] image, 32-key k-steps, key tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char td_smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(td_smem);               // [128][TD_RP]  K
-    bf16_t* Vs = Ks + TD_K * TD_RP;                                 // backward: [128][TD_RP] V
-    bf16_t* XT = BACKWARD ? Vs + TD_K * TD_RP : Ks + TD_K * TD_RP;  // [32][TD_TP]  forward: V^T; backward: K^T
-    bf16_t* Qs = XT + TD_HD * TD_TP;                                // [32][TD_RP]  Q
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(td_smem);               // [KMAX][TD_RP]  K
+    bf16_t* Vs = Ks + KMAX * TD_RP;                                 // backward: [KMAX][TD_RP] V
+    bf16_t* XT = BACKWARD ? Vs + KMAX * TD_RP : Ks + KMAX * TD_RP;  // [32][TP]  forward: V^T; backward: K^T
+    bf16_t* Qs = XT + TD_HD * TP;                                   // [32][TD_RP]  Q
     bf16_t* dOs = Qs + TD_Q * TD_RP;                                // backward: [32][TD_RP] dO
     bf16_t* Qt = dOs + TD_Q * TD_RP;                                // backward: [32 d][TD_PP] Q^T
     bf16_t* dOt = Qt + TD_HD * TD_PP;                               // backward: [32 d][TD_PP] dO^T
-    bf16_t* Pt = dOt + TD_HD * TD_PP;                               // backward: [128 key][TD_PP] (P * dropout factor)^T
-    bf16_t* dSt = Pt + TD_K * TD_PP;                                // backward: [128 key][TD_PP] dS^T
+    bf16_t* Pt = dOt + TD_HD * TD_PP;                               // backward: [KMAX key][TD_PP] (P * dropout factor)^T
+    bf16_t* dSt = Pt + KMAX * TD_PP;                                // backward: [KMAX key][TD_PP] dS^T
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -1797,15 +1831,15 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
     const float* kg = a.k + (size_t)ix.bkv * Lk * a.ldkv + h * TD_HD;
     const float* vg = a.v + (size_t)ix.bkv * Lk * a.ldkv + h * TD_HD;
     if constexpr (BACKWARD) {
-        td_stage<true, true, TD_K>(kg, a.ldkv, Lk, NKP, Ks, XT, TD_TP, tid);
-        td_stage<true, false, TD_K>(vg, a.ldkv, Lk, NKP, Vs, nullptr, 0, tid);
+        td_stage<true, true, KMAX>(kg, a.ldkv, Lk, NKP, Ks, XT, TP, tid);
+        td_stage<true, false, KMAX>(vg, a.ldkv, Lk, NKP, Vs, nullptr, 0, tid);
     } else {
-        td_stage<true, false, TD_K>(kg, a.ldkv, Lk, NKP, Ks, nullptr, 0, tid);
-        td_stage<false, true, TD_K>(vg, a.ldkv, Lk, NKP, nullptr, XT, TD_TP, tid);
+        td_stage<true, false, KMAX>(kg, a.ldkv, Lk, NKP, Ks, nullptr, 0, tid);
+        td_stage<false, true, KMAX>(vg, a.ldkv, Lk, NKP, nullptr, XT, TP, tid);
     }
-    f32x4 gkacc[4][2], gvacc[4][2];                                  // backward: dK / dV tiles (jj, dt) of this wave, over the passes
+    f32x4 gkacc[JJ][2], gvacc[JJ][2];                                // backward: dK / dV tiles (jj, dt) of this wave, over the passes
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj)
+    for (int jj = 0; jj < JJ; ++jj)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) { gkacc[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; gvacc[jj][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -1829,12 +1863,12 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
     Frag<bf16_t> qf, of;
     qf.v = *reinterpret_cast<const bf16x8*>(Qs + l * TD_RP + 8 * g);
     if constexpr (BACKWARD) of.v = *reinterpret_cast<const bf16x8*>(dOs + l * TD_RP + 8 * g);
-    f32x4 sacc[8], pacc[8];
-    float fdrop[8][4];                                              // backward: dropout factor of (query l, key)
+    f32x4 sacc[KT], pacc[KT];
+    float fdrop[KT][4];                                             // backward: dropout factor of (query l, key)
     const unsigned long long drow = (ix.dblock * Lq + l) * Lk;
     float mx = -INFINITY;
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt) {
+    for (int jt = 0; jt < KT; ++jt) {
         sacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (BACKWARD) pacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (jt < 2 * nkk) {
@@ -1859,16 +1893,16 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
     mx = rows4_max(mx);
     float sum = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < 8; ++jt)
+    for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f((sacc[jt][r] - mx) * sl2); sacc[jt][r] = e; sum += e; }
     sum = rows4_sum(sum);
     const float inv = 1.0f / sum;
     if constexpr (!BACKWARD) {
         // ---- O^T = V^T (P f)^T: un-normalised probabilities times the dropout factor as the B operand, 1 / sum on the result
-        Frag<bf16_t> pf[4];
+        Frag<bf16_t> pf[KK];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
                 const int jt = 2 * kk + (s8 >> 2), r = s8 & 3, j = 16 * jt + 4 * g + r;
@@ -1880,15 +1914,15 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
         for (int dt = 0; dt < 2; ++dt) {
             f32x4 oacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                if (kk < nkk) mma16(oacc, td_keyslot_frag(XT, 16 * dt + r16, kk, g), pf[kk]);
+            for (int kk = 0; kk < KK; ++kk)
+                if (kk < nkk) mma16(oacc, td_keyslot_frag<TP>(XT, 16 * dt + r16, kk, g), pf[kk]);
             if (l < Lq) *reinterpret_cast<f32x4*>(a.o + ((size_t)b * Lq + l) * a.ldo + h * TD_HD + 16 * dt + 4 * g) = oacc * inv;
         }
     } else {
         // ---- P = e / sum;  PD = P f (what multiplied V);  dp = dP f;  dS = P (dp - sum_j dp P) scale
         float dot = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 8; ++jt)
+        for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int j = 16 * jt + 4 * g + r;
@@ -1900,7 +1934,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
             }
         dot = rows4_sum(dot);
 #pragma unroll
-        for (int jt = 0; jt < 8; ++jt)
+        for (int jt = 0; jt < KT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = sacc[jt][r];
@@ -1912,23 +1946,23 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
                 }
             }
         // ---- dQ^T = K^T dS^T, dS^T from the registers
-        Frag<bf16_t> df[4];
+        Frag<bf16_t> df[KK];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) df[kk].v[s8] = static_cast<bf16_t>(pacc[2 * kk + (s8 >> 2)][s8 & 3]);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             f32x4 qacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                if (kk < nkk) mma16(qacc, td_keyslot_frag(XT, 16 * dt + r16, kk, g), df[kk]);
+            for (int kk = 0; kk < KK; ++kk)
+                if (kk < nkk) mma16(qacc, td_keyslot_frag<TP>(XT, 16 * dt + r16, kk, g), df[kk]);
             if (l < Lq) *reinterpret_cast<f32x4*>(a.dq + ((size_t)b * Lq + l) * a.lddq + h * TD_HD + 16 * dt + 4 * g) = qacc;
         }
         __syncthreads();                         // (P f)^T and dS^T of all 32 queries are in LDS
         // ---- dV += (P f)^T dO, dK += dS^T Q over the 32 queries (one k-step): key tiles jt = wave, wave + 2, ...
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < JJ; ++jj) {
             const int jt = wave + 2 * jj;
             if (jt < njt) {
                 Frag<bf16_t> pa, sa;
@@ -1953,7 +1987,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
         // dK / dV leave once: rows of image ix.bf (pass_loop: ix.bl — one copy for all the passes), added to the old values if kv_accumulate
         const int bo = a.pass_loop > 1 ? ix.bl : ix.bf;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < JJ; ++jj) {
             const int jt = wave + 2 * jj, j = 16 * jt + r16;
             if (jt < njt && j < Lk) {
 #pragma unroll
