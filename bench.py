@@ -161,7 +161,7 @@ class _StubModel(torch.nn.Module):
         return x.float().mean(dim=(1, 2, 3))[:, None, None].expand(x.shape[0], 26, 95).contiguous()
 
 
-def train_leg(dev, batch=384, steps=3, warmup=1):
+def train_leg(dev, batch=384, steps=5, warmup=2):
     """tools/train_bench.py's measurement, short: images/s of the training step (strhub/models/parseq/system.py:168-199 + loss.backward()
     + gradient_clip_val 20 + AdamW under OneCycleLR, train.py:62-71 / base.py:98-110) with synthetic crops and labels resident on the device."""
     from parseq_amd import create_model
@@ -424,7 +424,7 @@ def main():
             result['parity'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not args.no_train and args.model == 'parseq':
         # Row N3 on the driver's record (never part of `value`): the training step of BASELINE.json configs[4] on this GPU — 384 crops,
-        # K = 6 permutations, dropout 0.1, forward + backward + clip + AdamW in the bf16-operand mode — one warm-up step, three timed.
+        # K = 6 permutations, dropout 0.1, forward + backward + clip + AdamW in the bf16-operand mode — two warm-up steps, five timed.
         try:
             result['train'] = train_leg(dev)
         except Exception as e:
