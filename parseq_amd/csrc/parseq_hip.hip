@@ -1432,6 +1432,11 @@ struct TrainCtx {
 };
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// split-K: how many workgroups a product with few output tiles is cut into along the contraction (PARSEQ_TRAIN_SPLIT_TARGET overrides, for A/B)
+static int split_target() {
+    static const int t = [] { const char* e = getenv("PARSEQ_TRAIN_SPLIT_TARGET"); const int v = e ? atoi(e) : 0; return v >= 64 ? v : 512; }();
+    return t;
+}
 
 // asum (optional): [M] += row sums of A over k, folded into the product when it takes the bf16 matrix-core kernel; returns through
 // *asum_done whether it did (the caller runs the column-sum kernel otherwise)
@@ -1469,7 +1474,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
             return fail(PARSEQ_E_INVALID, "sgemm: shadow operands of a %d x %d x %d product are not laid out for the matrix-core kernels", M, N, K);
         int splits = 1;
         if (tiles < 256) {      // the same split as the fp32-in-memory path takes (32-deep stages), so that the two stay bit-identical
-            splits = std::min((512 + tiles - 1) / tiles, K / (4 * BG_BK));
+            splits = std::min((split_target() + tiles - 1) / tiles, K / (4 * BG_BK));
             splits = (int)std::min<size_t>((size_t)std::max(splits, 1), cx.scratch_floats / ((size_t)M * N + (size_t)M));
             splits = std::max(splits, 1);
         }
@@ -1480,8 +1485,14 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         if (asum_done) *asum_done = true;
         const dim3 grid_((unsigned)tiles, 1, splits);
         void (*kern)(const SgemmArgs, int, float*, int, int);
-        if (both) kern = mfma_bgemm16_kernel;
-        else if (deep_t) kern = mfma_bgemm16t_kernel;
+        // whole 128 x 128 tiles (every product of the PARSeq-S / ViTSTR encoders): the four-workgroups-per-CU forms (train_ops.h); the buffer
+        // loads' 32-bit byte offsets cover both operands with room to spare at any batch that fits the workspace
+        static const bool no_w4 = getenv("PARSEQ_TRAIN_GEMM_W3") != nullptr;
+        const bool whole = M % MG_BM == 0 && N % MG_BN == 0 && !no_w4 &&
+                           (size_t)M * (size_t)std::max(sam, sak) < ((size_t)1 << 29) && (size_t)N * (size_t)std::max(sbn, sbk) < ((size_t)1 << 29) &&
+                           (size_t)K * (size_t)std::max(sak, sbk) < ((size_t)1 << 29);
+        if (both) kern = whole ? mfma_bgemm16_kernel<true> : mfma_bgemm16_kernel<false>;
+        else if (deep_t) kern = whole ? mfma_bgemm16t_kernel<true> : mfma_bgemm16t_kernel<false>;
         else if (both_t) kern = mfma_bgemm_kernel<false, false, true, true>;
         else if (ext->b16) kern = sak == 1 ? (sbk == 1 ? mfma_bgemm_kernel<true, true, true> : mfma_bgemm_kernel<true, false, true>)
                                            : (sbk == 1 ? mfma_bgemm_kernel<false, true, true> : mfma_bgemm_kernel<false, false, true>);
@@ -1508,7 +1519,7 @@ static int sgemm(const TrainCtx& cx, const float* A, long sam, long sak, const f
         const int tiles = gm_ * gn_;
         int splits = 1;
         if (tiles < 256) {
-            splits = std::min((512 + tiles - 1) / tiles, K / (4 * bk));
+            splits = std::min((split_target() + tiles - 1) / tiles, K / (4 * bk));
             splits = (int)std::min<size_t>((size_t)std::max(splits, 1), cx.scratch_floats / ((size_t)M * N + (size_t)M));      // + the row-sum slots
             splits = std::max(splits, 1);
         }

@@ -559,7 +559,36 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
 // as before), the next stage waits in registers under the current stage's 32 MFMAs per wave.  Same tile order, accumulation order
 // (ascending k in steps of 32), split-K and epilogue as mfma_bgemm_kernel: bit-identical results.  K % 64 == 0.
 constexpr int BH_BK = 64, BH_LD = 72;
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// one 32-deep half of a 64-deep stage: 16 MFMAs of a wave's 64 x 64 tile.  ONE_B: the B fragments one at a time (the four-workgroup forms)
+template <bool ONE_B>
+__device__ __forceinline__ void bg16_stage_mfma(const bf16_t (*As)[72], const bf16_t (*Bs)[72], f32x4 (&acc)[4][4], int wm, int wn, int r16, int g, int kk) {
+    bf16x8 av[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
+    if constexpr (ONE_B) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 bj = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * j + r16][32 * kk + 8 * g]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bj, acc[i][j], 0, 0, 0);
+        }
+    } else {
+        bf16x8 bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * i + r16][32 * kk + 8 * g]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+}
+// WHOLE (M and N multiples of 128 — every product of the PARSeq-S / ViTSTR encoders): FOUR workgroups per CU.  The kernel waits on memory, not on
+// the matrix pipe (six 64-deep stages per tile at K = 384, one stage of register prefetch), so what it needs is more waves to switch to; at 140
+// registers it sat at three.  The loads become buffer loads — one resource per operand in SGPRs, ONE constant byte offset per thread and
+// operand in a VGPR, the piece's 32-row distance and the k position in the scalar offset: no 64-bit pointers, no per-piece offsets — and the
+// B fragments are read one at a time (16 instead of 32 fragment registers): 126 VGPRs, no scratch.
+template <bool WHOLE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WHOLE ? 4 : 3, WHOLE ? 4 : 3)))
 void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
     constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
     static_assert(2 * TILE_BYTES >= EP_STAGE_BYTES, "LDS block too small for the epilogue");
@@ -580,20 +609,39 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
     // thread = (row idx >> 3, 8 consecutive k at 8 (idx & 7)), idx = tid + 256 it; rows past the edge re-read the last valid row
-    const bf16_t* pa[4];
-    const bf16_t* pb[4];
+    const bf16_t* pa[WHOLE ? 1 : 4];
+    const bf16_t* pb[WHOLE ? 1 : 4];
+    __amdgpu_buffer_rsrc_t ares, bres;
+    unsigned oa = 0, ob = 0, pa_step = 0, pb_step = 0, kbyte = 0;
+    if constexpr (WHOLE) {
+        ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7FFFF000, 0x00020000);
+        bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, 0x7FFFF000, 0x00020000);
+        oa = 2u * ((unsigned)(m0 + (tid >> 3)) * (unsigned)a.sam + 8u * (tid & 7));
+        ob = 2u * ((unsigned)(n0 + (tid >> 3)) * (unsigned)a.sbn + 8u * (tid & 7));
+        pa_step = 64u * (unsigned)a.sam; pb_step = 64u * (unsigned)a.sbn;      // 32 rows, in bytes
+        kbyte = 2u * (unsigned)kbeg;
+    } else {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = tid + 256 * it;
-        pa[it] = reinterpret_cast<const bf16_t*>(a.A) + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.sam + kbeg + 8 * (idx & 7);
-        pb[it] = reinterpret_cast<const bf16_t*>(a.B) + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.sbn + kbeg + 8 * (idx & 7);
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;
+            pa[it] = reinterpret_cast<const bf16_t*>(a.A) + (size_t)min(m0 + (idx >> 3), a.M - 1) * a.sam + kbeg + 8 * (idx & 7);
+            pb[it] = reinterpret_cast<const bf16_t*>(a.B) + (size_t)min(n0 + (idx >> 3), a.N - 1) * a.sbn + kbeg + 8 * (idx & 7);
+        }
     }
     u32x4 ra[4], rb[4];
     auto fetch = [&]() {
+        if constexpr (WHOLE) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { ra[it] = *reinterpret_cast<const u32x4*>(pa[it]); pa[it] += BH_BK; }
+            for (int it = 0; it < 4; ++it) ra[it] = __builtin_amdgcn_raw_buffer_load_b128(ares, oa, kbyte + it * pa_step, 0);
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { rb[it] = *reinterpret_cast<const u32x4*>(pb[it]); pb[it] += BH_BK; }
+            for (int it = 0; it < 4; ++it) rb[it] = __builtin_amdgcn_raw_buffer_load_b128(bres, ob, kbyte + it * pb_step, 0);
+            kbyte += 2u * BH_BK;
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { ra[it] = *reinterpret_cast<const u32x4*>(pa[it]); pa[it] += BH_BK; }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { rb[it] = *reinterpret_cast<const u32x4*>(pb[it]); pb[it] += BH_BK; }
+        }
     };
     if (kbeg < kend) fetch();
     for (int k0 = kbeg; k0 < kend; k0 += BH_BK) {
@@ -607,16 +655,7 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
         if (k0 + BH_BK < kend) fetch();                 // in flight under this stage's MFMAs; first touched by the stores above, next round
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
-                bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * i + r16][32 * kk + 8 * g]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            bg16_stage_mfma<WHOLE>(As, Bs, acc, wm, wn, r16, g, kk);
         }
         __builtin_amdgcn_sched_barrier(0);              // the waits for the loads stay below the MFMAs
         __syncthreads();
@@ -630,7 +669,9 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
 // + the next stage in registers, as mfma_bgemm16_kernel; with 32-deep stages the kernel paid one exposed memory round trip per 16
 // MFMAs per wave (49 152-deep contractions in 15 splits: 102 stages of 1.9 us) — at 64 deep it pays one per 32.  Row sums of A (the bias
 // gradient, a.asum) are sums of the bf16 values.  K % 64 == 0, M % 4 == 0, N % 4 == 0.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+// WHOLE: as mfma_bgemm16_kernel<true> — four workgroups per CU, buffer loads with the k position of a piece in the scalar offset (128 VGPRs, no scratch)
+template <bool WHOLE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WHOLE ? 4 : 3, WHOLE ? 4 : 3)))
 void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
     constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
     static_assert(2 * TILE_BYTES >= EP_STAGE_BYTES && 2 * TILE_BYTES >= 8 * 128 * 4, "LDS block too small for the epilogue");
@@ -653,16 +694,36 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
     // thread = (outer group o4 = tid & 31: outer indices 4 o4 .. 4 o4 + 3, k octet kq = tid >> 5: k = 8 kq + it); groups past the edge
     // re-read the last valid group of four
     const int o4 = tid & 31, kq = tid >> 5;
-    const bf16_t* pa = reinterpret_cast<const bf16_t*>(a.A) + (size_t)(kbeg + 8 * kq) * a.sak + min(m0 + 4 * o4, a.M - 4);
-    const bf16_t* pb = reinterpret_cast<const bf16_t*>(a.B) + (size_t)(kbeg + 8 * kq) * a.sbk + min(n0 + 4 * o4, a.N - 4);
+    const bf16_t* pa = nullptr; const bf16_t* pb = nullptr;
     const long sa = a.sak, sb = a.sbk;
+    __amdgpu_buffer_rsrc_t ares, bres;
+    unsigned sa2 = 0, sb2 = 0, oa = 0, ob = 0, ka = 0, kb = 0;
+    if constexpr (WHOLE) {
+        ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7FFFF000, 0x00020000);
+        bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, 0x7FFFF000, 0x00020000);
+        sa2 = 2u * (unsigned)a.sak; sb2 = 2u * (unsigned)a.sbk;      // bytes per k
+        oa = 8u * (unsigned)kq * sa2 + 2u * (unsigned)(m0 + 4 * o4);
+        ob = 8u * (unsigned)kq * sb2 + 2u * (unsigned)(n0 + 4 * o4);
+        ka = (unsigned)kbeg * sa2; kb = (unsigned)kbeg * sb2;
+    } else {
+        pa = reinterpret_cast<const bf16_t*>(a.A) + (size_t)(kbeg + 8 * kq) * a.sak + min(m0 + 4 * o4, a.M - 4);
+        pb = reinterpret_cast<const bf16_t*>(a.B) + (size_t)(kbeg + 8 * kq) * a.sbk + min(n0 + 4 * o4, a.N - 4);
+    }
     u32x2 ra[8], rb[8];
     auto fetch = [&]() {
+        if constexpr (WHOLE) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) ra[it] = *reinterpret_cast<const u32x2*>(pa + it * sa);
+            for (int it = 0; it < 8; ++it) ra[it] = __builtin_amdgcn_raw_buffer_load_b64(ares, oa, ka + it * sa2, 0);
 #pragma unroll
-        for (int it = 0; it < 8; ++it) rb[it] = *reinterpret_cast<const u32x2*>(pb + it * sb);
-        pa += BH_BK * sa; pb += BH_BK * sb;
+            for (int it = 0; it < 8; ++it) rb[it] = __builtin_amdgcn_raw_buffer_load_b64(bres, ob, kb + it * sb2, 0);
+            ka += BH_BK * sa2; kb += BH_BK * sb2;
+        } else {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) ra[it] = *reinterpret_cast<const u32x2*>(pa + it * sa);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) rb[it] = *reinterpret_cast<const u32x2*>(pb + it * sb);
+            pa += BH_BK * sa; pb += BH_BK * sb;
+        }
     };
     // r[it] = {outer 0 | outer 1 << 16, outer 2 | outer 3 << 16} at k = 8 kq + it  ->  row (4 o4 + i): k = 8 kq .. 8 kq + 7 as four dwords
     auto park = [&](bf16_t (*tile)[BH_LD], const u32x2 (&r)[8]) {
@@ -691,16 +752,7 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
         if (k0 + BH_BK < kend) fetch();                 // in flight under this stage's MFMAs
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
-                bv[i] = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * i + r16][32 * kk + 8 * g]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            bg16_stage_mfma<WHOLE>(As, Bs, acc, wm, wn, r16, g, kk);
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
