@@ -26,7 +26,7 @@
 namespace pq {
 
 // (The timing ablations of this kernel — GELU / soft-max core / LDS-DMA issue / barriers / fragment reads / DMA waits removed one at
-// a time, profiles/r02_enc_ablation.log — and the rejected scheduling variants live on the branch `ablation-variants-r3`.)
+// a time, profiles/r02_enc_ablation.log — and the rejected scheduling variants are in the history at commit c342b0c (the parent of the pruning commit c0ffb4f).)
 
 // Per-block parameters, one entry per encoder block: ELEMENT offsets relative to two bases the kernel receives once — the bf16
 // weights (wqkv, wproj, w1, w2) relative to `wbase`, the fp32 vectors relative to `pbase`.  32-bit offsets (instead of twelve

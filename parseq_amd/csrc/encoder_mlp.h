@@ -40,7 +40,7 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 constexpr int MLP_BM = 128, MLP_NST = 8, MLP_DIST = 7, MLP_STAGE_BYTES = 128 * 128, MLP_HC = 64;
 
 // (The ablation variants of this kernel — no weight stream, no GELU, no MFMAs, no barriers, no LayerNorm prologue, phase time stamps —
-// that produced profiles/r01_panel_ablation.log live on the branch `ablation-variants-r3`.)
+// that produced profiles/r01_panel_ablation.log are in the history at commit c342b0c (the parent of the pruning commit c0ffb4f).)
 // RESIDENT: the fp32 rows of x are loaded ONCE, straight into the fc2 accumulators (the pair-permuted W2 row order makes the
 // accumulator layout of a tile pair identical to the LayerNorm'd operand-fragment layout: lane (r16, g) holds columns
 // 32 q + 8 g + [0, 8) of row r16), LayerNorm statistics are taken from the accumulators, and the epilogue only stores:

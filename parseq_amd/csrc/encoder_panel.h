@@ -91,8 +91,8 @@ __device__ __forceinline__ u32x4 swap_half_rows(const u32x4& v) {
 #endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// (Ablation variants — no stores, no LayerNorm prologue, no MFMAs, no stream waits: profiles/r01_panel_ablation.log — live on the
-// branch `ablation-variants-r3`.)
+// (Ablation variants — no stores, no LayerNorm prologue, no MFMAs, no stream waits: profiles/r01_panel_ablation.log — are in the
+// history at commit c342b0c, the parent of the pruning commit c0ffb4f.)
 template <int E, typename Epi>
 __global__ __launch_bounds__(256, 2)
 void ln_panel_gemm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,

@@ -29,7 +29,7 @@
 
 #include "common.h"
 
-// (Removed, kept on the branch `ablation-variants-r3`: the four-stage counted-vmcnt ring of the pre-split (PAIRS) loop — one workgroup
+// (Removed, kept in the history at commit c342b0c, the parent of the pruning commit c0ffb4f: the four-stage counted-vmcnt ring of the pre-split (PAIRS) loop — one workgroup
 // per CU, measured slower than two buffers x two workgroups: qkv 254 -> 305 us, fc1 347 -> 430, fc2 233 -> 261 — and the diagnostic
 // builds of the bf16x3 co-residency defect hunt, tools/x3_diag2.py.)
 
