@@ -287,12 +287,35 @@ struct BgOperand {
 constexpr int EP_LD = 132;       // floats per staged row: 128 + 4 (the four row groups of a store land on distinct banks)
 constexpr int EP_STAGE_BYTES = 64 * EP_LD * 4;
 __device__ __forceinline__ bool ep_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+// XCD-aware order of the workgroups of a launch.  The hardware deals consecutive workgroup ids (x fastest, then z) to the eight XCDs
+// round-robin; id L is mapped to the logical id (L % 8) * (T / 8) + L / 8 so that ONE XCD walks a contiguous range of logical ids, and logical
+// ids walk the N-tiles of a row panel first, then the row panels (a panel's consumers share an L2).  The tail that does not fill a group of
+// eight keeps its id.
+// SPLIT_AWARE (round 3, second half; the fp32-operand kernel): the split index is part of the walk — logical ids walk the tiles of split 0, then
+// of split 1, ... — because the tiles of one split all read the same k range of both operands and, spread over eight XCDs, every private L2
+// fetched that range for itself.  Counters per dW launch, before -> after: fp32 operands (the decoder's) 673 -> 290 MB from HBM (184 MB of
+// operands) and 124 -> 106 us; all-bf16 (the encoder's, mfma_bgemm16t_kernel) 472 -> 222 MB (190 MB of operands) but 102 -> 109 us — that kernel
+// was not waiting on HBM, and eight XCDs each serving an eighth of every split's tiles spread its L2 reads better — so the all-bf16 kernels
+// keep the split in blockIdx.z (profiles/r03_train_pmc_hbm_traffic.md, r03_train_pmc_fetch_after.md).
+struct BgTile { int tm, tn, z; };
+template <bool SPLIT_AWARE>
+__device__ __forceinline__ BgTile bg_tile(int gn, int gm) {
+    const int total = gn * gm;
+    const int T = SPLIT_AWARE ? total * (int)gridDim.z : total, L = (int)blockIdx.x + (SPLIT_AWARE ? total * (int)blockIdx.z : 0), whole = T & ~7;
+    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
+    BgTile t;
+    t.z = SPLIT_AWARE ? logical / total : (int)blockIdx.z;
+    const int in_split = SPLIT_AWARE ? logical - t.z * total : logical;
+    t.tn = in_split % gn; t.tm = in_split / gn;
+    return t;
+}
+
 __device__ __forceinline__ void bg_epilogue(const SgemmArgs& a, const f32x4 (&acc)[4][4], float* __restrict__ partial, float* __restrict__ stage,
-                                            int m0, int n0, int tid) {
+                                            int m0, int n0, int tid, int zsplit) {
     const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const bool direct = gridDim.z == 1;
-    float* __restrict__ out = direct ? a.C : partial + (size_t)blockIdx.z * a.M * a.N;
+    float* __restrict__ out = direct ? a.C : partial + (size_t)zsplit * a.M * a.N;
     const long ldo = direct ? a.ldc : a.N;
     const float* __restrict__ Rb = direct ? a.R : nullptr;
     const bool acc_c = direct && a.accumulate;
@@ -461,9 +484,8 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
     bf16_t (*Bs)[MG_BN][BG_LD] = reinterpret_cast<bf16_t (*)[MG_BN][BG_LD]>(smem + TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order (see above); the tail that does not fill a whole group of eight keeps its id
-    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
-    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
-    const int tn_ = logical % gn, tm_ = logical / gn;
+    const BgTile bt = bg_tile<true>(gn, gm);
+    const int tn_ = bt.tn, tm_ = bt.tm, zsplit = bt.z;
     const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int r16 = lane & 15, g = lane >> 4;
@@ -472,7 +494,7 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    const int kbeg = zsplit * k_chunk, kend = min(a.K, kbeg + k_chunk);
     OpA oa; OpB ob;
     oa.init(reinterpret_cast<const TA*>(a.A), a.sam, a.sak, m0, a.M, kbeg, tid);
     ob.init(reinterpret_cast<const TB*>(a.B), a.sbn, a.sbk, n0, a.N, kbeg, tid);
@@ -545,11 +567,11 @@ void mfma_bgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ parti
             if constexpr (AKF) v = red[tid];
             else v = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) + ((red[512 + tid] + red[640 + tid]) + (red[768 + tid] + red[896 + tid]));
             if (gridDim.z == 1) a.asum[m0 + tid] += v;
-            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)blockIdx.z * a.M + m0 + tid] = v;
+            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)zsplit * a.M + m0 + tid] = v;
         }
         __syncthreads();
     }
-    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
+    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid, zsplit);
 }
 
 // Both operands bf16 shadows with k contiguous (the forward products x W^T of the encoder, and dX = dY W through the transposed
@@ -596,9 +618,8 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
     bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
     bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
-    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
-    const int tn_ = logical % gn, tm_ = logical / gn;
+    const BgTile bt = bg_tile<false>(gn, gm);
+    const int tn_ = bt.tn, tm_ = bt.tm, zsplit = bt.z;
     const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int r16 = lane & 15, g = lane >> 4;
@@ -607,7 +628,7 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    const int kbeg = zsplit * k_chunk, kend = min(a.K, kbeg + k_chunk);
     // thread = (row idx >> 3, 8 consecutive k at 8 (idx & 7)), idx = tid + 256 it; rows past the edge re-read the last valid row
     const bf16_t* pa[WHOLE ? 1 : 4];
     const bf16_t* pb[WHOLE ? 1 : 4];
@@ -660,7 +681,7 @@ void mfma_bgemm16_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ par
         __builtin_amdgcn_sched_barrier(0);              // the waits for the loads stay below the MFMAs
         __syncthreads();
     }
-    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
+    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid, zsplit);
 }
 
 // The dW products dY^T X with BOTH operands bf16 in memory and outer-contiguous (the contraction index m is the row index of dY [m, n]
@@ -679,9 +700,8 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
     bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
     bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int total = gn * gm, L = blockIdx.x, whole = total & ~7;
-    const int logical = L < whole ? (L & 7) * (whole >> 3) + (L >> 3) : L;
-    const int tn_ = logical % gn, tm_ = logical / gn;
+    const BgTile bt = bg_tile<false>(gn, gm);
+    const int tn_ = bt.tn, tm_ = bt.tm, zsplit = bt.z;
     const int m0 = tm_ * MG_BM, n0 = tn_ * MG_BN;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int r16 = lane & 15, g = lane >> 4;
@@ -690,7 +710,7 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int kbeg = blockIdx.z * k_chunk, kend = min(a.K, kbeg + k_chunk);
+    const int kbeg = zsplit * k_chunk, kend = min(a.K, kbeg + k_chunk);
     // thread = (outer group o4 = tid & 31: outer indices 4 o4 .. 4 o4 + 3, k octet kq = tid >> 5: k = 8 kq + it); groups past the edge
     // re-read the last valid group of four
     const int o4 = tid & 31, kq = tid >> 5;
@@ -766,11 +786,11 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
         if (tid < 128 && m0 + tid < a.M) {
             const float v = ((red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid])) + ((red[512 + tid] + red[640 + tid]) + (red[768 + tid] + red[896 + tid]));
             if (gridDim.z == 1) a.asum[m0 + tid] += v;
-            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)blockIdx.z * a.M + m0 + tid] = v;
+            else partial[(size_t)gridDim.z * a.M * a.N + (size_t)zsplit * a.M + m0 + tid] = v;
         }
         __syncthreads();
     }
-    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid);
+    bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid, zsplit);
 }
 
 // bf16 shadows of a Linear weight W [N, K] (fp32 master): W16 [N, K] and its transpose Wt16 [K, N], once per step.  N, K multiples of 32.
