@@ -100,3 +100,53 @@ def test_split_layernorm_loader_is_compiled_without_packed_f32(built_lib, tmp_pa
         assert 'v_mfma' in asm, f'{sym}: disassembly is empty?'
         bad = re.findall(r'v_pk_(?:mul|fma|add)_f32', asm)
         assert not bad, f'{sym}: {len(bad)} packed-f32 VALU instructions — the ln_apply4 pins no longer hold'
+
+
+def test_occupancy_budgets_of_the_training_kernels(built_lib, tmp_path):
+    """Round 3's training-step gains that are pure residency: the whole-tile all-bf16 GEMMs hold FOUR workgroups per CU only at <= 128 VGPRs
+    without scratch (buffer loads with one VGPR offset per operand; `amdgpu_waves_per_eu(4, 4)` alone spilled 60 registers inside the loop),
+    and the 32-key instantiation of the decoder attention kernel holds its many small workgroups only while it stays well under the 128-key
+    one.  The numbers live in the shipped code object's metadata, so a compiler bump that silently undoes them fails here, on the CPU."""
+    import struct
+    import subprocess
+    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
+    if not os.path.exists(readelf):
+        pytest.skip('llvm-readelf not found')
+    blob = open(built_lib, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    at = blob.find(magic)
+    assert at >= 0
+    n = struct.unpack_from('<Q', blob, at + len(magic))[0]
+    off, co = at + len(magic) + 8, None
+    for _ in range(n):
+        o, size, tlen = struct.unpack_from('<QQQ', blob, off)
+        triple = blob[off + 24:off + 24 + tlen].decode()
+        off += 24 + tlen
+        if 'gfx950' in triple:
+            co = blob[at + o:at + o + size]
+    assert co is not None, 'no gfx950 code object in the library'
+    path = tmp_path / 'lib.co'
+    path.write_bytes(co)
+    notes = subprocess.run([readelf, '--notes', str(path)], capture_output=True, text=True, check=True).stdout
+    meta = {}
+    for blk in re.split(r'\n\s+- ', notes):
+        name = re.search(r'\.name:\s+(\S+)', blk)
+        if not name or '.vgpr_count' not in blk:
+            continue
+        get = lambda k: int((re.search(r'\.%s:\s+(\d+)' % k, blk) or [None, -1])[1])      # noqa: E731   (-1: the note does not carry the key)
+        meta[name.group(1)] = (get('vgpr_count'), get('vgpr_spill_count'), get('private_segment_fixed_size'), get('group_segment_fixed_size'))
+    names = subprocess.run(['/usr/bin/c++filt'], input='\n'.join(meta), capture_output=True, text=True, check=True).stdout.splitlines()
+    by_name = {re.sub(r'\(.*$', '', re.sub(r'^void (pq::)?', '', d)): v for d, v in zip(names, meta.values())}
+
+    def one(fragment):
+        hits = [(k, v) for k, v in by_name.items() if fragment in k]
+        assert len(hits) == 1, (fragment, [k for k, _ in hits])
+        return hits[0][1]
+
+    for kern in ('mfma_bgemm16_kernel<true>', 'mfma_bgemm16t_kernel<true>'):
+        vgpr, spills, scratch, lds = one(kern)
+        assert vgpr <= 128 and spills == 0 and scratch == 0, (kern, vgpr, spills, scratch)      # 512 / 128 = four waves per SIMD
+        assert lds < 0 or 4 * lds <= 160 * 1024, (kern, lds)                                     # and four workgroups' tiles in a CU's LDS (36 KiB each)
+    small, big = one('train_attn_dec_bf16_kernel<true, 2>'), one('train_attn_dec_bf16_kernel<true, 8>')
+    assert small[0] <= 128 and small[1] == 0 and small[2] == 0, small
+    assert big[1] == 0 and big[2] == 0 and big[0] <= 512, big
