@@ -253,7 +253,11 @@ int parseq_model_set_train_precision(parseq_model* m, int precision);
  *   grads             device fp32 [parseq_model_grad_elems]: ACCUMULATED into (zero it for a fresh step); encoder slots untouched
  *   dmemory           device fp32 [batch, tokens, embed_dim]: written
  *   workspace         device, parseq_train_decoder_workspace_bytes(...) bytes; after the call it holds the intermediates of
- *                     the last permutation (parseq_train_decoder_workspace_offset names them; used by the parity tests) */
+ *                     the last permutation (parseq_train_decoder_workspace_offset names them; used by the parity tests).
+ * The num_perms passes share every weight and differ in masks, dropout sites and (after two passes) targets only, so they run as
+ * ONE batch of num_perms * batch images (round 3): same masks bit for bit, same per-pass losses, gradients equal to the
+ * one-pass-after-the-other form up to fp32 summation order; the workspace holds num_perms copies of the per-pass buffers (4.5 GB
+ * at batch 384, 6 passes).  The environment variable PARSEQ_TRAIN_PERM_GROUP=g (read by both functions below) runs them g at a time. */
 size_t parseq_train_decoder_workspace_bytes(const parseq_model* m, int batch, int ctx_len, int num_perms);
 int64_t parseq_train_decoder_workspace_offset(const parseq_model* m, int batch, int ctx_len, int num_perms, const char* name);
 int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* tokens, const int32_t* targets,
