@@ -2,7 +2,9 @@
 // torch, on the encoder's shapes — to separate a tile's fixed cost (prologue + epilogue) from its per-stage cost and the stores from the rest:
 //   * K sweep at fixed M x N (K = 64 is ONE 64-deep stage): T(K) = fixed + per-stage * K / 64;
 //   * epilogue forms: no store at all (C = c16 = nullptr), bf16 only, fp32 only, fp32 + bf16, bf16 pre-activation + bf16 GELU (fc1's form);
-//   * the three-workgroup (WHOLE = false) and four-workgroup (WHOLE = true) forms of the kernel.
+//   * the three-workgroup (WHOLE = false) and four-workgroup (WHOLE = true) forms of the kernel;
+//   * hot (the same buffers every launch: operands and outputs live in the 256 MB Infinity Cache) vs cold (four copies in rotation);
+//   * the dW form (mfma_bgemm16t_kernel) over its split counts.
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iparseq_amd/csrc -o tools/microbench/train_gemm tools/microbench/train_gemm.hip && tools/microbench/train_gemm
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -16,13 +18,24 @@ using namespace pq;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-static float run(void (*kern)(const SgemmArgs, int, float*, int, int), const SgemmArgs& a, float* scratch, int iters) {
+// ROT > 1: every launch takes the next of ROT copies of the A operand and of the outputs, so that neither comes out of the 256 MB Infinity Cache
+// (what the products see inside the step); grid z = splits of the contraction (the dW products; partials go to `scratch`)
+struct Bufs { bf16_t* A[4]; bf16_t* c16[4]; bf16_t* g16[4]; float* C[4]; };
+static float run(void (*kern)(const SgemmArgs, int, float*, int, int), SgemmArgs a, const Bufs& b, bool c32, bool c16, bool g16, int rot, float* scratch,
+                 int iters, int splits = 1, bool a_is_rot = true) {
     const int gm = (a.M + MG_BM - 1) / MG_BM, gn = (a.N + MG_BN - 1) / MG_BN;
+    const int k_chunk = ((a.K + splits - 1) / splits + 63) / 64 * 64;
     hipEvent_t t0, t1;
     CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(gm * gn, 1, 1), dim3(256), 0, 0, a, a.K, scratch, gn, gm);
+    auto go = [&](int i) {
+        const int r = i % rot;
+        if (a_is_rot) a.A = reinterpret_cast<const float*>(b.A[r]); else a.B = reinterpret_cast<const float*>(b.A[r]);
+        a.C = c32 ? b.C[r] : nullptr; a.c16 = c16 ? b.c16[r] : nullptr; a.gelu_out16 = g16 ? b.g16[r] : nullptr;
+        hipLaunchKernelGGL(kern, dim3(gm * gn, 1, splits), dim3(256), 0, 0, a, k_chunk, scratch, gn, gm);
+    };
+    for (int i = 0; i < 4; ++i) go(i);
     CK(hipEventRecord(t0, 0));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(gm * gn, 1, 1), dim3(256), 0, 0, a, a.K, scratch, gn, gm);
+    for (int i = 0; i < iters; ++i) go(i);
     CK(hipEventRecord(t1, 0));
     CK(hipEventSynchronize(t1));
     CK(hipGetLastError());
@@ -32,34 +45,53 @@ static float run(void (*kern)(const SgemmArgs, int, float*, int, int), const Sge
 }
 
 int main(int argc, char** argv) {
-    const int M = argc > 1 ? atoi(argv[1]) : 49152, iters = 20;
+    const int M = 49152, iters = 20, ROT = 4;
     const int KMAX = 1536, NMAX = 1536;
     std::vector<unsigned short> h((size_t)M * KMAX);
     unsigned s = 12345u;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; const float f = ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f; unsigned u; memcpy(&u, &f, 4); v = (unsigned short)(u >> 16); }
-    bf16_t *A, *B, *c16, *g16; float *C, *bias, *scratch;
-    CK(hipMalloc(&A, (size_t)M * KMAX * 2)); CK(hipMalloc(&B, (size_t)NMAX * KMAX * 2));
-    CK(hipMalloc(&c16, (size_t)M * NMAX * 2)); CK(hipMalloc(&g16, (size_t)M * NMAX * 2)); CK(hipMalloc(&C, (size_t)M * NMAX * 4));
-    CK(hipMalloc(&bias, NMAX * 4)); CK(hipMalloc(&scratch, 1 << 20));
-    CK(hipMemcpy(A, h.data(), (size_t)M * KMAX * 2, hipMemcpyHostToDevice));
-    CK(hipMemcpy(B, h.data(), (size_t)NMAX * KMAX * 2, hipMemcpyHostToDevice));
+    Bufs b; bf16_t* B; float *bias, *scratch;
+    for (int r = 0; r < ROT; ++r) {
+        CK(hipMalloc(&b.A[r], (size_t)M * KMAX * 2)); CK(hipMalloc(&b.c16[r], (size_t)M * NMAX * 2)); CK(hipMalloc(&b.g16[r], (size_t)M * NMAX * 2));
+        CK(hipMalloc(&b.C[r], (size_t)M * NMAX * 4));
+        CK(hipMemcpy(b.A[r], h.data(), (size_t)M * KMAX * 2, hipMemcpyHostToDevice));
+    }
+    CK(hipMalloc(&B, (size_t)M * 384 * 2)); CK(hipMalloc(&bias, NMAX * 4)); CK(hipMalloc(&scratch, (size_t)64 << 20));
+    CK(hipMemcpy(B, h.data(), (size_t)M * 384 * 2, hipMemcpyHostToDevice));
     CK(hipMemset(bias, 0, NMAX * 4));
     struct Epi { const char* name; bool c32, c16, g16; };
     const Epi epis[] = {{"no store", false, false, false}, {"bf16", false, true, false}, {"fp32", true, false, false}, {"fp32+bf16", true, true, false},
                         {"bf16+gelu16", false, true, true}};
-    printf("| M x N x K | epilogue | 3 wg/CU us | 4 wg/CU us | TFLOP/s (4) | tiles |\n|---|---|---:|---:|---:|---:|\n");
-    const int shapes[][2] = {{384, 64}, {384, 128}, {384, 384}, {384, 1536}, {1152, 384}, {1536, 64}, {1536, 128}, {1536, 384}};
+    printf("forward / dX form (mfma_bgemm16_kernel): hot = the same buffers every launch, cold = %d copies of A and of the outputs in rotation\n\n", ROT);
+    printf("| M x N x K | epilogue | 3 wg/CU hot us | 4 wg/CU hot us | 4 wg/CU cold us | TFLOP/s (4, cold) | tiles |\n|---|---|---:|---:|---:|---:|---:|\n");
+    const int shapes[][2] = {{384, 64}, {384, 384}, {384, 1536}, {1152, 384}, {1536, 64}, {1536, 384}};
     for (const auto& sh : shapes) {
         const int N = sh[0], K = sh[1];
         for (const Epi& e : epis) {
-            if ((K == 64 || K == 128) && (e.c32 && e.c16)) continue;
+            if (K == 64 && (e.c32 && e.c16)) continue;
             SgemmArgs a{};
-            a.A = reinterpret_cast<const float*>(A); a.sam = K; a.sak = 1; a.B = reinterpret_cast<const float*>(B); a.sbk = 1; a.sbn = K;
-            a.bias = bias; a.R = nullptr; a.ldr = 0; a.rper = 1; a.C = e.c32 ? C : nullptr; a.ldc = N; a.M = M; a.N = N; a.K = K; a.alpha = 1.f;
-            a.a16 = a.b16 = 1; a.c16 = e.c16 ? c16 : nullptr; a.gelu_out16 = e.g16 ? g16 : nullptr;
-            const float t3 = run(mfma_bgemm16_kernel<false>, a, scratch, iters), t4 = run(mfma_bgemm16_kernel<true>, a, scratch, iters);
-            printf("| %d x %d x %d | %s | %.1f | %.1f | %.0f | %d |\n", M, N, K, e.name, t3, t4, 2.0 * M * N * K / t4 * 1e-6, (M / 128) * (N / 128));
+            a.sam = K; a.sak = 1; a.B = reinterpret_cast<const float*>(B); a.sbk = 1; a.sbn = K;
+            a.bias = bias; a.R = nullptr; a.ldr = 0; a.rper = 1; a.ldc = N; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.a16 = a.b16 = 1;
+            const float t3 = run(mfma_bgemm16_kernel<false>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
+            const float t4 = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
+            const float t4c = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters);
+            printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.0f | %d |\n", M, N, K, e.name, t3, t4, t4c, 2.0 * M * N * K / t4c * 1e-6, (M / 128) * (N / 128));
         }
+    }
+    // dW form: C[Nout, Kin] = dY^T X, both operands outer-contiguous bf16 (dY [rows, Nout], X [rows, Kin]), contraction over the 49 152 rows in `splits`
+    // workgroups along z writing fp32 partials (the fold is a separate kernel, not timed here)
+    printf("\ndW form (mfma_bgemm16t_kernel, partials only): dY [49152, Nout] (rotated when cold), X [49152, 384]\n\n");
+    printf("| Nout x Kin | splits | workgroups | 3 wg/CU hot us | 4 wg/CU hot us | 4 wg/CU cold us | TFLOP/s (4, cold) |\n|---|---:|---:|---:|---:|---:|---:|\n");
+    const int dws[][2] = {{1536, 15}, {1536, 28}, {1152, 19}, {384, 57}, {384, 110}};
+    for (const auto& d : dws) {
+        const int Nout = d[0], splits = d[1], Kin = 384;
+        SgemmArgs a{};
+        a.sam = 1; a.sak = Nout; a.B = reinterpret_cast<const float*>(B); a.sbk = Kin; a.sbn = 1;
+        a.ldc = Kin; a.M = Nout; a.N = Kin; a.K = M; a.alpha = 1.f; a.a16 = a.b16 = 1; a.rper = 1;
+        const float t3 = run(mfma_bgemm16t_kernel<false>, a, b, true, false, false, 1, scratch, iters, splits);
+        const float t4 = run(mfma_bgemm16t_kernel<true>, a, b, true, false, false, 1, scratch, iters, splits);
+        const float t4c = run(mfma_bgemm16t_kernel<true>, a, b, true, false, false, ROT, scratch, iters, splits);
+        printf("| %d x %d | %d | %d | %.1f | %.1f | %.1f | %.0f |\n", Nout, Kin, splits, (Nout / 128) * (Kin / 128) * splits, t3, t4, t4c, 2.0 * M * Nout * Kin / t4c * 1e-6);
     }
     return 0;
 }
