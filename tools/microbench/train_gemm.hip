@@ -16,6 +16,75 @@
 #include "train_ops.h"
 using namespace pq;
 
+// mfma_bgemm16_kernel<true> again with pieces cut out (MODE): 0 whole, 1 no epilogue, 2 no main loop (epilogue of zeros), 3 empty kernel,
+// 4 main loop without the MFMAs (loads, LDS stores, barriers), 5 main loop without the global loads (MFMAs on whatever LDS holds)
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ablate_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    if constexpr (MODE == 3) { if (a.M < 0) partial[threadIdx.x] = 1.f; return; }
+    bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
+    bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BgTile bt = bg_tile<false>(gn, gm);
+    const int m0 = bt.tm * MG_BM, n0 = bt.tn * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int kbeg = 0, kend = a.K;
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7FFFF000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, 0x7FFFF000, 0x00020000);
+    const unsigned oa = 2u * ((unsigned)(m0 + (tid >> 3)) * (unsigned)a.sam + 8u * (tid & 7));
+    const unsigned ob = 2u * ((unsigned)(n0 + (tid >> 3)) * (unsigned)a.sbn + 8u * (tid & 7));
+    const unsigned pa_step = 64u * (unsigned)a.sam, pb_step = 64u * (unsigned)a.sbn;
+    unsigned kbyte = 0;
+    u32x4 ra[4] = {}, rb[4] = {};
+    auto fetch = [&]() {
+        if constexpr (MODE != 5) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) ra[it] = __builtin_amdgcn_raw_buffer_load_b128(ares, oa, kbyte + it * pa_step, 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) rb[it] = __builtin_amdgcn_raw_buffer_load_b128(bres, ob, kbyte + it * pb_step, 0);
+        }
+        kbyte += 2u * BH_BK;
+    };
+    if constexpr (MODE != 2) {
+        fetch();
+        for (int k0 = kbeg; k0 < kend; k0 += BH_BK) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tid + 256 * it;
+                *reinterpret_cast<u32x4*>(&As[idx >> 3][8 * (idx & 7)]) = ra[it];
+                *reinterpret_cast<u32x4*>(&Bs[idx >> 3][8 * (idx & 7)]) = rb[it];
+            }
+            __syncthreads();
+            if (k0 + BH_BK < kend) fetch();
+            if constexpr (MODE != 4) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) bg16_stage_mfma<true>(As, Bs, acc, wm, wn, r16, g, kk);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+    if constexpr (MODE == 1 || MODE == 4 || MODE == 5) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (MODE == 4) t += __uint_as_float(ra[0][0] ^ rb[3][3]) + reinterpret_cast<const float*>(smem)[tid];
+        if (t == 1.2345e-33f) partial[tid] = t;      // never true: keeps the work alive
+    } else {
+        bg_epilogue(a, acc, partial, reinterpret_cast<float*>(smem), m0, n0, tid, 0);
+    }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // ROT > 1: every launch takes the next of ROT copies of the A operand and of the outputs, so that neither comes out of the 256 MB Infinity Cache
@@ -76,6 +145,22 @@ int main(int argc, char** argv) {
             const float t4 = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
             const float t4c = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters);
             printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.0f | %d |\n", M, N, K, e.name, t3, t4, t4c, 2.0 * M * N * K / t4c * 1e-6, (M / 128) * (N / 128));
+        }
+    }
+    printf("\nwhere a tile's time goes (mfma_bgemm16_kernel<true> with pieces cut out, hot, four workgroups per CU)\n\n");
+    printf("| M x N x K | epilogue | whole | no epilogue | no main loop | loop without MFMAs | loop without loads | empty kernel |\n|---|---|---:|---:|---:|---:|---:|---:|\n");
+    const int ab[][2] = {{384, 64}, {384, 384}, {1536, 384}, {384, 1536}};
+    for (const auto& sh : ab) {
+        const int N = sh[0], K = sh[1];
+        for (int ei = 0; ei < 2; ++ei) {
+            const Epi& e = epis[ei];
+            SgemmArgs a{};
+            a.sam = K; a.sak = 1; a.B = reinterpret_cast<const float*>(B); a.sbk = 1; a.sbn = K;
+            a.bias = bias; a.R = nullptr; a.ldr = 0; a.rper = 1; a.ldc = N; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.a16 = a.b16 = 1;
+            const float t0 = run(ablate_kernel<0>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), t1 = run(ablate_kernel<1>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
+            const float t2 = run(ablate_kernel<2>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), t4 = run(ablate_kernel<4>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
+            const float t5 = run(ablate_kernel<5>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), t3 = run(ablate_kernel<3>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
+            printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f |\n", M, N, K, e.name, t0, t1, t2, t4, t5, t3);
         }
     }
     // dW form: C[Nout, Kin] = dY^T X, both operands outer-contiguous bf16 (dY [rows, Nout], X [rows, Kin]), contraction over the 49 152 rows in `splits`
