@@ -85,6 +85,99 @@ void ablate_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, 
     }
 }
 
+// Candidate for round 4 (NOT in the library): the same product computed TRANSPOSED — MFMA operands swapped, so a lane holds D[m = 16 i + r16][n = 16 j + 4 g
+// + r], four consecutive columns of ONE row — and stored straight from the accumulators as 16-byte (fp32) / 8-byte (bf16) pieces: no trip through LDS.
+// Forms: bias, fp32 C and / or bf16 c16 and / or bf16 GELU; no residual, no accumulate, no split.  main() compares its outputs with the library kernel's bit for bit.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void cand_transposed_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
+    bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BgTile bt = bg_tile<false>(gn, gm);
+    const int m0 = bt.tm * MG_BM, n0 = bt.tn * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7FFFF000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, 0x7FFFF000, 0x00020000);
+    const unsigned oa = 2u * ((unsigned)(m0 + (tid >> 3)) * (unsigned)a.sam + 8u * (tid & 7));
+    const unsigned ob = 2u * ((unsigned)(n0 + (tid >> 3)) * (unsigned)a.sbn + 8u * (tid & 7));
+    const unsigned pa_step = 64u * (unsigned)a.sam, pb_step = 64u * (unsigned)a.sbn;
+    unsigned kbyte = 0;
+    u32x4 ra[4], rb[4];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ra[it] = __builtin_amdgcn_raw_buffer_load_b128(ares, oa, kbyte + it * pa_step, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rb[it] = __builtin_amdgcn_raw_buffer_load_b128(bres, ob, kbyte + it * pb_step, 0);
+        kbyte += 2u * BH_BK;
+    };
+    fetch();
+    for (int k0 = 0; k0 < a.K; k0 += BH_BK) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;
+            *reinterpret_cast<u32x4*>(&As[idx >> 3][8 * (idx & 7)]) = ra[it];
+            *reinterpret_cast<u32x4*>(&Bs[idx >> 3][8 * (idx & 7)]) = rb[it];
+        }
+        __syncthreads();
+        if (k0 + BH_BK < a.K) fetch();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 bj = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * j + r16][32 * kk + 8 * g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bj, av[i], acc[i][j], 0, 0, 0);      // D^T: rows = n, columns = m
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // lane: row m = m0 + wm + 16 i + r16, columns n0 + wn + 16 j + 4 g .. + 3
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int gn0 = n0 + wn + 16 * j + 4 * g;
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + gn0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t at = (size_t)(m0 + wm + 16 * i + r16) * a.ldc + gn0;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(a.alpha, acc[i][j][e], b4[e]);
+            if (a.C) *reinterpret_cast<f32x4*>(a.C + at) = o;
+            if (a.c16) {
+                union { u32x2 u; bf16_t e[4]; } hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh.e[e] = static_cast<bf16_t>(o[e]);
+                *reinterpret_cast<u32x2*>(a.c16 + at) = hh.u;
+            }
+            if (a.gelu_out16) {
+                union { u32x2 u; bf16_t e[4]; } hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh.e[e] = static_cast<bf16_t>(gelu_erf(o[e]));
+                *reinterpret_cast<u32x2*>(a.gelu_out16 + at) = hh.u;
+            }
+        }
+    }
+}
+__global__ void count_diff_kernel(const unsigned* x, const unsigned* y, size_t n, unsigned* out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned d = 0;
+    for (; i < n; i += (size_t)gridDim.x * 256) d += x[i] != y[i];
+    if (d) atomicAdd(out, d);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 // ROT > 1: every launch takes the next of ROT copies of the A operand and of the outputs, so that neither comes out of the 256 MB Infinity Cache
@@ -161,6 +254,35 @@ int main(int argc, char** argv) {
             const float t2 = run(ablate_kernel<2>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), t4 = run(ablate_kernel<4>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
             const float t5 = run(ablate_kernel<5>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), t3 = run(ablate_kernel<3>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
             printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f |\n", M, N, K, e.name, t0, t1, t2, t4, t5, t3);
+        }
+    }
+    printf("\ncandidate: transposed product, stores straight from the accumulators (vs mfma_bgemm16_kernel<true>; differing 32-bit words of the outputs)\n\n");
+    printf("| M x N x K | epilogue | library hot | candidate hot | library cold | candidate cold | words that differ |\n|---|---|---:|---:|---:|---:|---:|\n");
+    unsigned* dcount; CK(hipMalloc(&dcount, 4));
+    const int cs[][2] = {{384, 384}, {1152, 384}, {1536, 384}, {384, 1536}};
+    for (const auto& sh : cs) {
+        const int N = sh[0], K = sh[1];
+        for (int ei = 1; ei < 5; ++ei) {
+            const Epi& e = epis[ei];
+            SgemmArgs a{};
+            a.sam = K; a.sak = 1; a.B = reinterpret_cast<const float*>(B); a.sbk = 1; a.sbn = K;
+            a.bias = bias; a.R = nullptr; a.ldr = 0; a.rper = 1; a.ldc = N; a.M = M; a.N = N; a.K = K; a.alpha = 1.f; a.a16 = a.b16 = 1;
+            // correctness first: library -> copy 0 of the outputs, candidate -> copy 1, same operands
+            Bufs b0 = b, b1 = b;
+            b1.C[0] = b.C[1]; b1.c16[0] = b.c16[1]; b1.g16[0] = b.g16[1]; b1.A[0] = b.A[0];
+            CK(hipMemset(b.C[0], 0xFF, (size_t)M * N * 4)); CK(hipMemset(b.C[1], 0xEE, (size_t)M * N * 4));
+            CK(hipMemset(b.c16[0], 0xFF, (size_t)M * N * 2)); CK(hipMemset(b.c16[1], 0xEE, (size_t)M * N * 2));
+            CK(hipMemset(b.g16[0], 0xFF, (size_t)M * N * 2)); CK(hipMemset(b.g16[1], 0xEE, (size_t)M * N * 2));
+            run(mfma_bgemm16_kernel<true>, a, b0, e.c32, e.c16, e.g16, 1, scratch, 1);
+            run(cand_transposed_kernel, a, b1, e.c32, e.c16, e.g16, 1, scratch, 1);
+            CK(hipMemset(dcount, 0, 4));
+            if (e.c32) hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)b.C[0], (const unsigned*)b.C[1], (size_t)M * N, dcount);
+            if (e.c16) hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)b.c16[0], (const unsigned*)b.c16[1], (size_t)M * N / 2, dcount);
+            if (e.g16) hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)b.g16[0], (const unsigned*)b.g16[1], (size_t)M * N / 2, dcount);
+            unsigned diff = 0; CK(hipMemcpy(&diff, dcount, 4, hipMemcpyDeviceToHost));
+            const float l1 = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), c1 = run(cand_transposed_kernel, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
+            const float l4 = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters), c4 = run(cand_transposed_kernel, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters);
+            printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.1f | %u |\n", M, N, K, e.name, l1, c1, l4, c4, diff);
         }
     }
     // dW form: C[Nout, Kin] = dY^T X, both operands outer-contiguous bf16 (dY [rows, Nout], X [rows, Kin]), contraction over the 49 152 rows in `splits`
