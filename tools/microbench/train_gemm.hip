@@ -171,6 +171,103 @@ void cand_transposed_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ 
         }
     }
 }
+// Candidate 2 for round 4 (NOT in the library; written after the round's last GPU minute — compiled, never run): the transposed product again, but the
+// accumulators still go through LDS as in bg_epilogue — only now a lane holds four consecutive COLUMNS of a row, so the staging pass is 16
+// `ds_write_b128` per lane and half instead of 64 `ds_write_b32` (the epilogue alone, nothing stored, was 27.5 us of the 75 us 49 152 x 1536 x 384
+// product).  Read-back and stores are bg_epilogue's vec path for the forms below (bias, fp32 C and / or bf16 c16 and / or bf16 GELU).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void cand_staged_transposed_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial, int gn, int gm) {
+    constexpr int TILE_BYTES = MG_BM * BH_LD * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * TILE_BYTES];
+    bf16_t (*As)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem);
+    bf16_t (*Bs)[BH_LD] = reinterpret_cast<bf16_t (*)[BH_LD]>(smem + TILE_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const BgTile bt = bg_tile<false>(gn, gm);
+    const int m0 = bt.tm * MG_BM, n0 = bt.tn * MG_BN;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, 0x7FFFF000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.B), 0, 0x7FFFF000, 0x00020000);
+    const unsigned oa = 2u * ((unsigned)(m0 + (tid >> 3)) * (unsigned)a.sam + 8u * (tid & 7));
+    const unsigned ob = 2u * ((unsigned)(n0 + (tid >> 3)) * (unsigned)a.sbn + 8u * (tid & 7));
+    const unsigned pa_step = 64u * (unsigned)a.sam, pb_step = 64u * (unsigned)a.sbn;
+    unsigned kbyte = 0;
+    u32x4 ra[4], rb[4];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ra[it] = __builtin_amdgcn_raw_buffer_load_b128(ares, oa, kbyte + it * pa_step, 0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) rb[it] = __builtin_amdgcn_raw_buffer_load_b128(bres, ob, kbyte + it * pb_step, 0);
+        kbyte += 2u * BH_BK;
+    };
+    fetch();
+    for (int k0 = 0; k0 < a.K; k0 += BH_BK) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + 256 * it;
+            *reinterpret_cast<u32x4*>(&As[idx >> 3][8 * (idx & 7)]) = ra[it];
+            *reinterpret_cast<u32x4*>(&Bs[idx >> 3][8 * (idx & 7)]) = rb[it];
+        }
+        __syncthreads();
+        if (k0 + BH_BK < a.K) fetch();
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 av[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = *reinterpret_cast<const bf16x8*>(&As[wm + 16 * i + r16][32 * kk + 8 * g]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 bj = *reinterpret_cast<const bf16x8*>(&Bs[wn + 16 * j + r16][32 * kk + 8 * g]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bj, av[i], acc[i][j], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    float* stage = reinterpret_cast<float*>(smem);
+    const int c4 = tid & 31, gcol = n0 + 4 * c4;
+    f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + gcol);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if ((wave >> 1) == h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(stage + (16 * i + r16) * EP_LD + wn + 16 * j + 4 * g) = acc[i][j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = (tid >> 5) + 8 * q;
+            const size_t at = (size_t)(m0 + 64 * h + row) * a.ldc + gcol;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * EP_LD + 4 * c4);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(a.alpha, v[e], b4[e]);
+            if (a.C) *reinterpret_cast<f32x4*>(a.C + at) = o;
+            if (a.c16) {
+                union { u32x2 u; bf16_t e[4]; } hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh.e[e] = static_cast<bf16_t>(o[e]);
+                *reinterpret_cast<u32x2*>(a.c16 + at) = hh.u;
+            }
+            if (a.gelu_out16) {
+                union { u32x2 u; bf16_t e[4]; } hh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hh.e[e] = static_cast<bf16_t>(gelu_erf(o[e]));
+                *reinterpret_cast<u32x2*>(a.gelu_out16 + at) = hh.u;
+            }
+        }
+        __syncthreads();
+    }
+}
 __global__ void count_diff_kernel(const unsigned* x, const unsigned* y, size_t n, unsigned* out) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     unsigned d = 0;
@@ -257,7 +354,8 @@ int main(int argc, char** argv) {
         }
     }
     printf("\ncandidate: transposed product, stores straight from the accumulators (vs mfma_bgemm16_kernel<true>; differing 32-bit words of the outputs)\n\n");
-    printf("| M x N x K | epilogue | library hot | candidate hot | library cold | candidate cold | words that differ |\n|---|---|---:|---:|---:|---:|---:|\n");
+    printf("candidate 2: the transposed product with bg_epilogue's LDS staging, written as 16-byte pieces (compiled after the round's last GPU minute)\n\n");
+    printf("| M x N x K | epilogue | library hot | candidate hot | library cold | candidate cold | words that differ | cand. 2 hot | cand. 2 cold | cand. 2 words that differ |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|\n");
     unsigned* dcount; CK(hipMalloc(&dcount, 4));
     const int cs[][2] = {{384, 384}, {1152, 384}, {1536, 384}, {384, 1536}};
     for (const auto& sh : cs) {
@@ -282,7 +380,18 @@ int main(int argc, char** argv) {
             unsigned diff = 0; CK(hipMemcpy(&diff, dcount, 4, hipMemcpyDeviceToHost));
             const float l1 = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), c1 = run(cand_transposed_kernel, a, b, e.c32, e.c16, e.g16, 1, scratch, iters);
             const float l4 = run(mfma_bgemm16_kernel<true>, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters), c4 = run(cand_transposed_kernel, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters);
-            printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.1f | %u |\n", M, N, K, e.name, l1, c1, l4, c4, diff);
+            // candidate 2: outputs into copy 2, compared with the library's copy 0
+            Bufs b2 = b; b2.C[0] = b.C[2]; b2.c16[0] = b.c16[2]; b2.g16[0] = b.g16[2];
+            CK(hipMemset(b.C[2], 0xDD, (size_t)M * N * 4)); CK(hipMemset(b.c16[2], 0xDD, (size_t)M * N * 2)); CK(hipMemset(b.g16[2], 0xDD, (size_t)M * N * 2));
+            run(mfma_bgemm16_kernel<true>, a, b0, e.c32, e.c16, e.g16, 1, scratch, 1);
+            run(cand_staged_transposed_kernel, a, b2, e.c32, e.c16, e.g16, 1, scratch, 1);
+            CK(hipMemset(dcount, 0, 4));
+            if (e.c32) hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)b.C[0], (const unsigned*)b.C[2], (size_t)M * N, dcount);
+            if (e.c16) hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)b.c16[0], (const unsigned*)b.c16[2], (size_t)M * N / 2, dcount);
+            if (e.g16) hipLaunchKernelGGL(count_diff_kernel, dim3(1024), dim3(256), 0, 0, (const unsigned*)b.g16[0], (const unsigned*)b.g16[2], (size_t)M * N / 2, dcount);
+            unsigned diff2 = 0; CK(hipMemcpy(&diff2, dcount, 4, hipMemcpyDeviceToHost));
+            const float s1 = run(cand_staged_transposed_kernel, a, b, e.c32, e.c16, e.g16, 1, scratch, iters), s4 = run(cand_staged_transposed_kernel, a, b, e.c32, e.c16, e.g16, ROT, scratch, iters);
+            printf("| %d x %d x %d | %s | %.1f | %.1f | %.1f | %.1f | %u | %.1f | %.1f | %u |\n", M, N, K, e.name, l1, c1, l4, c4, diff, s1, s4, diff2);
         }
     }
     // dW form: C[Nout, Kin] = dY^T X, both operands outer-contiguous bf16 (dY [rows, Nout], X [rows, Kin]), contraction over the 49 152 rows in `splits`
