@@ -171,7 +171,7 @@ void cand_transposed_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ 
         }
     }
 }
-// Candidate 2 for round 4 (NOT in the library; written after the round's last GPU minute — compiled, never run): the transposed product again, but the
+// Candidate 2 (NOT in the library; measured with the round's last GPU seconds: bit-identical, no faster — profiles/r03_train_gemm_microbench.md): the transposed product again, but the
 // accumulators still go through LDS as in bg_epilogue — only now a lane holds four consecutive COLUMNS of a row, so the staging pass is 16
 // `ds_write_b128` per lane and half instead of 64 `ds_write_b32` (the epilogue alone, nothing stored, was 27.5 us of the 75 us 49 152 x 1536 x 384
 // product).  Read-back and stores are bg_epilogue's vec path for the forms below (bias, fp32 C and / or bf16 c16 and / or bf16 GELU).
@@ -354,7 +354,7 @@ int main(int argc, char** argv) {
         }
     }
     printf("\ncandidate: transposed product, stores straight from the accumulators (vs mfma_bgemm16_kernel<true>; differing 32-bit words of the outputs)\n\n");
-    printf("candidate 2: the transposed product with bg_epilogue's LDS staging, written as 16-byte pieces (compiled after the round's last GPU minute)\n\n");
+    printf("candidate 2: the transposed product with bg_epilogue's LDS staging, written as 16-byte pieces\n\n");
     printf("| M x N x K | epilogue | library hot | candidate hot | library cold | candidate cold | words that differ | cand. 2 hot | cand. 2 cold | cand. 2 words that differ |\n|---|---|---:|---:|---:|---:|---:|---:|---:|---:|\n");
     unsigned* dcount; CK(hipMalloc(&dcount, 4));
     const int cs[][2] = {{384, 384}, {1152, 384}, {1536, 384}, {384, 1536}};
