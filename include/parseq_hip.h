@@ -319,7 +319,7 @@ int parseq_op_ln_linear_pairs(const float* x, const float* gamma, const float* b
 /* dtype = PARSEQ_BF16X3: A is f32 [M, K], K a multiple of 32; W must be the block-planar hi / lo copy of the f32 weight that
  * parseq_op_split_pack(src f32 [numel], dst [numel * 4 bytes]) produces (numel a multiple of 32); C as for PARSEQ_F32. */
 int parseq_op_split_pack(const float* src, void* dst, int64_t numel, void* stream);
-/* Same as parseq_op_linear with an explicit tile configuration (tools/gemm_bench.py sweeps these; ids in parseq_hip.hip). */
+/* Same as parseq_op_linear with an explicit tile configuration (tools/gemm_bench.py sweeps these; ids in lib_ops.hip). */
 int parseq_op_linear_cfg(const void* A, const void* W, const float* bias, void* C, int dtype, int act, int M, int N, int K,
                          int cfg, void* stream);
 /* out[M, N] (bf16) = gelu(LayerNorm(x[M, 384]; gamma, beta, eps 1e-6) W^T + bias) through the register-resident-A panel

@@ -385,7 +385,7 @@ void dec_cross_attn_generic_kernel(const float* __restrict__ qc, const T* __rest
 //                     where the S^T accumulators already hold the probabilities; V^T fragments are gathered from an LDS copy)
 // Queries and probabilities are fp32 quantities in this decoder: each is fed to the bf16 MFMA as a
 // hi + lo pair (x = bf16(x) + bf16(x - bf16(x)), two MFMAs), which keeps ~16 mantissa bits instead of 8.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void dec_cross_attn_multi_mfma_kernel(const float* __restrict__ qc, const bf16_t* __restrict__ kmem, const bf16_t* __restrict__ vmem,
                                       int H, int Lq, float scale, bf16_t* __restrict__ out, int BH) {
     constexpr int NK = 128, VP = DEC_HD + 2;               // LDS pitch of a V row (elements): odd word count spreads banks
@@ -505,7 +505,7 @@ void dec_cross_attn_multi_mfma_kernel(const float* __restrict__ qc, const bf16_t
 // is a bf16 pair (hi, lo = value - hi) and every product three MFMAs (hi lo + lo hi + hi hi, fp32 accumulate) — K and V are split
 // as they are loaded, queries and probabilities exactly as in the bf16 kernel.  Two waves per workgroup (the V tile takes two
 // LDS planes per wave).  Replaces the VALU kernel dec_cross_attn_multi_kernel<float> for 128 memory tokens (250 -> ~60 us).
-__global__ __launch_bounds__(128)
+static __global__ __launch_bounds__(128)
 void dec_cross_attn_multi_mfma_x3_kernel(const float* __restrict__ qc, const float* __restrict__ kmem, const float* __restrict__ vmem,
                                          int H, int Lq, float scale, float* __restrict__ out, int BH) {
     constexpr int NK = 128, VP = DEC_HD + 2, WAVES = 2;

@@ -41,7 +41,7 @@ constexpr int DS_LA = 2;        // fragments read ahead from LDS into registers 
 // place from the row-major weight the same fragment is 16 half-used cache lines: measured 4x slower end to end.)
 // k is walked 64 at a time: lane group g takes k = 64 kp + 16 g + [0, 16) as the k-slots of TWO MFMAs (the slot
 // assignment is free as long as both operands agree).  Rows past N are zero in the packed copy.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void frag_pack_kernel(const bf16_t* __restrict__ W, int N, int K, int ldw, bf16_t* __restrict__ out, int tiles) {
     const int KP = K / 64;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece per thread
@@ -59,7 +59,7 @@ constexpr size_t frag_pack_elems(int N, int K) { return (size_t)((N + 15) / 16) 
 //   Wp[tile][kp][half][plane][lane][8],  plane 0 = bf16(W), plane 1 = bf16(W - plane 0)
 // (2 x frag_pack_elems bf16 elements), packed from the fp32 master.  A product is three MFMAs: W_hi A_lo + W_hi A_hi on the
 // hi unit, W_lo A_hi on the lo unit that follows it in the stream; the activations are split where they are parked in LDS.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void frag_pack_x3_kernel(const float* __restrict__ W, int N, int K, int ldw, bf16_t* __restrict__ out, int tiles) {
     const int KP = K / 64;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece per thread

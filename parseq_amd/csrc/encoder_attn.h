@@ -399,7 +399,7 @@ void attn_mfma_n_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__
 template <int NT32> constexpr size_t attn_mfma_n_lds() { return (size_t)32 * NT32 * ATT_KROWB + (size_t)ATT_HD * (32 * NT32 * 2 + 8); }
 
 // Exact-f32 attention: 128 threads, thread = query; K [128][64] and V^T [64][128] broadcast-read from LDS.
-__global__ __launch_bounds__(128)
+static __global__ __launch_bounds__(128)
 void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vt,
                      float* __restrict__ ao, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_att[];

@@ -798,7 +798,7 @@ inline bool make_wpair(const bf16_t* a, size_t a_elems, const bf16_t* b, size_t 
 }
 
 template <int E>
-inline hipError_t launch_attn_branch(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* Wqkv, const float* bqkv,
+hipError_t launch_attn_branch(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* Wqkv, const float* bqkv,
                                      const bf16_t* Wproj, const float* bproj, int M) {
     WPair wp;
     if (!make_wpair(Wqkv, (size_t)3 * E * E, Wproj, (size_t)E * E, &wp)) return hipErrorInvalidValue;
@@ -811,7 +811,7 @@ inline hipError_t launch_attn_branch(hipStream_t s, float* x, const float* gamma
 }
 
 template <int E>
-inline hipError_t launch_mlp_branch(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1, const float* b1,
+hipError_t launch_mlp_branch(hipStream_t s, float* x, const float* gamma, const float* beta, float eps, const bf16_t* W1, const float* b1,
                                     const bf16_t* W2, const float* b2, int M) {
     WPair wp;
     if (!make_wpair(W1, (size_t)4 * E * E, W2, (size_t)4 * E * E, &wp)) return hipErrorInvalidValue;
@@ -824,7 +824,7 @@ inline hipError_t launch_mlp_branch(hipStream_t s, float* x, const float* gamma,
 }
 
 template <int E>
-inline hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
+hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
                                     int depth, float eps, int M, const EncTailParams& tail = EncTailParams{0, 0, 0, 0, nullptr, nullptr, 0},
                                     const EncHeadParams& head = EncHeadParams{nullptr, 0, 0, nullptr}) {
     constexpr size_t lds = enc_blocks_lds<E>();
@@ -835,5 +835,20 @@ inline hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase
     hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M, tail, head);
     return hipGetLastError();
 }
+
+// The three kernels of this header are compiled in their own translation unit (kern_enc_blocks.hip defines PQ_INSTANTIATE_ENC_BLOCKS
+// and instantiates the launchers for E = 384); every other unit only calls them.
+#ifdef PQ_INSTANTIATE_ENC_BLOCKS
+#define PQ_ENC_BLOCKS_EXTERN
+#else
+#define PQ_ENC_BLOCKS_EXTERN extern
+#endif
+PQ_ENC_BLOCKS_EXTERN template hipError_t launch_attn_branch<384>(hipStream_t, float*, const float*, const float*, float, const bf16_t*, const float*, const bf16_t*,
+                                                                   const float*, int);
+PQ_ENC_BLOCKS_EXTERN template hipError_t launch_mlp_branch<384>(hipStream_t, float*, const float*, const float*, float, const bf16_t*, const float*, const bf16_t*,
+                                                                  const float*, int);
+PQ_ENC_BLOCKS_EXTERN template hipError_t launch_enc_blocks<384>(hipStream_t, float*, const bf16_t*, size_t, const float*, const EncBlockParams*, int, float, int,
+                                                                  const EncTailParams&, const EncHeadParams&);
+#undef PQ_ENC_BLOCKS_EXTERN
 
 }  // namespace pq

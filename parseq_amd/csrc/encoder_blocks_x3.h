@@ -6,7 +6,7 @@
 // 1.2e-7 erf form, not the polynomial of the bf16 mode), biases and the residual stream are fp32.
 //
 // What changes against the bf16 kernel:
-//   * weights come from the plan's block-planar hi | lo pack (parseq_hip.hip split_pack_kernel: 32 elements -> 64 B hi | 64 B lo,
+//   * weights come from the plan's block-planar hi | lo pack (lib_internal.h split_pack_kernel: 32 elements -> 64 B hi | 64 B lo,
 //     byte offsets equal those of the f32 master), so a 128-byte LDS row of a stage is ONE 32-wide k-block — hi fragment at the
 //     lane's offset, lo fragment at offset ^ 64 — instead of two k-steps; a GEMM slice that was one TRIPLE of 16 KiB stages is six
 //     stages here.  They run as PAIRS of stages under one workgroup barrier (2 x 48 = 96 MFMAs per wave per barrier, what a
@@ -843,7 +843,7 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 }
 
 template <int E>
-inline hipError_t launch_enc_blocks_x3(hipStream_t s, float* x, const void* wpack, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
+hipError_t launch_enc_blocks_x3(hipStream_t s, float* x, const void* wpack, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
                                        int depth, float eps, int M, float* scratch, const EncTailX3& tail = EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0}) {
     constexpr size_t lds = enc_blocks_x3_lds<E>();
     if (wbytes >= ((size_t)1 << 32) || M % 128 != 0) return hipErrorInvalidValue;
@@ -853,6 +853,13 @@ inline hipError_t launch_enc_blocks_x3(hipStream_t s, float* x, const void* wpac
     hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, s, x, reinterpret_cast<const unsigned char*>(wpack), (unsigned)wbytes, pbase, blocks, depth, eps, M, scratch, tail);
     return hipGetLastError();
 }
+
+// Compiled in its own translation unit (kern_enc_blocks_x3.hip defines PQ_INSTANTIATE_ENC_BLOCKS_X3); every other unit only calls it.
+#ifdef PQ_INSTANTIATE_ENC_BLOCKS_X3
+template hipError_t launch_enc_blocks_x3<384>(hipStream_t, float*, const void*, size_t, const float*, const EncBlockParams*, int, float, int, float*, const EncTailX3&);
+#else
+extern template hipError_t launch_enc_blocks_x3<384>(hipStream_t, float*, const void*, size_t, const float*, const EncBlockParams*, int, float, int, float*, const EncTailX3&);
+#endif
 
 }  // namespace x3
 }  // namespace pq

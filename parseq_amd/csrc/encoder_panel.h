@@ -29,7 +29,7 @@
 // (true for the first three stages of every column tile but the first).  The first version used A without the store
 // term; that is also correct but makes every wave sit out its own store latency once per column tile, and because all
 // 512 workgroups hit their epilogues together the stores arrived in 17 MB bursts: 88 us of a 194 us kernel
-// (tools/panel_bench.py ablations, profiles/r01_panel_ablation.log).
+// (ablations recorded in profiles/r01_panel_ablation.log; the harness that produced them was removed with the ablation variants, commit c0ffb4f).
 #pragma once
 #include <type_traits>
 

@@ -56,7 +56,7 @@ __device__ __forceinline__ int rs_clip8(int v) {
 }
 
 // out: uint8 [B][3][out_h][out_w].  ksh / ksv: LDS row pitch (max taps over the batch) of the horizontal / vertical table.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void resize_bicubic_kernel(const ImageDesc* __restrict__ images, int out_h, int out_w, int ksh, int ksv,
                            unsigned char* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rs[];

@@ -9,7 +9,7 @@ namespace pq {
 // second fp32 copy (the encoder's final norm is both the API's `memory` output and the decoder K/V GEMM operand).
 // torch.nn.LayerNorm semantics: biased variance, y = (x - mean) / sqrt(var + eps) * w + b  (ViT eps 1e-6, decoder 1e-5).
 // out[r][c] = a[r][c] + v[c]   (pos_embed + patch-embed bias: the table the one-launch encoder's head starts its accumulators from)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void add_rowvec_kernel(const float* __restrict__ a, const float* __restrict__ v, float* __restrict__ out, int rows, int cols) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < (size_t)rows * cols) out[i] = a[i] + v[i % cols];
@@ -170,7 +170,7 @@ void content_ln_kernel(const float* __restrict__ emb, const float* __restrict__ 
 // Greedy pick after AR step `step` (model.py:142-145): tok[b][step + 1] = argmax_c logits[b][step][c] (first max on
 // ties, as torch.argmax), and the batch-level early-exit test kept on the device: the first step at which every row
 // holds an EOS sets *ar_len = step + 1 (the number of logit positions the reference would have produced).
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void ar_argmax_kernel(const float* __restrict__ logits, int L, int C, int* __restrict__ tok, int ldt, int step,
                       int B, int eos_id, unsigned char* __restrict__ eos_seen, int* __restrict__ eos_rows,
                       int* __restrict__ ar_len, int record) {
@@ -203,7 +203,7 @@ void ar_argmax_kernel(const float* __restrict__ logits, int L, int C, int* __res
 // Caller-supplied context tokens (parseq_decode_logits / parseq_decode_hidden) index the decoder tables: ids outside
 // [0, ntok) are clamped into range instead of reading out of bounds (the reference raises on the host or trips a device
 // assert; this library cannot raise without a synchronisation, so it degrades to a valid id).
-__global__ void clamp_tokens_kernel(int* __restrict__ tok, int ldt, int B, int Lk, int ntok) {
+static __global__ void clamp_tokens_kernel(int* __restrict__ tok, int ldt, int B, int Lk, int ntok) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * Lk) return;
     int* p = tok + (size_t)(i / Lk) * ldt + (i % Lk);
@@ -213,7 +213,7 @@ __global__ void clamp_tokens_kernel(int* __restrict__ tok, int ldt, int B, int L
 
 // Refinement context (model.py:161-163): tok[b] = [bos, argmax(logits[b, :L-1])], and the key-padding mask
 // kpm[b][j] = (an EOS occurs at a position <= j).  One wave per image; lane p handles logits position p (L <= 64).
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void refine_prep_kernel(const float* __restrict__ logits, int L, int C, int* __restrict__ tok, int ldt,
                         unsigned char* __restrict__ kpm, int ldk, int B, int bos_id, int eos_id, int from_logits) {
     const int lane = threadIdx.x & 63;
@@ -239,7 +239,7 @@ void refine_prep_kernel(const float* __restrict__ logits, int L, int C, int* __r
 }
 
 // counters: ncounters ints, pairs (rows that hold an EOS, step count the reference would have returned) per AR chain
-__global__ void ar_init_kernel(int* __restrict__ tok, int ldt, int B, int bos_id, int pad_id, unsigned char* __restrict__ eos_seen,
+static __global__ void ar_init_kernel(int* __restrict__ tok, int ldt, int B, int bos_id, int pad_id, unsigned char* __restrict__ eos_seen,
                                int* __restrict__ counters, int ncounters, int num_steps) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B * ldt) tok[i] = (i % ldt == 0) ? bos_id : pad_id;
@@ -254,7 +254,7 @@ __global__ void ar_init_kernel(int* __restrict__ tok, int ldt, int B, int bos_id
 //   probs[b][l] = max_c softmax(logits[b][l])[c] = 1 / sum_c exp(logit_c - max)
 //   lengths[b]  = index of the first EOS, or L            (number of characters)
 //   conf[b]     = prod_{l < min(lengths[b] + 1, L)} probs[b][l]   (base.py:137 `prob.prod()`)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void postprocess_kernel(const float* __restrict__ logits, int B, int L, int C, int eos_id, int* __restrict__ ids,
                         int* __restrict__ lengths, float* __restrict__ probs, float* __restrict__ conf) {
     const int lane = threadIdx.x & 63;
@@ -300,7 +300,7 @@ void postprocess_kernel(const float* __restrict__ logits, int B, int L, int C, i
 //   F.cross_entropy(logits.flatten(end_dim=1), targets.flatten(), ignore_index=pad_id)  — mean over the non-ignored rows.
 // Pass 1: one wave per row, row_loss[r] = logsumexp(logits[r]) - logits[r][target[r]] (0 for ignored rows).
 // Pass 2: one workgroup sums the rows in a fixed order (deterministic) and writes the mean and the count.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void ce_rows_kernel(const float* __restrict__ logits, const int* __restrict__ targets, int rows, int C, int ignore_index,
                     float* __restrict__ row_loss) {
     const int lane = threadIdx.x & 63;
@@ -318,7 +318,7 @@ void ce_rows_kernel(const float* __restrict__ logits, const int* __restrict__ ta
     if (lane == 0) row_loss[r] = (mx + logf(sum)) - row[tgt];
 }
 
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void ce_reduce_kernel(const float* __restrict__ row_loss, const int* __restrict__ targets, int rows, int ignore_index,
                       float* __restrict__ loss_out, int* __restrict__ numel_out) {
     __shared__ float ssum[256];

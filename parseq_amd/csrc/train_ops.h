@@ -49,7 +49,7 @@ __device__ __forceinline__ float gelu_grad(float v);
 
 constexpr int SG_BM = 64, SG_BN = 64, SG_BK = 16;
 
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void sgemm_kernel(const SgemmArgs a) {
     __shared__ float As[SG_BK][SG_BM + 4];
     __shared__ float Bs[SG_BK][SG_BN + 4];
@@ -129,7 +129,7 @@ __device__ __forceinline__ void mg_load_tile(const float* __restrict__ base, lon
     }
 }
 
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void mfma_sgemm_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float As[MG_BK][MG_LD];
     __shared__ __attribute__((aligned(16))) float Bs[MG_BK][MG_LD];
@@ -794,7 +794,7 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
 }
 
 // bf16 shadows of a Linear weight W [N, K] (fp32 master): W16 [N, K] and its transpose Wt16 [K, N], once per step.  N, K multiples of 32.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void weight_shadow_kernel(const float* __restrict__ W, int N, int K, bf16_t* __restrict__ W16, bf16_t* __restrict__ Wt16) {
     __shared__ float t[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -811,20 +811,20 @@ void weight_shadow_kernel(const float* __restrict__ W, int N, int K, bf16_t* __r
 }
 
 // dst[Rd, Cd] = src[Rs, Cs] in its top-left corner, zeros elsewhere (Rd >= Rs, Cd >= Cs)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void pad_copy_kernel(const float* __restrict__ src, int Rs, int Cs, float* __restrict__ dst, int Rd, int Cd) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)Rd * Cd) return;
     const int r = (int)(i / Cd), c = (int)(i % Cd);
     dst[i] = (r < Rs && c < Cs) ? src[(size_t)r * Cs + c] : 0.f;
 }
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void add_into_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] += src[i];
 }
 
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, int splits) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)a.M * a.N;
     if (idx >= total) {                       // the threads past the product fold the row sums of A (partials behind the product's, [splits][M])
@@ -856,7 +856,7 @@ void splitk_reduce_kernel(const SgemmArgs a, const float* __restrict__ partial, 
 // Many rows: two deterministic stages (row chunks -> partials, then this kernel again over the partials).
 // 16 row groups x 64 columns per workgroup, rows added in a fixed order.  blockIdx.y = row chunk of `rows_per` rows; with more
 // than one chunk the kernel writes out[chunk][n] (a partial, never accumulated into).
-__global__ __launch_bounds__(1024)
+static __global__ __launch_bounds__(1024)
 void colsum_kernel(const float* __restrict__ A, long lda, int M, int N, float* __restrict__ out, int accumulate, int rows_per,
                    float* __restrict__ out2 = nullptr, int split = 0) {      // out2 (single-chunk form only): columns >= split go to out2[n - split]
     __shared__ float part[16][64];
@@ -927,7 +927,7 @@ void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 // chunks with colsum_kernel.  (Round 3: the first form wrote dy * xhat as a [rows, E] matrix and ran two column-sum passes over it and
 // over dy — 225 MB of extra traffic and two more launches per LayerNorm at 49 152 rows.)
 constexpr int LNB_ROWS = 4;       // one row per wave: 64 and 32 rows per workgroup (a serial row loop per wave, even with the next row prefetched) ran the kernel at 68-75 us where one row per wave runs it at HBM speed
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy, const float* __restrict__ add,
                    float* __restrict__ dx_out, float* __restrict__ partial, int rows, int E, float eps, bf16_t* __restrict__ dx16) {
     __shared__ float red[4][2][768];
@@ -1009,7 +1009,7 @@ void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w, con
 }
 
 // exact-erf GELU and its derivative (F.gelu default; modules.py:43,77)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void gelu_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, size_t n) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;      // four elements per thread (16-byte accesses); the tail one by one
     if (i + 4 <= n) {
@@ -1024,7 +1024,7 @@ __device__ __forceinline__ float gelu_grad(float v) {
     const float pdf = __expf(-0.5f * v * v) * 0.39894228040143267794f;
     return fmaf(v, pdf, cdf);
 }
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ dact, float* __restrict__ dpre, size_t n) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i + 4 <= n) {
@@ -1038,21 +1038,21 @@ void gelu_bwd_kernel(const float* __restrict__ pre, const float* __restrict__ da
 // dst[i] = src[i] over a table of pieces, one workgroup per piece (parseq_model_get_params: the master weights back into the caller's tensors)
 struct CopyPiece { const float* src; float* dst; int n; };
 constexpr int COPY_PIECE_ELEMS = 8192;
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void copy_pieces_kernel(const CopyPiece* __restrict__ pieces) {
     const CopyPiece c = pieces[blockIdx.x];
     for (int i = threadIdx.x; i < c.n; i += 256) c.dst[i] = c.src[i];
 }
 
 // y = a + b (elementwise)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = a[i] + b[i];
 }
 
 // Content stream of the teacher-forced decode (model.py:95-98): row (b, j) = sqrt(E) * emb[tok[b][j]] + (j ? pos_queries[j-1] : 0)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void train_content_kernel(const float* __restrict__ emb, const float* __restrict__ posq, const int* __restrict__ tok, int ldt, int L, int E,
                           float scale, float* __restrict__ out) {
     const int row = blockIdx.x, b = row / L, j = row % L;
@@ -1067,7 +1067,7 @@ void train_content_kernel(const float* __restrict__ emb, const float* __restrict
 // Round 3: the rows are cut into gridDim.y chunks of rows_per (a multiple of 256) rows, workgroup (v, c) writes the unscaled sum of ITS rows
 // to partial[v][c][E] and embed_bwd_fold_kernel adds the chunks up in ascending order — <pad> is ~45 % of a batch, and ONE workgroup
 // walking its 4 500 rows was 0.58 ms of the step.  partial == nullptr (gridDim.y == 1): the single-stage form, straight into demb.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void embed_bwd_kernel(const float* __restrict__ dcontent, const int* __restrict__ tok, int ldt, int B, int L, int E, float scale,
                       float* __restrict__ demb, float* __restrict__ partial, int rows_per) {
     __shared__ unsigned long long hits[4];
@@ -1123,7 +1123,7 @@ void embed_bwd_kernel(const float* __restrict__ dcontent, const int* __restrict_
     }
 }
 // d emb[v] += scale * (the chunks of embed_bwd_kernel in ascending order); one workgroup per token id
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void embed_bwd_fold_kernel(const float* __restrict__ partial, int chunks, int E, float scale, float* __restrict__ demb) {
     const int v = blockIdx.x;
     for (int c = threadIdx.x; c < E; c += 256) {
@@ -1134,7 +1134,7 @@ void embed_bwd_fold_kernel(const float* __restrict__ partial, int chunks, int E,
 }
 
 // d(total loss) / d logits, in place: kept rows (softmax - onehot) * inv_total, ignored rows 0.  One wave per row.
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void ce_bwd_kernel(float* __restrict__ logits, const int* __restrict__ targets, int rows, int C, int ignore_index, float inv_total) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1156,7 +1156,7 @@ void ce_bwd_kernel(float* __restrict__ logits, const int* __restrict__ targets, 
 }
 
 // loss = sum_k n_k * loss_k / sum_k n_k   (system.py:189-196)
-__global__ void loss_combine_kernel(const float* __restrict__ losses, const int* __restrict__ counts, int K, float* __restrict__ out) {
+static __global__ void loss_combine_kernel(const float* __restrict__ losses, const int* __restrict__ counts, int K, float* __restrict__ out) {
     if (threadIdx.x || blockIdx.x) return;
     float num = 0.f; int den = 0;
     for (int k = 0; k < K; ++k) { num += losses[k] * (float)counts[k]; den += counts[k]; }
@@ -1193,7 +1193,7 @@ __host__ __device__ __forceinline__ float drop_factor(const DropSpec& d, unsigne
 // pass p draws site `site + 8 p` on the element index WITHIN the pass — what a launch of its own per pass would draw — so that a step may
 // run its K passes as one batch of K * B images without changing a single mask bit.  x_shared: x holds one pass ([n_pass]) that every pass reads.
 // grid: (ceil(n_pass / 256), passes)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void dropout_passes_kernel(const float* x, int x_shared, const float* R, float* y, size_t n_pass, DropSpec d, unsigned site) {
     const size_t li = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (li >= n_pass) return;
@@ -1201,7 +1201,7 @@ void dropout_passes_kernel(const float* x, int x_shared, const float* R, float* 
     const float v = x[x_shared ? li : i] * drop_factor(d, site + 8u * blockIdx.y, li);
     y[i] = R ? R[i] + v : v;
 }
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void dropout_rows_passes_kernel(const float* __restrict__ table, int L, int E, float* __restrict__ y, size_t n_pass, DropSpec d, unsigned site) {
     const size_t li = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (li >= n_pass) return;
@@ -1210,7 +1210,7 @@ void dropout_rows_passes_kernel(const float* __restrict__ table, int L, int E, f
 }
 // dpre = drop(dact) * gelu'(pre) over [passes][n_pass] elements (grid (ceil(n_pass / 1024), passes), n_pass % 4 == 0): the dropout inside the MLP
 // (site `site + 8 p`, element index within the pass — the mask dropout_passes_kernel drew in the forward) and the GELU backward in one pass
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void gelu_bwd_drop_passes_kernel(const float* __restrict__ pre, const float* dact, float* dpre, size_t n_pass, DropSpec d, unsigned site) {
     const size_t li = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (li >= n_pass) return;
@@ -1221,7 +1221,7 @@ void gelu_bwd_drop_passes_kernel(const float* __restrict__ pre, const float* dac
                                                        g.z * drop_factor(d, st, li + 2) * gelu_grad(v.z), g.w * drop_factor(d, st, li + 3) * gelu_grad(v.w));
 }
 // y[li] (+)= sum over the passes, in ascending order, of drop(x[p][li]) (d.thresh == 0: a plain sum of the passes)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void dropout_sum_passes_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n_pass, int passes, DropSpec d, unsigned site, int accumulate) {
     const size_t li = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (li >= n_pass) return;
@@ -1230,7 +1230,7 @@ void dropout_sum_passes_kernel(const float* __restrict__ x, float* __restrict__ 
     y[li] = t;
 }
 // y[i] (+)= sum over the passes of x[p][i], four elements per thread (n_pass a multiple of 4, 16-byte aligned)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void sum_passes_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n_pass, int passes, int accumulate) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n_pass) return;
@@ -2076,7 +2076,7 @@ void train_attn_dec_bf16_kernel(const TrainAttnArgs a) {
 }
 
 // im2col of the patch embedding: row (b, gy, gx), column (c, ky, kx) = img[b][c][gy * ph + ky][gx * pw + kx]   (fp32)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw, float* __restrict__ out) {
     const int gw = W / pw, gh = H / ph, pk = 3 * ph * pw;
     const int row = blockIdx.x, b = row / (gh * gw), gy = (row / gw) % gh, gx = row % gw;
@@ -2093,7 +2093,7 @@ void patches_kernel(const float* __restrict__ img, int H, int W, int ph, int pw,
 constexpr int SUMSQ_BLOCKS = 1024;
 
 // partial[block] = sum of g[i]^2 over the block's grid-stride slice (fixed order: deterministic)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
     __shared__ float red[256];
     float s = 0.f;
@@ -2106,7 +2106,7 @@ void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restri
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void sumsq_final_kernel(const float* __restrict__ partial, float* __restrict__ norm_out) {
     __shared__ float red[256];
     float s = 0.f;
@@ -2123,7 +2123,7 @@ void sumsq_final_kernel(const float* __restrict__ partial, float* __restrict__ n
 // torch.optim.AdamW (single-tensor path), with the clip coefficient min(1, max_norm / (norm + 1e-6)) applied to the gradient
 // on the fly when `norm` is given:   p *= 1 - lr wd;  m = lerp(m, g, 1 - b1);  v = b2 v + (1 - b2) g^2;
 //                                    p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
-__global__ __launch_bounds__(256)
+static __global__ __launch_bounds__(256)
 void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt, const float* __restrict__ norm, float max_norm) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

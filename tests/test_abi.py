@@ -61,40 +61,58 @@ def test_missing_library_raises(monkeypatch, tmp_path):
         _native.lib()
 
 
+def _tool(*names):
+    """First of `names` found on PATH or under the ROCm LLVM bin directory, else None."""
+    import shutil
+    for n in names:
+        for cand in (shutil.which(n), os.path.join('/opt/rocm/lib/llvm/bin', n), os.path.join('/opt/rocm/llvm/bin', n)):
+            if cand and os.path.exists(cand):
+                return cand
+    return None
+
+
+def _gfx950_code_objects(lib_path, tmp_path):
+    """The library is several translation units, each with its own offload bundle: every gfx950 code object, written to files."""
+    import struct
+    blob = open(lib_path, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    paths, at = [], blob.find(magic)
+    while at >= 0:
+        n = struct.unpack_from('<Q', blob, at + len(magic))[0]
+        off = at + len(magic) + 8
+        for _ in range(n):
+            o, size, tlen = struct.unpack_from('<QQQ', blob, off)
+            triple = blob[off + 24:off + 24 + tlen].decode()
+            off += 24 + tlen
+            if 'gfx950' in triple and size:
+                path = tmp_path / f'lib{len(paths)}.co'
+                path.write_bytes(blob[at + o:at + o + size])
+                paths.append(path)
+        at = blob.find(magic, at + len(magic))
+    assert paths, 'no gfx950 code object in the library'
+    return paths
+
+
 def test_split_layernorm_loader_is_compiled_without_packed_f32(built_lib, tmp_path):
     """gemm.h ln_apply4: the bf16x3 GEMMs with the LayerNorm-fused A-loader produced wrong values (two workgroups per CU) while the
     loader's (x - mean) * rstd * gamma + beta was compiled to v_pk_mul_f32 / v_pk_fma_f32; empty-asm pins keep the SLP vectoriser
     from forming them.  A compiler bump could undo that silently, so the shipped code object is checked: the
     gemm_kernel<float, ..., ALayerNorm<float, E>, EpiStore / EpiGelu, SPLIT> instances (decoder q-projection / linear1 / head forms,
     whose epilogues have no packed arithmetic of their own) must not contain a packed-f32 multiply / fma / add."""
-    import struct
     import subprocess
-    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-    if not os.path.exists(objdump):
-        pytest.skip('llvm-objdump not found')
-    blob = open(built_lib, 'rb').read()
-    magic = b'__CLANG_OFFLOAD_BUNDLE__'
-    at = blob.find(magic)
-    assert at >= 0
-    n = struct.unpack_from('<Q', blob, at + len(magic))[0]
-    off, co = at + len(magic) + 8, None
-    for _ in range(n):
-        o, size, tlen = struct.unpack_from('<QQQ', blob, off)
-        triple = blob[off + 24:off + 24 + tlen].decode()
-        off += 24 + tlen
-        if 'gfx950' in triple:
-            co = blob[at + o:at + o + size]
-    assert co is not None, 'no gfx950 code object in the library'
-    path = tmp_path / 'lib.co'
-    path.write_bytes(co)
-    syms = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--symbols', '--wide', str(path)], capture_output=True, text=True, check=True).stdout
-    mangled = sorted({ln.split()[-1] for ln in syms.splitlines() if ' FUNC ' in ln and ln.split()[-1].startswith('_Z')})
-    names = subprocess.run(['/usr/bin/c++filt'], input='\n'.join(mangled), capture_output=True, text=True, check=True).stdout.splitlines()
-    want = [m for m, d in zip(mangled, names)
-            if 'gemm_kernel<float' in d and 'ALayerNorm<float' in d and ('EpiStore<float>' in d or 'EpiGelu<float>' in d)
-            and re.search(r'>, true, (false|true)>\(', d)]
+    objdump, readelf, cxxfilt = _tool('llvm-objdump'), _tool('llvm-readelf'), _tool('c++filt', 'llvm-cxxfilt')
+    if not (objdump and readelf and cxxfilt):
+        pytest.skip('llvm-objdump / llvm-readelf / c++filt not found')
+    want = []
+    for path in _gfx950_code_objects(built_lib, tmp_path):
+        syms = subprocess.run([readelf, '--symbols', '--wide', str(path)], capture_output=True, text=True, check=True).stdout
+        mangled = sorted({ln.split()[-1] for ln in syms.splitlines() if ' FUNC ' in ln and ln.split()[-1].startswith('_Z')})
+        names = subprocess.run([cxxfilt], input='\n'.join(mangled), capture_output=True, text=True, check=True).stdout.splitlines()
+        want += [(path, m) for m, d in zip(mangled, names)
+                 if 'gemm_kernel<float' in d and 'ALayerNorm<float' in d and ('EpiStore<float>' in d or 'EpiGelu<float>' in d)
+                 and re.search(r'>, true, (false|true)>\(', d)]
     assert len(want) >= 6, f'expected the SPLIT ALayerNorm GEMM instances in the code object, found {len(want)}'
-    for sym in want:
+    for path, sym in want:
         asm = subprocess.run([objdump, '-d', '--no-show-raw-insn', f'--disassemble-symbols={sym}', str(path)],
                              capture_output=True, text=True, check=True).stdout
         assert 'v_mfma' in asm, f'{sym}: disassembly is empty?'
@@ -107,35 +125,20 @@ def test_occupancy_budgets_of_the_training_kernels(built_lib, tmp_path):
     without scratch (buffer loads with one VGPR offset per operand; `amdgpu_waves_per_eu(4, 4)` alone spilled 60 registers inside the loop),
     and the 32-key instantiation of the decoder attention kernel holds its many small workgroups only while it stays well under the 128-key
     one.  The numbers live in the shipped code object's metadata, so a compiler bump that silently undoes them fails here, on the CPU."""
-    import struct
     import subprocess
-    readelf = '/opt/rocm/lib/llvm/bin/llvm-readelf'
-    if not os.path.exists(readelf):
-        pytest.skip('llvm-readelf not found')
-    blob = open(built_lib, 'rb').read()
-    magic = b'__CLANG_OFFLOAD_BUNDLE__'
-    at = blob.find(magic)
-    assert at >= 0
-    n = struct.unpack_from('<Q', blob, at + len(magic))[0]
-    off, co = at + len(magic) + 8, None
-    for _ in range(n):
-        o, size, tlen = struct.unpack_from('<QQQ', blob, off)
-        triple = blob[off + 24:off + 24 + tlen].decode()
-        off += 24 + tlen
-        if 'gfx950' in triple:
-            co = blob[at + o:at + o + size]
-    assert co is not None, 'no gfx950 code object in the library'
-    path = tmp_path / 'lib.co'
-    path.write_bytes(co)
-    notes = subprocess.run([readelf, '--notes', str(path)], capture_output=True, text=True, check=True).stdout
+    readelf, cxxfilt = _tool('llvm-readelf'), _tool('c++filt', 'llvm-cxxfilt')
+    if not (readelf and cxxfilt):
+        pytest.skip('llvm-readelf / c++filt not found')
     meta = {}
-    for blk in re.split(r'\n\s+- ', notes):
-        name = re.search(r'\.name:\s+(\S+)', blk)
-        if not name or '.vgpr_count' not in blk:
-            continue
-        get = lambda k: int((re.search(r'\.%s:\s+(\d+)' % k, blk) or [None, -1])[1])      # noqa: E731   (-1: the note does not carry the key)
-        meta[name.group(1)] = (get('vgpr_count'), get('vgpr_spill_count'), get('private_segment_fixed_size'), get('group_segment_fixed_size'))
-    names = subprocess.run(['/usr/bin/c++filt'], input='\n'.join(meta), capture_output=True, text=True, check=True).stdout.splitlines()
+    for path in _gfx950_code_objects(built_lib, tmp_path):
+        notes = subprocess.run([readelf, '--notes', str(path)], capture_output=True, text=True, check=True).stdout
+        for blk in re.split(r'\n\s+- ', notes):
+            name = re.search(r'\.name:\s+(\S+)', blk)
+            if not name or '.vgpr_count' not in blk:
+                continue
+            get = lambda k: int((re.search(r'\.%s:\s+(\d+)' % k, blk) or [None, -1])[1])      # noqa: E731   (-1: the note does not carry the key)
+            meta[name.group(1)] = (get('vgpr_count'), get('vgpr_spill_count'), get('private_segment_fixed_size'), get('group_segment_fixed_size'))
+    names = subprocess.run([cxxfilt], input='\n'.join(meta), capture_output=True, text=True, check=True).stdout.splitlines()
     by_name = {re.sub(r'\(.*$', '', re.sub(r'^void (pq::)?', '', d)): v for d, v in zip(names, meta.values())}
 
     def one(fragment):

@@ -635,6 +635,41 @@ def test_batch_64_step_uses_the_matrix_core_gemms():
 
 
 @pytest.mark.gpu
+def test_large_batch_step_is_the_weighted_sum_of_its_halves():
+    """704 crops with a 25-character label: 6 x 704 x 26 = 109 824 decoder rows and 90 112 encoder rows per LayerNorm backward — more than
+    the fixed 16 M-float scratch held as partial rows (the step used to abort there); the layouts now size the scratch from the
+    row count.  Property that needs no oracle at this size: with the permutations given and dropout off, the loss is a mean over the
+    non-<pad> targets, so the whole batch's gradient is the target-count-weighted sum of its two halves' gradients."""
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import loss_and_grads, loss_denominator
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    gen = torch.Generator().manual_seed(5)
+    B = 704
+    images = synth_images(B, cfg, seed=31).to(DEV)
+    lengths = torch.randint(1, 26, (B,), generator=gen).tolist()
+    lengths[3] = lengths[B // 2 + 3] = 25                      # both halves see L = 26
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+    m.rng = np.random.default_rng(8)
+    torch.manual_seed(9)
+    whole = loss_and_grads(m, images, labels, dropout=0.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(whole.loss)
+    halves = [loss_and_grads(m, images[i:i + B // 2], labels[i:i + B // 2], perms=whole.perms, dropout=0.0) for i in (0, B // 2)]
+    n = [loss_denominator(labels[i:i + B // 2], whole.perms.shape[0]) for i in (0, B // 2)]
+    want_loss = (n[0] * float(halves[0].loss) + n[1] * float(halves[1].loss)) / (n[0] + n[1])
+    assert abs(float(whole.loss) - want_loss) <= 2e-5 * want_loss
+    want = (n[0] * halves[0].flat.double() + n[1] * halves[1].flat.double()) / (n[0] + n[1])
+    got = whole.flat.double()
+    rel = float((got - want).norm() / want.norm())
+    assert rel <= 2e-3, rel                                     # bf16-operand mode: only the dW contractions' summation order differs
+    for key in ('encoder.norm.weight', 'encoder.blocks.0.norm1.bias', 'decoder.norm.weight', 'decoder.layers.0.norm_c.bias'):
+        g, w = whole.grads[key].double(), (n[0] * halves[0].grads[key].double() + n[1] * halves[1].grads[key].double()) / (n[0] + n[1])
+        assert float((g - w).abs().max()) <= 2e-3 * float(w.abs().max()) + 1e-9, key
+
+
+@pytest.mark.gpu
 def test_bf16_operand_step_within_the_rounding_budget():
     """system.train_precision = 'bf16' (parseq_model_set_train_precision: both operands of every aligned Linear product rounded to
     bfloat16, fp32 accumulate, fp32 everything else — train_ops.h mfma_bgemm_kernel) on the batch-64 step whose Linears all take the

@@ -126,7 +126,7 @@ def test_vitstr_plan_refuses_parseq_entry_points(gold):
 @pytest.mark.gpu
 def test_vitstr_batch_512_tail_rows_take_the_generic_kernels(gold):
     """512 x 129 rows = 516 row tiles of 128: the 512 leading tiles go to the fused kernels (whole rounds on 256 CUs), the last
-    512 rows to the per-op kernels (parseq_hip.hip: main_rows).  Images fully inside the leading tiles reproduce the small-batch
+    512 rows to the per-op kernels (lib_encode.hip: main_rows).  Images fully inside the leading tiles reproduce the small-batch
     result bit for bit; the last four (different fp32 summation order in two GEMMs per layer) within the bf16 bar."""
     g, _ = gold
     m = _make('bf16')
