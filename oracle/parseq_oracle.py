@@ -73,18 +73,29 @@ class OracleConfig:
 # rounding helpers
 # ----------------------------------------------------------------------------------------------------------
 
-def _r(x: Tensor, rounding: Optional[str]) -> Tensor:
-    """Round to the storage type of the throughput mode and come back to fp32 (identity in exact mode)."""
+def _r(x: Tensor, rounding, site: str = '') -> Tensor:
+    """Round to a storage type and come back to fp32 (identity in exact mode).  `rounding` is None, a type name applied at every
+    rounding point ('bf16': the throughput mode), or a dict {site: type name} that rounds only the named sites (the cheaper-exact-mode
+    study of tools/cheap_exact_study.py): 'enc.act' / 'enc.w' / 'dec.act' / 'dec.w' (the two operands of the Linear products),
+    'img', 'enc.qkv', 'enc.p' (encoder attention operands), 'dec.kv' (the decoder's stored K / V)."""
+    if isinstance(rounding, dict):
+        rounding = rounding.get(site)
     if rounding is None:
         return x
     if rounding == 'bf16':
         return x.to(torch.bfloat16).to(torch.float32)
+    if rounding == 'fp16':
+        return x.to(torch.float16).to(torch.float32)
+    if rounding == 'bf16+8':      # bf16 hi + an 8-bit residual on the hi's exponent: 16 significant bits
+        hi = x.to(torch.bfloat16).to(torch.float32)
+        ulp = torch.exp2(torch.floor(torch.log2(hi.abs().clamp_min(1e-38))) - 7.0)      # bf16 ulp of hi
+        return hi + torch.round((x - hi) / ulp * 256.0) * ulp / 256.0
     raise ValueError(rounding)
 
 
-def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], rounding: Optional[str]) -> Tensor:
+def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], rounding, site: str = 'dec') -> Tensor:
     """y = x W^T + b with both GEMM operands rounded (fp32 accumulate), bias added in fp32."""
-    return F.linear(_r(x, rounding), _r(w, rounding), b)
+    return F.linear(_r(x, rounding, site + '.act'), _r(w, rounding, site + '.w'), b)
 
 
 def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
@@ -102,7 +113,7 @@ def vit_features(sd: dict, prefix: str, cfg: OracleConfig, images: Tensor, round
     hd = E // H
     B = images.shape[0]
     # PatchEmbed: Conv2d(k = stride = patch) then flatten(2).transpose(1, 2); token t = gy * grid_w + gx
-    x = F.conv2d(_r(images, rounding), _r(sd[prefix + 'patch_embed.proj.weight'], rounding),
+    x = F.conv2d(_r(images, rounding, 'img'), _r(sd[prefix + 'patch_embed.proj.weight'], rounding, 'enc.w'),
                  sd[prefix + 'patch_embed.proj.bias'], stride=tuple(cfg.patch_size))
     x = x.flatten(2).transpose(1, 2)
     if prefix + 'cls_token' in sd:
@@ -112,24 +123,24 @@ def vit_features(sd: dict, prefix: str, cfg: OracleConfig, images: Tensor, round
     for i in range(cfg.enc_depth):
         p = f'{prefix}blocks.{i}.'
         h = _ln(x, sd[p + 'norm1.weight'], sd[p + 'norm1.bias'], cfg.enc_ln_eps)
-        qkv = _linear(h, sd[p + 'attn.qkv.weight'], sd[p + 'attn.qkv.bias'], rounding)
+        qkv = _linear(h, sd[p + 'attn.qkv.weight'], sd[p + 'attn.qkv.bias'], rounding, 'enc')
         qkv = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
         q, k, v = qkv.unbind(0)
-        if rounding is None:
+        if rounding is None or (isinstance(rounding, dict) and 'enc.qkv' not in rounding and 'enc.p' not in rounding):
             a = F.scaled_dot_product_attention(q, k, v)  # default scale = hd ** -0.5, no mask
         else:
             # HIP bf16 path: q (pre-scaled by the exact power of two 0.125... generally hd**-0.5), k, v stored
             # bf16; scores/softmax fp32; un-normalised p rounded to bf16 for P.V; row sum kept in fp32.
-            q, k, v = _r(q, rounding), _r(k, rounding), _r(v, rounding)
+            q, k, v = _r(q, rounding, 'enc.qkv'), _r(k, rounding, 'enc.qkv'), _r(v, rounding, 'enc.qkv')
             s = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
             m = s.amax(-1, keepdim=True)
             pexp = torch.exp(s - m)
-            a = (_r(pexp, rounding) @ v) / pexp.sum(-1, keepdim=True)
+            a = (_r(pexp, rounding, 'enc.p') @ v) / pexp.sum(-1, keepdim=True)
         a = a.transpose(1, 2).reshape(B, N, E)
-        x = x + _linear(a, sd[p + 'attn.proj.weight'], sd[p + 'attn.proj.bias'], rounding)
+        x = x + _linear(a, sd[p + 'attn.proj.weight'], sd[p + 'attn.proj.bias'], rounding, 'enc')
         h = _ln(x, sd[p + 'norm2.weight'], sd[p + 'norm2.bias'], cfg.enc_ln_eps)
-        h = F.gelu(_linear(h, sd[p + 'mlp.fc1.weight'], sd[p + 'mlp.fc1.bias'], rounding))
-        x = x + _linear(h, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], rounding)
+        h = F.gelu(_linear(h, sd[p + 'mlp.fc1.weight'], sd[p + 'mlp.fc1.bias'], rounding, 'enc'))
+        x = x + _linear(h, sd[p + 'mlp.fc2.weight'], sd[p + 'mlp.fc2.bias'], rounding, 'enc')
     return _ln(x, sd[prefix + 'norm.weight'], sd[prefix + 'norm.bias'], cfg.enc_ln_eps)
 
 
@@ -160,7 +171,7 @@ def mha(sd: dict, prefix: str, num_heads: int, query: Tensor, key: Tensor,
     kv = _linear(key, w[E:], b[E:], rounding)
     k, v = kv[..., :E], kv[..., E:]
     if rounding is not None:
-        k, v = _r(k, rounding), _r(v, rounding)   # K/V are stored bf16 (memory K/V cache, content K/V table)
+        k, v = _r(k, rounding, 'dec.kv'), _r(v, rounding, 'dec.kv')   # K/V are stored bf16 (memory K/V cache, content K/V table)
     q = q.reshape(B, Lq, num_heads, hd).transpose(1, 2).reshape(B * num_heads, Lq, hd)
     k = k.reshape(B, Lk, num_heads, hd).transpose(1, 2).reshape(B * num_heads, Lk, hd)
     v = v.reshape(B, Lk, num_heads, hd).transpose(1, 2).reshape(B * num_heads, Lk, hd)

@@ -103,9 +103,17 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             x3::EncTailX3 et{p->enc_tail.norm_w, p->enc_tail.norm_b, p->enc_tail.wkv, p->enc_tail.bkv, nullptr, nullptr, p->enc_tail.heads};
             if (tail) { et.kmem = reinterpret_cast<float*>(p->kmem); et.vmem = reinterpret_cast<float*>(p->vmem); }
             {
+                // PARSEQ_X3_SPLIT=n (diagnostics): the blocks in n launches of depth / n, x through HBM between them (100 MB out + in at batch
+                // 512) — shorter persistent workgroups, for the A/B of how a second batch's decoder interleaves with this launch
+                static const int split = [] { const char* e = getenv("PARSEQ_X3_SPLIT"); const int v = e ? atoi(e) : 1; return v >= 1 ? v : 1; }();
                 ProfScope ps_(&p->prof, T_BLOCKS, s);
-                HIPCHK((x3::launch_enc_blocks_x3<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev, c.enc_depth,
-                                                      c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), et)));
+                const int per = (c.enc_depth + split - 1) / split;
+                for (int l0 = 0; l0 < c.enc_depth; l0 += per) {
+                    const int d = std::min(per, c.enc_depth - l0);
+                    const bool last = l0 + d >= c.enc_depth;
+                    HIPCHK((x3::launch_enc_blocks_x3<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev + l0, d,
+                                                          c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), last ? et : x3::EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0})));
+                }
             }
             if (tail) { p->last_batch = B; return 0; }
             blocks_done = true;

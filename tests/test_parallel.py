@@ -259,7 +259,7 @@ def test_bench_py_force_dist_runs_the_rccl_path_on_one_gpu():
     """The distributed path of bench.py on the one GPU a test box has: RCCL process group of one rank, the real all_gather_into_tensor
     inside the timed step, two batches in flight on separate streams next to the communicator's streams (GPU_MAX_HW_QUEUES=8, DESIGN.md
     section 6).  Short: 5 steps, no profile / CPU baseline / parity legs."""
-    rc, lines, out, err = _bench_line(['--force-dist', '--steps', '5', '--warmup', '2', '--repeats', '2', '--no-profile', '--no-cpu-baseline', '--no-parity'],
+    rc, lines, out, err = _bench_line(['--force-dist', '--steps', '5', '--warmup', '2', '--repeats', '2', '--no-profile', '--no-cpu-baseline', '--no-parity', '--no-train', '--no-natural-exit', '--no-throughput-mode'],
                                       {}, 900)
     assert rc == 0, err
     assert len(lines) == 1, out
