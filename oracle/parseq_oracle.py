@@ -77,7 +77,7 @@ def _r(x: Tensor, rounding, site: str = '') -> Tensor:
     """Round to a storage type and come back to fp32 (identity in exact mode).  `rounding` is None, a type name applied at every
     rounding point ('bf16': the throughput mode), or a dict {site: type name} that rounds only the named sites (the cheaper-exact-mode
     study of tools/cheap_exact_study.py): 'enc.act' / 'enc.w' / 'dec.act' / 'dec.w' (the two operands of the Linear products),
-    'img', 'enc.qkv', 'enc.p' (encoder attention operands), 'dec.kv' (the decoder's stored K / V)."""
+    'img', 'enc.qkv', 'enc.p' (encoder attention operands), 'dec.kv' (the decoder's stored K / V; 'dec.k' / 'dec.v' one of them)."""
     if isinstance(rounding, dict):
         rounding = rounding.get(site)
     if rounding is None:
@@ -171,7 +171,8 @@ def mha(sd: dict, prefix: str, num_heads: int, query: Tensor, key: Tensor,
     kv = _linear(key, w[E:], b[E:], rounding)
     k, v = kv[..., :E], kv[..., E:]
     if rounding is not None:
-        k, v = _r(k, rounding, 'dec.kv'), _r(v, rounding, 'dec.kv')   # K/V are stored bf16 (memory K/V cache, content K/V table)
+        k, v = _r(_r(k, rounding, 'dec.kv'), rounding if isinstance(rounding, dict) else None, 'dec.k'), \
+               _r(_r(v, rounding, 'dec.kv'), rounding if isinstance(rounding, dict) else None, 'dec.v')   # K/V are stored bf16 (memory K/V cache, content K/V table)
     q = q.reshape(B, Lq, num_heads, hd).transpose(1, 2).reshape(B * num_heads, Lq, hd)
     k = k.reshape(B, Lk, num_heads, hd).transpose(1, 2).reshape(B * num_heads, Lk, hd)
     v = v.reshape(B, Lk, num_heads, hd).transpose(1, 2).reshape(B * num_heads, Lk, hd)

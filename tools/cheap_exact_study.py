@@ -33,6 +33,9 @@ CANDIDATES = {
     'dec K/V fp16': {'dec.kv': 'fp16'},
     'dec K/V bf16 + 8-bit residual': {'dec.kv': 'bf16+8'},
     'dec K/V bf16': {'dec.kv': 'bf16'},
+    'dec K 24-bit, V bf16': {'dec.k': 'bf16+8', 'dec.v': 'bf16'},
+    'dec K 24-bit, V fp16': {'dec.k': 'bf16+8', 'dec.v': 'fp16'},
+    'dec K fp16, V 24-bit': {'dec.k': 'fp16', 'dec.v': 'bf16+8'},
     'dec W fp16 (2 products)': {'dec.w': 'fp16'},
     'enc W fp16 + attention fp16 + dec K/V fp16': {'enc.w': 'fp16', 'enc.qkv': 'fp16', 'enc.p': 'fp16', 'dec.kv': 'fp16'},
     'bf16 everywhere (the throughput mode)': 'bf16',
