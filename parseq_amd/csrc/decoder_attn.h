@@ -258,6 +258,107 @@ void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict_
     }
 }
 
+// ---- 24-bit K / V rows (bf16x3 mode, PARSeq-S geometry) -----------------------------------------------------------------------------
+// The cross-attention is the HBM stream of the memory's K and V (26 times per forward), and the 1e-3 logit tolerance needs 16
+// significant bits of them, not 24 (profiles/r04_cheap_exact_study.md: 1.6e-5 on the logits; fp16 rows cost 6e-4, bf16 rows 4e-3).
+// Storage: the f32 value rounded to 16 significant bits, bits 31..16 in a u16 plane [B][H][128][32] and bits 15..8 in a u8 plane of
+// the same shape `plane_elems` elements behind it — 3 bytes per element, rebuilt with ONE v_perm_b32 each.  Written by
+// encoder_blocks_x3.h kv_phase; plans whose K / V come from the generic GEMM (encode() + decode(), parseq_set_memory) keep f32 rows.
+__device__ __forceinline__ float f24_even(unsigned hw, unsigned lw, int i) {      // element i (0, 2, 4, 6 of a piece): hi in hw[15:0]
+    return __uint_as_float(__builtin_amdgcn_perm(hw, lw, 0x0504000cu | ((unsigned)(i & 3) << 8)));
+}
+__device__ __forceinline__ float f24_odd(unsigned hw, unsigned lw, int i) {       // element i (1, 3, 5, 7): hi in hw[31:16]
+    return __uint_as_float(__builtin_amdgcn_perm(hw, lw, 0x0706000cu | ((unsigned)(i & 3) << 8)));
+}
+// the 8 elements of a (16-byte u16, 8-byte u8) piece pair
+__device__ __forceinline__ void f24_unpack8(const u32x4& hi, const uint2& lo, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        const unsigned lw = i < 4 ? lo.x : lo.y;
+        v[i] = f24_even(hi[i >> 1], lw, i);
+        v[i + 1] = f24_odd(hi[i >> 1], lw, i + 1);
+    }
+}
+
+// dec_cross_attn_ar_kernel on 24-bit rows: lane (kl = lane / 4, dl = lane % 4) takes elements 8 dl .. 8 dl + 7 of key row 16 c + kl —
+// one 16-byte and one 8-byte load per piece, a KiB and half a KiB contiguous per wave load; all 32 loads of a head in flight first.
+template <int E>
+__global__ __launch_bounds__(E)
+void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const unsigned char* __restrict__ kmem, const unsigned char* __restrict__ vmem,
+                                size_t plane_elems, float scale, float* __restrict__ out) {
+    constexpr int H = E / DEC_HD, NK = 128, LPR = 4, KPL = 16, NL = 8;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = E / 64, b = blockIdx.x;
+    const int kl = lane / LPR, dl = lane % LPR;
+    auto over_keys_sum = [](float v) {
+        v = dpp_add<0x124>(v);     // row_ror:4
+        v = dpp_add<0x128>(v);     // row_ror:8
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+    auto over_keys_max = [](float v) {
+        v = dpp_max<0x124>(v);
+        v = dpp_max<0x128>(v);
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        return v;
+    };
+    for (int h = wid; h < H; h += nw) {
+        const size_t at = (((size_t)b * H + h) * NK + kl) * DEC_HD + dl * 8;
+        const unsigned char* kh = kmem + at * 2; const unsigned char* kq = kmem + plane_elems * 2 + at;
+        const unsigned char* vh = vmem + at * 2; const unsigned char* vq = vmem + plane_elems * 2 + at;
+        u32x4 khi[NL], vhi[NL];
+        uint2 klo[NL], vlo[NL];
+#pragma unroll
+        for (int c = 0; c < NL; ++c) khi[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kh + (size_t)c * KPL * DEC_HD * 2));
+#pragma unroll
+        for (int c = 0; c < NL; ++c) { const unsigned long long t = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(kq + (size_t)c * KPL * DEC_HD)); klo[c] = make_uint2((unsigned)t, (unsigned)(t >> 32)); }
+#pragma unroll
+        for (int c = 0; c < NL; ++c) vhi[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vh + (size_t)c * KPL * DEC_HD * 2));
+#pragma unroll
+        for (int c = 0; c < NL; ++c) { const unsigned long long t = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(vq + (size_t)c * KPL * DEC_HD)); vlo[c] = make_uint2((unsigned)t, (unsigned)(t >> 32)); }
+        float qv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = qc[(size_t)b * E + h * DEC_HD + dl * 8 + i] * scale;
+        float s[NL], mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+            float kv[8];
+            f24_unpack8(khi[c], klo[c], kv);
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d = fmaf(qv[i], kv[i], d);
+            d = dpp_add<0xB1>(d);                              // quad: the four lanes of one key row
+            d = dpp_add<0x4E>(d);
+            s[c] = d;
+            mx = fmaxf(mx, d);
+        }
+        mx = over_keys_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) { s[c] = expf(s[c] - mx); sum += s[c]; }
+        const float inv = 1.0f / over_keys_sum(sum);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < NL; ++c) {
+            const float pc = s[c] * inv;
+            float vv[8];
+            f24_unpack8(vhi[c], vlo[c], vv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(pc, vv[i], acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = over_keys_sum(acc[i]);
+        if (kl == 0) {
+            float* o = out + (size_t)b * E + h * DEC_HD + dl * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        }
+    }
+}
+
 // Multi-query cross-attention (refinement / NAR): one workgroup of 128 threads per (image, head), Lq <= 32 queries.
 // qc fp32 [B*Lq][E]; out T [B*Lq][E].
 template <typename T>
@@ -505,9 +606,11 @@ void dec_cross_attn_multi_mfma_kernel(const float* __restrict__ qc, const bf16_t
 // is a bf16 pair (hi, lo = value - hi) and every product three MFMAs (hi lo + lo hi + hi hi, fp32 accumulate) — K and V are split
 // as they are loaded, queries and probabilities exactly as in the bf16 kernel.  Two waves per workgroup (the V tile takes two
 // LDS planes per wave).  Replaces the VALU kernel dec_cross_attn_multi_kernel<float> for 128 memory tokens (250 -> ~60 us).
-static __global__ __launch_bounds__(128)
+// F24: K / V are the 24-bit rows described above (kmem / vmem point at the u16 planes, the u8 planes sit plane_elems elements behind).
+template <bool F24>
+__global__ __launch_bounds__(128)
 void dec_cross_attn_multi_mfma_x3_kernel(const float* __restrict__ qc, const float* __restrict__ kmem, const float* __restrict__ vmem,
-                                         int H, int Lq, float scale, float* __restrict__ out, int BH) {
+                                         int H, int Lq, float scale, float* __restrict__ out, int BH, size_t plane_elems) {
     constexpr int NK = 128, VP = DEC_HD + 2, WAVES = 2;
     __shared__ __attribute__((aligned(16))) bf16_t sv[WAVES][2][NK * VP];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
@@ -517,15 +620,42 @@ void dec_cross_attn_multi_mfma_x3_kernel(const float* __restrict__ qc, const flo
     const float* kg = kmem + (size_t)bh * NK * DEC_HD;
     const float* vg = vmem + (size_t)bh * NK * DEC_HD;
     // V: 16-byte piece p = 64 c + lane of the [key][32] tile -> key = p >> 3, d = 4 (p & 7); all loads issued first
+    // (24-bit rows: 8 elements per piece pair, p = 64 c + lane -> key = p >> 2, d = 8 (p & 3), c < 8)
     f32x4 vraw[16];
+    if constexpr (F24) {
+        const unsigned char* vh = reinterpret_cast<const unsigned char*>(vmem) + (size_t)bh * NK * DEC_HD * 2;
+        const unsigned char* vq = reinterpret_cast<const unsigned char*>(vmem) + plane_elems * 2 + (size_t)bh * NK * DEC_HD;
+        u32x4 hi[8]; uint2 lo[8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) vraw[c] = *reinterpret_cast<const f32x4*>(vg + (size_t)(64 * c + lane) * 4);
+        for (int c = 0; c < 8; ++c) hi[c] = *reinterpret_cast<const u32x4*>(vh + (size_t)(64 * c + lane) * 16);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) lo[c] = *reinterpret_cast<const uint2*>(vq + (size_t)(64 * c + lane) * 8);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v[8];
+            f24_unpack8(hi[c], lo[c], v);
+            vraw[2 * c] = f32x4{v[0], v[1], v[2], v[3]}; vraw[2 * c + 1] = f32x4{v[4], v[5], v[6], v[7]};
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) vraw[c] = *reinterpret_cast<const f32x4*>(vg + (size_t)(64 * c + lane) * 4);
+    }
     // K fragments: lane (key = 16 kt + r16, g) takes d = 8 g .. 8 g + 7
     Frag<bf16_t> khi[8], klo[8];
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(kg + (kt * 16 + r16) * DEC_HD + 8 * g);
-        const f32x4 x0 = src[0], x1 = src[1];
+        f32x4 x0, x1;
+        if constexpr (F24) {
+            const size_t at = (size_t)bh * NK * DEC_HD + (kt * 16 + r16) * DEC_HD + 8 * g;
+            const u32x4 hi = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(kmem) + at * 2);
+            const uint2 lo = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(kmem) + plane_elems * 2 + at);
+            float v[8];
+            f24_unpack8(hi, lo, v);
+            x0 = f32x4{v[0], v[1], v[2], v[3]}; x1 = f32x4{v[4], v[5], v[6], v[7]};
+        } else {
+            const f32x4* src = reinterpret_cast<const f32x4*>(kg + (kt * 16 + r16) * DEC_HD + 8 * g);
+            x0 = src[0]; x1 = src[1];
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16_t h0 = from_f32<bf16_t>(x0[i]), h1 = from_f32<bf16_t>(x1[i]);
@@ -556,7 +686,8 @@ void dec_cross_attn_multi_mfma_x3_kernel(const float* __restrict__ qc, const flo
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int key = 8 * c + (lane >> 3), d = 4 * (lane & 7);
+        // f32 rows: piece c of the lane; 24-bit rows: half (c & 1) of piece pair c >> 1
+        const int key = F24 ? 16 * (c >> 1) + (lane >> 2) : 8 * c + (lane >> 3), d = F24 ? 8 * (lane & 3) + 4 * (c & 1) : 4 * (lane & 7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bf16_t hi = from_f32<bf16_t>(vraw[c][i]);

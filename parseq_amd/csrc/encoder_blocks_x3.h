@@ -668,6 +668,75 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
     }
 }
 
+// ---- head: x = patches W_pe^T + (pos_embed + bias) in the bf16x3 arithmetic (encoder_blocks.h patch_head, three products) ---------
+// 32 x 128 crops, (4, 8) patches: k-block c of a patch row is channel c's 4 x 8 pixels, and a lane's eight k-slots of it (8 g + [0, 8))
+// are ONE run of eight pixels — row 4 gy + g, columns 8 gx .. 8 gx + 7.  The 384 x 96 weight is nine stages of the pack (three 128-row
+// groups x three k-blocks at a 384-byte row pitch), all issued at once into the LDS the blocks have not touched yet.  The accumulators
+// start from the posb table ([128][E] f32 = pos_embed + patch-embed bias, built once per plan); pixels are split into (hi, lo) like any
+// other operand (u8 pixels after the reference transform (v / 255 - 0.5) / 0.5, strhub/data/module.py:78-81; bf16 pixels have lo = 0).
+// The stage loads' scalar offsets go 512 bytes below the weight's origin (StreamLane::issue_v): it must start >= 128 elements into the pack.
+struct EncHeadX3 {
+    const void* images; int img_dtype;      // EB_IMG_F32 / EB_IMG_BF16 / EB_IMG_U8; images == nullptr: no head, x is loaded
+    unsigned wpe;                           // element offset of patch_embed.proj.weight in the pack
+    const float* posb;
+};
+constexpr unsigned X3_HEAD_MIN_WPE = 128;
+
+template <int E>
+__device__ __forceinline__ void patch_head_x3(const EncHeadX3& hp, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, int wid, int lane, int image,
+                                              f32x4 (&acc)[E / 16][2]) {
+    static_assert(E == 384 && 9 * STAGE <= (int)enc_blocks_x3_lds<384>(), "three 128-row groups; nine stages fit the launch's LDS");
+    constexpr int PK = 96, IH = 32, IW = 128;
+    const int rr = lane & 15, g = lane >> 4;
+    const unsigned vpe = StreamLaneX::calc<1>(lane, wid, PK);
+    static_for<0, 9>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, ng = st / 3, kb = st % 3;
+        issue_stage(wrsrc, vpe, (hp.wpe + (unsigned)(ng * 128 * PK + kb * 32)) * 4u, 4u * PK, ring + st * STAGE + wid * 4096);
+    });
+    load_x_to_acc<E>(hp.posb, 0, 128, wid, rr, g, acc);
+    bf16x8 ph[2][3], pl[2][3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int token = 32 * wid + 16 * j + rr, gy = token >> 4, gx = token & 15;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t e0 = (((size_t)image * 3 + c) * IH + gy * 4 + g) * IW + gx * 8;
+            float v[8];
+            if (hp.img_dtype == EB_IMG_F32) {
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(hp.images) + e0);
+                const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(hp.images) + e0 + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            } else if (hp.img_dtype == EB_IMG_BF16) {
+                const bf16x8 f = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(hp.images) + e0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = static_cast<float>(f[i]);
+            } else {
+                const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(hp.images) + e0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned b = ((i < 4 ? u.x : u.y) >> (8 * (i & 3))) & 0xffu;
+                    v[i] = ((float)b / 255.0f - 0.5f) / 0.5f;
+                }
+            }
+            split8(v, ph[j][c], pl[j][c]);
+        }
+    }
+    x3_wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int fo0 = stage_frag_off(opaque_lane()), fo1 = fo0 ^ 64;
+    static_for<0, 9>([&](auto sc) {
+        constexpr int st = decltype(sc)::value, ng = st / 3, kb = st % 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16x8 wh = *reinterpret_cast<const bf16x8*>(ring + st * STAGE + i * 2048 + fo0);
+            const bf16x8 wl = *reinterpret_cast<const bf16x8*>(ring + st * STAGE + i * 2048 + fo1);
+            mma3_w(acc[ng * 8 + i][0], acc[ng * 8 + i][1], wh, wl, ph[0][kb], pl[0][kb], ph[1][kb], pl[1][kb]);
+        }
+    });
+}
+
 // ---- tail: K | V = LayerNorm_final(x) Wkv^T + bkv, head-split f32 [B][heads][128][32] (the storage type of precision bf16x3) ----
 template <int E, int RING>
 __device__ __forceinline__ void kv_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int wid, int m, int s, int q = -1) {
@@ -685,7 +754,7 @@ __device__ __forceinline__ void kv_prefetch(const StreamLaneX& sl, unsigned char
 }
 template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void kv_phase(unsigned char* ring, const float* sbkv, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, const StreamLaneX& sl,
-                                         int wid, int image, int heads, float* __restrict__ kmem, float* __restrict__ vmem,
+                                         int wid, int image, int heads, float* __restrict__ kmem, float* __restrict__ vmem, size_t plane_elems,
                                          const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32]) {
     constexpr int NC = 2 * E / 64, NP = 3 * NC, D = RING - 1;
     for (int c = 0; c < NC; ++c) {
@@ -715,6 +784,26 @@ __device__ __forceinline__ void kv_phase(unsigned char* ring, const float* sbkv,
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 const int token = 32 * wid + 16 * j + rr;
+                if (plane_elems) {
+                    // 24-bit rows (decoder_attn.h F24): the value rounded to 16 significant bits, bits 31..16 to the u16 plane at `dst`, bits
+                    // 15..8 to the u8 plane `plane_elems` elements (2 bytes each) behind it — 16 + 8 bytes per lane instead of 32
+                    const size_t at = (((size_t)image * heads + 2 * cc + pr) * 128 + token) * 32 + 8 * g;
+                    unsigned w[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        w[r] = __float_as_uint(acc1[2 * pr][j][r] + bp0[32 * pr + r]) + 0x80u;
+                        w[4 + r] = __float_as_uint(acc1[2 * pr + 1][j][r] + bp0[32 * pr + 4 + r]) + 0x80u;
+                    }
+                    u32x4 hi; uint2 lo;
+                    hi[0] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u); hi[1] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+                    hi[2] = __builtin_amdgcn_perm(w[5], w[4], 0x07060302u); hi[3] = __builtin_amdgcn_perm(w[7], w[6], 0x07060302u);
+                    lo.x = __builtin_amdgcn_perm(__builtin_amdgcn_perm(w[3], w[2], 0x05010501u), __builtin_amdgcn_perm(w[1], w[0], 0x05010501u), 0x05040100u);
+                    lo.y = __builtin_amdgcn_perm(__builtin_amdgcn_perm(w[7], w[6], 0x05010501u), __builtin_amdgcn_perm(w[5], w[4], 0x05010501u), 0x05040100u);
+                    unsigned char* hp = reinterpret_cast<unsigned char*>(dst);
+                    *reinterpret_cast<u32x4*>(hp + at * 2) = hi;
+                    *reinterpret_cast<uint2*>(hp + plane_elems * 2 + at) = lo;
+                    continue;
+                }
                 float* o = dst + (((size_t)image * heads + 2 * cc + pr) * 128 + token) * 32 + 8 * g;
                 *reinterpret_cast<float4*>(o) = make_float4(acc1[2 * pr][j][0] + bp0[32 * pr], acc1[2 * pr][j][1] + bp0[32 * pr + 1],
                                                             acc1[2 * pr][j][2] + bp0[32 * pr + 2], acc1[2 * pr][j][3] + bp0[32 * pr + 3]);
@@ -729,13 +818,15 @@ struct EncTailX3 {
     unsigned norm_w, norm_b, wkv, bkv;
     float* kmem; float* vmem;
     int heads;
+    size_t plane_elems = 0;      // != 0: K and V leave as 24-bit rows (u16 plane at kmem / vmem, u8 plane plane_elems elements behind it)
 };
 
 // wpack: the block-planar hi | lo copy of the f32 master (`wbytes` = 4 bytes per master element); pbase: the f32 master (vectors)
 template <int E>
 __global__ __launch_bounds__(256, 1)
 void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict__ wpack, unsigned wbytes, const float* __restrict__ pbase,
-                          const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, float* __restrict__ scratch, const EncTailX3 tail) {
+                          const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, float* __restrict__ scratch, const EncTailX3 tail,
+                          const EncHeadX3 head) {
     constexpr int F = 4 * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;
@@ -752,7 +843,8 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 
     f32x4 acc[E / 16][2];
     bf16x8 ah[2][E / 32], al[2][E / 32];
-    load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
+    if (head.images) patch_head_x3<E>(head, ring, wrsrc, wid, lane, blockIdx.x, acc);
+    else load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
     float* xbuf = scratch + (size_t)blockIdx.x * (2 * 48 * 1024);      // 48 pieces x 256 lanes x 4 floats: the parked residual stream
     float* obuf = xbuf + 48 * 1024;                                     // ... and the attention output fragments
 
@@ -839,26 +931,29 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
     params_to_lds(sp + 3 * E, pbase + tail.norm_b, E, tid);
     __syncthreads();
     ln_acc_to_frag<E>(acc, sp + 2 * E, sp + 3 * E, eps, g, ah, al);
-    kv_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, ah, al);
+    kv_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, tail.plane_elems, ah, al);
 }
 
 template <int E>
 hipError_t launch_enc_blocks_x3(hipStream_t s, float* x, const void* wpack, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
-                                       int depth, float eps, int M, float* scratch, const EncTailX3& tail = EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0}) {
+                                       int depth, float eps, int M, float* scratch, const EncTailX3& tail = EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0},
+                                       const EncHeadX3& head = EncHeadX3{nullptr, 0, 0, nullptr}) {
     constexpr size_t lds = enc_blocks_x3_lds<E>();
     if (wbytes >= ((size_t)1 << 32) || M % 128 != 0) return hipErrorInvalidValue;
     auto kern = enc_blocks_x3_kernel<E>;
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, s, x, reinterpret_cast<const unsigned char*>(wpack), (unsigned)wbytes, pbase, blocks, depth, eps, M, scratch, tail);
+    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, s, x, reinterpret_cast<const unsigned char*>(wpack), (unsigned)wbytes, pbase, blocks, depth, eps, M, scratch, tail, head);
     return hipGetLastError();
 }
 
 // Compiled in its own translation unit (kern_enc_blocks_x3.hip defines PQ_INSTANTIATE_ENC_BLOCKS_X3); every other unit only calls it.
 #ifdef PQ_INSTANTIATE_ENC_BLOCKS_X3
-template hipError_t launch_enc_blocks_x3<384>(hipStream_t, float*, const void*, size_t, const float*, const EncBlockParams*, int, float, int, float*, const EncTailX3&);
+template hipError_t launch_enc_blocks_x3<384>(hipStream_t, float*, const void*, size_t, const float*, const EncBlockParams*, int, float, int, float*, const EncTailX3&,
+                                              const EncHeadX3&);
 #else
-extern template hipError_t launch_enc_blocks_x3<384>(hipStream_t, float*, const void*, size_t, const float*, const EncBlockParams*, int, float, int, float*, const EncTailX3&);
+extern template hipError_t launch_enc_blocks_x3<384>(hipStream_t, float*, const void*, size_t, const float*, const EncBlockParams*, int, float, int, float*, const EncTailX3&,
+                                              const EncHeadX3&);
 #endif
 
 }  // namespace x3

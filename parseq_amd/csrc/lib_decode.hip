@@ -30,12 +30,24 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(dec_cross_attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((dec_cross_attn_generic_kernel<T>), dim3(B * H), dim3(128), lds, s, qc_, kmem, vmem, H, Lq, NK, scale, ca);
     } else if (Lq == 1) {
+        if constexpr (sizeof(T) == 4 && E == 384) {
+            if (p->kv24) {
+                hipLaunchKernelGGL((dec_cross_attn_ar24_kernel<E>), dim3(B), dim3(E), 0, s, qc_, reinterpret_cast<const unsigned char*>(p->kmem),
+                                   reinterpret_cast<const unsigned char*>(p->vmem), p->kv_plane_elems, scale, ca);
+                HIPCHK(hipGetLastError());
+                return 0;
+            }
+        }
+        if (p->kv24) return fail(PARSEQ_E_STATE, "cross-attention: 24-bit K / V rows but no kernel for this geometry");
         hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, qc_, kmem, vmem, scale, ca);
     } else if constexpr (sizeof(T) == 2) {
         hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
     } else {
-        if (g_split)      // bf16x3: the matrix-core kernel on bf16 pairs
-            hipLaunchKernelGGL(dec_cross_attn_multi_mfma_x3_kernel, dim3((B * H + 1) / 2), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
+        if (g_split && p->kv24)      // bf16x3: the matrix-core kernel on bf16 pairs, K / V from the 24-bit rows of the one-launch encoder's tail
+            hipLaunchKernelGGL(dec_cross_attn_multi_mfma_x3_kernel<true>, dim3((B * H + 1) / 2), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H, p->kv_plane_elems);
+        else if (g_split)
+            hipLaunchKernelGGL(dec_cross_attn_multi_mfma_x3_kernel<false>, dim3((B * H + 1) / 2), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H, (size_t)0);
+        else if (p->kv24) return fail(PARSEQ_E_STATE, "cross-attention: 24-bit K / V rows outside the bf16x3 mode");
         else
             hipLaunchKernelGGL((dec_cross_attn_multi_kernel<T>), dim3(B * H), dim3(128), 0, s, qc_, kmem, vmem, H, Lq, scale, ca);
     }
@@ -396,6 +408,7 @@ static int set_memory_impl(parseq_plan* p, const float* memory, int B, hipStream
     EpiHeads<T> ek; static_cast<EpiBase&>(ek) = epi_base(M, 2 * E, m->p(d + "in_proj_bias") + E);
     ek.seg[0] = reinterpret_cast<T*>(p->kmem); ek.seg[1] = reinterpret_cast<T*>(p->vmem); ek.seg[2] = nullptr;
     ek.E = E; ek.heads = c.dec_heads; ek.hd = DEC_HD; ek.tokens = N; ek.tr_from = 2;
+    p->kv24 = false;      // rows in the storage type from the generic GEMM
     ProfScope ps_(&p->prof, T_KVMEM, s);
     CHK((run_gemm<T>(s, ARowMajor<T>{a, E}, W.w(d + "in_proj_weight") + (size_t)E * E, E, M, 2 * E, E, ek, E % 128 != 0)));
     p->last_batch = B;

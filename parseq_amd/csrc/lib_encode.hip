@@ -23,7 +23,10 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     const bool head_in_launch = sizeof(T) == 2 && !m->vitstr && p->fused_head && p->fused_blocks && p->fused_attn && p->mlp_resident &&
                                 E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128 &&
                                 p->wpe_off >= EB_HEAD_MIN_WPE;     // see EB_HEAD_MIN_WPE (always true with pos_embed ahead of the weight)
-    if (head_in_launch) {
+    // the same for the bf16x3 one-launch encoder (encoder_blocks_x3.h patch_head_x3; conditions of its launch below)
+    const bool head_x3 = sizeof(T) == 4 && g_split && p->fused_x3 && p->fused_blocks && p->fused_head && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 &&
+                         N == ATT_N && M % 128 == 0 && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128 && p->wpe_off >= x3::X3_HEAD_MIN_WPE;
+    if (head_in_launch || head_x3) {
         // nothing here: x is produced inside the launch
     } else if (!m->vitstr) {
         ProfScope ps_(&p->prof, T_PATCH, s);
@@ -102,6 +105,10 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
             const bool tail = p->fused_tail && memory_out == nullptr && c.dec_heads * DEC_HD == E;
             x3::EncTailX3 et{p->enc_tail.norm_w, p->enc_tail.norm_b, p->enc_tail.wkv, p->enc_tail.bkv, nullptr, nullptr, p->enc_tail.heads};
             if (tail) { et.kmem = reinterpret_cast<float*>(p->kmem); et.vmem = reinterpret_cast<float*>(p->vmem); }
+            // the tail's K / V rows as 24-bit floats (3 bytes per element: decoder_attn.h F24) — the cross-attention kernels of this
+            // geometry read either format, whichever the last producer left (p->kv24)
+            if (tail && p->kv24_enabled && N == 128) et.plane_elems = p->kv_plane_elems;
+            p->kv24 = tail && et.plane_elems != 0;
             {
                 // PARSEQ_X3_SPLIT=n (diagnostics): the blocks in n launches of depth / n, x through HBM between them (100 MB out + in at batch
                 // 512) — shorter persistent workgroups, for the A/B of how a second batch's decoder interleaves with this launch
@@ -111,8 +118,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                 for (int l0 = 0; l0 < c.enc_depth; l0 += per) {
                     const int d = std::min(per, c.enc_depth - l0);
                     const bool last = l0 + d >= c.enc_depth;
+                    x3::EncHeadX3 eh{nullptr, 0, 0, nullptr};
+                    if (head_x3 && l0 == 0) {
+                        eh.images = images; eh.img_dtype = sizeof(TI) == 1 ? EB_IMG_U8 : (sizeof(TI) == 2 ? EB_IMG_BF16 : EB_IMG_F32);
+                        eh.wpe = p->wpe_off; eh.posb = p->posb;
+                    }
                     HIPCHK((x3::launch_enc_blocks_x3<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev + l0, d,
-                                                          c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), last ? et : x3::EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0})));
+                                                          c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), last ? et : x3::EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0}, eh)));
                 }
             }
             if (tail) { p->last_batch = B; return 0; }
@@ -220,6 +232,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     p->last_batch = B;
     if (m->vitstr) return 0;          // no decoder: the head reads xn (parseq_vitstr_forward)
     const std::string d = "decoder.layers.0.cross_attn.";
+    p->kv24 = false;      // f32 / bf16 rows from the generic GEMM
     {
         EpiHeads<T> ek; static_cast<EpiBase&>(ek) = epi_base(M, 2 * E, m->p(d + "in_proj_bias") + E);
         ek.seg[0] = reinterpret_cast<T*>(p->kmem); ek.seg[1] = reinterpret_cast<T*>(p->vmem); ek.seg[2] = nullptr;

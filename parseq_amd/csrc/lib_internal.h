@@ -253,6 +253,9 @@ struct parseq_plan {
     unsigned char* qmask_user = nullptr;  // [npos][LDT] staging for parseq_decode_logits
     int* counters = nullptr;       // [0] rows that have seen an EOS, [1] step at which the reference would have stopped (ar_len)
     int last_batch = 0;            // batch of the most recent parseq_encode (kvmem valid for it)
+    bool kv24 = false;             // what kmem / vmem hold right now: f32 rows, or (bf16x3 one-launch encoder with its tail) the 24-bit rows of decoder_attn.h
+    size_t kv_plane_elems = 0;     // elements of one K (or V) plane at max_batch: the u8 plane sits this many 2-byte elements behind the u16 plane
+    bool kv24_enabled = getenv("PARSEQ_NO_KV24") == nullptr;      // diagnostics: keep f32 K / V rows in the bf16x3 mode
     int num_cus = 256;             // compute units of the device (tail-round avoidance of the one- and two-workgroup-per-CU kernels)
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
     bool fused_attn = getenv("PARSEQ_NO_FUSED_ATTN") == nullptr;   // diagnostics: qkv panel GEMM + attention + proj GEMM instead of encoder_attn_fused.h

@@ -214,6 +214,13 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
             hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, m->master, reinterpret_cast<unsigned char*>(p->wpack), n);
             HIPCHK(hipGetLastError());
             CHK(build_block_table(p, s));      // the one-launch encoder of this precision (encoder_blocks_x3.h)
+            if (!m->vitstr) {                  // ... and its head: pos_embed + patch-embed bias as one table, the weight's offset in the pack
+                const int E_ = m->cfg.embed_dim, rows_ = m->tokens;
+                p->wpe_off = (unsigned)m->params[m->index.at(m->enc + "patch_embed.proj.weight")].offset;
+                hipLaunchKernelGGL(add_rowvec_kernel, dim3((unsigned)(((size_t)rows_ * E_ + 255) / 256)), dim3(256), 0, s, m->p(m->enc + "pos_embed"),
+                                   m->p(m->enc + "patch_embed.proj.bias"), p->posb, rows_, E_);
+                HIPCHK(hipGetLastError());
+            }
             if (p->wstep[0]) {       // decoder weights as hi | lo fragment pairs for the fused AR step, from the fp32 master
                 const int E = m->cfg.embed_dim, Fd = E * m->cfg.dec_mlp_ratio;
                 const std::string d = "decoder.layers.0.";
@@ -285,6 +292,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     if (step_ok) for (int i = 0; i < 6; ++i) p->wstep[i] = reinterpret_cast<bf16_t*>(a + o_wstep[i]);
     p->wpack = a + o_wpack; p->kvtab = a + o_kvtab; p->qself = (float*)(a + o_qself); p->ctab_ln = a + o_ctab;
     p->x = (float*)(a + o_x); p->xn = a + o_xn; p->q = a + o_q; p->k = a + o_k; p->vt = a + o_vt; p->ao = a + o_ao; p->h = a + o_h;
+    p->kv_plane_elems = rows * E;      // elements of K (or V) at max_batch: [B][H][tokens][32]
     p->kmem = a + o_kmem; p->vmem = a + o_vtmem; p->stab = (float*)(a + o_stab); p->sa = a + o_sa; p->tn = a + o_tn; p->ca = a + o_ca; p->hdn = a + o_hdn;
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
     p->blocks_dev = reinterpret_cast<EncBlockParams*>(a + o_blocks);

@@ -198,7 +198,7 @@ def test_test_step_contract(name, models, golden):
     assert abs(res.confidence - want_conf) <= 1e-2 * max(1.0, want_conf)
 
 
-@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16', 'bf16x3'])
 def test_uint8_input_is_normalised_in_the_patch_embed(name, models, precision):
     """Row N2: raw uint8 pixels through parseq_forward(images_dtype=PARSEQ_U8) == the reference transform's
     ToTensor + Normalize(0.5, 0.5) (oracle.normalize_u8) fed as a float tensor, bit for bit (every pixel value occurs)."""
@@ -218,6 +218,29 @@ def test_uint8_input_is_normalised_in_the_patch_embed(name, models, precision):
         mem_u8 = m.model.encode(u8.to(DEV)).cpu()
         mem_f = m.model.encode(ref_in.to(DEV)).cpu()
     assert torch.equal(mem_u8, mem_f)
+
+
+def test_patch_head_of_the_bf16x3_encoder(golden, monkeypatch):
+    """encoder_blocks_x3.h patch_head_x3 (the (4, 8) patch embedding as the head of the bf16x3 one-launch encoder: pixels split into
+    bf16 pairs, weight stages from the hi | lo pack, accumulators started from the pos_embed + bias table) against the same model with
+    the patch embedding as its own GEMM launch (PARSEQ_NO_FUSED_HEAD=1): same operands and products, only the fp32 summation order
+    differs (bias + pos_embed first instead of last) — and both within the encoder bar of the reference's own memory."""
+    g, _ = golden('parseq')
+    images = g['images'].to(DEV)
+    fused = make_model('parseq', 'bf16x3')
+    with torch.inference_mode():
+        a = fused.model.encode(images).cpu()
+        a16 = fused.model.encode(images.bfloat16()).cpu()      # bf16 pixels: exact in f32, lo planes zero
+    monkeypatch.setenv('PARSEQ_NO_FUSED_HEAD', '1')
+    sep = make_model('parseq', 'bf16x3')                         # the switch is read when a plan is created
+    with torch.inference_mode():
+        b = sep.model.encode(images).cpu()
+        b16 = sep.model.encode(images.bfloat16()).cpu()
+    for tag, x, y in (('f32 pixels', a, b), ('bf16 pixels', a16, b16)):
+        d, msg = report(f'bf16x3 patch head in-launch vs separate GEMM ({tag})', x, y)
+        assert 0 < d <= 2e-4, msg                               # measured 4.9e-5 on values of O(4): twelve blocks downstream of a 1e-7 difference in x
+    err, msg = report('bf16x3 memory with the in-launch head vs reference', a, g['memory'])
+    assert err <= 5e-4, msg
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
@@ -300,6 +323,38 @@ def test_encoder_tail_in_launch_vs_separate(golden, monkeypatch):
     d, msg = report('encoder tail in-launch vs separate launches (bf16, NAR)', a, b)
     assert d <= 2e-2, msg
     assert (a.argmax(-1) == b.argmax(-1)).float().mean() >= 0.99
+
+
+def test_kv_rows_24_bit_vs_f32(golden, monkeypatch):
+    """bf16x3 mode, PARSeq-S: the one-launch encoder's tail leaves the decoder's K / V rows as 24-bit floats (16 significant bits in a
+    u16 + a u8 plane: decoder_attn.h F24; 25 % less of the AR loop's HBM stream) against the same model with f32 rows
+    (PARSEQ_NO_KV24=1) — AR loop (dec_cross_attn_ar24_kernel) and refinement pass (dec_cross_attn_multi_mfma_x3_kernel<true>).  The CPU
+    study (profiles/r04_cheap_exact_study.md) puts the format's cost at 1.6e-5 on the logits; both must stay within 1e-3 of the
+    reference's own outputs.  encode() + decode() on the same model keeps f32 rows (generic GEMM) and must still agree."""
+    g, _ = golden('parseq')
+    images = g['images'].to(DEV)
+    m24 = make_model('parseq', 'bf16x3')
+    a_nar, a_ar = _run(m24, images, 'nar1'), _run(m24, images, 'ar1')
+    for mode, got in (('nar1', a_nar), ('ar1', a_ar)):
+        d, msg = report(f'24-bit K / V rows vs reference golden ({mode})', got, g[f'logits.{mode}'])
+        assert d <= 1e-3, msg
+        assert torch.equal(got.argmax(-1).cpu(), g[f'logits.{mode}'].argmax(-1)), msg
+    monkeypatch.setenv('PARSEQ_NO_KV24', '1')
+    m32 = make_model('parseq', 'bf16x3')                     # the switch is read when a plan is created
+    b_nar, b_ar = _run(m32, images, 'nar1'), _run(m32, images, 'ar1')
+    d, msg = report('24-bit vs f32 K / V rows (bf16x3, NAR + 1 refinement)', a_nar, b_nar)
+    assert 0 < d <= 1e-4, msg                                # different storage (d > 0: the 24-bit path really ran), far inside the tolerance
+    d, msg = report('24-bit vs f32 K / V rows (bf16x3, AR + 1 refinement)', a_ar, b_ar)
+    assert d <= 1e-4, msg
+    # the reference idiom on the 24-bit model: encode() leaves f32 rows behind (generic GEMM), decode() must read THOSE
+    with torch.inference_mode():
+        mem = m24.model.encode(images)
+        tgt = torch.full((images.shape[0], 1), m24.tokenizer.bos_id, dtype=torch.long, device=DEV)
+        out = m24.model.head(m24.model.decode(tgt, mem, tgt_query=m24.model.pos_queries[:, :1]))      # AR step 0: context <bos>, query 0
+        again = _run(m24, images, 'ar1')                     # and a forward afterwards switches back to 24-bit rows
+    d, msg = report('decode() after encode() on a model whose forward uses 24-bit rows', out[:, 0].float().cpu(), g['logits.ar0'][:, 0])
+    assert d <= 1e-3, msg
+    assert torch.equal(again, a_ar)
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
