@@ -1,5 +1,6 @@
 // The bf16x3 one-launch encoder alone, as a small shared library: tools/x3_variants.sh builds it under different -D switches
 // (X3_AHEAD, X3_MLP_RING, X3_ABLATE ...) in seconds each and tools/x3_variant_bench.py times the builds against each other on one GPU.
+#define PQ_INSTANTIATE_ENC_BLOCKS_X3      // this unit instantiates the launcher itself
 #include "encoder_blocks_x3.h"
 #include <vector>
 using namespace pq;
