@@ -95,12 +95,6 @@ __device__ __forceinline__ void mma3_1(f32x4& c, const bf16x8& ah, const bf16x8&
 #ifndef X3_ISSUE_MODE
 #define X3_ISSUE_MODE 0        // LDS-DMA pieces of a later pair: 0 = a stage's four at each stage boundary, 1 = all eight at the pair's start, 2 = one per two positions (12 MFMAs)
 #endif
-#ifndef X3_STORE_AWARE
-#define X3_STORE_AWARE 0       // (measured: no difference, profiles/r04_x3_encoder_variants.md) s_waitcnt vmcnt immediates that let the global stores issued behind a weight stage stay in flight (head loop, tail)
-#endif
-#ifndef X3_GELU_FILL
-#define X3_GELU_FILL 0         // 1: the GELU of a hidden chunk's second half issues under the fc2 MFMAs of its first half (run_pair2_fill)
-#endif
 #ifndef X3_VOFF_RECOMPUTE
 #define X3_VOFF_RECOMPUTE 0    // 1: the per-lane DMA offsets are recomputed at every stage issue instead of living in three registers
 #endif
@@ -187,55 +181,6 @@ __device__ __forceinline__ void run_pair2(const unsigned char* st0, const unsign
 template <int AHEAD = 2, class Mma, class Issue, class Mid = NoMid>
 __device__ __forceinline__ void run_pair(const unsigned char* grp, Mma&& mma, Issue&& issue, Mid&& mid = Mid{}) {
     run_pair2<AHEAD>(grp, grp + STAGE, mma, issue, mid);
-}
-
-// run_pair2 with VALU work riding in the MFMA stream: fill(pp), pp = 0 .. 7, is called once per PAIR of positions (12 MFMAs, 192
-// matrix-pipe cycles = 36 spare issue slots) and the scheduling groups place two of its VALU instructions behind every MFMA, so a
-// dependent chain like the GELU of one element pair issues while the matrix pipe is busy instead of between two pairs of stages.
-#ifndef X3_FILL_VALU
-#define X3_FILL_VALU 2         // VALU instructions requested behind each MFMA of a filled position pair
-#endif
-template <int AHEAD = 2, class Mma, class Issue, class Fill>
-__device__ __forceinline__ void run_pair2_fill(const unsigned char* st0, const unsigned char* st1, Mma&& mma, Issue&& issue, Fill&& fill) {
-    const int ln = opaque_lane();
-    const int fo0 = stage_frag_off(ln), fo1 = fo0 ^ 64;
-    constexpr int NB = AHEAD + 1;
-    bf16x8 wh[NB], wl[NB];
-    static_for<0, AHEAD>([&](auto nc) {
-        constexpr int n = decltype(nc)::value;
-        wh[n] = *reinterpret_cast<const bf16x8*>(st0 + n * 2048 + fo0); wl[n] = *reinterpret_cast<const bf16x8*>(st0 + n * 2048 + fo1);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, 8>([&](auto pc) {
-        constexpr int pp = decltype(pc)::value;
-        if constexpr (pp == 0 || pp == 4) {
-            issue(pp >> 2, -1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        auto done = fill(pp);      // returns a callable that pins the slice's results to this region (an empty volatile asm on them): without it
-                                   // instruction selection sinks the whole chain to its first use, one pair of stages later
-        static_for<0, 2>([&](auto sc) {
-            constexpr int n = 2 * pp + decltype(sc)::value, s = n >> 3, i = n & 7, nn = n + AHEAD;
-            if constexpr (nn < 16) {
-                const unsigned char* src = ((nn >> 3) ? st1 : st0) + (nn & 7) * 2048;
-                wh[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo0);
-                wl[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo1);
-            }
-            mma(s, i, wh[n % NB], wl[n % NB]);
-        });
-        done();
-        static_for<0, 2>([&](auto sc) {
-            constexpr int nn = 2 * pp + decltype(sc)::value + AHEAD;
-            static_for<0, 2>([&](auto hc) {
-                if constexpr (nn < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                static_for<0, 3>([&](auto) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x402, X3_FILL_VALU, 0);
-                });
-            });
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    });
 }
 
 template <int N> __device__ __forceinline__ void x3_wait_vmcnt() { if constexpr ((X3_ABLATE & 32) == 0) wait_vmcnt<N>(); }
@@ -365,13 +310,9 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
         static_for<0, 9>([&](auto nc) {
             constexpr int n = decltype(nc)::value, u = n / 3, pp = n % 3;
             const int m = 9 * h + n;                             // pair index of the phase
-            // this pair has landed; the stage after it may be in flight.  vmcnt counts stores too and retires in issue order, so at the first
-            // pair of a head the global stores issued after that stage — the parked accumulator tiles before head 0, the previous head's
-            // eight O pieces otherwise — are allowed to be in flight as well: waiting for them put a store's round trip on the critical
-            // path seven times per block
-            if constexpr (n == 0 && X3_STORE_AWARE && (X3_ABLATE & 8) == 0) {
-                if (h == 0) x3_wait_vmcnt<4 + 2 * X3_PARK_TILES>(); else x3_wait_vmcnt<4 + 8>();
-            } else if (m + 1 < 9 * H) x3_wait_vmcnt<4>(); else x3_wait_vmcnt<0>();
+            // this pair has landed; the stage after it may be in flight.  (vmcnt also counts the global stores issued behind that stage — parked
+            // tiles, the previous head's O pieces; letting them fly too was measured and changes nothing: profiles/r04_x3_encoder_variants.md)
+            if (m + 1 < 9 * H) x3_wait_vmcnt<4>(); else x3_wait_vmcnt<0>();
             pair_fence();
             if constexpr (pp == 0) {
 #pragma unroll
@@ -675,17 +616,6 @@ __device__ __forceinline__ void gelu_frag(const f32x4 (&acc1)[4][2], const float
     }
 }
 
-// GELU of hidden units (2 w, 2 w + 1) of a fragment's eight for row tile j — elements q0, q0 + 1 of accumulator tile `t` — as one dword of
-// the hi fragment and one of the lo fragment: what gelu_frag does for a whole fragment, in eight independent pieces for run_pair2_fill
-__device__ __forceinline__ void gelu_pair(const f32x4& t, int q0, float b0, float b1, unsigned& hi, unsigned& lo) {
-    const float v0 = x3_gelu(acc_read(t[q0]) + b0), v1 = x3_gelu(acc_read(t[q0 + 1]) + b1);
-    typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2_t;
-    bf16x2_t h, l;
-    h[0] = static_cast<bf16_t>(v0); h[1] = static_cast<bf16_t>(v1);
-    l[0] = static_cast<bf16_t>(v0 - static_cast<float>(h[0])); l[1] = static_cast<bf16_t>(v1 - static_cast<float>(h[1]));
-    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
-}
-
 // al1_lds != nullptr: the lo fragments of row tile 1 live in the wave's LDS region (al[1][.] is not read)
 template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
@@ -697,9 +627,6 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         const bool last = c + 1 == NCH;
         f32x4 acc1[4][2];
         bf16x8 hh[2], hl[2];
-#if X3_GELU_FILL
-        u32x4 hh1[2], hl1[2];      // the second k-block's fragments, built dword by dword under the first k-block's fc2 MFMAs
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -733,34 +660,10 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                     mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
             } else {
-#if X3_GELU_FILL
-                // the GELU of the chunk's second 32 hidden units (fc2's k-block 1, first used by stage 1 of pair 4) rides under pair 3 — fc2's
-                // k-block 0 — one element pair per position pair; pairs 4 and 5 pick the fragments by k-block
-                auto mma2 = [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
-                    const int t = 2 * (r - 3) + s, kb = t / 3, ng = t % 3;
-                    if (kb == 0) mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
-                    else mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, __builtin_bit_cast(bf16x8, hh1[0]), __builtin_bit_cast(bf16x8, hl1[0]),
-                                __builtin_bit_cast(bf16x8, hh1[1]), __builtin_bit_cast(bf16x8, hl1[1]));
-                };
-                if constexpr (r == 3) {
-                    run_pair2_fill<AHEAD>(grp, grp + STAGE, mma2, issue, [&](int pp) {
-                        const int j = pp >> 2, w = pp & 3, tl = 2 + (w >> 1), q0 = 2 * (w & 1);      // constants after inlining
-                        unsigned hi_, lo_;
-                        gelu_pair(acc1[tl][j], q0, bp[32 + 4 * (w >> 1) + q0], bp[32 + 4 * (w >> 1) + q0 + 1], hi_, lo_);
-                        return [&hh1, &hl1, j, w, hi_, lo_]() mutable {
-                            asm volatile("" : "+v"(hi_), "+v"(lo_));
-                            hh1[j][w] = hi_; hl1[j][w] = lo_;
-                        };
-                    });
-                } else {
-                    run_pair<AHEAD>(grp, mma2, issue);
-                }
-#else
                 run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                     const int t = 2 * (r - 3) + s, ng = t % 3;
                     mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
                 }, issue, mid);
-#endif
             }
             if constexpr (r == 2) gelu_frag(acc1, bp, 0, hh, hl);
         });
@@ -865,10 +768,7 @@ __device__ __forceinline__ void kv_phase(unsigned char* ring, const float* sbkv,
             const int m = 3 * c + pp;
             static_for<0, D>([&](auto dc) {        // pairs behind this one still in flight: min(D - 1, NP - 1 - m)
                 constexpr int d = decltype(dc)::value;
-                // (first pair of a chunk after the first: the previous chunk's eight row stores were issued behind those pairs and may fly too)
-                if ((NP - 1 - m < D - 1 ? NP - 1 - m : D - 1) == d) {
-                    if (pp == 0 && c > 0 && X3_STORE_AWARE) x3_wait_vmcnt<8 * d + 8>(); else x3_wait_vmcnt<8 * d>();
-                }
+                if ((NP - 1 - m < D - 1 ? NP - 1 - m : D - 1) == d) x3_wait_vmcnt<8 * d>();
             });
             pair_fence();
             run_pair<AHEAD>(ring + (m % RING) * PAIRB, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
