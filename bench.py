@@ -184,38 +184,71 @@ class _StubModel(torch.nn.Module):
         return x.float().mean(dim=(1, 2, 3))[:, None, None].expand(x.shape[0], 26, 95).contiguous()
 
 
-def train_leg(dev, batch=384, steps=5, warmup=2):
+def stub_train_leg(dist, world, rank, batch=384, steps=3):
+    """PARSEQ_BENCH_STUB=1: the multi-rank plumbing of the training leg (per-rank shard, one collective per step, barrier + MAX over ranks,
+    whole-job accounting) with no training work at all."""
+    g = torch.ones(1024) * (rank + 1)
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if dist is not None:
+            dist.all_reduce(g)
+    if dist is not None:
+        dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return {'metric': 'stub', 'value': round(world * batch * steps / float(el), 1), 'unit': 'images/s', 'steps': steps, 'batch': batch,
+            'global_batch': world * batch, 'n_gpus': world, 'stub': True}
+
+
+def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
     """tools/train_bench.py's measurement, short: images/s of the training step (strhub/models/parseq/system.py:168-199 + loss.backward()
-    + gradient_clip_val 20 + AdamW under OneCycleLR, train.py:62-71 / base.py:98-110) with synthetic crops and labels resident on the device."""
+    + gradient_clip_val 20 + AdamW under OneCycleLR, train.py:62-71 / base.py:98-110) with synthetic crops and labels resident on the device.
+    With more than one rank (BASELINE.json configs[4]: global batch 3072 = 8 x 384): every rank steps on its own 384-crop shard, the gradient
+    all-reduce (RCCL) rides behind the backward's segment events (parseq_amd/train.py TrainStep), the timed region is bracketed by barriers
+    and the MAX over ranks is what the whole-job figure is computed from."""
     from parseq_amd import create_model
     from parseq_amd.train import TrainStep
     torch.manual_seed(0)
     system = create_model('parseq', precision='bf16').to(dev)
     system.train_precision = 'bf16'
-    g = torch.Generator().manual_seed(4321)
+    g = torch.Generator().manual_seed(4321 + rank)
     ih, iw = system.hparams.img_size
     images = (torch.rand(batch, 3, ih, iw, generator=g) * 2 - 1).to(dev)
     charset = system.hparams.charset_train
     lengths = torch.randint(1, 26, (batch,), generator=g).tolist()
     lengths[0] = 25
     labels = [''.join(charset[int(i)] for i in torch.randint(0, len(charset), (n,), generator=g)) for n in lengths]
-    step = TrainStep(system, total_steps=steps + warmup + 1, num_devices=1)
+    step = TrainStep(system, total_steps=steps + warmup + 1, num_devices=world)
     for _ in range(warmup):
         step(images, labels)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step(images, labels)
     torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
     # algorithmic FLOPs of one step (2 x MAC; forward + dX + dW = 3 x the forward products): encoder 12 x 239.08 + 4.72 MMAC per image,
     # decoder per image 6 passes x 26 rows x (14 E^2 + 95 E) MAC + the memory K / V projection once (128 x 2 E^2), E = 384
     E = 384
     mmac_img = 12 * 239.08 + 4.72 + (6 * 26 * (14 * E * E + 95 * E) + 128 * 2 * E * E) / 1e6
-    tflop = 3 * 2 * mmac_img * 1e6 * batch / 1e12
+    tflop = 3 * 2 * mmac_img * 1e6 * batch / 1e12      # per GPU
     ms = 1e3 * el / steps
-    return {'metric': 'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], one GPU)',
-            'value': round(batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
+    return {'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], {world} GPU' + ('s, gradient all-reduce over RCCL)' if world > 1 else ')'),
+            'value': round(world * batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
+            'global_batch': world * batch, 'n_gpus': world,
             'dtype': 'bf16 operands (Linear and attention products), fp32 accumulate / master weights / LayerNorm / soft-max / loss / AdamW',
             'dropout': float(system.hparams.dropout), 'final_loss': round(float(loss), 4), 'algorithmic_tflop_per_step': round(tflop, 3),
             'achieved_tflops': round(tflop / (ms * 1e-3), 1), 'frac_of_bf16_mfma_peak': round(tflop / (ms * 1e-3) / PEAK['bf16'], 4)}
@@ -270,7 +303,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if STUB:
         dev = torch.device('cpu')
-        args.no_profile = args.no_cpu_baseline = args.no_parity = args.no_train = True
+        args.no_profile = args.no_cpu_baseline = args.no_parity = True
         torch.cuda.synchronize = lambda *a, **k: None          # this process only: the timed-region code below runs unchanged
     else:
         if torch.cuda.device_count() <= local_rank:
@@ -392,6 +425,9 @@ def main():
     }
     if STUB:
         result['stub'] = True
+    if rank == 0:       # the last timed step's logits, hashed: two runs of the same configuration (e.g. with and without --force-dist) must agree
+        import hashlib
+        result['output_sha256_16'] = hashlib.sha256(out.detach().float().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
     gf = GFLOP_PER_IMG.get((args.model, args.refine_iters))
     if gf and not STUB:
         result['end_to_end_tflops'] = round(value * gf / 1e3, 2)
@@ -505,13 +541,16 @@ def main():
             del tm
         except Exception as e:
             result['throughput_mode'] = {'error': f'{type(e).__name__}: {e}'}
-    if rank == 0 and world == 1 and not args.no_train and args.model == 'parseq':
-        # Row N3 on the driver's record (never part of `value`): the training step of BASELINE.json configs[4] on this GPU — 384 crops,
-        # K = 6 permutations, dropout 0.1, forward + backward + clip + AdamW in the bf16-operand mode — two warm-up steps, five timed.
+    if not args.no_train and args.model == 'parseq' and not (STUB and world == 1):
+        # Row N3 on the driver's record (never part of `value`): the training step of BASELINE.json configs[4] — 384 crops per GPU, K = 6
+        # permutations, dropout 0.1, forward + backward + (N > 1: gradient all-reduce) + clip + AdamW in the bf16-operand mode — two warm-up
+        # steps, five timed.  EVERY rank runs it (the step is collective); rank 0 reports the whole job.
         try:
-            result['train'] = train_leg(dev)
+            tr = stub_train_leg(dist, world, rank) if STUB else train_leg(dev, dist=dist if world > 1 else None, world=world, rank=rank)
         except Exception as e:
-            result['train'] = {'error': f'{type(e).__name__}: {e}'}
+            tr = {'error': f'{type(e).__name__}: {e}'}
+        if rank == 0:
+            result['train'] = tr
     if rank == 0:
         # the headline, unambiguous: `value` is the timed dtype's throughput; whether that dtype meets the north star's 1e-3 / argmax bar
         # on the timed weights and inputs is stated next to it, with the throughput of the mode that does

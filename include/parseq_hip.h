@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 4
+#define PARSEQ_ABI_VERSION 5
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -275,6 +275,18 @@ int parseq_train_encoder_forward(parseq_model* m, const float* images, int batch
                                  size_t workspace_bytes, void* stream);
 int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int batch, float* grads, void* workspace,
                                   size_t workspace_bytes, void* stream);
+
+/* Gradient segments (ABI 5): the hook for overlapping the data-parallel all-reduce with the encoder's backward — what DDP's bucketed
+ * reducer does under the reference's Trainer(strategy=DDPStrategy(...), reference train.py:65-71, 88-96).  The flat gradient buffer
+ * becomes final piecewise: the decoder's part before parseq_train_encoder_backward starts, then the encoder's blocks from the last to
+ * the first.  parseq_train_grad_segments = number of segments (enc_depth + 1; 0 for ViTSTR); segment `index` (in completion order) is
+ * the element range [*begin, *end) of the buffer — the ranges tile [0, parseq_model_grad_elems) — and *event (may be NULL) is a
+ * hipEvent_t the most recent parseq_train_encoder_backward recorded on its stream right after the last kernel that writes the range.
+ * parseq_stream_wait_event makes `stream` wait for it (hipStreamWaitEvent), so that a collective enqueued on that stream starts as
+ * soon as its bucket is final while the backward keeps running. */
+int parseq_train_grad_segments(const parseq_model* m);
+int parseq_train_grad_segment(parseq_model* m, int index, int64_t* begin, int64_t* end, void** event);
+int parseq_stream_wait_event(void* stream, void* event);
 
 /* Optimiser half of the training step (strhub/models/base.py:98-107: timm create_optimizer_v2('adamw') = torch.optim.AdamW;
  * configs/main.yaml:39 gradient_clip_val = torch.nn.utils.clip_grad_norm_), over the flat buffers:

@@ -16,7 +16,7 @@ from . import build as _build
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8, PARSEQ_BF16X3 = 0, 1, 2, 3
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING = 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ParseqConfig(C.Structure):
@@ -76,6 +76,9 @@ SIGNATURES = {
     'parseq_train_encoder_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int]),
     'parseq_train_encoder_forward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'parseq_train_encoder_backward': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'parseq_train_grad_segments': (C.c_int, [C.c_void_p]),
+    'parseq_train_grad_segment': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
+    'parseq_stream_wait_event': (C.c_int, [C.c_void_p, C.c_void_p]),
     'parseq_grad_norm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_adamw_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),

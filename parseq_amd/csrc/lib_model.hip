@@ -75,6 +75,7 @@ extern "C" void parseq_model_destroy(parseq_model* m) {
     DevGuard dg(m->device);
     if (m->master) (void)hipFree(m->master);
     if (m->out_chunks) (void)hipFree(m->out_chunks);
+    for (hipEvent_t e : m->grad_events) (void)hipEventDestroy(e);
     delete m;
 }
 

@@ -743,6 +743,52 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     return run_layernorm<float>(s, w + o.x_last, P("norm.weight"), P("norm.bias"), memory_out, nullptr, MS, E, eps);
 }
 
+// ---- gradient segments: the hook for overlapping the data-parallel all-reduce with the encoder's backward -----------------------------
+// The reference trains under Lightning's DDP strategy (train.py:65-71): gradient buckets are all-reduced while the backward is still
+// running.  Here the gradients live in ONE flat buffer laid out like the master weights — pos_queries | encoder.pos_embed, patch_embed |
+// blocks 0 .. depth-1 | encoder.norm | decoder.*, head.*, text_embed.* — and become final in this order: the decoder's part (and
+// pos_queries) before the encoder's backward starts, then encoder.norm and the blocks from the last to the first, then pos_embed /
+// patch_embed.  Segment k (completion order) is a contiguous range of the buffer; parseq_train_encoder_backward records event k on its
+// stream right after the last kernel that writes into it:
+//   0: [decoder begin, end)            1: [block depth-1 begin, decoder begin)  (with encoder.norm)
+//   1 + j: block depth-1-j, j = 1 .. depth-2          depth: [0, block 0 end)   (pos_queries, pos_embed, patch_embed, block 0)
+static int64_t grad_block_begin(const parseq_model* m, int i) { return (int64_t)m->params[m->index.at(m->enc + "blocks." + std::to_string(i) + ".norm1.weight")].offset; }
+static int grad_segment_range(const parseq_model* m, int k, int64_t* begin, int64_t* end) {
+    const int depth = m->cfg.enc_depth;
+    if (m->vitstr || depth < 2) return fail(PARSEQ_E_INVALID, "gradient segments are defined for the PARSeq training step (depth >= 2)");
+    if (k < 0 || k > depth) return fail(PARSEQ_E_INVALID, "gradient segment %d outside [0, %d]", k, depth);
+    const int64_t dec = (int64_t)m->params[m->index.at("decoder.layers.0.self_attn.in_proj_weight")].offset;
+    if (k == 0) { *begin = dec; *end = (int64_t)m->master_elems; }
+    else if (k == 1) { *begin = grad_block_begin(m, depth - 1); *end = dec; }
+    else if (k < depth) { *begin = grad_block_begin(m, depth - k); *end = grad_block_begin(m, depth - k + 1); }
+    else { *begin = 0; *end = grad_block_begin(m, 1); }
+    return 0;
+}
+static int grad_event_record(parseq_model* m, int k, hipStream_t s) {
+    while ((int)m->grad_events.size() <= m->cfg.enc_depth) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        m->grad_events.push_back(e);
+    }
+    HIPCHK(hipEventRecord(m->grad_events[k], s));
+    return 0;
+}
+extern "C" int parseq_train_grad_segments(const parseq_model* m) { return (m && !m->vitstr && m->cfg.enc_depth >= 2) ? m->cfg.enc_depth + 1 : 0; }
+extern "C" int parseq_train_grad_segment(parseq_model* m, int index, int64_t* begin, int64_t* end, void** event) {
+    if (!m || !begin || !end) return fail(PARSEQ_E_INVALID, "null argument");
+    CHK(grad_segment_range(m, index, begin, end));
+    if (event) {
+        if ((int)m->grad_events.size() <= index) return fail(PARSEQ_E_STATE, "gradient segment %d: no backward has recorded its event yet", index);
+        *event = (void*)m->grad_events[index];
+    }
+    return 0;
+}
+extern "C" int parseq_stream_wait_event(void* stream, void* event) {
+    if (!event) return fail(PARSEQ_E_INVALID, "null event");
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return 0;
+}
+
 extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int batch, float* grads, void* workspace, size_t workspace_bytes,
                                              void* stream) {
     if (!dmemory || !grads) return fail(PARSEQ_E_INVALID, "null argument");
@@ -766,8 +812,12 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
                     (shadows ? 1 : 0) | (only16 ? 2 : 0));
     bf16_t* d_x16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_x16) : nullptr;
     bf16_t* d_h16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_h16) : nullptr;
+    const bool segs = m->cfg.enc_depth >= 2;
+    if (segs) CHK(grad_event_record(m, 0, s));      // the decoder's gradients were written by parseq_train_decoder, earlier on this stream
     CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps, d_x16));
     for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
+        // block i + 1 (and, behind the last block, encoder.norm) is final: segment depth - 1 - i
+        if (segs && i < m->cfg.enc_depth - 1 && i >= 0) CHK(grad_event_record(m, m->cfg.enc_depth - 1 - i, s));
         const std::string p = "blocks." + std::to_string(i) + ".";
         float* x = w + o.x(i); float* qkv = x + o.qkv; float* ao = x + o.ao; float* x_mid = x + o.x_mid; float* hpre = x + o.hpre;
         if (shadows) {
@@ -808,7 +858,9 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps));          // d_x = d x
     }
     CHK(colsum(cx, d_x, (long)S * E, batch, S * E, G("pos_embed"), true));
-    return lin_bwd(cx, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK);
+    CHK(lin_bwd(cx, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK));
+    if (segs) CHK(grad_event_record(m, m->cfg.enc_depth, s));      // block 0, patch_embed, pos_embed (and pos_queries): everything is final
+    return 0;
 }
 
 // ---- training step, optimiser ---------------------------------------------------------------------------------------------

@@ -99,3 +99,36 @@ def average_gradients(flat: Tensor, group=None, bucket_elems: int = 6 * 1024 * 1
         w.wait()
     flat.mul_(1.0 / world)
     return flat
+
+
+def average_gradient_segments(flat: Tensor, segments, group=None, wait=None, comm_stream=None, force: bool = False) -> Tensor:
+    """`average_gradients` overlapped with the backward that is still producing `flat` (DDP's bucketed reducer, reference
+    train.py:65-71): `segments` = [(begin, end, event)] in the order the ranges of the flat gradient buffer become final
+    (parseq_train_grad_segment).  For each one, `wait(comm_stream, event)` makes the side stream wait for the segment's event
+    (parseq_stream_wait_event) and the segment's all-reduce is enqueued with that stream current — the collective's own stream
+    starts behind it, i.e. as soon as the bucket is final, while the main stream is still running the earlier blocks' backward.
+    The caller's current stream then waits for every collective and scales by 1 / world.  With `wait` / `comm_stream` None (CPU
+    tensors under gloo in the tests) the segments are reduced in order on the spot.  `force`: run the collectives in a one-rank group too."""
+    import contextlib
+
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1 and not force:
+        return flat
+    covered = sorted((b, e) for b, e, _ in segments)
+    if covered[0][0] != 0 or covered[-1][1] != flat.numel() or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
+        raise ValueError('gradient segments do not tile the flat buffer')
+    works = []
+    for begin, end, event in segments:
+        ctx = contextlib.nullcontext()
+        if comm_stream is not None:
+            if wait is not None and event is not None:
+                wait(comm_stream, event)
+            ctx = torch.cuda.stream(comm_stream)
+        with ctx:
+            works.append(dist.all_reduce(flat[begin:end], op=dist.ReduceOp.SUM, group=group, async_op=True))
+    for w in works:
+        w.wait()
+    if world > 1:
+        flat.mul_(1.0 / world)
+    return flat

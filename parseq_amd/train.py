@@ -54,6 +54,18 @@ def param_views(native_model, flat: Tensor, shapes: Dict[str, Sequence[int]]) ->
     return out
 
 
+def grad_segments(native_model):
+    """[(begin, end, event)] of the flat gradient buffer in the order the training step's backward finishes them
+    (parseq_train_grad_segment; valid after a parseq_train_encoder_backward on this model)."""
+    lib = _native.lib()
+    out = []
+    for k in range(lib.parseq_train_grad_segments(native_model)):
+        b, e, ev = C.c_int64(), C.c_int64(), C.c_void_p()
+        _native.check(lib.parseq_train_grad_segment(native_model, k, C.byref(b), C.byref(e), C.byref(ev)))
+        out.append((b.value, e.value, ev.value))
+    return out
+
+
 def loss_denominator(labels, num_perms: int) -> int:
     """Sum over the permutation passes of their count of non-<pad> targets (system.py:183-196), from the labels alone: every
     label contributes its characters plus <eos> to the first two passes and its characters only to the later ones."""
@@ -176,6 +188,9 @@ class TrainStep:
         self.pct_start = system.warmup_pct if warmup_pct is None else warmup_pct
         self.clip_val, self.betas, self.eps = clip_val, betas, eps
         self.process_group = process_group
+        self.overlap_allreduce = True       # segment-wise all-reduce behind the backward's events (False: one pass after the backward)
+        self.force_collectives = False      # run the collectives in a one-rank group too (self-test of the overlapped path on one GPU)
+        self._comm_stream = None
         self.step_count = 0
         lib = _native.lib()
         model = system.model
@@ -197,11 +212,20 @@ class TrainStep:
     def __call__(self, images: Tensor, labels, perms: Optional[Tensor] = None) -> Tensor:
         lib = _native.lib()
         system, model = self.system, self.system.model
-        res = loss_and_grads(system, images, labels, perms)
-        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            from .parallel import average_gradients
-            average_gradients(res.flat, self.process_group)
+        res = loss_and_grads(system, images, labels, perms)      # enqueued, not waited for: the device is still in the backward here
         native = model._sync_native().model
+        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            from .parallel import average_gradient_segments, average_gradients
+            if self.overlap_allreduce and res.flat.is_cuda and lib.parseq_train_grad_segments(native) > 0:
+                # the all-reduce of each gradient segment starts when the backward has finished writing it (events recorded by
+                # parseq_train_encoder_backward), on a side stream, while the earlier blocks' backward is still running
+                if self._comm_stream is None:
+                    self._comm_stream = torch.cuda.Stream(device=res.flat.device)
+                average_gradient_segments(res.flat, grad_segments(native), self.process_group,
+                                          wait=lambda st, ev: _native.check(lib.parseq_stream_wait_event(C.c_void_p(st.cuda_stream), C.c_void_p(ev))),
+                                          comm_stream=self._comm_stream, force=self.force_collectives)
+            else:
+                average_gradients(res.flat, self.process_group)
         stream = _native.stream_ptr(res.flat)
         norm = None
         if self.clip_val:

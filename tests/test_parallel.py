@@ -161,6 +161,46 @@ def test_two_rank_gloo_gradient_average():
     assert sorted(r[0] for r in results) == [0, 1] and all(r[1] for r in results)
 
 
+def _segment_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from parseq_amd.parallel import average_gradient_segments, average_gradients
+        n = 5000
+        mine = (torch.arange(n, dtype=torch.float32) % 97) * (rank + 1) + rank
+        ref = average_gradients(mine.clone(), bucket_elems=512)
+        # completion order of the training step's backward: the tail of the buffer first, then the middle ranges back to front, the head last
+        segs = [(4000, 5000, None), (3000, 4000, None), (2000, 3000, None), (700, 2000, None), (0, 700, None)]
+        out = average_gradient_segments(mine, segs)
+        ok = out.data_ptr() == mine.data_ptr() and torch.equal(out, ref)
+        try:
+            average_gradient_segments(mine.clone(), [(0, 700, None), (800, 5000, None)])     # a hole: refused before any collective is issued
+            ok = False
+        except ValueError:
+            pass
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_segments_equal_the_bucketed_average():
+    """The overlapped form of the data-parallel gradient step (parallel.average_gradient_segments: one all-reduce per gradient segment
+    in the order the backward finishes them — reference train.py:65-71, DDP's reducer) gives bit for bit what the one-pass bucketed
+    average gives, and refuses a segment list that does not tile the buffer."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_segment_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1] and all(r[1] for r in results)
+
+
 # ---- the real model + RCCL on two GPUs (skipped on a 1-GPU box: the driver's multi-GPU tier and any 2+-GPU box run it) ----
 
 def _nccl_worker(rank, world, port, q):
@@ -247,6 +287,8 @@ def test_bench_py_two_ranks_print_one_line_for_the_whole_job():
     assert d['config']['output_shape'] == [1024, 26, 95]                 # every rank ends a step holding the logits of all 1024 crops
     assert abs(d['value'] - 1024 * 3 / (d['ms_per_step'] * 3e-3)) <= 1e-3 * d['value']      # whole-job crops / max-over-ranks time
     assert 'stub' in d['data']                                           # and the line cannot be mistaken for a measurement
+    # the training leg's multi-rank form: every rank steps on its own 384-crop shard, rank 0 reports the whole job (configs[4]: 8 x 384)
+    assert d['train']['stub'] is True and d['train']['n_gpus'] == 2 and d['train']['global_batch'] == 768 and d['train']['value'] > 0
 
 
 def test_bench_py_refuses_a_world_size_that_contradicts_gpus():
@@ -265,3 +307,9 @@ def test_bench_py_force_dist_runs_the_rccl_path_on_one_gpu():
     assert len(lines) == 1, out
     d = lines[0]
     assert d['n_gpus'] == 1 and d['config']['output_shape'] == [512, 26, 95] and d['value'] > 0 and d['sequential_value'] > 0
+    # the same run without the process group: the collectives must not change a bit of the logits (two batches in flight in both)
+    rc2, lines2, out2, err2 = _bench_line(['--steps', '5', '--warmup', '2', '--repeats', '2', '--no-profile', '--no-cpu-baseline', '--no-parity', '--no-train',
+                                           '--no-natural-exit', '--no-throughput-mode'], {}, 900)
+    assert rc2 == 0 and len(lines2) == 1, err2
+    assert d['config']['steps_in_flight'] == lines2[0]['config']['steps_in_flight'] >= 2
+    assert d['output_sha256_16'] == lines2[0]['output_sha256_16'], (d['output_sha256_16'], lines2[0]['output_sha256_16'])

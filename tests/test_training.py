@@ -670,6 +670,61 @@ def test_large_batch_step_is_the_weighted_sum_of_its_halves():
 
 
 @pytest.mark.gpu
+def test_overlapped_allreduce_step_equals_the_plain_step():
+    """The data-parallel step with the gradient all-reduce riding behind the backward's events (TrainStep.overlap_allreduce: one RCCL
+    all-reduce per gradient segment on a side stream, started by the event parseq_train_encoder_backward records when that segment is
+    final — DDP's bucketed reducer, reference train.py:65-71) against the same step with no collective at all, on the one GPU a test box
+    has: a one-rank RCCL group with the collectives forced.  One rank's all-reduce is the identity, so loss and every updated weight must
+    agree bit for bit after two steps — which they only do if every segment was reduced after its last writer and before the optimiser
+    read it.  Also: the segments tile the flat buffer in the documented completion order and carry live events."""
+    import socket
+
+    import torch.distributed as dist
+    from gpu_util import DEV, make_model
+    from parseq_amd import _native
+    from parseq_amd.train import TrainStep, grad_segments
+    cfg = CONFIGS['parseq']
+    gen = torch.Generator().manual_seed(3)
+    B = 48
+    images = synth_images(B, cfg, seed=21).to(DEV)
+    lengths = torch.randint(1, 26, (B,), generator=gen).tolist()
+    lengths[0] = 25
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        runs = []
+        for overlapped in (True, False):
+            m = make_model('parseq', 'bf16')
+            m.train()
+            m.train_precision = 'bf16'
+            m.rng = np.random.default_rng(11)
+            torch.manual_seed(12)
+            step = TrainStep(m, total_steps=10)
+            step.overlap_allreduce, step.force_collectives = overlapped, overlapped
+            losses = [float(step(images, labels)) for _ in range(2)]
+            torch.cuda.synchronize()
+            runs.append((losses, {k: v.detach().clone() for k, v in m.model.state_dict().items()}, step))
+        (la, wa, sa), (lb, wb, _) = runs
+        assert la == lb, (la, lb)
+        assert all(torch.equal(wa[k], wb[k]) for k in wa), [k for k in wa if not torch.equal(wa[k], wb[k])][:5]
+        assert sa._comm_stream is not None                       # the overlapped path really ran
+        native = sa.system.model._sync_native().model
+        segs = grad_segments(native)
+        n = _native.lib().parseq_model_grad_elems(native)
+        assert len(segs) == cfg.enc_depth + 1 and all(ev for _, _, ev in segs)
+        assert segs[0][1] == n and segs[-1][0] == 0               # the decoder's part first, the head of the buffer last
+        assert [b for b, _, _ in segs] == sorted((b for b, _, _ in segs), reverse=True)      # back to front
+        assert all(a[0] == b[1] for a, b in zip(segs, segs[1:]))  # contiguous: they tile [0, n)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_bf16_operand_step_within_the_rounding_budget():
     """system.train_precision = 'bf16' (parseq_model_set_train_precision: both operands of every aligned Linear product rounded to
     bfloat16, fp32 accumulate, fp32 everything else — train_ops.h mfma_bgemm_kernel) on the batch-64 step whose Linears all take the
