@@ -246,7 +246,20 @@ def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
     mmac_img = 12 * 239.08 + 4.72 + (6 * 26 * (14 * E * E + 95 * E) + 128 * 2 * E * E) / 1e6
     tflop = 3 * 2 * mmac_img * 1e6 * batch / 1e12      # per GPU
     ms = 1e3 * el / steps
-    return {'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], {world} GPU' + ('s, gradient all-reduce over RCCL)' if world > 1 else ')'),
+    # the step's dominant kernel (the encoder's forward / dX products), from the committed kernel trace + counter pass of tools/train_bench.py
+    # (profiles/train_kernels.json: average launch time, launches per step, MFMA-busy) — bench.py does not re-profile the training step
+    roof = None
+    kpath = os.path.join(ROOT, 'profiles', 'train_kernels.json')
+    if os.path.exists(kpath):
+        rec = json.load(open(kpath)).get('mfma_bgemm16_kernel')
+        if rec and rec.get('batch') == batch:
+            fl = 2 * 12 * 2.0 * batch * 128 * (3 * E * E + E * E + 2 * 4 * E * E) / rec['launches_per_step']      # forward + dX of the four Linears, per launch
+            ach = fl / (rec['avg_us'] * 1e-6) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'mfma_bgemm16_kernel (encoder forward / dX products)', 'achieved': round(ach, 1), 'peak': PEAK['bf16'], 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK['bf16'], 4), 'avg_launch_us': rec['avg_us'], 'launches_per_step': rec['launches_per_step'],
+                    'share_of_step': rec.get('share'), 'mfma_busy_pct': rec.get('mfma_busy_pct'), 'source': rec.get('source')}
+    return {'roofline': roof,
+            'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], {world} GPU' + ('s, gradient all-reduce over RCCL)' if world > 1 else ')'),
             'value': round(world * batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
             'global_batch': world * batch, 'n_gpus': world,
             'dtype': 'bf16 operands (Linear and attention products), fp32 accumulate / master weights / LayerNorm / soft-max / loss / AdamW',

@@ -243,6 +243,51 @@ def test_bf16_operand_rounding_budget(train_golden):
     assert 1e-3 < rel[len(rel) // 2] < 2e-2 and rel[-1] < 6e-2 and min(cos) > 0.998
 
 
+def test_bf16_operand_budget_against_bf16_mixed_autocast(train_golden):
+    """The reference trains under `precision: bf16-mixed` (configs/main.yaml, train.py:62-64 — torch.autocast), where a Linear / matmul ROUNDS
+    ITS OUTPUT to bfloat16 as well as its operands.  The device's bf16-operand mode is gated by a budget against the EXACT fp32 backward
+    (test_bf16_operand_rounding_budget); this test holds that budget against what autocast itself does to the same step: autograd through
+    the oracle's training_loss under torch.autocast('cpu', bfloat16) — (1) the operand-rounding model is at least as close to the exact
+    gradients as autocast is (it keeps fp32 outputs), tensor by tensor in the median and in the worst case; (2) the two reduced-precision
+    gradients are as close to each other as their distances to the exact ones allow."""
+    from oracle import decoder_backward as DB, encoder_backward as EB
+    g, meta = train_golden
+    cfg = CONFIGS['parseq']
+    sd = synth_state_dict(cfg, 0)
+    tgt = Tokenizer(CHARSET_94).encode(meta['labels'])
+    perms = g['perms'].long()
+
+    def hand(rounding):
+        ctx = DB.rounding(rounding) if rounding else __import__('contextlib').nullcontext()
+        with torch.no_grad(), ctx:
+            memory, saved = EB.forward(sd, cfg, g['images'])
+            loss, _, grads, dmem = DB.loss_and_grads(sd, cfg, memory, tgt, perms, O.attn_masks_from_perm)
+            grads.update(EB.backward(sd, cfg, saved, dmem))
+        return float(loss), grads
+
+    exact_loss, exact = hand(None)
+    ours_loss, ours = hand('bf16')
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.autocast('cpu', dtype=torch.bfloat16):
+        ac_loss, _, _ = O.training_loss(leaf, cfg, g['images'], tgt, perms)
+    ac_loss.float().backward()
+    ac = {k: v.grad.float() for k, v in leaf.items() if v.grad is not None}
+    assert abs(float(ac_loss.detach()) - exact_loss) <= 2e-2 * exact_loss and abs(ours_loss - exact_loss) <= 5e-4 * exact_loss
+    rel = lambda a, b: float((a.double() - b.double()).norm() / a.double().norm())
+    ours_e, ac_e, between = [], [], []
+    for k, a in exact.items():
+        if float(a.double().norm()) < 1e-7 or k not in ac:
+            continue
+        ours_e.append(rel(a, ours[k])); ac_e.append(rel(a, ac[k])); between.append(rel(ac[k], ours[k]))
+    assert len(ours_e) >= 170
+    med = lambda v: sorted(v)[len(v) // 2]
+    print(f'bf16-operand vs exact: median {med(ours_e):.2e} worst {max(ours_e):.2e}; autocast vs exact: median {med(ac_e):.2e} worst {max(ac_e):.2e}; '
+          f'between them: median {med(between):.2e} worst {max(between):.2e}')
+    assert med(ours_e) <= med(ac_e) and max(ours_e) <= max(ac_e)                 # (1): never looser than the reference's own precision mode
+    assert med(ours_e) < 2e-2 and max(ours_e) < 6e-2                             # the budget the device gate uses
+    assert all(b <= 1.5 * (o + a) + 1e-6 for b, o, a in zip(between, ours_e, ac_e))      # (2): triangle inequality with slack for the norm's base
+
+
 def _autograd_decoder_loss(sd, cfg, memory, tgt, perms, drop):
     """The training loss with dropout masks from `drop`, written with plain differentiable torch ops (F.layer_norm, F.softmax,
     F.gelu, F.embedding) — independent of the operator code in oracle/decoder_backward.py — for autograd to differentiate."""
