@@ -303,7 +303,8 @@ def main():
     ap.add_argument('--no-train', action='store_true', help='skip the short training-step leg (SURVEY.md section 8f row N3 / BASELINE.json configs[4]) reported as "train"')
     ap.add_argument('--force-dist', action='store_true', help='self-test: initialise the RCCL process group and run the collectives even with one rank')
     ap.add_argument('--repeats', type=int, default=5, help='repetitions of the K-step timed region; the median is reported, min / max alongside')
-    ap.add_argument('--streams', type=int, default=2, help='batches in flight for `value` (independent workspaces on separate HIP streams); '
+    ap.add_argument('--streams', type=int, default=3, help='batches in flight for `value` (independent workspaces on separate HIP streams; three measured best on one MI355X: '
+                    '57.0 k vs 54.7 k with two or four in the exact mode, 128.7 k vs 121 k in bf16 — profiles/r04_streams_sweep.md); '
                     'the one-call-at-a-time figure is always measured too and reported as sequential_value')
     args = ap.parse_args()
 
