@@ -115,7 +115,26 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
         # differing position (a first divergence at a margin above 2e-3 would be a real failure).
         top2 = ref[:, :L].topk(2, -1).values
         margin = (top2[..., 0] - top2[..., 1])
+        # AR decoding decides in the AR pass: a flip there changes the refinement's cloze context of EVERY position, so the causal divergence of a
+        # crop is looked for in the AR-stage logits (the same two models with refine_iters = 0) first and in the refined logits only if those agree
+        ar_margin, ar_first = None, {}
+        if model.model.decode_ar and model.model.refine_iters > 0:
+            keep = model.model.refine_iters, fp32.model.refine_iters
+            try:
+                model.model.refine_iters = fp32.model.refine_iters = 0
+                ga, ra = model(x, 25).float(), fp32(x.float(), 25).float()
+            finally:
+                model.model.refine_iters, fp32.model.refine_iters = keep
+            t2 = ra.topk(2, -1).values
+            ar_margin = t2[..., 0] - t2[..., 1]
+            dar = ga.argmax(-1) != ra.argmax(-1)
+            for i in torch.nonzero(dar.any(-1)).flatten().tolist():
+                pos = int(torch.nonzero(dar[i]).flatten()[0])
+                ar_first[i] = {'crop': i, 'stage': 'AR pass', 'position': pos, 'fp32_margin': round(float(ar_margin[i, pos]), 8),
+                               'abs_diff_there': round(float((ga[i, pos] - ra[i, pos]).abs().max()), 8)}
         decidable = margin.min(-1).values > 2e-3
+        if ar_margin is not None:
+            decidable &= ar_margin.min(-1).values > 2e-3
         nd = int(decidable.sum())
         out['decidable_crops'] = nd
         if nd:
@@ -125,9 +144,12 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
             out['strings_agree_decidable'] = round(sum(a == b for a, b, d_ in zip(s_got, s_ref, decidable.tolist()) if d_) / nd, 6)
         diff = (got[:, :L].argmax(-1) != ref[:, :L].argmax(-1))
         firsts = []
-        for i in torch.nonzero(diff.any(-1)).flatten().tolist():
+        for i in sorted(set(torch.nonzero(diff.any(-1)).flatten().tolist()) | set(ar_first)):
+            if i in ar_first:
+                firsts.append(ar_first[i])
+                continue
             pos = int(torch.nonzero(diff[i]).flatten()[0])
-            firsts.append({'crop': i, 'position': pos, 'fp32_margin': round(float(margin[i, pos]), 8),
+            firsts.append({'crop': i, 'stage': 'final logits', 'position': pos, 'fp32_margin': round(float(margin[i, pos]), 8),
                            'abs_diff_there': round(float((got[i, pos] - ref[i, pos]).abs().max()), 8)})
         out['first_divergences'] = firsts[:8]
         out['divergences_at_near_ties_only'] = all(f['fp32_margin'] <= 2e-3 for f in firsts)
