@@ -94,6 +94,7 @@ __device__ __forceinline__ void mma3_1(f32x4& c, const bf16x8& ah, const bf16x8&
 #endif
 #ifndef X3_ISSUE_MODE
 #define X3_ISSUE_MODE 0        // LDS-DMA pieces of a later pair: 0 = a stage's four at each stage boundary, 1 = all eight at the pair's start, 2 = one per two positions (12 MFMAs)
+                               // (staggering the four waves' issue positions was measured 6 - 17 % slower: profiles/r04_x3_encoder_variants.md)
 #endif
 #ifndef X3_VOFF_RECOMPUTE
 #define X3_VOFF_RECOMPUTE 0    // 1: the per-lane DMA offsets are recomputed at every stage issue instead of living in three registers
