@@ -364,7 +364,7 @@ class PARSeq(_NativeBacked):
         self.max_label_length = max_label_length
         self.decode_ar = decode_ar
         self.refine_iters = refine_iters
-        self.precision = precision or os.environ.get('PARSEQ_AMD_PRECISION', 'bf16')
+        self.precision = precision or os.environ.get('PARSEQ_AMD_PRECISION', 'bf16x3')      # the mode that meets the reference within 1e-3; 'bf16' = throughput mode
         self._cfg = dict(num_tokens=num_tokens, img_size=tuple(img_size), patch_size=tuple(patch_size), embed_dim=embed_dim,
                          enc_num_heads=enc_num_heads, enc_mlp_ratio=enc_mlp_ratio, enc_depth=enc_depth,
                          dec_num_heads=dec_num_heads, dec_mlp_ratio=dec_mlp_ratio, dec_depth=dec_depth)

@@ -31,7 +31,7 @@ class Model(_NativeBacked):
         if not qkv_bias:
             raise ValueError('qkv_bias=False is not supported (the reference always passes True)')
         self.num_classes = num_classes
-        self.precision = precision or os.environ.get('PARSEQ_AMD_PRECISION', 'bf16')
+        self.precision = precision or os.environ.get('PARSEQ_AMD_PRECISION', 'bf16x3')      # the mode that meets the reference within 1e-3; 'bf16' = throughput mode
         self._cfg = dict(img_size=tuple(img_size), patch_size=tuple(patch_size), embed_dim=embed_dim, depth=depth,
                          num_heads=num_heads, mlp_ratio=mlp_ratio)
         n_tok = (img_size[0] // patch_size[0]) * (img_size[1] // patch_size[1])
