@@ -671,232 +671,6 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
     }
 }
 
-// ---- MLP phase, software-pipelined over the hidden chunks (X3_MLP_PIPE) ---------------------------------------------------------------
-// The exact-erf GELU of a chunk is ~2 k cycles of VALU / transcendental work that, in mlp_phase, runs as two blocks with the matrix pipe idle
-// (the kernel's largest removable item: -6.9 % without it).  One in-order wave can co-issue about one VALU instruction — and a transcendental at
-// a tenth of its stand-alone cost — behind every MFMA (tools/microbench/mfma_chain.hip), but only work that does not depend on the MFMAs around
-// it.  So the chunks are pipelined: fc1 of chunk c + 1 runs BEFORE fc2 of chunk c, and the GELU of chunk c rides in fc1(c + 1)'s MFMA stream:
-//     fc1(0) | read-out(0) | { fc1(c + 1) with GELU(c) riding ; fc2(c) ; read-out(c + 1) } for c = 0 .. NCH - 2 | GELU(NCH - 1) ; fc2(NCH - 1)
-// read-out: the chunk's 32 pre-activations per lane (+ bias) leave the accumulators for VGPRs, so that fc1(c + 1) can reuse the chunk accumulators.
-// Same products in the same order per accumulator: bit-identical to mlp_phase.  Pair g of the phase lives in ring group g % RING (RING = 3: pairs of
-// the loop body sit in group w % 3, w = 0 .. 5) and is issued D = RING - 1 pairs ahead; its weights: g < 3: fc1(0), r = g; g = 3 + 6 b + w:
-// b < NCH - 1 ? (w < 3 ? fc1(b + 1), r = w : fc2(b), r = w) : fc2(NCH - 1), r = 3 + w.
-#ifndef X3_MLP_PIPE
-#define X3_MLP_PIPE 0
-#endif
-#ifndef X3_FILL_VALU
-#define X3_FILL_VALU 2         // VALU / transcendental instructions requested behind each MFMA of a position group that carries GELU work
-#endif
-// The exact-erf GELU of an element pair (common.h gelu_erf / fast_erf, operation for operation) in three slices of ~10 instructions, one per
-// position of a pair of stages, so that every slice sits behind six MFMAs of its own: A = argument, reciprocal, exponential (the four
-// transcendentals), B = the degree-4 polynomial in t, C = erf, GELU and the hi / lo split.  The state between slices is pinned to its position's
-// scheduling region by an empty volatile asm (instruction selection would otherwise sink the whole chain to its first use).
-struct GeluPairState { float x[2], z[2], t[2], e[2], p[2]; };
-__device__ __forceinline__ void gelu_slice_a(GeluPairState& g, float x0, float x1) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        g.x[i] = i ? x1 : x0;
-        g.z[i] = g.x[i] * 0.70710678118654752440f;
-        const float ax = fabsf(g.z[i]);
-        g.t[i] = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-        g.e[i] = __expf(-ax * ax);
-    }
-}
-__device__ __forceinline__ void gelu_slice_b(GeluPairState& g) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        float p = fmaf(1.061405429f, g.t[i], -1.453152027f);
-        p = fmaf(p, g.t[i], 1.421413741f);
-        p = fmaf(p, g.t[i], -0.284496736f);
-        g.p[i] = fmaf(p, g.t[i], 0.254829592f);
-    }
-}
-__device__ __forceinline__ void gelu_slice_c(const GeluPairState& g, unsigned& hi, unsigned& lo) {
-    float v[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const float r = 1.0f - g.p[i] * g.t[i] * g.e[i];
-        v[i] = 0.5f * g.x[i] * (1.0f + copysignf(r, g.z[i]));
-    }
-    typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2_t;
-    bf16x2_t h, l;
-    h[0] = static_cast<bf16_t>(v[0]); h[1] = static_cast<bf16_t>(v[1]);
-    l[0] = static_cast<bf16_t>(v[0] - static_cast<float>(h[0])); l[1] = static_cast<bf16_t>(v[1] - static_cast<float>(h[1]));
-    hi = __builtin_bit_cast(unsigned, h); lo = __builtin_bit_cast(unsigned, l);
-}
-template <int SLICE> __device__ __forceinline__ void pin_state(GeluPairState& g) {
-    if constexpr (SLICE == 0) asm volatile("" : "+v"(g.z[0]), "+v"(g.z[1]), "+v"(g.t[0]), "+v"(g.t[1]), "+v"(g.e[0]), "+v"(g.e[1]));
-    else asm volatile("" : "+v"(g.p[0]), "+v"(g.p[1]));
-}
-// run_pair with VALU work riding in the MFMA stream: fill(n), n = 0 .. 15 (an integral_constant), is called at the start of position n — a slice of
-// work that does not depend on this pair's MFMAs — and returns a callable that pins the slice's results to the position's scheduling region.
-template <int AHEAD = 2, class Mma, class Issue, class Fill>
-__device__ __forceinline__ void run_pair_fill(const unsigned char* grp, Mma&& mma, Issue&& issue, Fill&& fill) {
-    const unsigned char* st0 = grp; const unsigned char* st1 = grp + STAGE;
-    const int ln = opaque_lane();
-    const int fo0 = stage_frag_off(ln), fo1 = fo0 ^ 64;
-    constexpr int NB = AHEAD + 1;
-    bf16x8 wh[NB], wl[NB];
-    static_for<0, AHEAD>([&](auto nc) {
-        constexpr int n = decltype(nc)::value;
-        wh[n] = *reinterpret_cast<const bf16x8*>(st0 + n * 2048 + fo0); wl[n] = *reinterpret_cast<const bf16x8*>(st0 + n * 2048 + fo1);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, 16>([&](auto nc) {
-        constexpr int n = decltype(nc)::value, s = n >> 3, i = n & 7, nn = n + AHEAD;
-        if constexpr (i == 0) { issue(s, -1); __builtin_amdgcn_sched_barrier(0); }
-        auto done = fill(nc);
-        if constexpr (nn < 16) {
-            const unsigned char* src = ((nn >> 3) ? st1 : st0) + (nn & 7) * 2048;
-            wh[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo0);
-            wl[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo1);
-        }
-        mma(s, i, wh[n % NB], wl[n % NB]);
-        done();
-        static_for<0, 2>([&](auto) {
-            if constexpr (nn < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            static_for<0, 3>([&](auto) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x402, X3_FILL_VALU, 0);
-            });
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    });
-}
-
-template <int E, int RING, int AHEAD>
-__device__ __forceinline__ void mlp_phase_pipe(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
-                                               const StreamLaneX& sl, int wid, const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32],
-                                               f32x4 (&acc2)[E / 16][2], const unsigned char* al1_lds = nullptr) {
-    constexpr int F = 4 * E, NCH = F / 64, D = RING - 1;
-    static_assert(E == 384 && RING == 3, "written for E = 384 and three pair groups");
-    const int g16 = opaque_lane() >> 4;
-    // the wave's LDS-DMA pieces of stage s of the pair that is fc1 (r < 3) / fc2 (r >= 3) pair r of chunk c, into ring group `grp`
-    auto issue_pair = [&](int grp, int c, int r, int s, int q) {
-        unsigned char* dst = ring + grp * PAIRB + s * STAGE + wid * 4096;
-        if (r < 3) issue_stage(wrsrc, sl.template voff<0>(), (w1_off + (unsigned)(c * 64 * E + (2 * r + s) * 64)) * 4u, 4u * E, dst, q);
-        else {
-            const int t = 2 * (r - 3) + s, kb = t / 3, ng = t - 3 * kb;
-            issue_stage(wrsrc, sl.template voff<2>(), (w2_off + (unsigned)(ng * 128 * F + c * 64 + kb * 32)) * 4u, 4u * F, dst, q);
-        }
-    };
-    f32x4 acc1[4][2];
-    auto zero_acc1 = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+a"(acc1[i][0]), "+a"(acc1[i][1]));      // the chunk accumulators belong in the accumulator half of the file
-        }
-    };
-    float pre[2][2][8];        // [k-block of fc2][row tile][element]: the chunk's pre-activations + bias, in gelu_frag's element order
-    auto read_out = [&](int c) {
-        const float* bp = sb1 + c * 64 + 8 * g16;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pre[kb][j][e] = acc1[2 * kb + (e >> 2)][j][e & 3] + bp[32 * kb + e];
-    };
-    u32x4 hh[2][2], hl[2][2];  // [k-block][row tile]: GELU'd hidden fragments of the chunk whose fc2 runs next
-    GeluPairState gs, gs15;    // the element pair whose GELU is in flight, and the sixteenth pair (one slice per fc1 pair)
-    auto fc1_mma = [&](int r, const bf16x8 (&l1)[4]) {
-        return [&, r](int s, int i, const bf16x8& wh, const bf16x8& wl) {
-            const int kb = 4 * r + 2 * s + (i >> 2);
-            if (al1_lds != nullptr) mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], l1[2 * s + (i >> 2)]);
-            else mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
-        };
-    };
-    auto load_l1 = [&](int r, bf16x8 (&l1)[4]) {
-        if (al1_lds != nullptr) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) l1[q] = *reinterpret_cast<const bf16x8*>(al1_lds + (4 * r + q) * 1024);
-        }
-    };
-    auto fc2_mma = [&](int r) {
-        return [&, r](int s, int i, const bf16x8& wh, const bf16x8& wl) {
-            const int t = 2 * (r - 3) + s, kb = t / 3, ng = t % 3;
-            mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, __builtin_bit_cast(bf16x8, hh[kb][0]), __builtin_bit_cast(bf16x8, hl[kb][0]),
-                   __builtin_bit_cast(bf16x8, hh[kb][1]), __builtin_bit_cast(bf16x8, hl[kb][1]));
-        };
-    };
-    // ---- prologue: fc1 of chunk 0 (pairs 0 .. 2 of the phase; 0 and 1 were prefetched), issuing pairs 2 .. 4 = fc1(0) r = 2, fc1(1) r = 0, 1
-    zero_acc1();
-    static_for<0, 3>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        x3_wait_vmcnt<8 * (D - 1)>();
-        pair_fence();
-        bf16x8 l1[4];
-        load_l1(r, l1);
-        run_pair<AHEAD>(ring + (r % RING) * PAIRB, fc1_mma(r, l1),
-                        [&](int s, int q) { if constexpr (r == 0) issue_pair(2, 0, 2, s, q); else issue_pair((r + D) % RING, 1, r - 1, s, q); });
-    });
-    read_out(0);
-    zero_acc1();
-    for (int b = 0; b < NCH - 1; ++b) {
-        const bool last = b + 1 == NCH - 1;       // the pairs after this iteration's are the closing fc2(NCH - 1)
-        // ---- fc1 of chunk b + 1 (pairs w = 0 .. 2 of the iteration) with the GELU of chunk b riding: 16 element pairs, 6 + 5 + 5 over the three pairs
-        static_for<0, 3>([&](auto wc) {
-            constexpr int w = decltype(wc)::value;
-            x3_wait_vmcnt<8 * (D - 1)>();
-            pair_fence();
-            bf16x8 l1[4];
-            load_l1(w, l1);
-            // pair w + 2 of the iteration: w = 0: fc1(b + 1) r = 2; w = 1, 2: fc2(b) r = 3, 4
-            auto issue = [&](int s, int q) { if constexpr (w == 0) issue_pair(2, b + 1, 2, s, q); else issue_pair((w + D) % RING, b, w + 2, s, q); };
-            // positions 0 .. 14: element pair 5 w + n / 3 of the chunk's sixteen, slice n % 3; position 15: slice w of the sixteenth pair
-            run_pair_fill<AHEAD>(ring + (w % RING) * PAIRB, fc1_mma(w, l1), issue, [&](auto nc) {
-                constexpr int n = decltype(nc)::value;
-                constexpr int ep = n < 15 ? 5 * w + n / 3 : 15, slice = n < 15 ? n % 3 : w;
-                constexpr int kb = ep >> 3, j = (ep >> 2) & 1, dw = ep & 3;
-                GeluPairState& g = n < 15 ? gs : gs15;
-                unsigned hi_ = 0, lo_ = 0;
-                if constexpr (slice == 0) gelu_slice_a(g, pre[kb][j][2 * dw], pre[kb][j][2 * dw + 1]);
-                else if constexpr (slice == 1) gelu_slice_b(g);
-                else gelu_slice_c(g, hi_, lo_);
-                return [&g, &hh, &hl, hi_, lo_]() mutable {
-                    if constexpr (slice == 2) {
-                        asm volatile("" : "+v"(hi_), "+v"(lo_));
-                        hh[kb][j][dw] = hi_; hl[kb][j][dw] = lo_;
-                    } else pin_state<slice>(g);
-                };
-            });
-        });
-        // ---- fc2 of chunk b (pairs w = 3 .. 5), issuing fc2(b) r = 5 and then the next iteration's fc1(b + 2) r = 0, 1 — or, after the last
-        // iteration, the closing fc2(NCH - 1) r = 3, 4
-        static_for<3, 6>([&](auto wc) {
-            constexpr int w = decltype(wc)::value;
-            x3_wait_vmcnt<8 * (D - 1)>();
-            pair_fence();
-            auto issue = [&](int s, int q) {
-                if constexpr (w == 3) issue_pair(2, b, 5, s, q);
-                else if (last) issue_pair((w + D) % RING, NCH - 1, w - 1, s, q);      // w = 4, 5 -> r = 3, 4 in groups 0, 1
-                else issue_pair((w + D) % RING, b + 2, w - 4, s, q);                  // w = 4, 5 -> fc1(b + 2) r = 0, 1
-            };
-            run_pair<AHEAD>(ring + (w % RING) * PAIRB, fc2_mma(w), issue);
-        });
-        read_out(b + 1);
-        zero_acc1();
-    }
-    // ---- closing: GELU of the last chunk as a block, then its fc2 (pairs 0 .. 2 after the loop, groups 0 .. 2; r = 3, 4 are in flight, r = 5 goes out now)
-#pragma unroll
-    for (int ep = 0; ep < 16; ++ep) {
-        const int kb = ep >> 3, j = (ep >> 2) & 1, dw = ep & 3;
-        unsigned hi_, lo_;
-        GeluPairState g;
-        gelu_slice_a(g, pre[kb][j][2 * dw], pre[kb][j][2 * dw + 1]);
-        gelu_slice_b(g);
-        gelu_slice_c(g, hi_, lo_);
-        hh[kb][j][dw] = hi_; hl[kb][j][dw] = lo_;
-    }
-    static_for<0, 3>([&](auto ec) {
-        constexpr int e = decltype(ec)::value;
-        x3_wait_vmcnt<8 * ((2 - e) < (D - 1) ? (2 - e) : (D - 1))>();
-        pair_fence();
-        run_pair<AHEAD>(ring + (e % RING) * PAIRB, fc2_mma(3 + e), [&](int s, int q) { if constexpr (e == 0) issue_pair(2, NCH - 1, 5, s, q); });
-    });
-}
-
 // ---- head: x = patches W_pe^T + (pos_embed + bias) in the bf16x3 arithmetic (encoder_blocks.h patch_head, three products) ---------
 // 32 x 128 crops, (4, 8) patches: k-block c of a patch row is channel c's 4 x 8 pixels, and a lane's eight k-slots of it (8 g + [0, 8))
 // are ONE run of eight pixels — row 4 gy + g, columns 8 gx .. 8 gx + 7.  The 384 x 96 weight is nine stages of the pack (three 128-row
@@ -1142,11 +916,7 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 #ifdef X3_MARK
         asm volatile("; X3MARK MLP");
 #endif
-#if X3_MLP_PIPE
-        mlp_phase_pipe<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc);
-#else
         mlp_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc);
-#endif
 #ifdef X3_MARK
         asm volatile("; X3MARK MLPEND");
 #endif
