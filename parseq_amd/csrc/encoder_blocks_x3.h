@@ -96,6 +96,24 @@ __device__ __forceinline__ void mma3_1(f32x4& c, const bf16x8& ah, const bf16x8&
 #define X3_ISSUE_MODE 0        // LDS-DMA pieces of a later pair: 0 = a stage's four at each stage boundary, 1 = all eight at the pair's start, 2 = one per two positions (12 MFMAs)
                                // (staggering the four waves' issue positions was measured 6 - 17 % slower: profiles/r04_x3_encoder_variants.md)
 #endif
+// X3_TIMERS=1 (tools/x3_variants.sh builds only): every wave accumulates s_memtime ticks per phase of the kernel and stores them over its image's rows of x
+// (free after the first load; tools/x3_variant_bench.py --timers reads them back).  Slots: 0 parameters + LayerNorm 1, 1 park, 2 head loop: q / k / v pairs,
+// 3 head loop: q / k / v epilogues (bias, split, K / V^T images), 4 head loop: S, soft-max, P V, O stores, 5 unpark + O reload, 6 proj, 7 parameters + LayerNorm 2,
+// 8 MLP: fc1 pairs, 9 MLP: GELU blocks, 10 MLP: fc2 pairs, 11 tail, 12 biases / everything else.  The s_memtime reads wait for lgkmcnt(0): the timed build is ~1 % slower.
+#ifndef X3_TIMERS
+#define X3_TIMERS 0
+#endif
+#if X3_TIMERS
+struct X3Timers { long long acc[13]; long long last; };
+__device__ __forceinline__ void x3_tick(X3Timers& t, int slot) { const long long now = clock64(); t.acc[slot] += now - t.last; t.last = now; }
+#define X3_TICK(slot) x3_tick(*x3t, slot)
+#define X3_TARG , X3Timers* x3t
+#define X3_TPASS , x3t
+#else
+#define X3_TICK(slot)
+#define X3_TARG
+#define X3_TPASS
+#endif
 #ifndef X3_VOFF_RECOMPUTE
 #define X3_VOFF_RECOMPUTE 0    // 1: the per-lane DMA offsets are recomputed at every stage issue instead of living in three registers
 #endif
@@ -298,7 +316,7 @@ __device__ __forceinline__ void heads_prefetch(const StreamLaneX& sl, unsigned c
 template <int E, int AHEAD>
 __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* img, const float* sbq, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off,
                                             float scale, const StreamLaneX& sl, int wid, int tid, const bf16x8 (&ah)[2][E / 32],
-                                            const bf16x8 (&al)[2][E / 32], float* __restrict__ obuf) {
+                                            const bf16x8 (&al)[2][E / 32], float* __restrict__ obuf X3_TARG) {
     constexpr int H = E / 64;
     static_assert(E == 384, "written for E = 384");
     unsigned char* kimg_h = img; unsigned char* kimg_l = img + KIMG_B;
@@ -333,6 +351,7 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                     mma3_a(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
             }
+            X3_TICK(2);
             if constexpr (u < 2 && pp == 2) {
                 // q -> fragments, k -> the K image planes (rows in the order the P fragments need: encoder_attn_fused.h)
                 const int ln = opaque_lane();
@@ -358,6 +377,7 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                             *reinterpret_cast<bf16x8*>(kimg_l + off) = fl;
                         }
                     }
+                X3_TICK(3);
             } else if constexpr (u == 2 && pp == 2) {
                 const int ln = opaque_lane();
                 const int rr = ln & 15, g = ln >> 4;
@@ -381,6 +401,7 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                X3_TICK(3);
 #if X3_SOFTMAX_JOINT
                 // S^T = K Q^T, soft-max, O^T = V^T P^T for both 16-query row tiles at once: every K / V^T fragment is read once
                 f32x4 sc[2][8];
@@ -539,7 +560,8 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                     }
                 }
 #endif
-            }
+                X3_TICK(4);
+            } else { X3_TICK(3); }
         });
     }
 }
@@ -621,7 +643,7 @@ __device__ __forceinline__ void gelu_frag(const f32x4 (&acc1)[4][2], const float
 template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
                                           const StreamLaneX& sl, int wid, const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32],
-                                          f32x4 (&acc2)[E / 16][2], const unsigned char* al1_lds = nullptr) {
+                                          f32x4 (&acc2)[E / 16][2] X3_TARG, const unsigned char* al1_lds = nullptr) {
     constexpr int F = 4 * E, NCH = F / 64, D = RING - 1;
     static_assert(E == 384 && (RING == 3 || RING == 4), "written for E = 384");
     for (int c = 0; c < NCH; ++c) {
@@ -644,7 +666,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                 if constexpr (r + D < 6) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c, r + D, s, q);
                 else if (!last) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, r + D - 6, s, q);
             };
-            auto mid = [&]() { if constexpr (r == 4) gelu_frag(acc1, bp, 1, hh, hl); };      // (k-block 0, row group 2) was stage 0 of pair 4
+            auto mid = [&]() { if constexpr (r == 4) { X3_TICK(10); gelu_frag(acc1, bp, 1, hh, hl); X3_TICK(9); } };      // (k-block 0, row group 2) was stage 0 of pair 4
             const unsigned char* grp = ring + ((6 * c + r) % RING) * PAIRB;
             if constexpr (r < 3) {
                 if (al1_lds != nullptr) {
@@ -666,7 +688,8 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                     mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
                 }, issue, mid);
             }
-            if constexpr (r == 2) gelu_frag(acc1, bp, 0, hh, hl);
+            if constexpr (r < 3) { X3_TICK(8); } else { X3_TICK(10); }
+            if constexpr (r == 2) { gelu_frag(acc1, bp, 0, hh, hl); X3_TICK(9); }
         });
     }
 }
@@ -846,6 +869,12 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 
     f32x4 acc[E / 16][2];
     bf16x8 ah[2][E / 32], al[2][E / 32];
+#if X3_TIMERS
+    X3Timers x3t_storage; X3Timers* x3t = &x3t_storage;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x3t->acc[i] = 0;
+    x3t->last = clock64();
+#endif
     if (head.images) patch_head_x3<E>(head, ring, wrsrc, wid, lane, blockIdx.x, acc);
     else load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
     float* xbuf = scratch + (size_t)blockIdx.x * (2 * 48 * 1024);      // 48 pieces x 256 lanes x 4 floats: the parked residual stream
@@ -865,14 +894,16 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
         asm volatile("; X3MARK LN1");
 #endif
         ln_acc_to_frag<E>(acc, sph + 4 * E, sph + 5 * E, eps, g, ah, al);
+        X3_TICK(0);
 #ifdef X3_MARK
         asm volatile("; X3MARK PARK");
 #endif
         if constexpr ((X3_ABLATE & 8) == 0) park_acc<E>(acc, xbuf, tid);
+        X3_TICK(1);
 #ifdef X3_MARK
         asm volatile("; X3MARK HEADS");
 #endif
-        heads_phase<E, X3_AHEAD>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, wid, tid, ah, al, obuf);
+        heads_phase<E, X3_AHEAD>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, wid, tid, ah, al, obuf X3_TPASS);
         // ---- attention branch, proj: x and the O fragments come back (each lane re-reads what it wrote)
         __syncthreads();                                                // every wave is done with the K / V^T images and the ring
 #ifdef X3_MARK
@@ -893,11 +924,14 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
                 ah[j][kb] = *reinterpret_cast<const bf16x8*>(o);
                 al[j][kb] = *reinterpret_cast<const bf16x8*>(o + 256 * 4);
             }
+        X3_TICK(5);
 #ifdef X3_MARK
         asm volatile("; X3MARK PROJ");
 #endif
         proj_phase<E, X3_MLP_RING, X3_AHEAD>(ring, wrsrc, bp->wproj, sl, wid, ah, al, acc);
+        X3_TICK(6);
         add_bias_to_acc<E>(sph + 3 * E, g, acc);
+        X3_TICK(12);
         // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
         __syncthreads();
 #ifdef X3_MARK
@@ -913,14 +947,16 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
         asm volatile("; X3MARK LN2");
 #endif
         ln_acc_to_frag<E>(acc, sp + F + E, sp + F + 2 * E, eps, g, ah, al);
+        X3_TICK(7);
 #ifdef X3_MARK
         asm volatile("; X3MARK MLP");
 #endif
-        mlp_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc);
+        mlp_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc X3_TPASS);
 #ifdef X3_MARK
         asm volatile("; X3MARK MLPEND");
 #endif
         add_bias_to_acc<E>(sp + F, g, acc);
+        X3_TICK(12);
     }
     if (tail.kmem == nullptr) {
         store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
@@ -935,6 +971,13 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
     __syncthreads();
     ln_acc_to_frag<E>(acc, sp + 2 * E, sp + 3 * E, eps, g, ah, al);
     kv_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, tail.plane_elems, ah, al);
+#if X3_TIMERS
+    X3_TICK(11);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) reinterpret_cast<long long*>(x + ((size_t)m0 + 32 * wid) * E)[i] = x3t->acc[i];
+    }
+#endif
 }
 
 template <int E>

@@ -44,6 +44,9 @@ table = torch.empty(depth * 48, dtype=torch.uint8, device=DEV)
 scratch = torch.empty(images * 393216 // 4, dtype=torch.float32, device=DEV)
 x0 = torch.randn(M, E, generator=g).to(DEV)
 kmem = torch.empty(images, 12, 128, 32, device=DEV); vmem = torch.empty_like(kmem)
+TIMERS = '--timers' in sys.argv       # the named build was compiled with -DX3_TIMERS=1: print its per-phase s_memtime ticks (encoder_blocks_x3.h X3_TIMERS)
+if TIMERS:
+    sys.argv.remove('--timers')
 names = sys.argv[1:] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
 libs = {}
 for n in names:
@@ -80,3 +83,17 @@ print(f'| build | median ms | min ms | max|dK| vs {names[0]} |\n|---|---:|---:|-
 for n in names:
     t = sorted(times[n])
     print(f'| {n} | {t[len(t) // 2]:.3f} | {t[0]:.3f} | {diffs[n]:.3e} |')
+
+if TIMERS:
+    SLOTS = ['parameters + LayerNorm 1', 'park', 'head loop: q / k / v pairs', 'head loop: q / k / v epilogues', 'head loop: S, soft-max, P V, O stores', 'unpark + O reload', 'proj',
+             'parameters + LayerNorm 2', 'MLP: fc1 pairs', 'MLP: GELU blocks', 'MLP: fc2 pairs', 'tail (final LayerNorm + K | V)', 'biases / rest']
+    n = names[-1]
+    x = x0.clone()
+    r = libs[n].x3_variant_run(nat.ptr(x), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32, nat.ptr(kmem), nat.ptr(vmem), nat.stream_ptr())
+    torch.cuda.synchronize()
+    t = x.view(torch.int64).view(M, E // 2)[torch.arange(images * 4, device=DEV) * 32][:, :13].double()      # one row of 13 counters per wave
+    tot = t.sum(1)
+    print(f'\n| phase of `enc_blocks_x3_kernel` (build {n}, mean over {t.shape[0]} waves) | s_memtime ticks per wave | share |\n|---|---:|---:|')
+    for i, name in enumerate(SLOTS):
+        print(f'| {name} | {t[:, i].mean():,.0f} | {100 * t[:, i].sum() / tot.sum():.1f} % |')
+    print(f'| total | {tot.mean():,.0f} | (min {tot.min():,.0f}, max {tot.max():,.0f}) |')
