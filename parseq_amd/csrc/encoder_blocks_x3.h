@@ -11,9 +11,10 @@
 //     lane's offset, lo fragment at offset ^ 64 — instead of two k-steps; a GEMM slice that was one TRIPLE of 16 KiB stages is six
 //     stages here.  They run as PAIRS of stages under one workgroup barrier (2 x 48 = 96 MFMAs per wave per barrier, what a
 //     bf16 triple has);
-//   * LDS: the K and V^T images exist twice (hi and lo planes, 70 KiB), which leaves the attention phase a ring of two pair groups
-//     (64 KiB) — the prefetch distance in MFMA time is that of the bf16 kernel's two triple groups; the MLP phase runs four pair
-//     groups (128 KiB), three pairs ahead;
+//   * LDS: the K and V^T images exist twice (hi and lo planes, 70 KiB), which leaves the head loop a ring of five single stages
+//     (80 KiB, pairs of stages per barrier); proj and the tail run pairs through three 32 KiB groups; the MLP phase (round 4) runs
+//     TRIPLES of stages — 144 MFMAs per wave per barrier — through three 48 KiB groups, two triples ahead: every group of stages
+//     pays ~45 % on top of its MFMA time for its wait, barrier, cold fragment reads and DMA burst, so fewer, longer groups (-2.6 %);
 //   * registers: the LayerNorm'd operand is 192 registers (hi + lo) next to the 192 of x, so the working set has 128 left: weight
 //     fragments are read two positions ahead through three rotating (hi, lo) buffers instead of 8 + 8, the soft-max and P V run one
 //     16-query row tile at a time.
@@ -32,7 +33,7 @@ namespace x3 {
 #define X3_ABLATE 0
 #endif
 #ifndef X3_MLP_RING
-#define X3_MLP_RING 3          // pair groups of the MLP phase
+#define X3_MLP_RING 3          // pair groups of proj and the tail (the MLP phase itself runs triples: MLP_RING_B)
 #endif
 #ifndef X3_AHEAD
 #define X3_AHEAD 2             // weight-fragment positions read ahead of the MFMAs
@@ -40,17 +41,21 @@ namespace x3 {
 constexpr int STAGE = 16384, PAIRB = 2 * STAGE;
 constexpr int KIMG_B = 128 * AF_KROWB, VIMG_B = 64 * AF_VROWB;           // one plane of the K / V^T image
 // LDS map.  Head loop: a ring of HEADS_SLOTS single stages | the K hi, K lo, V^T hi, V^T lo image planes | 6E parameter floats.
-// proj / MLP / tail: X3_MLP_RING pair groups | 7E parameter floats (proj reads its bias from the head loop's block, which its ring does not reach).
+// proj / MLP / tail: three 48 KiB groups (MLP: triples; proj, tail: X3_MLP_RING pair groups in the first 96 KiB) | 7E parameter floats (proj reads its bias from the head
+// loop's block, which neither its ring nor the MLP's parameter block reaches).
 constexpr int HEADS_SLOTS = 5;
 constexpr int IMG_OFF = HEADS_SLOTS * STAGE;                             // 81920
 constexpr int HEADS_PARAM_OFF = IMG_OFF + 2 * KIMG_B + 2 * VIMG_B;       // 153600
-constexpr int MLP_RING_B = X3_MLP_RING * PAIRB;
+// the MLP phase runs its weight stages three to a barrier (four TRIPLES per hidden chunk: fc1 | fc1 | fc2 k-block 0 | fc2 k-block 1, the two GELU blocks exactly at group
+// boundaries) through three 48 KiB ring groups; proj and the tail run PAIRS through the first 96 KiB of the same region
+constexpr int MLP_RING_B = 3 * 3 * STAGE;
 constexpr int MLP_PARAM_OFF = MLP_RING_B;
 template <int E> constexpr size_t enc_blocks_x3_lds() {
     constexpr size_t a = (size_t)HEADS_PARAM_OFF + (size_t)(6 * E) * sizeof(float), b = (size_t)MLP_PARAM_OFF + (size_t)(7 * E) * sizeof(float);
     return a > b ? a : b;
 }
-static_assert(enc_blocks_x3_lds<384>() <= 163840 && MLP_RING_B + 7 * 384 * 4 <= HEADS_PARAM_OFF, "LDS map");
+// (the MLP / tail parameter block may reach into the head loop's bqkv slots — reloaded for every block — but not into the proj bias behind them, which proj reads)
+static_assert(enc_blocks_x3_lds<384>() <= 163840 && MLP_RING_B + 7 * 384 * 4 <= HEADS_PARAM_OFF + 3 * 384 * 4, "LDS map");
 
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -599,30 +604,7 @@ __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_
     });
 }
 
-// ---- MLP phase: acc2 += fc2(gelu(fc1(a) + b1))  (bias of fc2 NOT added) --------------------------------------------------------
-// Per 64-wide hidden chunk six pairs: fc1 (64 rows x K = 384: six stages of 64 rows x two k-blocks) and fc2 (384 outputs x K = 64:
-// six stages of 128 rows x one k-block, ordered k-block-major: stage t = (k-block t / 3, row group t % 3), so that the GELU'd hidden
-// fragments of ONE k-block are live at a time — the second k-block's GELU runs at the stage boundary inside the middle pair).
-// Pair n of the phase (0 .. 6 * chunks) lives in group n % RING and is issued during pair n - (RING - 1).
-template <int E, int RING>
-__device__ __forceinline__ void mlp_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
-                                          int wid, int c, int r, int s, int q = -1) {
-    constexpr int F = 4 * E;
-    unsigned char* dst = ring + ((6 * c + r) % RING) * PAIRB + s * STAGE + wid * 4096;
-    if (r < 3) issue_stage(wrsrc, sl.template voff<0>(), (w1_off + (unsigned)(c * 64 * E + (2 * r + s) * 64)) * 4u, 4u * E, dst, q);
-    else {
-        const int t = 2 * (r - 3) + s, kb = t / 3, ng = t - 3 * kb;
-        issue_stage(wrsrc, sl.template voff<2>(), (w2_off + (unsigned)(ng * 128 * F + c * 64 + kb * 32)) * 4u, 4u * F, dst, q);
-    }
-}
-template <int E, int RING>
-__device__ __forceinline__ void mlp_prefetch(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int wid) {
-    static_for<0, RING - 1>([&](auto rc) {
-        mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, 0, decltype(rc)::value, 0);
-        mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, 0, decltype(rc)::value, 1);
-    });
-}
-
+// ---- MLP phase: acc2 += fc2(gelu(fc1(a) + b1))  (bias of fc2 NOT added): mlp_phase3 below.  Its GELU block:
 // GELU of hidden units 32 pr + [0, 32) of the chunk for both row tiles -> (hi, lo) fragments
 __device__ __forceinline__ void gelu_frag(const f32x4 (&acc1)[4][2], const float* bp, int pr, bf16x8 (&hh)[2], bf16x8 (&hl)[2]) {
 #pragma unroll
@@ -639,13 +621,63 @@ __device__ __forceinline__ void gelu_frag(const f32x4 (&acc1)[4][2], const float
     }
 }
 
-// al1_lds != nullptr: the lo fragments of row tile 1 live in the wave's LDS region (al[1][.] is not read)
-template <int E, int RING, int AHEAD>
-__device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
-                                          const StreamLaneX& sl, int wid, const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32],
-                                          f32x4 (&acc2)[E / 16][2] X3_TARG, const unsigned char* al1_lds = nullptr) {
-    constexpr int F = 4 * E, NCH = F / 64, D = RING - 1;
-    static_assert(E == 384 && (RING == 3 || RING == 4), "written for E = 384");
+// ---- MLP phase on TRIPLES of stages --------------------------------------------------------------------------------------------------
+// Every group of stages pays a fixed price on top of its MFMAs — the vmcnt wait, the workgroup barrier and its skew, the cold fragment reads behind it (measured: ~45 % on top of a
+// pair's MFMA time, profiles/r04_x3_encoder_variants.md) — so fewer, longer groups: a hidden chunk's twelve stages as four triples (144 MFMAs per wave per barrier) whose
+// boundaries are exactly where the two GELU blocks sit.  NS contiguous stages from `grp`; mma(s, i, wh, wl) / issue(s, q) as in run_pair2.
+template <int NS, int AHEAD = 2, class Mma, class Issue>
+__device__ __forceinline__ void run_group(const unsigned char* grp, Mma&& mma, Issue&& issue) {
+    const int ln = opaque_lane();
+    const int fo0 = stage_frag_off(ln), fo1 = fo0 ^ 64;
+    constexpr int NB = AHEAD + 1, NPOS = 8 * NS;
+    bf16x8 wh[NB], wl[NB];
+    static_for<0, AHEAD>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        wh[n] = *reinterpret_cast<const bf16x8*>(grp + n * 2048 + fo0); wl[n] = *reinterpret_cast<const bf16x8*>(grp + n * 2048 + fo1);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, NPOS>([&](auto nc) {
+        constexpr int n = decltype(nc)::value, s = n >> 3, i = n & 7, nn = n + AHEAD;
+        if constexpr (i == 0) { issue(s, -1); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (nn < NPOS) {
+            const unsigned char* src = grp + (nn >> 3) * STAGE + (nn & 7) * 2048;
+            wh[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo0);
+            wl[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo1);
+        }
+        mma(s, i, wh[n % NB], wl[n % NB]);
+        if constexpr (nn < NPOS) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+constexpr int TRIPB = 3 * STAGE;
+// triple k of chunk c (k = 0, 1: fc1 stages 3 k .. 3 k + 2; k = 2, 3: fc2 k-block k - 2, row groups 0 .. 2), stage s, into ring group (4 c + k) % 3
+template <int E>
+__device__ __forceinline__ void mlp3_issue(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
+                                           int wid, int c, int k, int s, int q = -1) {
+    constexpr int F = 4 * E;
+    unsigned char* dst = ring + ((4 * c + k) % 3) * TRIPB + s * STAGE + wid * 4096;
+    if (k < 2) issue_stage(wrsrc, sl.template voff<0>(), (w1_off + (unsigned)(c * 64 * E + (3 * k + s) * 64)) * 4u, 4u * E, dst, q);
+    else issue_stage(wrsrc, sl.template voff<2>(), (w2_off + (unsigned)(s * 128 * F + c * 64 + (k - 2) * 32)) * 4u, 4u * F, dst, q);
+}
+template <int E>
+__device__ __forceinline__ void mlp3_prefetch(const StreamLaneX& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int wid) {
+    static_for<0, 2>([&](auto kc) {
+        static_for<0, 3>([&](auto sc) { mlp3_issue<E>(sl, ring, wrsrc, w1_off, w2_off, wid, 0, decltype(kc)::value, decltype(sc)::value); });
+    });
+}
+template <int E, int AHEAD>
+__device__ __forceinline__ void mlp_phase3(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
+                                           const StreamLaneX& sl, int wid, const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32],
+                                           f32x4 (&acc2)[E / 16][2] X3_TARG) {
+    constexpr int F = 4 * E, NCH = F / 64;
+    static_assert(E == 384, "written for E = 384");
     for (int c = 0; c < NCH; ++c) {
         const bool last = c + 1 == NCH;
         f32x4 acc1[4][2];
@@ -653,43 +685,36 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            asm volatile("" : "+a"(acc1[i][0]), "+a"(acc1[i][1]));      // the chunk accumulators belong in the accumulator half of the file
+            asm volatile("" : "+a"(acc1[i][0]), "+a"(acc1[i][1]));
         }
-        static_for<0, 6>([&](auto rc) {
-            constexpr int r = decltype(rc)::value;
-            // in flight behind this pair: the next D - 1 pairs (8 pieces per wave each), fewer at the end of the phase
-            if (!last) x3_wait_vmcnt<8 * (D - 1)>(); else x3_wait_vmcnt<8 * ((5 - r) < (D - 1) ? (5 - r) : (D - 1))>();
+        const int g = opaque_lane() >> 4;
+        const float* bp = sb1 + c * 64 + 8 * g;
+        static_for<0, 4>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k >= 2) {      // hidden units 32 (k - 2) .. + 32 of the chunk — this triple's k-block — before the wait and the barrier, not behind them
+                gelu_frag(acc1, bp, k - 2, hh, hl);
+                X3_TICK(9);
+            }
+            // in flight behind this triple: the next one (12 pieces per wave) — none behind the phase's last
+            if (!last || k < 3) x3_wait_vmcnt<12>(); else x3_wait_vmcnt<0>();
             pair_fence();
-            const int g = opaque_lane() >> 4;
-            const float* bp = sb1 + c * 64 + 8 * g;
-            auto issue = [&](int s, int q) {
-                if constexpr (r + D < 6) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c, r + D, s, q);
-                else if (!last) mlp_issue<E, RING>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, r + D - 6, s, q);
+            auto issue = [&](int s, int q) {      // the triple two ahead
+                if constexpr (k < 2) mlp3_issue<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c, k + 2, s, q);
+                else if (!last) mlp3_issue<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, k - 2, s, q);
             };
-            auto mid = [&]() { if constexpr (r == 4) { X3_TICK(10); gelu_frag(acc1, bp, 1, hh, hl); X3_TICK(9); } };      // (k-block 0, row group 2) was stage 0 of pair 4
-            const unsigned char* grp = ring + ((6 * c + r) % RING) * PAIRB;
-            if constexpr (r < 3) {
-                if (al1_lds != nullptr) {
-                    bf16x8 l1[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) l1[q] = *reinterpret_cast<const bf16x8*>(al1_lds + (4 * r + q) * 1024);
-                    run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
-                        const int kb = 4 * r + 2 * s + (i >> 2);
-                        mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], l1[2 * s + (i >> 2)]);
-                    }, issue);
-                } else
-                run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
-                    const int kb = 4 * r + 2 * s + (i >> 2);
+            const unsigned char* grp = ring + ((4 * c + k) % 3) * TRIPB;
+            if constexpr (k < 2) {
+                run_group<3, AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+                    const int kb = 2 * (3 * k + s) + (i >> 2);
                     mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
+                X3_TICK(8);
             } else {
-                run_pair<AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
-                    const int t = 2 * (r - 3) + s, ng = t % 3;
-                    mma3_w(acc2[ng * 8 + i][0], acc2[ng * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
-                }, issue, mid);
+                run_group<3, AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+                    mma3_w(acc2[s * 8 + i][0], acc2[s * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
+                }, issue);
+                X3_TICK(10);
             }
-            if constexpr (r < 3) { X3_TICK(8); } else { X3_TICK(10); }
-            if constexpr (r == 2) { gelu_frag(acc1, bp, 0, hh, hl); X3_TICK(9); }
         });
     }
 }
@@ -937,7 +962,7 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 #ifdef X3_MARK
         asm volatile("; X3MARK MLPPRE");
 #endif
-        mlp_prefetch<E, X3_MLP_RING>(sl, ring, wrsrc, bp->w1, bp->w2, wid);
+        mlp3_prefetch<E>(sl, ring, wrsrc, bp->w1, bp->w2, wid);
         params_to_lds(sp, pbase + bp->b1, F, tid);
         params_to_lds(sp + F, pbase + bp->b2, E, tid);
         params_to_lds(sp + F + E, pbase + bp->ln2_w, E, tid);
@@ -951,7 +976,7 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 #ifdef X3_MARK
         asm volatile("; X3MARK MLP");
 #endif
-        mlp_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc X3_TPASS);
+        mlp_phase3<E, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc X3_TPASS);
 #ifdef X3_MARK
         asm volatile("; X3MARK MLPEND");
 #endif
