@@ -197,10 +197,34 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, const floa
 // used as a token id to index the decoder tables.
 constexpr int ARGMAX_NONE = 0x7fffffff;
 __device__ __forceinline__ bool argmax_take(float v, int i, float best, int bi) {
-    const bool vn = v != v, bn = best != best;
-    return vn ? (!bn || i < bi) : (!bn && (v > best || (v == best && i < bi)));
+    // bitwise on purpose: the short-circuit form compiles to a tree of divergent branches (27 of them per wave-wide arg-max)
+    const bool vn = v != v, bn = best != best, lt = i < bi;
+    return (vn & (!bn | lt)) | (!vn & !bn & ((v > best) | ((v == best) & lt)));
 }
 __device__ __forceinline__ int argmax_final(int bi, int C) { return bi < C ? bi : 0; }
+// Wave-wide arg-max of (best, bi) pairs under argmax_take's total order (so the combining order does not matter): four DPP steps make
+// every row of 16 lanes uniform, four readlanes combine the rows.  Every lane ends with the winner.  (The __shfl_xor butterfly it replaces
+// is twelve dependent ds_bpermute round trips: ~2 us of the AR step's pick, tools/ds_step_timers.py.)
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp_step(float& best, int& bi) {
+    const float ov = dpp_mov<CTRL>(best);
+    const int oi = __builtin_amdgcn_update_dpp(0, bi, CTRL, 0xF, 0xF, true);
+    if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
+}
+__device__ __forceinline__ void wave_argmax(float& best, int& bi) {
+    argmax_dpp_step<0xB1>(best, bi);
+    argmax_dpp_step<0x4E>(best, bi);
+    argmax_dpp_step<0x141>(best, bi);
+    argmax_dpp_step<0x140>(best, bi);
+    float b = lane_bcast(best, 0); int i = __builtin_amdgcn_readlane(bi, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const float ov = lane_bcast(best, r);
+        const int oi = __builtin_amdgcn_readlane(bi, r);
+        if (argmax_take(ov, oi, b, i)) { b = ov; i = oi; }
+    }
+    best = b; bi = i;
+}
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel.  One LdsAttr per launch site remembers
 // (bit per device ordinal, lock-free) on which devices the attribute has been raised, so that a process driving several GPUs

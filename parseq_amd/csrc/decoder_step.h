@@ -34,6 +34,20 @@ constexpr int DS_NW = 8;        // waves per workgroup; 16-wide output column ti
 constexpr int DS_RING = PQ_DS_RING;      // 1-KB LDS slots per wave: fragment copies in flight (64 KB per CU)
 constexpr int DS_LA = 2;        // fragments read ahead from LDS into registers (hides the ds_read latency behind MFMAs)
 
+// DS_TIMERS=1 (diagnostic builds only, tools/ds_step_timers.py): wave 0 of workgroup 0 stamps s_memtime (100 MHz) after every phase of the two
+// step kernels; the mlp kernel parks its stamps behind the partial sums, the next mid kernel writes both sets OVER row 0's logits of the
+// position it finishes (slots 0-7 its own, 16-20 the mlp kernel's) — the picks come from LDS, so the decode itself is unchanged.
+#ifndef DS_TIMERS
+#define DS_TIMERS 0
+#endif
+#if DS_TIMERS
+#define DS_T0() const unsigned long long ds_t0 = __builtin_amdgcn_s_memtime(); unsigned ds_tk[8] = {}
+#define DS_TICK(i) ds_tk[i] = (unsigned)(__builtin_amdgcn_s_memtime() - ds_t0)
+#else
+#define DS_T0()
+#define DS_TICK(i)
+#endif
+
 // Fragment-ordered weights.  A [N][K] row-major weight is re-packed once per weight set (frag_pack_kernel) into
 //   Wp[tile = n / 16][kp = k / 64][half][lane = (n & 15) + 16 g][8]  =  W[16 tile + (lane & 15)][64 kp + 16 g + 8 half + 0..7]
 // i.e. unit (tile, kp, half) is the 1-KB MFMA operand fragment of one wave, contiguous in memory, and the units of one
@@ -181,68 +195,112 @@ __device__ __forceinline__ void ds_layernorm_rows(const float* tl, int PT, bf16_
     }
 }
 
-// Table self-attention of ONE row by one wave, registers only (decoder_attn.h: dec_self_attn_kernel): lane l works for head
+// Table self-attention of R rows by one wave, registers only (decoder_attn.h: dec_self_attn_kernel): lane l works for head
 // h = l >> 2: it scores keys j = (l & 3) + 4 c, the quad reduces max / sum over DPP, and the same lane then mixes value
-// columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.  tokv: lane j holds token j
-// of the row's context (j < Lk).  Result: bf16 row of E values at `arow` (LDS).
+// columns d = 8 l .. 8 l + 7 (which belong to head l >> 2) with probabilities quad-broadcast.  tokv[r]: lane j holds token j
+// of row r's context (j < Lk).  Result: bf16 row of E values at arow + r * lda (LDS).
 // X3: the K | V table is f32 and the result row is written as a bf16 pair (hi at arow, lo at arow + a_lo).
-template <int E, bool X3 = false>
-__device__ __forceinline__ void ds_self_attn_row(const float* __restrict__ stab, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ kvtab,
-                                                 int tokv, int ntok, int npos, int Lk, int pos, bf16_t* arow, int a_lo = 0) {
+// The gathers are the phase's whole cost (a third of the mid kernel when every key's value row was its own round trip behind its own
+// branch: tools/ds_step_timers.py), so they go out in groups: the R rows' score lookups together, then the value rows of KG keys of all
+// R rows per uniform branch, the first group before the scores are even looked up.  Keys past Lk in a group read key Lk - 1's row
+// against a probability of exactly zero, so every accumulator sees the same fmaf chain as one key at a time (acc + 0 * v == acc).
+#ifndef PQ_DS_SA_KG
+#define PQ_DS_SA_KG 0           // keys per group of value gathers; 0 = 8 (f32 table) / 16 (bf16 table): 64 value registers per row in flight
+#endif
+template <int E, bool X3 = false, int R = 1>
+__device__ __forceinline__ void ds_self_attn_rows(const float* __restrict__ stab, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ kvtab,
+                                                  const int (&tokv)[R], int ntok, int npos, int Lk, int pos, bf16_t* arow, int lda, int a_lo = 0) {
     static_assert(DEC_HD == 32 && DEC_MAXL == 32, "lane mapping assumes 32-wide heads and <= 32 keys");
     constexpr int H = E / DEC_HD;
+    constexpr int KG = PQ_DS_SA_KG ? PQ_DS_SA_KG : (X3 ? 8 : 16);
     const int lane = threadIdx.x & 63;
     const int h = lane >> 2, q = lane & 3;
     const bool live = h < H;
-    float sc[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const int j = q + 4 * c;
-        const int tj = __shfl(tokv, j, 64);
-        sc[c] = (live && j < Lk) ? stab[(((size_t)pos * npos + j) * ntok + tj) * H + h] : -INFINITY;
-        mx = fmaxf(mx, sc[c]);
-    }
-    mx = fmaxf(mx, dpp_mov<0xB1>(mx));
-    mx = fmaxf(mx, dpp_mov<0x4E>(mx));
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sc[c] = (q + 4 * c < Lk) ? expf(sc[c] - mx) : 0.f; sum += sc[c]; }
-    sum += dpp_mov<0xB1>(sum);
-    sum += dpp_mov<0x4E>(sum);
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) sc[c] *= inv;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int d0 = live ? 8 * lane : 0;
+    using VT = typename std::conditional<X3, f32x4, bf16x8>::type;
+    constexpr int VP = X3 ? 2 : 1;                // 16-byte pieces per lane and key
+    VT v[R][KG][VP];
+    auto gather = [&](int g0) {                   // value rows of keys g0 .. g0 + KG - 1 of every row (clamped to the last key)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        // key j = 4 c + qq: its probability sits in lane (quad base + qq), register sc[c]
-        const float pq4[4] = {dpp_mov<0x00>(sc[c]), dpp_mov<0x55>(sc[c]), dpp_mov<0xAA>(sc[c]), dpp_mov<0xFF>(sc[c])};
+        for (int r = 0; r < R; ++r) {
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-            const int j = 4 * c + qq;
-            if (j < Lk) {
-                const int tj = __builtin_amdgcn_readlane(tokv, j);
+            for (int k = 0; k < KG; ++k) {
+                const int jc = min(g0 + k, Lk - 1);
+                const int tj = __builtin_amdgcn_readlane(tokv[r], jc);
+                const VT* vp = reinterpret_cast<const VT*>(kvtab + (unsigned)((jc * ntok + tj) * (2 * E) + E) + d0);      // 32-bit on purpose: the table is npos x ntok x 2E elements
+#pragma unroll
+                for (int i = 0; i < VP; ++i) v[r][k][i] = vp[i];
+            }
+        }
+    };
+    gather(0);                                    // they depend on the tokens only: in flight under the score lookups and the soft-max
+    float sc[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int j = q + 4 * c;
+            const int tj = __shfl(tokv[r], j, 64);
+            sc[r][c] = (live && j < Lk) ? stab[(unsigned)(((pos * npos + j) * ntok + tj) * H + h)] : -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mx = fmaxf(mx, sc[r][c]);
+        mx = fmaxf(mx, dpp_mov<0xB1>(mx));
+        mx = fmaxf(mx, dpp_mov<0x4E>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { sc[r][c] = (q + 4 * c < Lk) ? expf(sc[r][c] - mx) : 0.f; sum += sc[r][c]; }
+        sum += dpp_mov<0xB1>(sum);
+        sum += dpp_mov<0x4E>(sum);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sc[r][c] *= inv;
+    }
+    float acc[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[r][i] = 0.f;
+    auto mix = [&](auto g0c) {
+        constexpr int g0 = decltype(g0c)::value;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+            for (int k = 0; k < KG; ++k) {
+                // key j = 4 c + qq: its probability sits in lane (quad base + qq), register sc[c] (zero past Lk)
+                const int c = (g0 + k) >> 2, qq = (g0 + k) & 3;
+                const float pj = qq == 0 ? dpp_mov<0x00>(sc[r][c]) : qq == 1 ? dpp_mov<0x55>(sc[r][c]) : qq == 2 ? dpp_mov<0xAA>(sc[r][c]) : dpp_mov<0xFF>(sc[r][c]);
                 if constexpr (X3) {
-                    const f32x4* vp = reinterpret_cast<const f32x4*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
-                    const f32x4 v0 = vp[0], v1 = vp[1];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { acc[i] = fmaf(pq4[qq], v0[i], acc[i]); acc[4 + i] = fmaf(pq4[qq], v1[i], acc[4 + i]); }
+                    for (int i = 0; i < 4; ++i) { acc[r][i] = fmaf(pj, v[r][k][0][i], acc[r][i]); acc[r][4 + i] = fmaf(pj, v[r][k][1][i], acc[r][4 + i]); }
                 } else {
-                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(kvtab + ((size_t)j * ntok + tj) * (2 * E) + E + d0);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] = fmaf(pq4[qq], to_f32(v[i]), acc[i]);
+                    for (int i = 0; i < 8; ++i) acc[r][i] = fmaf(pj, to_f32(v[r][k][0][i]), acc[r][i]);
                 }
             }
         }
-    }
+    };
+    mix(std::integral_constant<int, 0>{});
+    static_for<1, 32 / KG>([&](auto gc) {
+        constexpr int g0 = decltype(gc)::value * KG;
+        if (g0 < Lk) {
+            gather(g0);
+            mix(std::integral_constant<int, g0>{});
+        }
+    });
     if (live) {
-        bf16x8 o, ol;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { o[i] = from_f32<bf16_t>(acc[i]); ol[i] = from_f32<bf16_t>(acc[i] - to_f32(o[i])); }
-        *reinterpret_cast<bf16x8*>(arow + d0) = o;
-        if constexpr (X3) *reinterpret_cast<bf16x8*>(arow + a_lo + d0) = ol;
+        for (int r = 0; r < R; ++r) {
+            bf16x8 o, ol;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o[i] = from_f32<bf16_t>(acc[r][i]); ol[i] = from_f32<bf16_t>(acc[r][i] - to_f32(o[i])); }
+            *reinterpret_cast<bf16x8*>(arow + r * lda + d0) = o;
+            if constexpr (X3) *reinterpret_cast<bf16x8*>(arow + r * lda + a_lo + d0) = ol;
+        }
     }
 }
 
@@ -271,12 +329,15 @@ void dec_step_pre_kernel(const float* __restrict__ stab, const bf16_t* __restric
 
     // self-attention of rows 2w, 2w + 1, one wave per row
     ds_prefetch<E, TN>(Wo, TILES, wave, wring);
+    {
+        constexpr int RPW = DS_ROWS / DS_NW;
+        int tokv[RPW];
 #pragma unroll
-    for (int rr = 0; rr < DS_ROWS / DS_NW; ++rr) {
-        const int row = wave * (DS_ROWS / DS_NW) + rr;
-        const int b = min(row0 + row, M - 1);
-        const int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
-        ds_self_attn_row<E>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + row * PA);
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int b = min(row0 + wave * RPW + rr, M - 1);
+            tokv[rr] = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
+        }
+        ds_self_attn_rows<E, false, RPW>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + wave * RPW * PA, PA);
     }
     __syncthreads();
 
@@ -438,12 +499,7 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
             const float v = lg[row * PL + c];
             if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
-        }
+        wave_argmax(best, bi);
         bi = argmax_final(bi, C);
         if (lane == 0) {
             tok[(size_t)b * ldt + pos + 1] = bi;
@@ -463,21 +519,44 @@ void dec_step_post_kernel(const bf16_t* __restrict__ ca, const float* __restrict
 //                         EOS bookkeeping) AND starts step i (self-attention with the token it has just picked ->
 //                         out_proj -> norm1 -> q-projection), 16 rows per workgroup
 //   dec_cross_attn_ar_kernel (step i)
-//   dec_step_mlp_kernel   cross out_proj + residual -> norm2 -> linear1 + GELU -> linear2 for a QUARTER of the hidden units per
-//                         workgroup (ds_split<E>() workgroups per row tile): each streams 3 x 0.3 MB of weights instead
-//                         of 3 MB; the partial products of linear2 go to global memory and are summed, in a fixed order, by
+//   dec_step_mlp_kernel   cross out_proj + residual -> norm2 -> linear1 + GELU -> linear2 for a SIXTH of the hidden units per
+//                         workgroup (ds_split<E>() workgroups per row tile; a quarter until round 4): each streams 0.3 + 2 x 0.1 MB of
+//                         weights (bf16; twice that as bf16 pairs) instead of 3 MB; the partial products of linear2 go to global memory and are summed, in a fixed order, by
 //                         the next mid kernel
 // Same three launches per step as the pre / post arrangement, but the longest weight stream per CU drops from 3.0 MB to
-// 0.9 MB and the token never leaves the workgroup between the pick and the next self-attention.
+// 0.7 MB and the token never leaves the workgroup between the pick and the next self-attention.
 // =====================================================================================================================
-template <int E> constexpr int ds_split() { return E >= 384 ? 4 : 2; }   // workgroups per row tile in dec_step_mlp_kernel
+#ifndef PQ_DS_SPLIT_384
+#define PQ_DS_SPLIT_384 6       // 4 before round 4's timers: every split streams the whole cross out_proj, so the shares of linear1 / linear2 are what shrinks
+#endif
+template <int E> constexpr int ds_split() { return E >= 384 ? PQ_DS_SPLIT_384 : 2; }   // workgroups per row tile in dec_step_mlp_kernel
 
 // X3 (bf16x3 arithmetic): every bf16 activation buffer is a hi plane followed by a lo plane
+// The small per-column parameters (LayerNorm affines, biases, the position query) are staged into LDS by the first instructions of the
+// launch — one round trip shared with the activation loads — instead of being fetched where they are used: each such use was its own
+// exposed L2 round trip in the middle of the chain (tools/ds_step_timers.py: ~1 us per LayerNorm for 0.3 us of arithmetic).
+template <int E> constexpr int ds_mid_params() { return 7 * E + 128; }      // lnf w | lnf b | head bias (128) | bo | pos query | ln1 w | ln1 b | bq
+template <int E> constexpr int ds_mlp_params() { return 3 * E + 4 * E / ds_split<E>(); }   // bco | ln2 w | ln2 b | this split's b1
 template <int E, bool X3 = false> constexpr size_t dec_step_mid_lds() {
-    return (size_t)DS_ROWS * ((E + 8) * 2 * (X3 ? 2 : 1) + (E + 4) * 4 + 128 * 4) + (size_t)DS_NW * DS_RING * 1024;
+    return (size_t)DS_ROWS * ((E + 8) * 2 * (X3 ? 2 : 1) + (E + 4) * 4 + 128 * 4) + (size_t)ds_mid_params<E>() * 4 + (size_t)DS_NW * DS_RING * 1024;
 }
 template <int E, bool X3 = false> constexpr size_t dec_step_mlp_lds() {
-    return (size_t)DS_ROWS * (((E + 8) * 2 + (4 * E / ds_split<E>() + 8) * 2) * (X3 ? 2 : 1) + (E + 4) * 4) + (size_t)DS_NW * DS_RING * 1024;
+    return (size_t)DS_ROWS * (((E + 8) * 2 + (4 * E / ds_split<E>() + 8) * 2) * (X3 ? 2 : 1) + (E + 4) * 4) + (size_t)ds_mlp_params<E>() * 4 + (size_t)DS_NW * DS_RING * 1024;
+}
+// dst[k][0, n[k]) = src[k][0, valid[k]) followed by zeros, n[k] <= threads per workgroup.  Two halves: the loads go out first thing in the
+// launch, branch-free (clamped index), so all segments share one round trip with the activation loads that follow them; the LDS stores
+// come after those have been issued.
+template <int NSEG>
+__device__ __forceinline__ void ds_params_load(float (&v)[NSEG], const float* const (&src)[NSEG], const int (&valid)[NSEG]) {
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k) v[k] = src[k][min((int)threadIdx.x, valid[k] - 1)];
+}
+template <int NSEG>
+__device__ __forceinline__ void ds_params_store(const float (&v)[NSEG], float* const (&dst)[NSEG], const int (&n)[NSEG], const int (&valid)[NSEG]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NSEG; ++k)
+        if (t < n[k]) dst[k][t] = t < valid[k] ? v[k] : 0.f;
 }
 
 // tq: fp32 [M][E], t' of the step being finished (written by dec_step_mlp_kernel split 0); partial: fp32 [DS_SPLIT][M][E].
@@ -505,11 +584,26 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
     float* tl = reinterpret_cast<float*>(abuf + NPL * DS_ROWS * PA);    // [DS_ROWS][PT]
     float* lg = tl + DS_ROWS * PT;                                     // [DS_ROWS][PL]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    unsigned char* wring = reinterpret_cast<unsigned char*>(lg + DS_ROWS * PL) + wave * DS_RING * 1024;
+    float* prm = lg + DS_ROWS * PL;                                    // [ds_mid_params<E>()]
+    float* const s_lnf_w = prm, * const s_lnf_b = prm + E, * const s_bh = prm + 2 * E, * const s_bo = prm + 2 * E + 128, * const s_posq = prm + 3 * E + 128,
+         * const s_ln1_w = prm + 4 * E + 128, * const s_ln1_b = prm + 5 * E + 128, * const s_bq = prm + 6 * E + 128;
+    unsigned char* wring = reinterpret_cast<unsigned char*>(prm + ds_mid_params<E>()) + wave * DS_RING * 1024;
     const int row0 = blockIdx.x * DS_ROWS;
-    int picked[RPW];
+    int picked[RPW], tokv[RPW];
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) picked[rr] = -1;
+    for (int rr = 0; rr < RPW; ++rr) {
+        picked[rr] = -1;
+        // the context tokens of the step being started are in memory already, all but the one this launch is about to pick: their
+        // load goes out first, one round trip fewer in front of the self-attention
+        tokv[rr] = (do_start && lane <= pos) ? tok[(size_t)min(row0 + wave * RPW + rr, M - 1) * ldt + lane] : 0;
+    }
+    DS_T0();
+    static_assert(E <= 64 * DS_NW, "one parameter per thread and segment");
+    float* const prm_dst[8] = {s_lnf_w, s_lnf_b, s_bh, s_bo, s_posq, s_ln1_w, s_ln1_b, s_bq};
+    const float* const prm_src[8] = {lnf_w, lnf_b, bh, bo, pos_queries + (size_t)min(pos, npos - 1) * E, ln1_w, ln1_b, bq};
+    const int prm_n[8] = {E, E, 128, E, E, E, E, E}, prm_valid[8] = {E, E, C, E, E, E, E, E};
+    float prm_v[8];
+    ds_params_load<8>(prm_v, prm_src, prm_valid);
 
     if (do_finish) {
         // t'' = t' + b2 + partial[0] + partial[1] + ...   (fixed order: deterministic).  These loads go out BEFORE the head's
@@ -524,10 +618,13 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             for (int sp = 0; sp < DS_SPLIT; ++sp) v += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * M * E + gr);
             *reinterpret_cast<f32x4*>(tl + row * PT + c) = v;
         }
+        ds_params_store<8>(prm_v, prm_dst, prm_n, prm_valid);
         ds_prefetch<E, 1, NPL>(Wh, (C + 15) / 16, wave, wring);
         __syncthreads();
-        ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, lnf_w, lnf_b, eps, wave, ALO);
+        DS_TICK(0);
+        ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, s_lnf_w, s_lnf_b, eps, wave, ALO);
         __syncthreads();
+        DS_TICK(1);
         {
             f32x4 acc[1] = {};
             ds_wave_gemm<E, 1, true, NPL>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc, 0, 0, ALO);
@@ -536,13 +633,14 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (n + r < C) {
-                    const float v = acc[0][r] + bh[n + r];
+                    const float v = acc[0][r] + s_bh[n + r];
                     lg[r16 * PL + n + r] = v;
                     if (row0 + r16 < M) logits[((size_t)(row0 + r16) * Ltot + (pos - 1)) * C + n + r] = v;
                 }
             }
         }
         __syncthreads();                                     // lg complete; abuf free for the next step's self-attention
+        DS_TICK(2);
         if (argmax_mode) {
 #pragma unroll
             for (int rr = 0; rr < RPW; ++rr) {
@@ -552,12 +650,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                     const float v = lg[row * PL + c];
                     if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(bi, o, 64);
-                    if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
-                }
+                wave_argmax(best, bi);
                 bi = argmax_final(bi, C);
                 picked[rr] = bi;
                 if (lane == 0 && b < M) {
@@ -571,23 +664,24 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             }
         }
     } else if (do_start) {
+        ds_params_store<8>(prm_v, prm_dst, prm_n, prm_valid);
         ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
     }
     if (!do_start) return;
+    DS_TICK(3);
 
     const int Lk = pos + 1;
-    // self-attention of rows 2w, 2w + 1: context tokens from global, the newest one straight from the pick above
+    // self-attention of rows 2w, 2w + 1: context tokens from the load at the top, the newest one straight from the pick above
+    {
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-        const int row = wave * RPW + rr;
-        const int b = min(row0 + row, M - 1);
-        int tokv = lane < Lk ? tok[(size_t)b * ldt + lane] : 0;
-        if (picked[rr] >= 0 && lane == pos) tokv = picked[rr];
-        ds_self_attn_row<E, X3>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + row * PA, ALO);
+        for (int rr = 0; rr < RPW; ++rr)
+            if (picked[rr] >= 0 && lane == pos) tokv[rr] = picked[rr];
+        ds_self_attn_rows<E, X3, RPW>(stab, kvtab, tokv, ntok, npos, Lk, pos, abuf + wave * RPW * PA, PA, ALO);
     }
     __syncthreads();
+    DS_TICK(4);
     {   // t = pos_queries[pos] + sa @ Wo^T + bo
-        const float* posq = pos_queries + (size_t)pos * E;
+        const float* posq = s_posq;
         f32x4 acc[TN] = {};
         ds_wave_gemm<E, TN, true, NPL>(abuf, PA, Wo, TILES, wave, wring, acc, 0, 0, ALO);
         ds_prefetch<E, TN, NPL>(Wq, TILES, wave, wring);
@@ -596,7 +690,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             const int tile = wave + DS_NW * t;
             if (tile < TILES) {
                 const int n = tile * 16 + 4 * g;
-                const float4 bv = *reinterpret_cast<const float4*>(bo + n);
+                const float4 bv = *reinterpret_cast<const float4*>(s_bo + n);
                 const float4 pv = *reinterpret_cast<const float4*>(posq + n);
                 f32x4 o = {acc[t][0] + bv.x + pv.x, acc[t][1] + bv.y + pv.y, acc[t][2] + bv.z + pv.z, acc[t][3] + bv.w + pv.w};
                 *reinterpret_cast<f32x4*>(tl + r16 * PT + n) = o;
@@ -605,8 +699,10 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
         }
     }
     __syncthreads();
-    ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, ln1_w, ln1_b, eps, wave, ALO);
+    DS_TICK(5);
+    ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, s_ln1_w, s_ln1_b, eps, wave, ALO);
     __syncthreads();
+    DS_TICK(6);
     {   // qc = norm1(t) @ Wq^T + bq
         f32x4 acc[TN] = {};
         ds_wave_gemm<E, TN, true, NPL>(abuf, PA, Wq, TILES, wave, wring, acc, 0, 0, ALO);
@@ -615,12 +711,20 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
             const int tile = wave + DS_NW * t;
             if (tile < TILES && row0 + r16 < M) {
                 const int n = tile * 16 + 4 * g;
-                const float4 bv = *reinterpret_cast<const float4*>(bq + n);
+                const float4 bv = *reinterpret_cast<const float4*>(s_bq + n);
                 f32x4 o = {acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w};
                 *reinterpret_cast<f32x4*>(qc_out + (size_t)(row0 + r16) * E + n) = o;
             }
         }
     }
+#if DS_TIMERS
+    DS_TICK(7);
+    if (do_finish && blockIdx.x == 0 && threadIdx.x == 0) {
+        float* dst = logits + (size_t)(pos - 1) * C;
+        for (int i = 0; i < 8; ++i) dst[i] = (float)ds_tk[i];
+        for (int i = 0; i < 5; ++i) dst[16 + i] = partial[(size_t)DS_SPLIT * M * E + i];
+    }
+#endif
 }
 
 // grid: row tiles x DS_SPLIT.  ca bf16 [M][E]; t_in fp32 [M][E] (from the mid kernel); tq_out fp32 [M][E] receives
@@ -643,9 +747,18 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
     bf16_t* hbuf = abuf + PL * DS_ROWS * PA;                           // [PL][DS_ROWS][PH]
     float* tl = reinterpret_cast<float*>(hbuf + PL * DS_ROWS * PH);    // [DS_ROWS][PT]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
-    unsigned char* wring = reinterpret_cast<unsigned char*>(tl + DS_ROWS * PT) + wave * DS_RING * 1024;
+    float* prm = tl + DS_ROWS * PT;                                    // [ds_mlp_params<E>()]
+    float* const s_bco = prm, * const s_ln2_w = prm + E, * const s_ln2_b = prm + 2 * E, * const s_b1 = prm + 3 * E;
+    unsigned char* wring = reinterpret_cast<unsigned char*>(prm + ds_mlp_params<E>()) + wave * DS_RING * 1024;
     const int rt = blockIdx.x / DS_SPLIT, sp = blockIdx.x - rt * DS_SPLIT;
     const int row0 = rt * DS_ROWS;
+    DS_T0();
+    static_assert(E <= 64 * DS_NW && FS <= 64 * DS_NW, "one parameter per thread and segment");
+    float* const prm_dst[4] = {s_bco, s_ln2_w, s_ln2_b, s_b1};
+    const float* const prm_src[4] = {bco, ln2_w, ln2_b, b1 + sp * FS};
+    const int prm_n[4] = {E, E, E, FS};
+    float prm_v[4];
+    ds_params_load<4>(prm_v, prm_src, prm_n);
 
     for (int i = threadIdx.x; i < DS_ROWS * (E / 8); i += 64 * DS_NW) {
         const int row = i / (E / 8), c = (i - row * (E / 8)) * 8;
@@ -670,8 +783,10 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
         const int gr = min(row0 + row, M - 1);
         *reinterpret_cast<f32x4*>(tl + row * PT + c) = *reinterpret_cast<const f32x4*>(t_in + (size_t)gr * E + c);
     }
+    ds_params_store<4>(prm_v, prm_dst, prm_n, prm_n);
     ds_prefetch<E, TN, PL>(Wco, TILES, wave, wring);           // after the activation loads (in-order return, see the mid kernel)
     __syncthreads();
+    DS_TICK(0);
     {   // t' = t + ca @ Wco^T + bco   (every split needs it for norm2; split 0 publishes it)
         f32x4 acc[TN] = {};
         ds_wave_gemm<E, TN, true, PL>(abuf, PA, Wco, TILES, wave, wring, acc, 0, 0, ALO);
@@ -681,7 +796,7 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
             const int tile = wave + DS_NW * t;
             if (tile < TILES) {
                 const int n = tile * 16 + 4 * g;
-                const float4 bv = *reinterpret_cast<const float4*>(bco + n);
+                const float4 bv = *reinterpret_cast<const float4*>(s_bco + n);
                 f32x4* p = reinterpret_cast<f32x4*>(tl + r16 * PT + n);
                 f32x4 o = *p;
                 o[0] += acc[t][0] + bv.x; o[1] += acc[t][1] + bv.y; o[2] += acc[t][2] + bv.z; o[3] += acc[t][3] + bv.w;
@@ -691,8 +806,10 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
         }
     }
     __syncthreads();
-    ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, ln2_w, ln2_b, eps, wave, ALO);
+    DS_TICK(1);
+    ds_layernorm_rows<E, X3>(tl, PT, abuf, PA, s_ln2_w, s_ln2_b, eps, wave, ALO);
     __syncthreads();
+    DS_TICK(2);
     {   // h[:, split] = gelu(norm2(t') @ W1[split]^T + b1[split])
         f32x4 acc[TN1] = {};
         ds_wave_gemm<E, TN1, true, PL>(abuf, PA, W1 + (size_t)sp * (FS / 16) * (E / 64) * (1024 * PL), FS / 16, wave, wring, acc, 0, 0, ALO);
@@ -700,7 +817,7 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
 #pragma unroll
         for (int t = 0; t < TN1; ++t) {
             const int n = (wave + DS_NW * t) * 16 + 4 * g;
-            const float4 bv = *reinterpret_cast<const float4*>(b1 + sp * FS + n);
+            const float4 bv = *reinterpret_cast<const float4*>(s_b1 + n);
             if constexpr (X3) {
                 const float o[4] = {gelu_erf(acc[t][0] + bv.x), gelu_erf(acc[t][1] + bv.y), gelu_erf(acc[t][2] + bv.z), gelu_erf(acc[t][3] + bv.w)};
                 float ol[4];
@@ -715,6 +832,7 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
         }
     }
     __syncthreads();
+    DS_TICK(3);
     {   // partial[split] = h[:, split] @ W2[:, split]^T
         f32x4 acc[TN] = {};
         ds_wave_gemm<FS, TN, true, PL>(hbuf, PH, W2, TILES, wave, wring, acc, sp * (FS / 64), F / 64, HLO);
@@ -728,6 +846,11 @@ void dec_step_mlp_kernel(const typename std::conditional<X3, float, bf16_t>::typ
             }
         }
     }
+#if DS_TIMERS
+    DS_TICK(4);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 5; ++i) partial[(size_t)DS_SPLIT * M * E + i] = (float)ds_tk[i];
+#endif
 }
 
 }  // namespace pq

@@ -183,12 +183,7 @@ void ar_argmax_kernel(const float* __restrict__ logits, int L, int C, int* __res
         const float v = row[c];
         if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
-    }
+    wave_argmax(best, bi);
     bi = argmax_final(bi, C);
     if (lane == 0) {
         tok[(size_t)b * ldt + step + 1] = bi;
@@ -268,12 +263,7 @@ void postprocess_kernel(const float* __restrict__ logits, int B, int L, int C, i
             const float v = row[c];
             if (argmax_take(v, c, best, bi)) { best = v; bi = c; }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (argmax_take(ov, oi, best, bi)) { best = ov; bi = oi; }
-        }
+        wave_argmax(best, bi);
         bi = argmax_final(bi, C);
         float sum = 0.f;
         for (int c = lane; c < C; c += 64) sum += expf(row[c] - best);
