@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 5
+#define PARSEQ_ABI_VERSION 6
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -81,7 +81,12 @@ enum {
 
 enum {
     PARSEQ_FLAG_DECODE_AR = 1,   /* model.decode_ar (model.py:53,119): autoregressive vs one-shot NAR decoding */
-    PARSEQ_FLAG_TESTING = 2      /* max_length was None (model.py:106): batch-level early exit applies (model.py:144-145) */
+    PARSEQ_FLAG_TESTING = 2,     /* max_length was None (model.py:106): batch-level early exit applies (model.py:144-145) */
+    PARSEQ_FLAG_LATENCY = 4      /* (ABI 6) a hint, never a change of semantics: this forward has the device to itself (the reference's one call
+                                  * at a time), so the AR step may spread its out_proj -> norm1 -> q-projection chain over three workgroups per
+                                  * row tile (decoder_step.h DS_QS: a shorter dependent chain for ~2x the compute-unit time of that kernel).
+                                  * Leave it clear when several forwards are in flight on different streams — there the compute units
+                                  * the wider step takes are another batch's.  Results of the two forms differ by rounding only. */
 };
 
 enum {

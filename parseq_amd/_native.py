@@ -15,8 +15,8 @@ from . import build as _build
 
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8, PARSEQ_BF16X3 = 0, 1, 2, 3
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
-FLAG_DECODE_AR, FLAG_TESTING = 1, 2
-ABI_VERSION = 5
+FLAG_DECODE_AR, FLAG_TESTING, FLAG_LATENCY = 1, 2, 4
+ABI_VERSION = 6
 
 
 class ParseqConfig(C.Structure):

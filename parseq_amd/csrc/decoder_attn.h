@@ -184,9 +184,47 @@ void dec_self_attn_wave_kernel(const float* __restrict__ stab, const T* __restri
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) { return v + dpp_mov<CTRL>(v); }
 template <int CTRL> __device__ __forceinline__ float dpp_max(float v) { return fmaxf(v, dpp_mov<CTRL>(v)); }
 
+// Where an AR step's cross-attention query comes from.  nsplit == 0: qc [M][E] as the q-projection wrote it.  nsplit > 0 (decoder_step.h,
+// dec_step_mid_kernel<.., QS > 1>): the step's out_proj -> norm1 -> q-projection chain was split over nsplit workgroups per row tile, each
+// owning E / nsplit columns of x = out_proj(...) + residual; what they left is, per split s, qp[s][M][E] = ((x - m) * ln_w)[:, cols of s] @
+// Wq[:, cols of s]^T with m an estimate of the row mean good to rounding, and stats[s][M][2] = sum (x - m), sum (x - m)^2 over the
+// split's columns.  With d = sum_s S1 / E (the estimate's error), var = sum_s S2 / E - d^2:
+//     q = rsqrt(var + eps) * (sum_s qp[s] - d * cq) + bq2,     cq = Wq @ ln_w,   bq2 = Wq @ ln_b + bq   (folded once per weight set)
+// — LayerNorm's two-pass arithmetic on centred values, with the division by the standard deviation moved behind the product.
+struct QAsm {
+    const float* qp = nullptr; const float* stats = nullptr; const float* cq = nullptr; const float* bq2 = nullptr;
+    int nsplit = 0, M = 0; float inv_e = 0.f, eps = 0.f;
+};
+// qv[0, N) = scale * q[b][n0 .. n0 + N), N a multiple of 4
+template <int N>
+__device__ __forceinline__ void q_assemble(const QAsm& qa, const float* __restrict__ qc, int b, int E, int n0, float scale, float (&qv)[N]) {
+    if (qa.nsplit == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) qv[i] = qc[(size_t)b * E + n0 + i] * scale;
+        return;
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) qv[i] = 0.f;
+    for (int s = 0; s < qa.nsplit; ++s) {
+        const float2 st = *reinterpret_cast<const float2*>(qa.stats + ((size_t)s * qa.M + b) * 2);
+        s1 += st.x; s2 += st.y;
+        const float* src = qa.qp + ((size_t)s * qa.M + b) * E + n0;
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(src + i);
+            qv[i] += v.x; qv[i + 1] += v.y; qv[i + 2] += v.z; qv[i + 3] += v.w;
+        }
+    }
+    const float d = s1 * qa.inv_e;
+    const float rstd = 1.0f / sqrtf(s2 * qa.inv_e - d * d + qa.eps);
+#pragma unroll
+    for (int i = 0; i < N; ++i) qv[i] = (rstd * (qv[i] - d * qa.cq[n0 + i]) + qa.bq2[n0 + i]) * scale;
+}
+
 template <typename T, int E>
 __global__ __launch_bounds__(E)
-void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict__ kmem, const T* __restrict__ vmem,
+void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const QAsm qa, const T* __restrict__ kmem, const T* __restrict__ vmem,
                               float scale, T* __restrict__ out) {
     constexpr int H = E / DEC_HD, NK = 128;
     constexpr int EPC = 16 / (int)sizeof(T);           // elements per 16-byte piece: 8 (bf16) or 4 (f32)
@@ -223,8 +261,7 @@ void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const T* __restrict_
 #pragma unroll
         for (int c = 0; c < NL; ++c) vr[c].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)c * KPL * DEC_HD));
         float qv[EPC];
-#pragma unroll
-        for (int i = 0; i < EPC; ++i) qv[i] = qc[(size_t)b * E + h * DEC_HD + dl * EPC + i] * scale;
+        q_assemble<EPC>(qa, qc, b, E, h * DEC_HD + dl * EPC, scale, qv);
         float s[NL], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < NL; ++c) {
@@ -284,7 +321,7 @@ __device__ __forceinline__ void f24_unpack8(const u32x4& hi, const uint2& lo, fl
 // one 16-byte and one 8-byte load per piece, a KiB and half a KiB contiguous per wave load; all 32 loads of a head in flight first.
 template <int E>
 __global__ __launch_bounds__(E)
-void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const unsigned char* __restrict__ kmem, const unsigned char* __restrict__ vmem,
+void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const QAsm qa, const unsigned char* __restrict__ kmem, const unsigned char* __restrict__ vmem,
                                 size_t plane_elems, float scale, float* __restrict__ out) {
     constexpr int H = E / DEC_HD, NK = 128, LPR = 4, KPL = 16, NL = 8;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = E / 64, b = blockIdx.x;
@@ -318,8 +355,7 @@ void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const unsigned cha
 #pragma unroll
         for (int c = 0; c < NL; ++c) { const unsigned long long t = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(vq + (size_t)c * KPL * DEC_HD)); vlo[c] = make_uint2((unsigned)t, (unsigned)(t >> 32)); }
         float qv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qv[i] = qc[(size_t)b * E + h * DEC_HD + dl * 8 + i] * scale;
+        q_assemble<8>(qa, qc, b, E, h * DEC_HD + dl * 8, scale, qv);
         float s[NL], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < NL; ++c) {

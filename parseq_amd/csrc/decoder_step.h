@@ -559,11 +559,45 @@ __device__ __forceinline__ void ds_params_store(const float (&v)[NSEG], float* c
         if (t < n[k]) dst[k][t] = t < valid[k] ? v[k] : 0.f;
 }
 
+// ---- the mid kernel's start half split over DS_QS workgroups per row tile (round 4) ---------------------------------------------------------
+// out_proj and the q-projection are two 0.3 MB (bf16; 0.6 MB as pairs) weight streams through ONE CU each, 10 of the mid kernel's 25 us.
+// With QS > 1, workgroup qs of a row tile owns columns [qs E/QS, (qs + 1) E/QS) of x = pos_query + sa @ Wo^T + bo: it streams only those
+// rows of Wo, and only those K-columns of Wq — the q-projection becomes a K-split whose partial sums the cross-attention kernel adds up
+// (decoder_attn.h QAsm / q_assemble; the launch boundary is the exchange, no grid-wide hand-off inside a launch).  norm1 sits between the
+// two products and needs the row's mean and variance: the mean is known BEFORE x is, mean(x) = c0[pos] + sa . wbar with wbar the column
+// means of Wo (dec_qfold_kernel, folded once per weight set), so every workgroup centres its own columns, multiplies them by ln_w, and
+// leaves sum (x - m) and sum (x - m)^2 of its columns for the consumer, which finishes LayerNorm behind the product (two-pass arithmetic on
+// centred values; the estimate's rounding error d is corrected exactly).  The finish half (partial sums -> decoder.norm -> head -> pick)
+// and the table self-attention are computed by every workgroup of the tile (each needs the picked token and the whole sa row); only
+// workgroup 0 writes logits / tok / EOS bookkeeping.
+constexpr int DS_QS = 3;        // E / DS_QS must be a multiple of 64 (k-chunks of the fragment packs): 128 columns at E = 384, 64 at E = 192
+
+// qfold = [wbar E | cq E | bq2 E | c0 npos]:  wbar[k] = mean_n Wo[n][k] on the operand values the product sees (T = bf16: the rounded
+// weights), cq[n] = sum_k ln_w[k] Wq[n][k], bq2[n] = sum_k ln_b[k] Wq[n][k] + bq[n], c0[pos] = mean_n (pos_queries[pos][n] + bo[n]).
+template <typename T>
+__global__ __launch_bounds__(512)
+void dec_qfold_kernel(const T* __restrict__ Wo, const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ ln_w,
+                      const float* __restrict__ ln_b, const float* __restrict__ bo, const float* __restrict__ pos_queries, int E, int npos,
+                      float* __restrict__ qfold) {
+    const int t = threadIdx.x;
+    if (t < E) {
+        float sw = 0.f, sc = 0.f, sb = 0.f;
+        for (int n = 0; n < E; ++n) sw += to_f32(Wo[(size_t)n * E + t]);
+        for (int k = 0; k < E; ++k) { const float w = Wq[(size_t)t * E + k]; sc = fmaf(ln_w[k], w, sc); sb = fmaf(ln_b[k], w, sb); }
+        qfold[t] = sw / (float)E; qfold[E + t] = sc; qfold[2 * E + t] = sb + bq[t];
+    }
+    if (t < npos) {
+        float s0 = 0.f;
+        for (int n = 0; n < E; ++n) s0 += pos_queries[(size_t)t * E + n] + bo[n];
+        qfold[3 * E + t] = s0 / (float)E;
+    }
+}
+
 // tq: fp32 [M][E], t' of the step being finished (written by dec_step_mlp_kernel split 0); partial: fp32 [DS_SPLIT][M][E].
 // pos: the step being started (its query position); the step being finished is pos - 1.  Lk = pos + 1 context tokens.
 // X3: bf16x3 arithmetic — Wh / Wo / Wq are frag_pack_x3_kernel packs, kvtab is f32, every MFMA operand a bf16 pair; the
 // element-wise parts (table soft-max, LayerNorm, residuals, pick) are the same fp32 code.
-template <int E, bool X3 = false>
+template <int E, bool X3 = false, int QS = 1>
 __global__ __launch_bounds__(64 * DS_NW)
 void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                          // finish
@@ -575,9 +609,12 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                          const float* __restrict__ stab, const typename std::conditional<X3, float, bf16_t>::type* __restrict__ kvtab, int* __restrict__ tok, int ldt, int ntok,
                          int npos, const bf16_t* __restrict__ Wo, const float* __restrict__ bo, const float* __restrict__ pos_queries,
                          const float* __restrict__ ln1_w, const float* __restrict__ ln1_b, const bf16_t* __restrict__ Wq,
-                         const float* __restrict__ bq, float* __restrict__ t_out, float* __restrict__ qc_out) {
+                         const float* __restrict__ bq, float* __restrict__ t_out, float* __restrict__ qc_out,
+                         const float* __restrict__ qfold, float* __restrict__ qstats) {
     constexpr int PA = E + 8, PT = E + 4, TILES = E / 16, TN = (TILES + DS_NW - 1) / DS_NW, PL = 128, RPW = DS_ROWS / DS_NW;
     constexpr int DS_SPLIT = ds_split<E>();
+    constexpr int EN = E / QS, TS = EN / 16, TNS = (TS + DS_NW - 1) / DS_NW;      // QS > 1: this workgroup's columns of x, their tiles
+    static_assert(QS == 1 || EN % 64 == 0, "a split's columns are whole k-chunks of the fragment packs");
     constexpr int NPL = X3 ? 2 : 1, ALO = DS_ROWS * PA;                 // planes per operand; element offset of the lo plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_ds[];
     bf16_t* abuf = reinterpret_cast<bf16_t*>(smem_ds);                 // [NPL][DS_ROWS][PA]
@@ -588,7 +625,9 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
     float* const s_lnf_w = prm, * const s_lnf_b = prm + E, * const s_bh = prm + 2 * E, * const s_bo = prm + 2 * E + 128, * const s_posq = prm + 3 * E + 128,
          * const s_ln1_w = prm + 4 * E + 128, * const s_ln1_b = prm + 5 * E + 128, * const s_bq = prm + 6 * E + 128;
     unsigned char* wring = reinterpret_cast<unsigned char*>(prm + ds_mid_params<E>()) + wave * DS_RING * 1024;
-    const int row0 = blockIdx.x * DS_ROWS;
+    const int qs = QS > 1 ? (int)(blockIdx.x % QS) : 0;                // QS > 1: grid = row tiles x QS, this workgroup's share of the start half
+    const int row0 = (int)(blockIdx.x / QS) * DS_ROWS;
+    if (QS > 1 && !do_start && qs != 0) return;                        // the trailing finish-only launch is workgroup 0's alone
     int picked[RPW], tokv[RPW];
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
@@ -600,7 +639,9 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
     DS_T0();
     static_assert(E <= 64 * DS_NW, "one parameter per thread and segment");
     float* const prm_dst[8] = {s_lnf_w, s_lnf_b, s_bh, s_bo, s_posq, s_ln1_w, s_ln1_b, s_bq};
-    const float* const prm_src[8] = {lnf_w, lnf_b, bh, bo, pos_queries + (size_t)min(pos, npos - 1) * E, ln1_w, ln1_b, bq};
+    // QS > 1: norm1's shift and the q-projection's bias are folded into the consumer's bq2; the slot of ln1_b holds wbar
+    const float* const prm_src[8] = {lnf_w, lnf_b, bh, bo, pos_queries + (size_t)min(pos, npos - 1) * E, ln1_w, QS > 1 ? qfold : ln1_b, bq};
+    const float c0 = QS > 1 ? qfold[3 * E + min(pos, npos - 1)] : 0.f;
     const int prm_n[8] = {E, E, 128, E, E, E, E, E}, prm_valid[8] = {E, E, C, E, E, E, E, E};
     float prm_v[8];
     ds_params_load<8>(prm_v, prm_src, prm_valid);
@@ -628,14 +669,17 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
         {
             f32x4 acc[1] = {};
             ds_wave_gemm<E, 1, true, NPL>(abuf, PA, Wh, (C + 15) / 16, wave, wring, acc, 0, 0, ALO);
-            if (do_start) ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
+            if (do_start) {
+                if constexpr (QS > 1) ds_prefetch<E, TNS, NPL>(Wo + (size_t)qs * TS * (E / 64) * (1024 * NPL), TS, wave, wring);
+                else ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
+            }
             const int n = wave * 16 + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (n + r < C) {
                     const float v = acc[0][r] + s_bh[n + r];
                     lg[r16 * PL + n + r] = v;
-                    if (row0 + r16 < M) logits[((size_t)(row0 + r16) * Ltot + (pos - 1)) * C + n + r] = v;
+                    if (qs == 0 && row0 + r16 < M) logits[((size_t)(row0 + r16) * Ltot + (pos - 1)) * C + n + r] = v;
                 }
             }
         }
@@ -653,7 +697,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                 wave_argmax(best, bi);
                 bi = argmax_final(bi, C);
                 picked[rr] = bi;
-                if (lane == 0 && b < M) {
+                if (qs == 0 && lane == 0 && b < M) {
                     tok[(size_t)b * ldt + pos] = bi;
                     if (argmax_mode == 2 && bi == eos_id && !eos_seen[b]) {
                         eos_seen[b] = 1;
@@ -665,7 +709,8 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
         }
     } else if (do_start) {
         ds_params_store<8>(prm_v, prm_dst, prm_n, prm_valid);
-        ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
+        if constexpr (QS > 1) ds_prefetch<E, TNS, NPL>(Wo + (size_t)qs * TS * (E / 64) * (1024 * NPL), TS, wave, wring);
+        else ds_prefetch<E, TN, NPL>(Wo, TILES, wave, wring);
     }
     if (!do_start) return;
     DS_TICK(3);
@@ -680,6 +725,75 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
     }
     __syncthreads();
     DS_TICK(4);
+    if constexpr (QS > 1) {
+        const int n0 = qs * EN;
+        float* mt = lg;                                      // [DS_ROWS] row-mean estimates (the logits tile is dead after the pick)
+        // m = c0[pos] + sa . wbar  (= the mean of the row of x this tile's workgroups are about to compute, to rounding)
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = wave * RPW + rr;
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < E / 64; ++i) {
+                const int c = lane + 64 * i;
+                float a = to_f32(abuf[row * PA + c]);
+                if constexpr (X3) a += to_f32(abuf[ALO + row * PA + c]);
+                dot = fmaf(a, s_ln1_b[c], dot);              // the slot holds wbar
+            }
+            dot = wave_sum(dot);
+            if (lane == 0) mt[row] = dot + c0;
+        }
+        {   // x[:, cols] = pos_queries[pos] + sa @ Wo[cols]^T + bo
+            f32x4 acc[TNS] = {};
+            ds_wave_gemm<E, TNS, true, NPL>(abuf, PA, Wo + (size_t)qs * TS * (E / 64) * (1024 * NPL), TS, wave, wring, acc, 0, 0, ALO);
+            ds_prefetch<EN, TN, NPL>(Wq, TILES, wave, wring, qs * (EN / 64), E / 64);
+#pragma unroll
+            for (int t = 0; t < TNS; ++t) {
+                const int tile = wave + DS_NW * t;
+                if (tile < TS) {
+                    const int nl = tile * 16 + 4 * g, n = n0 + nl;
+                    const float4 bv = *reinterpret_cast<const float4*>(s_bo + n);
+                    const float4 pv = *reinterpret_cast<const float4*>(s_posq + n);
+                    f32x4 o = {acc[t][0] + bv.x + pv.x, acc[t][1] + bv.y + pv.y, acc[t][2] + bv.z + pv.z, acc[t][3] + bv.w + pv.w};
+                    *reinterpret_cast<f32x4*>(tl + r16 * PT + nl) = o;
+                    if (row0 + r16 < M) *reinterpret_cast<f32x4*>(t_out + (size_t)(row0 + r16) * E + n) = o;
+                }
+            }
+        }
+        __syncthreads();
+        DS_TICK(5);
+        // centred, scaled columns as the q-projection's A operand (local columns 0 .. EN - 1); the column sums for the consumer
+#pragma unroll
+        for (int rr = 0; rr < RPW; ++rr) {
+            const int row = wave * RPW + rr;
+            const float m = mt[row];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < EN / 64; ++i) {
+                const int c = lane + 64 * i;
+                const float d = tl[row * PT + c] - m;
+                s1 += d; s2 = fmaf(d, d, s2);
+                const float y = d * s_ln1_w[n0 + c];
+                const bf16_t hi = from_f32<bf16_t>(y);
+                abuf[row * PA + c] = hi;
+                if constexpr (X3) abuf[ALO + row * PA + c] = from_f32<bf16_t>(y - to_f32(hi));
+            }
+            s1 = wave_sum(s1); s2 = wave_sum(s2);
+            if (lane == 0 && row0 + row < M) *reinterpret_cast<float2*>(qstats + ((size_t)qs * M + row0 + row) * 2) = make_float2(s1, s2);
+        }
+        __syncthreads();
+        DS_TICK(6);
+        {   // qp[qs] = ((x - m) * ln_w)[:, cols] @ Wq[:, cols]^T
+            f32x4 acc[TN] = {};
+            ds_wave_gemm<EN, TN, true, NPL>(abuf, PA, Wq, TILES, wave, wring, acc, qs * (EN / 64), E / 64, ALO);
+            float* dst = qc_out + (size_t)qs * M * E;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int tile = wave + DS_NW * t;
+                if (tile < TILES && row0 + r16 < M) *reinterpret_cast<f32x4*>(dst + (size_t)(row0 + r16) * E + tile * 16 + 4 * g) = acc[t];
+            }
+        }
+    } else {
     {   // t = pos_queries[pos] + sa @ Wo^T + bo
         const float* posq = s_posq;
         f32x4 acc[TN] = {};
@@ -716,6 +830,7 @@ void dec_step_mid_kernel(int do_finish, int do_start, int pos, int M,
                 *reinterpret_cast<f32x4*>(qc_out + (size_t)(row0 + r16) * E + n) = o;
             }
         }
+    }
     }
 #if DS_TIMERS
     DS_TICK(7);

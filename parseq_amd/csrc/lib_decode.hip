@@ -7,10 +7,11 @@
 // Cross-attention of Lq queries per image against the plan's cached memory K / V: tuned kernels for 128 memory tokens
 // (streaming AR kernel, MFMA multi-query kernel), the key-count-generic kernel otherwise.
 template <typename T, int E>
-static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca) {
+static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, float scale, T* ca, const QAsm qa = QAsm{}) {
     const int H = p->m->cfg.dec_heads, NK = p->m->tokens;
     const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
     const float* qc_ = p->qc;
+    if (qa.nsplit && (NK != 128 || Lq != 1)) return fail(PARSEQ_E_STATE, "cross-attention: split q-projection outside the AR step kernels");
     if (NK != 128) {
         if constexpr (sizeof(T) == 2) {
             const int nt16 = (NK + 15) / 16;
@@ -32,14 +33,14 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
     } else if (Lq == 1) {
         if constexpr (sizeof(T) == 4 && E == 384) {
             if (p->kv24) {
-                hipLaunchKernelGGL((dec_cross_attn_ar24_kernel<E>), dim3(B), dim3(E), 0, s, qc_, reinterpret_cast<const unsigned char*>(p->kmem),
+                hipLaunchKernelGGL((dec_cross_attn_ar24_kernel<E>), dim3(B), dim3(E), 0, s, qc_, qa, reinterpret_cast<const unsigned char*>(p->kmem),
                                    reinterpret_cast<const unsigned char*>(p->vmem), p->kv_plane_elems, scale, ca);
                 HIPCHK(hipGetLastError());
                 return 0;
             }
         }
         if (p->kv24) return fail(PARSEQ_E_STATE, "cross-attention: 24-bit K / V rows but no kernel for this geometry");
-        hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, qc_, kmem, vmem, scale, ca);
+        hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, qc_, qa, kmem, vmem, scale, ca);
     } else if constexpr (sizeof(T) == 2) {
         hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
     } else {
@@ -178,7 +179,7 @@ static int decode_pass(parseq_plan* p, hipStream_t s, int B, int Lk, int i0, int
 // storage; E <= 384): step i's logits are produced by the mid kernel of step i + 1 (and by one trailing finish-only launch after
 // the last step).
 template <int E, bool X3 = false>
-static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing) {
+static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, float* logits, bool testing, bool latency) {
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
     const int M = B, C = m->classes, npos = c.max_label_length + 1;
@@ -193,27 +194,39 @@ static int ar_loop_fused(parseq_plan* p, hipStream_t s, int B, int num_steps, fl
     unsigned char* eos_seen = p->eos_seen;
     const float scale = sqrtf(1.0f / (float)DEC_HD);
     const dim3 grid((M + DS_ROWS - 1) / DS_ROWS), block(64 * DS_NW);
-    static LdsAttr attr_mid, attr_mlp;
+    static LdsAttr attr_mid, attr_midq, attr_mlp;
     HIPCHK(attr_mid.ensure(reinterpret_cast<const void*>(dec_step_mid_kernel<E, X3>), dec_step_mid_lds<E, X3>()));
+    HIPCHK(attr_midq.ensure(reinterpret_cast<const void*>(dec_step_mid_kernel<E, X3, DS_QS>), dec_step_mid_lds<E, X3>()));
     HIPCHK(attr_mlp.ensure(reinterpret_cast<const void*>(dec_step_mlp_kernel<E, X3>), dec_step_mlp_lds<E, X3>()));
+    // The start half of the mid kernel split over DS_QS workgroups per row tile (decoder_step.h): the q-projection arrives at the
+    // cross-attention as partial sums behind t' in the q buffer ([M][E] t' | [DS_QS][M][E] partials | [DS_QS][M][2] column sums; the buffer
+    // holds npos rows per image).  Only the two AR cross-attention kernels know how to read that (128 memory tokens).
+    // Taken when the caller says this forward is alone on the device (PARSEQ_FLAG_LATENCY): the wider step is a shorter chain but costs
+    // about twice the compute-unit time, which batches in flight on other streams would rather have (profiles/r04_ar_step_timers.md).
+    const bool qsplit = latency && p->qsplit && m->tokens == 128 && npos >= DS_QS + 2;
+    float* qp = tq + (size_t)M * E;
+    float* qstats = qp + (size_t)DS_QS * M * E;
+    QAsm qa;
+    if (qsplit) { qa.qp = qp; qa.stats = qstats; qa.cq = p->qfold + E; qa.bq2 = p->qfold + 2 * E; qa.nsplit = DS_QS; qa.M = M; qa.inv_e = 1.0f / (float)E; qa.eps = c.dec_ln_eps; }
     for (int i = 0; i <= num_steps; ++i) {
         const int do_finish = i > 0, do_start = i < num_steps;
         // the pick of position i - 1 feeds step i: needed while there is a step to start
         const int argmax_mode = do_start ? (testing ? 2 : 1) : 0;
         {
             ProfScope ps_(&p->prof, T_DEC_PRE, s);
-            hipLaunchKernelGGL((dec_step_mid_kernel<E, X3>), grid, block, (dec_step_mid_lds<E, X3>()), s, do_finish, do_start, i, M,
+            const auto mid = qsplit ? dec_step_mid_kernel<E, X3, DS_QS> : dec_step_mid_kernel<E, X3, 1>;
+            hipLaunchKernelGGL(mid, dim3(grid.x * (qsplit ? DS_QS : 1)), block, (dec_step_mid_lds<E, X3>()), s, do_finish, do_start, i, M,
                                tq, partial, m->p(d + "linear2.bias"), m->p("decoder.norm.weight"), m->p("decoder.norm.bias"), c.dec_ln_eps,
                                p->wstep[5], m->p("head.bias"), C, logits, num_steps, argmax_mode, c.eos_id, eos_seen, eos_rows, ar_len,
                                p->stab, reinterpret_cast<const TS*>(p->kvtab), tok, LDT, c.num_tokens, npos, p->wstep[0],
                                m->p(d + "self_attn.out_proj.bias"), m->p("pos_queries"), m->p(d + "norm1.weight"), m->p(d + "norm1.bias"),
-                               p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), t, tq);
+                               p->wstep[1], m->p(d + "cross_attn.in_proj_bias"), t, qsplit ? qp : tq, p->qfold, qstats);
             HIPCHK(hipGetLastError());
         }
         if (!do_start) break;
         {
             ProfScope ps_(&p->prof, T_DEC_CA, s);
-            CHK((run_cross_attention<TS, E>(p, s, B, 1, scale, ca)));
+            CHK((run_cross_attention<TS, E>(p, s, B, 1, scale, ca, qa)));
         }
         {
             ProfScope ps_(&p->prof, T_DEC_POST, s);
@@ -231,7 +244,7 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
     const parseq_model* m = p->m;
     const parseq_config& c = m->cfg;
     const int C = m->classes;
-    const bool ar = flags & PARSEQ_FLAG_DECODE_AR, testing = flags & PARSEQ_FLAG_TESTING;
+    const bool ar = flags & PARSEQ_FLAG_DECODE_AR, testing = flags & PARSEQ_FLAG_TESTING, latency = flags & PARSEQ_FLAG_LATENCY;
     int* eos_rows = p->counters; int* ar_len = p->counters + 1;
     hipLaunchKernelGGL(ar_init_kernel, dim3((B * LDT + 255) / 256), dim3(256), 0, s, p->tok, LDT, B, c.bos_id, c.pad_id, p->eos_seen, p->counters, 2, num_steps);
     HIPCHK(hipGetLastError());
@@ -241,14 +254,14 @@ static int forward_impl(parseq_plan* p, int B, int flags, int refine_iters, int 
         bool done = false;
         if constexpr (sizeof(T) == 2) {
             if (p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4) {
-                if (c.embed_dim == 384) { CHK((ar_loop_fused<384>(p, s, B, num_steps, logits, testing))); done = true; }
-                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192>(p, s, B, num_steps, logits, testing))); done = true; }
+                if (c.embed_dim == 384) { CHK((ar_loop_fused<384>(p, s, B, num_steps, logits, testing, latency))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192>(p, s, B, num_steps, logits, testing, latency))); done = true; }
             }
         } else {
             // bf16x3: the same fused step on bf16 pairs (f32 tables, f32 memory K / V); the fp32 mode keeps the per-op kernels
             if (p->precision == PARSEQ_BF16X3 && p->wstep[0] && p->fused_step && C <= 128 && c.dec_mlp_ratio == 4) {
-                if (c.embed_dim == 384) { CHK((ar_loop_fused<384, true>(p, s, B, num_steps, logits, testing))); done = true; }
-                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192, true>(p, s, B, num_steps, logits, testing))); done = true; }
+                if (c.embed_dim == 384) { CHK((ar_loop_fused<384, true>(p, s, B, num_steps, logits, testing, latency))); done = true; }
+                else if (c.embed_dim == 192) { CHK((ar_loop_fused<192, true>(p, s, B, num_steps, logits, testing, latency))); done = true; }
             }
         }
         for (int i = 0; !done && i < num_steps; ++i) {

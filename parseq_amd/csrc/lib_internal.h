@@ -261,6 +261,8 @@ struct parseq_plan {
     bool kv24_enabled = getenv("PARSEQ_NO_KV24") == nullptr;      // diagnostics: keep f32 K / V rows in the bf16x3 mode
     int num_cus = 256;             // compute units of the device (tail-round avoidance of the one- and two-workgroup-per-CU kernels)
     bool fused_step = getenv("PARSEQ_NO_FUSED_STEP") == nullptr;   // diagnostics: fall back to the per-op AR step
+    float* qfold = nullptr;        // [wbar E | cq E | bq2 E | c0 npos] of the split mid kernel (decoder_step.h dec_qfold_kernel), per weight set
+    bool qsplit = getenv("PARSEQ_NO_QSPLIT") == nullptr;         // diagnostics: the mid kernel's start half on one workgroup per row tile
     bool fused_attn = getenv("PARSEQ_NO_FUSED_ATTN") == nullptr;   // diagnostics: qkv panel GEMM + attention + proj GEMM instead of encoder_attn_fused.h
     bool mlp_resident = getenv("PARSEQ_MLP_RELOAD") == nullptr;    // diagnostics: the fused MLP's first form (x re-read by the epilogue)
     bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h

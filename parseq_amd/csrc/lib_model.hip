@@ -208,6 +208,10 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
                                    src[i].K, p->wstep[i], tiles);
                 HIPCHK(hipGetLastError());
             }
+            hipLaunchKernelGGL(dec_qfold_kernel<bf16_t>, dim3(1), dim3(512), 0, s, src[0].w, m->p(d + "cross_attn.in_proj_weight"), m->p(d + "cross_attn.in_proj_bias"),
+                               m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), m->p(d + "self_attn.out_proj.bias"), m->p("pos_queries"), E,
+                               m->cfg.max_label_length + 1, p->qfold);
+            HIPCHK(hipGetLastError());
         }
     } else {
         if (p->precision == PARSEQ_BF16X3) {
@@ -236,6 +240,10 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
                                        src[i].K, p->wstep[i], tiles);
                     HIPCHK(hipGetLastError());
                 }
+                hipLaunchKernelGGL(dec_qfold_kernel<float>, dim3(1), dim3(512), 0, s, src[0].w, src[1].w, m->p(d + "cross_attn.in_proj_bias"),
+                                   m->p(d + "norm1.weight"), m->p(d + "norm1.bias"), m->p(d + "self_attn.out_proj.bias"), m->p("pos_queries"), E,
+                                   m->cfg.max_label_length + 1, p->qfold);
+                HIPCHK(hipGetLastError());
             }
         }
         SplitScope ss(p->precision == PARSEQ_BF16X3);
@@ -286,6 +294,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t o_cloze = carve(off, npos * LDT), o_qmu = carve(off, npos * LDT), o_cnt = carve(off, 64);
     const size_t o_blocks = carve(off, (size_t)c.enc_depth * sizeof(EncBlockParams));
     const size_t o_posb = carve(off, N * E * 4);
+    const size_t o_qfold = carve(off, (3 * E + npos) * 4);
     p->arena_bytes = off;
     hipError_t e = hipMalloc(&p->arena, off);
     if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
@@ -298,6 +307,7 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     p->t = (float*)(a + o_t); p->qc = (float*)(a + o_qc);
     p->blocks_dev = reinterpret_cast<EncBlockParams*>(a + o_blocks);
     p->posb = reinterpret_cast<float*>(a + o_posb);
+    p->qfold = reinterpret_cast<float*>(a + o_qfold);
     p->tok = (int*)(a + o_tok); p->kpm = a + o_kpm; p->eos_seen = a + o_eos; p->cloze = a + o_cloze; p->qmask_user = a + o_qmu; p->counters = (int*)(a + o_cnt);
     int r = pack_weights(p, (hipStream_t)stream);
     if (r != 0) { parseq_plan_destroy(p); return r; }

@@ -494,7 +494,7 @@ class PARSeq(_NativeBacked):
                                                          _native.ptr(kpm), _native.ptr(out), _native.stream_ptr(self._device)))
         return out
 
-    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None, slot: int = 0,
+    def forward(self, tokenizer: Tokenizer, images: Tensor, max_length: Optional[int] = None, slot: Optional[int] = None,
                 return_length: bool = False):
         """model.py:105-169.  Returns logits [B, L, num_tokens - 2] (fp32).
 
@@ -504,20 +504,24 @@ class PARSeq(_NativeBacked):
 
         `slot` selects one of several independent workspaces (plans): calls that use different slots on different
         streams may be in flight at the same time (bench.py --streams 2 overlaps the latency-bound AR decode of one batch
-        with the encoder of the next).  The default is the reference's behaviour: one call at a time, stream-ordered."""
+        with the encoder of the next).  The default (`slot=None`) is the reference's behaviour: one call at a time,
+        stream-ordered, on workspace 0 — and it tells the library so (PARSEQ_FLAG_LATENCY): with the device to itself the AR step
+        spreads over more compute units, a shorter dependent chain.  An explicit slot (0 included) says other batches are in flight
+        and keeps the narrower step, whose compute units they need; the two forms differ by rounding only."""
         testing = max_length is None
         max_length = self.max_label_length if max_length is None else min(max_length, self.max_label_length)
         num_steps = max_length + 1
         images = self._check_images(images)
         B = images.shape[0]
-        plan = self._plan(B, slot)
+        plan = self._plan(B, 0 if slot is None else slot)
         key = getattr(self, '_memory_key', None)
         if key is not None and key[2] == plan.value:
             self._memory_key = None             # this plan's cached K / V now belong to these images, not to an encode() result
         if (tokenizer.bos_id, tokenizer.eos_id, tokenizer.pad_id) != self._special_ids(tokenizer):
             raise RuntimeError('tokenizer special ids changed after the native model was built')
         logits = torch.empty(B, num_steps, self._cfg['num_tokens'] - 2, dtype=torch.float32, device=images.device)
-        flags = (_native.FLAG_DECODE_AR if self.decode_ar else 0) | (_native.FLAG_TESTING if testing else 0)
+        flags = ((_native.FLAG_DECODE_AR if self.decode_ar else 0) | (_native.FLAG_TESTING if testing else 0)
+                 | (_native.FLAG_LATENCY if slot is None else 0))
         out_len = C.c_int(0)
         _native.check(_native.lib().parseq_forward(plan, _native.ptr(images), _native.dtype_code(images.dtype), B, flags,
                                                    int(self.refine_iters), num_steps, _native.ptr(logits),

@@ -237,11 +237,11 @@ class PARSeq(nn.Module):
     def precision(self, value: str) -> None:
         self.model.precision = value
 
-    def forward(self, images: Tensor, max_length: Optional[int] = None, slot: int = 0) -> Tensor:
+    def forward(self, images: Tensor, max_length: Optional[int] = None, slot: Optional[int] = None) -> Tensor:
         """Inference (system.py:87-88): images [N, 3, H, W] -> logits [N, L, C].  (`slot`: see model.PARSeq.forward.)"""
         return self.model.forward(self.tokenizer, images, max_length, slot)
 
-    def forward_with_length(self, images: Tensor, max_length: Optional[int] = None, slot: int = 0):
+    def forward_with_length(self, images: Tensor, max_length: Optional[int] = None, slot: Optional[int] = None):
         """(logits of all num_steps positions, L): `forward` is `logits[:, :L]`.  L < num_steps only for AR decoding without
         refinement and `max_length=None` (the batch-level early exit of model.py:144-145)."""
         return self.model.forward(self.tokenizer, images, max_length, slot, return_length=True)

@@ -357,6 +357,50 @@ def test_kv_rows_24_bit_vs_f32(golden, monkeypatch):
     assert torch.equal(again, a_ar)
 
 
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16'])
+def test_ar_step_split_over_workgroups_vs_one_workgroup(golden, models, monkeypatch, name, precision):
+    """The AR step's out_proj -> norm1 -> q-projection chain split over DS_QS workgroups per row tile (decoder_step.h
+    dec_step_mid_kernel<.., QS = 3>: column slices of out_proj, the q-projection as a K-split whose partial sums the cross-attention
+    kernel adds up, LayerNorm finished behind the product from a mean known in advance and exchanged column sums) — what a forward that has
+    the device to itself runs (PARSEQ_FLAG_LATENCY: the default call, no `slot`) — against the same chain on one workgroup per tile (an
+    explicit slot: batches in flight).  Same products, different summation order and a LayerNorm scaled after instead of before the
+    product: the bf16x3 logits may differ by rounding only; both must stay within the tolerance of the reference's own outputs.
+    PARSEQ_NO_QSPLIT=1 (read when a plan is created) turns the split off altogether: then the two calls are the same computation."""
+    g, _ = golden(name)
+    images = g['images'].to(DEV)
+    m = models[precision]
+
+    def narrow(mode):
+        ar, ri, ml = MODES[mode]
+        m.model.decode_ar, m.model.refine_iters = ar, ri
+        with torch.inference_mode():
+            out = m(images, ml, slot=0)
+        torch.cuda.synchronize()
+        return out.float().cpu()
+    a0, a1 = _run(m, images, 'ar0'), _run(m, images, 'ar1')
+    b0, b1 = narrow('ar0'), narrow('ar1')
+    if precision == 'bf16x3':
+        for mode, got in (('ar0', a0), ('ar1', a1), ('ar0', b0), ('ar1', b1)):
+            d, msg = report(f'AR step vs reference golden ({name}, {mode})', got, g[f'logits.{mode}'])
+            assert d <= 1e-3, msg
+            assert torch.equal(got.argmax(-1).cpu(), g[f'logits.{mode}'].argmax(-1)), msg
+        d, msg = report(f'split vs one-workgroup AR step ({name}, bf16x3, AR)', a0, b0)
+        assert 0 < d <= 1e-4, msg                            # d > 0: the split path really ran
+        d, msg = report(f'split vs one-workgroup AR step ({name}, bf16x3, AR + 1 refinement)', a1, b1)
+        assert d <= 1e-4, msg
+    else:
+        # bf16 operands: the two forms round different intermediates ((x - m) ln_w against the normalised row); both sit at the mode's
+        # own distance from the exact result, so they are compared through it
+        ref = g['logits.ar0']
+        da, _ = report(f'split AR step vs golden ({name}, bf16)', a0, ref)
+        db, _ = report(f'one-workgroup AR step vs golden ({name}, bf16)', b0, ref)
+        assert torch.isfinite(a0).all() and not torch.equal(a0, b0)
+        assert da <= max(2.0 * db, 0.05), (da, db)
+    monkeypatch.setenv('PARSEQ_NO_QSPLIT', '1')
+    off = make_model(name, precision)
+    assert torch.equal(_run(off, images, 'ar0'), b0)
+
+
 @pytest.mark.parametrize('precision', ['bf16', 'bf16x3'])
 def test_slots_and_streams_give_identical_results(models, golden, name, precision):
     """`slot=k` workspaces on separate streams (bench.py --streams 2) must not interfere: two batches in flight reproduce the
@@ -367,7 +411,7 @@ def test_slots_and_streams_give_identical_results(models, golden, name, precisio
     a = g['images'].repeat(8, 1, 1, 1).to(DEV)
     b = a.flip(0).contiguous()
     with torch.inference_mode():
-        ref_a, ref_b = m(a, 25).clone(), m(b, 25).clone()
+        ref_a, ref_b = m(a, 25, slot=0).clone(), m(b, 25, slot=0).clone()      # an explicit slot: the in-flight form of the AR step
         torch.cuda.synchronize()          # the reference runs used slot 0 on the default stream: drain before reusing it elsewhere
         s0, s1 = torch.cuda.Stream(), torch.cuda.Stream()
         outs = []
