@@ -195,34 +195,45 @@ struct QAsm {
     const float* qp = nullptr; const float* stats = nullptr; const float* cq = nullptr; const float* bq2 = nullptr;
     int nsplit = 0, M = 0; float inv_e = 0.f, eps = 0.f;
 };
-// qv[0, N) = scale * q[b][n0 .. n0 + N), N a multiple of 4
-template <int N>
-__device__ __forceinline__ void q_assemble(const QAsm& qa, const float* __restrict__ qc, int b, int E, int n0, float scale, float (&qv)[N]) {
-    if (qa.nsplit == 0) {
+constexpr int DS_QS = 3;        // workgroups per row tile of the split mid kernel (decoder_step.h); E / DS_QS must be a multiple of 64
+// How the two AR kernels read it: thread t of the image's workgroup loads what element t of the query needs as the launch's FIRST loads
+// (one dword per split: coalesced, not one 16-byte piece per lane and head — that form cost the kernel 2-3 us of load issue), every wave then
+// puts its first head's K / V loads in flight, and only then is the element finished, parked in LDS and the workgroup synchronised.  Vector
+// memory returns in order: query loads issued behind the K / V stream, or one round trip per split inside a loop, wait for the whole
+// stream first (measured: + 5.7 us per step); a run-time branch on the form between the loads and their use made the scheduler sink the
+// K / V loads into the arithmetic (half the bytes in flight) — hence one instantiation per form and a sched_barrier behind the loads.
+template <bool SPLIT>
+struct QOne { float part[SPLIT ? DS_QS : 1]; float2 st[DS_QS]; float cq, bq; };
+template <bool SPLIT>
+__device__ __forceinline__ void q_issue(const QAsm& qa, const float* __restrict__ qc, int b, int E, int n, QOne<SPLIT>& r) {
+    if constexpr (!SPLIT) {
+        r.part[0] = qc[(size_t)b * E + n];
+    } else {
 #pragma unroll
-        for (int i = 0; i < N; ++i) qv[i] = qc[(size_t)b * E + n0 + i] * scale;
-        return;
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < N; ++i) qv[i] = 0.f;
-    for (int s = 0; s < qa.nsplit; ++s) {
-        const float2 st = *reinterpret_cast<const float2*>(qa.stats + ((size_t)s * qa.M + b) * 2);
-        s1 += st.x; s2 += st.y;
-        const float* src = qa.qp + ((size_t)s * qa.M + b) * E + n0;
-#pragma unroll
-        for (int i = 0; i < N; i += 4) {
-            const float4 v = *reinterpret_cast<const float4*>(src + i);
-            qv[i] += v.x; qv[i + 1] += v.y; qv[i + 2] += v.z; qv[i + 3] += v.w;
+        for (int s = 0; s < DS_QS; ++s) {
+            r.st[s] = *reinterpret_cast<const float2*>(qa.stats + ((size_t)s * qa.M + b) * 2);
+            r.part[s] = qa.qp[((size_t)s * qa.M + b) * E + n];
         }
+        r.cq = qa.cq[n]; r.bq = qa.bq2[n];
     }
-    const float d = s1 * qa.inv_e;
-    const float rstd = 1.0f / sqrtf(s2 * qa.inv_e - d * d + qa.eps);
+}
+template <bool SPLIT>
+__device__ __forceinline__ float q_finish(const QAsm& qa, const QOne<SPLIT>& r, float scale) {
+    if constexpr (!SPLIT) {
+        return r.part[0] * scale;
+    } else {
+        float s1 = 0.f, s2 = 0.f, q = r.part[0];
 #pragma unroll
-    for (int i = 0; i < N; ++i) qv[i] = (rstd * (qv[i] - d * qa.cq[n0 + i]) + qa.bq2[n0 + i]) * scale;
+        for (int s = 0; s < DS_QS; ++s) { s1 += r.st[s].x; s2 += r.st[s].y; }
+#pragma unroll
+        for (int s = 1; s < DS_QS; ++s) q += r.part[s];
+        const float d = s1 * qa.inv_e;
+        const float rstd = 1.0f / sqrtf(s2 * qa.inv_e - d * d + qa.eps);
+        return (rstd * (q - d * r.cq) + r.bq) * scale;
+    }
 }
 
-template <typename T, int E>
+template <typename T, int E, bool QSPLIT = false>
 __global__ __launch_bounds__(E)
 void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const QAsm qa, const T* __restrict__ kmem, const T* __restrict__ vmem,
                               float scale, T* __restrict__ out) {
@@ -249,7 +260,11 @@ void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const QAsm qa, const
         v = fmaxf(v, __shfl_xor(v, 32, 64));
         return v;
     };
-    for (int h = wid; h < H; h += nw) {
+    __shared__ __attribute__((aligned(16))) float qs[E];
+    QOne<QSPLIT> q1;
+    q_issue<QSPLIT>(qa, qc, b, E, (int)threadIdx.x, q1);
+    bool first = true;
+    for (int h = wid; h < H; h += nw) {              // exactly two heads per wave (H = 2 nw): the barrier below is uniform
         const T* kb = kmem + (((size_t)b * H + h) * NK + kl) * DEC_HD + dl * EPC;
         const T* vb = vmem + (((size_t)b * H + h) * NK + kl) * DEC_HD + dl * EPC;
         union Piece { u32x4 u; T e[EPC]; };
@@ -260,8 +275,19 @@ void dec_cross_attn_ar_kernel(const float* __restrict__ qc, const QAsm qa, const
         for (int c = 0; c < NL; ++c) kr[c].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + (size_t)c * KPL * DEC_HD));
 #pragma unroll
         for (int c = 0; c < NL; ++c) vr[c].u = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (size_t)c * KPL * DEC_HD));
+        __builtin_amdgcn_sched_barrier(0);                 // every load of the head is in flight before the first is waited for
+        if (first) {
+            qs[threadIdx.x] = q_finish<QSPLIT>(qa, q1, scale);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            first = false;
+        }
         float qv[EPC];
-        q_assemble<EPC>(qa, qc, b, E, h * DEC_HD + dl * EPC, scale, qv);
+#pragma unroll
+        for (int i = 0; i < EPC; i += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(qs + h * DEC_HD + dl * EPC + i);
+            qv[i] = v4.x; qv[i + 1] = v4.y; qv[i + 2] = v4.z; qv[i + 3] = v4.w;
+        }
         float s[NL], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < NL; ++c) {
@@ -319,7 +345,7 @@ __device__ __forceinline__ void f24_unpack8(const u32x4& hi, const uint2& lo, fl
 
 // dec_cross_attn_ar_kernel on 24-bit rows: lane (kl = lane / 4, dl = lane % 4) takes elements 8 dl .. 8 dl + 7 of key row 16 c + kl —
 // one 16-byte and one 8-byte load per piece, a KiB and half a KiB contiguous per wave load; all 32 loads of a head in flight first.
-template <int E>
+template <int E, bool QSPLIT = false>
 __global__ __launch_bounds__(E)
 void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const QAsm qa, const unsigned char* __restrict__ kmem, const unsigned char* __restrict__ vmem,
                                 size_t plane_elems, float scale, float* __restrict__ out) {
@@ -340,7 +366,11 @@ void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const QAsm qa, con
         v = fmaxf(v, __shfl_xor(v, 32, 64));
         return v;
     };
-    for (int h = wid; h < H; h += nw) {
+    __shared__ __attribute__((aligned(16))) float qs[E];
+    QOne<QSPLIT> q1;
+    q_issue<QSPLIT>(qa, qc, b, E, (int)threadIdx.x, q1);
+    bool first = true;
+    for (int h = wid; h < H; h += nw) {              // exactly two heads per wave (H = 2 nw): the barrier below is uniform
         const size_t at = (((size_t)b * H + h) * NK + kl) * DEC_HD + dl * 8;
         const unsigned char* kh = kmem + at * 2; const unsigned char* kq = kmem + plane_elems * 2 + at;
         const unsigned char* vh = vmem + at * 2; const unsigned char* vq = vmem + plane_elems * 2 + at;
@@ -354,8 +384,19 @@ void dec_cross_attn_ar24_kernel(const float* __restrict__ qc, const QAsm qa, con
         for (int c = 0; c < NL; ++c) vhi[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vh + (size_t)c * KPL * DEC_HD * 2));
 #pragma unroll
         for (int c = 0; c < NL; ++c) { const unsigned long long t = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(vq + (size_t)c * KPL * DEC_HD)); vlo[c] = make_uint2((unsigned)t, (unsigned)(t >> 32)); }
+        __builtin_amdgcn_sched_barrier(0);                 // every load of the head is in flight before the first is waited for
+        if (first) {
+            qs[threadIdx.x] = q_finish<QSPLIT>(qa, q1, scale);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            first = false;
+        }
         float qv[8];
-        q_assemble<8>(qa, qc, b, E, h * DEC_HD + dl * 8, scale, qv);
+#pragma unroll
+        for (int i = 0; i < 8; i += 4) {
+            const float4 v4 = *reinterpret_cast<const float4*>(qs + h * DEC_HD + dl * 8 + i);
+            qv[i] = v4.x; qv[i + 1] = v4.y; qv[i + 2] = v4.z; qv[i + 3] = v4.w;
+        }
         float s[NL], mx = -INFINITY;
 #pragma unroll
         for (int c = 0; c < NL; ++c) {

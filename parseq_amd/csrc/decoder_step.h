@@ -570,7 +570,7 @@ __device__ __forceinline__ void ds_params_store(const float (&v)[NSEG], float* c
 // centred values; the estimate's rounding error d is corrected exactly).  The finish half (partial sums -> decoder.norm -> head -> pick)
 // and the table self-attention are computed by every workgroup of the tile (each needs the picked token and the whole sa row); only
 // workgroup 0 writes logits / tok / EOS bookkeeping.
-constexpr int DS_QS = 3;        // E / DS_QS must be a multiple of 64 (k-chunks of the fragment packs): 128 columns at E = 384, 64 at E = 192
+// (DS_QS = 3, decoder_attn.h: E / DS_QS must be a multiple of 64, the k-chunks of the fragment packs — 128 columns at E = 384, 64 at E = 192.)
 
 // qfold = [wbar E | cq E | bq2 E | c0 npos]:  wbar[k] = mean_n Wo[n][k] on the operand values the product sees (T = bf16: the rounded
 // weights), cq[n] = sum_k ln_w[k] Wq[n][k], bq2[n] = sum_k ln_b[k] Wq[n][k] + bq[n], c0[pos] = mean_n (pos_queries[pos][n] + bo[n]).

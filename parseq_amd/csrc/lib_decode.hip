@@ -11,7 +11,7 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
     const int H = p->m->cfg.dec_heads, NK = p->m->tokens;
     const T* kmem = reinterpret_cast<const T*>(p->kmem); const T* vmem = reinterpret_cast<const T*>(p->vmem);
     const float* qc_ = p->qc;
-    if (qa.nsplit && (NK != 128 || Lq != 1)) return fail(PARSEQ_E_STATE, "cross-attention: split q-projection outside the AR step kernels");
+    if (qa.nsplit && (qa.nsplit != DS_QS || NK != 128 || Lq != 1)) return fail(PARSEQ_E_STATE, "cross-attention: split q-projection outside the AR step kernels");
     if (NK != 128) {
         if constexpr (sizeof(T) == 2) {
             const int nt16 = (NK + 15) / 16;
@@ -33,14 +33,18 @@ static int run_cross_attention(parseq_plan* p, hipStream_t s, int B, int Lq, flo
     } else if (Lq == 1) {
         if constexpr (sizeof(T) == 4 && E == 384) {
             if (p->kv24) {
-                hipLaunchKernelGGL((dec_cross_attn_ar24_kernel<E>), dim3(B), dim3(E), 0, s, qc_, qa, reinterpret_cast<const unsigned char*>(p->kmem),
+                const auto kern = qa.nsplit ? dec_cross_attn_ar24_kernel<E, true> : dec_cross_attn_ar24_kernel<E, false>;
+                hipLaunchKernelGGL(kern, dim3(B), dim3(E), 0, s, qc_, qa, reinterpret_cast<const unsigned char*>(p->kmem),
                                    reinterpret_cast<const unsigned char*>(p->vmem), p->kv_plane_elems, scale, ca);
                 HIPCHK(hipGetLastError());
                 return 0;
             }
         }
         if (p->kv24) return fail(PARSEQ_E_STATE, "cross-attention: 24-bit K / V rows but no kernel for this geometry");
-        hipLaunchKernelGGL((dec_cross_attn_ar_kernel<T, E>), dim3(B), dim3(E), 0, s, qc_, qa, kmem, vmem, scale, ca);
+        auto kern = dec_cross_attn_ar_kernel<T, E, false>;
+        if constexpr (E <= 384) { if (qa.nsplit) kern = dec_cross_attn_ar_kernel<T, E, true>; }      // the split step exists for the fused AR loop's widths only
+        else if (qa.nsplit) return fail(PARSEQ_E_STATE, "cross-attention: split q-projection at embed_dim %d", E);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(E), 0, s, qc_, qa, kmem, vmem, scale, ca);
     } else if constexpr (sizeof(T) == 2) {
         hipLaunchKernelGGL(dec_cross_attn_multi_mfma_kernel, dim3((B * H + 3) / 4), dim3(256), 0, s, qc_, kmem, vmem, H, Lq, scale, ca, B * H);
     } else {

@@ -6,6 +6,7 @@
 #   bench [args]     bench.py with the given arguments, the JSON line to gpurun_out/bench_<R>.json, headline keys printed
 #   ab <name=ENV=V,ENV=V> ...   short exact-mode bench runs under each environment (switch A/Bs on one box)
 #   profiles         rocprofv3 kernel stats (exact mode and bf16 mode) + FETCH / WRITE / MFMA-busy counter passes (separate --pmc runs) -> summaries
+#   seqprof          rocprofv3 kernel stats of bench.py --streams 1 (one forward at a time), exact mode and bf16 mode
 #   sq <kernel-substring> [bench args]   SQ counter passes over bench.py --steps 1 for one kernel (tools/pmc_generic.py)
 #   tcc              L2 hit / miss and memory-side request counters for the decoder kernels and the encoder
 #   x3v <builds...>  builds of the bf16x3 encoder against each other (tools/x3_variants.sh -> parseq_amd/lib/x3v/*.so)
@@ -56,6 +57,15 @@ profiles)
     python tools/pmc_summary.py $(db gpurun_out/pmc_${prec}_FETCH) $(db gpurun_out/pmc_${prec}_WRITE) --json gpurun_out/${R}_pmc_traffic_$prec.json > gpurun_out/${R}_pmc_hbm_traffic_$prec.md; head -8 gpurun_out/${R}_pmc_hbm_traffic_$prec.md
     python tools/pmc_mfma_summary.py $(db gpurun_out/pmc_${prec}_SQ_VA) > gpurun_out/${R}_pmc_mfma_util_$prec.md; head -6 gpurun_out/${R}_pmc_mfma_util_$prec.md
     rm -rf gpurun_out/prof_$prec gpurun_out/pmc_${prec}_*
+  done ;;
+seqprof)   # kernel stats of one forward at a time (--streams 1: the latency form of the AR step), both matrix-core modes
+  P="--steps 5 --warmup 2 --repeats 1 --streams 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode"
+  for prec in bf16x3 bf16; do
+    rm -rf gpurun_out/prof_$prec
+    timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$prec -o p -- python bench.py --precision $prec $P > gpurun_out/prof_$prec.log 2>&1
+    python tools/rocprof_summary.py $(db gpurun_out/prof_$prec) > gpurun_out/${R}_rocprof_kernel_stats_${prec}_one_at_a_time.md; head -14 gpurun_out/${R}_rocprof_kernel_stats_${prec}_one_at_a_time.md
+    tail -1 gpurun_out/prof_$prec.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$prec', d['value'], d['ms_per_step'])"
+    rm -rf gpurun_out/prof_$prec
   done ;;
 sq)
   kern=$1; shift; i=0
