@@ -47,7 +47,7 @@ kmem = torch.empty(images, 12, 128, 32, device=DEV); vmem = torch.empty_like(kme
 TIMERS = '--timers' in sys.argv       # the named build was compiled with -DX3_TIMERS=1: print its per-phase s_memtime ticks (encoder_blocks_x3.h X3_TIMERS)
 if TIMERS:
     sys.argv.remove('--timers')
-names = sys.argv[1:] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
+names = [a for i, a in enumerate(sys.argv[1:]) if a != '--sustained' and (i == 0 or sys.argv[i] != '--sustained')] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
 libs = {}
 for n in names:
     L = C.CDLL(os.path.join(ROOT, 'parseq_amd/lib/x3v', n + '.so'))
@@ -62,6 +62,29 @@ def run(L):
     assert r == 0, r
 
 
+if '--sustained' in sys.argv:      # N launches of the first build back to back (events between them, one synchronise at the end), then again after an idle
+    import time
+    k = sys.argv.index('--sustained'); N = int(sys.argv[k + 1]); names = [n for n in names if n not in ('--sustained', sys.argv[k + 1])]
+    L = libs[names[0]] if names and names[0] in libs else list(libs.values())[0]
+
+    def burst(n):
+        x = x0.clone(); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            assert L.x3_variant_run(nat.ptr(x), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32, nat.ptr(kmem), nat.ptr(vmem), nat.stream_ptr()) == 0
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+    burst(3)
+    time.sleep(3.0)
+    t = burst(N)
+    print('after 3 s idle, launches back to back, ms:', ' '.join(f'{i}:{t[i]:.2f}' for i in sorted(set([0, 1, 2, 3, 5, 10, 20, 40, 80, N - 1])) if i < N))
+    print(f'first 3 mean {sum(t[:3]) / 3:.3f}   last 10 mean {sum(t[-10:]) / 10:.3f}   min {min(t):.3f}  max {max(t):.3f}')
+    time.sleep(3.0)
+    t2 = burst(5)
+    print('after another 3 s idle:', ' '.join(f'{v:.2f}' for v in t2))
+    sys.exit(0)
 times = {n: [] for n in names}
 ref = None
 diffs = {}
