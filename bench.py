@@ -453,8 +453,9 @@ def main():
                                f'({"natural exit" if args.natural_exit else "26 steps forced"}) + {args.refine_iters} refine iter '
                                f'({named if named else "not a BASELINE.json configuration"}); random-init weights (reference init, seed 0); '
                                f'inputs resident in HBM as {"bf16" if args.precision == "bf16" else "fp32"}; {dtype_note}; '
-                               f'sequential_value = one step at a time (the reference\'s call pattern: the apples-to-apples figure for this configuration), '
-                               f'value = {args.streams} steps in flight on separate HIP streams ({args.streams * B} crops resident per GPU); '
+                               f'sequential_value = one step at a time (the reference\'s call pattern: the apples-to-apples figure for this configuration; the default call, '
+                               f'which tells the library the forward has the device to itself — PARSEQ_FLAG_LATENCY: a wider AR step, same results up to rounding), '
+                               f'value = {args.streams} steps in flight on separate HIP streams, each on its own workspace slot ({args.streams * B} crops resident per GPU); '
                                f'throughput_mode = the same two measurements with bf16 operands (BASELINE.json\'s "bf16" wording; outside the tolerance, reported for reference only)',
                    'global_batch': world * B, 'parallelism': f'dp{world}' + (' + RCCL all-gather of logits' if world > 1 else ''),
                    'output_shape': list(out.shape), 'steps_in_flight': args.streams},
