@@ -563,7 +563,7 @@ __device__ __forceinline__ void ds_params_store(const float (&v)[NSEG], float* c
 // out_proj and the q-projection are two 0.3 MB (bf16; 0.6 MB as pairs) weight streams through ONE CU each, 10 of the mid kernel's 25 us.
 // With QS > 1, workgroup qs of a row tile owns columns [qs E/QS, (qs + 1) E/QS) of x = pos_query + sa @ Wo^T + bo: it streams only those
 // rows of Wo, and only those K-columns of Wq — the q-projection becomes a K-split whose partial sums the cross-attention kernel adds up
-// (decoder_attn.h QAsm / q_assemble; the launch boundary is the exchange, no grid-wide hand-off inside a launch).  norm1 sits between the
+// (decoder_attn.h QAsm / q_issue / q_finish; the launch boundary is the exchange, no grid-wide hand-off inside a launch).  norm1 sits between the
 // two products and needs the row's mean and variance: the mean is known BEFORE x is, mean(x) = c0[pos] + sa . wbar with wbar the column
 // means of Wo (dec_qfold_kernel, folded once per weight set), so every workgroup centres its own columns, multiplies them by ln_w, and
 // leaves sum (x - m) and sum (x - m)^2 of its columns for the consumer, which finishes LayerNorm behind the product (two-pass arithmetic on
