@@ -28,7 +28,7 @@ namespace x3 {
 
 // Timing ablations (results are WRONG with any bit set; tools/x3_variants.sh builds them, tools/x3_variant_bench.py times them):
 // 1 GELU -> identity, 2 no exp in the soft-max, 4 no LDS-DMA issue, 8 no park / unpark / O round trip, 16 no pair barriers, 32 no waits for
-// the LDS-DMA
+// the LDS-DMA, 64 one MFMA per product instead of three (hi x hi: the structure's time on bf16 operands)
 #ifndef X3_ABLATE
 #define X3_ABLATE 0
 #endif
@@ -74,19 +74,24 @@ __device__ __forceinline__ float x3_exp2(float x) { if constexpr ((X3_ABLATE & 2
 // weights as the first operand (q, k, fc1, proj, fc2, K|V chunks)
 __device__ __forceinline__ void mma3_w(f32x4& c0, f32x4& c1, const bf16x8& wh, const bf16x8& wl, const bf16x8& ah0, const bf16x8& al0,
                                        const bf16x8& ah1, const bf16x8& al1) {
-    c0 = PQ_X3_MFMA(wl, ah0, c0); c1 = PQ_X3_MFMA(wl, ah1, c1);
-    c0 = PQ_X3_MFMA(wh, al0, c0); c1 = PQ_X3_MFMA(wh, al1, c1);
+    if constexpr ((X3_ABLATE & 64) == 0) {      // 64: ONE product (hi x hi only) — how fast this structure would run bf16 operands (wrong results by construction)
+        c0 = PQ_X3_MFMA(wl, ah0, c0); c1 = PQ_X3_MFMA(wl, ah1, c1);
+        c0 = PQ_X3_MFMA(wh, al0, c0); c1 = PQ_X3_MFMA(wh, al1, c1);
+    }
     c0 = PQ_X3_MFMA(wh, ah0, c0); c1 = PQ_X3_MFMA(wh, ah1, c1);
 }
 // weights as the second operand (the v chunk: V^T)
 __device__ __forceinline__ void mma3_a(f32x4& c0, f32x4& c1, const bf16x8& wh, const bf16x8& wl, const bf16x8& ah0, const bf16x8& al0,
                                        const bf16x8& ah1, const bf16x8& al1) {
-    c0 = PQ_X3_MFMA(al0, wh, c0); c1 = PQ_X3_MFMA(al1, wh, c1);
-    c0 = PQ_X3_MFMA(ah0, wl, c0); c1 = PQ_X3_MFMA(ah1, wl, c1);
+    if constexpr ((X3_ABLATE & 64) == 0) {
+        c0 = PQ_X3_MFMA(al0, wh, c0); c1 = PQ_X3_MFMA(al1, wh, c1);
+        c0 = PQ_X3_MFMA(ah0, wl, c0); c1 = PQ_X3_MFMA(ah1, wl, c1);
+    }
     c0 = PQ_X3_MFMA(ah0, wh, c0); c1 = PQ_X3_MFMA(ah1, wh, c1);
 }
 __device__ __forceinline__ void mma3_1(f32x4& c, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
-    c = PQ_X3_MFMA(al, bh, c); c = PQ_X3_MFMA(ah, bl, c); c = PQ_X3_MFMA(ah, bh, c);
+    if constexpr ((X3_ABLATE & 64) == 0) { c = PQ_X3_MFMA(al, bh, c); c = PQ_X3_MFMA(ah, bl, c); }
+    c = PQ_X3_MFMA(ah, bh, c);
 }
 
 // Per-lane DMA source offsets in BYTES of the block-planar pack (StreamLane of encoder_blocks.h with 4-byte elements: the row
