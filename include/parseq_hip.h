@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 6
+#define PARSEQ_ABI_VERSION 7
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -378,6 +378,11 @@ int parseq_op_enc_head_tail(float* x, const void* images, int images_dtype, cons
  * Test hook (the product path builds the tables once per plan); uploads the table synchronously. */
 int parseq_op_enc_blocks_x3(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
                             int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream);
+/* The same launch through the kernel parseq_forward runs since ABI 7 (encoder_blocks_x3w.h: eight waves of 16 rows per workgroup, two per
+ * SIMD, instead of four of 32); same arguments, bit-identical results.  parseq_op_enc_blocks_x3 stays on the four-wave kernel as the
+ * reference of that identity (PARSEQ_X3_FOUR_WAVES=1 puts it back under parseq_forward). */
+int parseq_op_enc_blocks_x3w(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
+                             int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream);
 /* The forms of parseq_op_mlp: variant 0 = x re-read by the epilogue; 10 = x resident in the fc2 accumulators (the form the per-layer
  * encoder path uses); 11 = the phase function the one-launch encoder is built from (encoder_blocks.h mlp_branch_kernel). */
 int parseq_op_mlp_variant(float* x, const float* gamma, const float* beta, const void* W1, const float* b1, const void* W2,

@@ -16,7 +16,7 @@ from . import build as _build
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8, PARSEQ_BF16X3 = 0, 1, 2, 3
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING, FLAG_LATENCY = 1, 2, 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ParseqConfig(C.Structure):
@@ -105,6 +105,8 @@ SIGNATURES = {
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'parseq_op_enc_blocks_x3': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p]),
+    'parseq_op_enc_blocks_x3w': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_op_encoder_attention': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                               C.c_void_p]),
 }

@@ -3,7 +3,7 @@
 The shared library is the product: there is no pure-Python or CPU execution path.  It is built in-tree so that it
 travels with the repository snapshot to the GPU box (it is git-ignored, not gpurun-ignored).
 
-The library is seven translation units (UNITS) compiled in parallel and linked once; a unit is recompiled when the
+The library is eight translation units (UNITS) compiled in parallel and linked once; a unit is recompiled when the
 SHA-256 of its source, of every header under csrc/, of include/parseq_hip.h and of the compiler flags differs from the one
 recorded beside its object file (content, not mtime: a fresh checkout with an up-to-date library does not rebuild, an
 edited header always does).  Wall time of a full build on 8 cores: under a minute (the longest unit ≈ 45 s); the single
@@ -24,10 +24,12 @@ LIB_DIR = os.path.join(HERE, 'lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')          # git-ignored AND gpurun-ignored (as are the obj_<suffix> of A/B builds): only .so files travel
 LIB_PATH = os.path.join(LIB_DIR, 'libparseq_hip.so')
 STAMP_PATH = LIB_PATH + '.sha256'
-UNITS = ['lib_model', 'lib_encode', 'lib_decode', 'lib_train', 'lib_ops', 'kern_enc_blocks', 'kern_enc_blocks_x3']
+UNITS = ['lib_model', 'lib_encode', 'lib_decode', 'lib_train', 'lib_ops', 'kern_enc_blocks', 'kern_enc_blocks_x3', 'kern_enc_blocks_x3w']
 SOURCES = [u + '.hip' for u in UNITS]
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join('..', '..', 'include', 'parseq_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed']
+# per-unit flags on top of FLAGS: the two-waves-per-SIMD bf16x3 encoder keeps its accumulators in VGPRs (encoder_blocks_x3w.h)
+UNIT_FLAGS = {'kern_enc_blocks_x3w': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _hipcc() -> str:
@@ -47,7 +49,7 @@ def _headers_digest() -> bytes:
     for f in HEADERS:
         with open(os.path.join(CSRC, f), 'rb') as fh:
             h.update(f.encode() + b'\0' + fh.read() + b'\0')
-    h.update(' '.join(FLAGS + _extra_flags()).encode())
+    h.update(' '.join(FLAGS + _extra_flags() + [u + '=' + ' '.join(f) for u, f in sorted(UNIT_FLAGS.items())]).encode())
     return h.digest()
 
 
@@ -76,7 +78,7 @@ def _compile(unit: str, want: str, verbose: bool) -> None:
     stamp = obj + '.sha256'
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return
-    cmd = [_hipcc()] + FLAGS + _extra_flags() + ['-c', os.path.join(CSRC, unit + '.hip'), '-o', obj]
+    cmd = [_hipcc()] + FLAGS + UNIT_FLAGS.get(unit, []) + _extra_flags() + ['-c', os.path.join(CSRC, unit + '.hip'), '-o', obj]
     if verbose:
         print('[parseq_amd.build]', ' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
@@ -113,7 +115,7 @@ def build_variant(suffix: str, flags: list[str], units: list[str] | None = None)
     os.makedirs(vdir, exist_ok=True)
 
     def one(u: str) -> None:
-        subprocess.run([_hipcc()] + FLAGS + flags + ['-c', os.path.join(CSRC, u + '.hip'), '-o', os.path.join(vdir, u + '.o')], check=True)
+        subprocess.run([_hipcc()] + FLAGS + UNIT_FLAGS.get(u, []) + flags + ['-c', os.path.join(CSRC, u + '.hip'), '-o', os.path.join(vdir, u + '.o')], check=True)
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as pool:
         for fut in [pool.submit(one, u) for u in units]:
             fut.result()

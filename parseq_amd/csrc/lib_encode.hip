@@ -99,7 +99,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
     bool blocks_done = fused_blocks;
     if constexpr (!kBf16) {
         // bf16x3, PARSeq-S geometry: the twelve blocks — and, when nobody asked for `memory` itself, the final LayerNorm and the decoder's
-        // K / V projection of it — in one launch with x resident in registers (encoder_blocks_x3.h); the MLP hidden buffer (idle on this
+        // K / V projection of it — in one launch with x resident in registers (encoder_blocks_x3w.h: eight waves of 16 rows; encoder_blocks_x3.h: four of 32); the MLP hidden buffer (idle on this
         // path) is the launch's per-image scratch (the parked residual stream and the attention output, 384 KiB per image)
         if (g_split && p->fused_x3 && p->fused_blocks && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && M % 128 == 0) {
             const bool tail = p->fused_tail && memory_out == nullptr && c.dec_heads * DEC_HD == E;
@@ -123,8 +123,13 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                         eh.images = images; eh.img_dtype = sizeof(TI) == 1 ? EB_IMG_U8 : (sizeof(TI) == 2 ? EB_IMG_BF16 : EB_IMG_F32);
                         eh.wpe = p->wpe_off; eh.posb = p->posb;
                     }
-                    HIPCHK((x3::launch_enc_blocks_x3<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev + l0, d,
-                                                          c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), last ? et : x3::EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0}, eh)));
+                    const x3::EncTailX3 et_l = last ? et : x3::EncTailX3{0, 0, 0, 0, nullptr, nullptr, 0};
+                    if (p->x3_four_waves)
+                        HIPCHK((x3::launch_enc_blocks_x3<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev + l0, d,
+                                                              c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), et_l, eh)));
+                    else
+                        HIPCHK((x3w::launch_enc_blocks_x3w<384>(s, p->x, p->wpack, m->master_elems * sizeof(float), m->master, p->blocks_dev + l0, d,
+                                                                c.enc_ln_eps, M, reinterpret_cast<float*>(p->h), et_l, eh)));
                 }
             }
             if (tail) { p->last_batch = B; return 0; }

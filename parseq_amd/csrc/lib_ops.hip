@@ -281,8 +281,8 @@ extern "C" int parseq_op_enc_head_tail(float* x, const void* images, int images_
 // buffer); offsets: HOST array of depth * 12 element offsets into `master`, per block in EncBlockParams order (norm1 w, b, Wqkv, bqkv,
 // Wproj, bproj, norm2 w, b, W1, b1, W2, b2).  tail_offsets (HOST, 4 element offsets: final norm w, b, Wkv [768, 384], bkv [768]) with
 // kmem / vmem (f32 [M / 128][12][128][32]) != NULL: instead of storing x the launch ends with K | V = LayerNorm(x) Wkv^T + bkv.
-extern "C" int parseq_op_enc_blocks_x3(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
-                                       int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream) {
+static int enc_blocks_x3_op(bool eight_waves, float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
+                            int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream) {
     CHK(check_arch());
     if (!x || !master || !pack || !offsets || !table_ws || !scratch || depth <= 0 || M <= 0 || (M % 128) || master_elems <= 0 || (master_elems % 32))
         return fail(PARSEQ_E_INVALID, "bad argument (M must be a multiple of 128: whole images; master_elems a multiple of 32)");
@@ -298,9 +298,22 @@ extern "C" int parseq_op_enc_blocks_x3(float* x, const float* master, const void
     HIPCHK(hipMemcpy(table_ws, host.data(), host.size() * sizeof(EncBlockParams), hipMemcpyHostToDevice));      // test hook: synchronous upload
     x3::EncTailX3 et{0, 0, 0, 0, nullptr, nullptr, 12};
     if (kmem) { et.norm_w = tail_offsets[0]; et.norm_b = tail_offsets[1]; et.wkv = tail_offsets[2]; et.bkv = tail_offsets[3]; et.kmem = kmem; et.vmem = vmem; }
-    HIPCHK((x3::launch_enc_blocks_x3<384>((hipStream_t)stream, x, pack, (size_t)master_elems * sizeof(float), master,
-                                          reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M, scratch, et)));
+    if (eight_waves)
+        HIPCHK((x3w::launch_enc_blocks_x3w<384>((hipStream_t)stream, x, pack, (size_t)master_elems * sizeof(float), master,
+                                                reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M, scratch, et)));
+    else
+        HIPCHK((x3::launch_enc_blocks_x3<384>((hipStream_t)stream, x, pack, (size_t)master_elems * sizeof(float), master,
+                                              reinterpret_cast<const EncBlockParams*>(table_ws), depth, 1e-6f, M, scratch, et)));
     return 0;
+}
+extern "C" int parseq_op_enc_blocks_x3(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
+                                       int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream) {
+    return enc_blocks_x3_op(false, x, master, pack, master_elems, offsets, depth, M, table_ws, scratch, tail_offsets, kmem, vmem, stream);
+}
+// the same through the two-waves-per-SIMD kernel (encoder_blocks_x3w.h: what parseq_forward runs); bit-identical to parseq_op_enc_blocks_x3
+extern "C" int parseq_op_enc_blocks_x3w(float* x, const float* master, const void* pack, int64_t master_elems, const uint32_t* offsets, int depth,
+                                        int M, void* table_ws, float* scratch, const uint32_t* tail_offsets, float* kmem, float* vmem, void* stream) {
+    return enc_blocks_x3_op(true, x, master, pack, master_elems, offsets, depth, M, table_ws, scratch, tail_offsets, kmem, vmem, stream);
 }
 
 // LayerNorm + Linear + GELU through the panel kernel (E = 384); `variant` must be 0 (kept in the signature: ABI 4).

@@ -368,6 +368,55 @@ def test_encoder_blocks_x3_one_launch(images, depth, tail):
         assert err <= 1e-3
 
 
+@pytest.mark.parametrize('images,depth,tail', [(1, 1, False), (3, 2, True), (5, 12, True), (512, 1, True)])
+def test_encoder_blocks_x3_eight_waves_bit_identical(images, depth, tail):
+    """encoder_blocks_x3w.h (eight waves of 16 rows, two per SIMD: what parseq_forward launches) against encoder_blocks_x3.h (four waves of 32 rows) on the same
+    inputs: every accumulator receives the same products in the same order, so x / the K | V rows must agree BIT FOR BIT (the four-wave kernel is the one the
+    fp64 reference test above holds); 512 images = two rounds of workgroups per compute unit."""
+    nat, lib = native()
+    E, F = 384, 1536
+    M = images * 128
+    g = torch.Generator().manual_seed(77)
+    shapes = [(E,), (E,), (3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (F, E), (F,), (E, F), (E,)]
+    tens = []
+    for l in range(depth):
+        for i, sh in enumerate(shapes):
+            t = torch.randn(*sh, generator=g)
+            tens.append(t / sh[1] ** 0.5 if len(sh) == 2 else (1 + 0.1 * t if i in (0, 6) else 0.1 * t))
+    tens += [1 + 0.1 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g), torch.randn(2 * E, E, generator=g) / E ** 0.5, 0.1 * torch.randn(2 * E, generator=g)]
+    offs, total = [], 0
+    for t in tens:
+        offs.append(total)
+        total += (t.numel() + 31) // 32 * 32
+    master = torch.zeros(total)
+    for t, o in zip(tens, offs):
+        master[o:o + t.numel()] = t.reshape(-1)
+    md = master.to(DEV)
+    pack = torch.empty(total, dtype=torch.float32, device=DEV)
+    nat.check(lib.parseq_op_split_pack(nat.ptr(md), nat.ptr(pack), total, nat.stream_ptr()))
+    o32 = (C.c_uint32 * (12 * depth))(*offs[:12 * depth])
+    t32 = (C.c_uint32 * 4)(*offs[12 * depth:])
+    table = torch.empty(depth * 48, dtype=torch.uint8, device=DEV)
+    scratch = torch.empty(images * 393216 // 4, dtype=torch.float32, device=DEV)
+    x = torch.randn(M, E, generator=g)
+    outs = []
+    for fn in (lib.parseq_op_enc_blocks_x3, lib.parseq_op_enc_blocks_x3w):
+        xd = x.to(DEV).clone()
+        kmem = torch.full((images, 12, 128, 32), float('nan'), dtype=torch.float32, device=DEV)
+        vmem = torch.full((images, 12, 128, 32), float('nan'), dtype=torch.float32, device=DEV)
+        nat.check(fn(nat.ptr(xd), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32,
+                     nat.ptr(kmem) if tail else None, nat.ptr(vmem) if tail else None, nat.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((xd, kmem, vmem))
+    if tail:
+        assert bool(torch.isfinite(outs[1][1]).all()) and bool(torch.isfinite(outs[1][2]).all())
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]), \
+            f'K / V rows differ: max |dK| {float((outs[0][1] - outs[1][1]).abs().max()):.3e}, max |dV| {float((outs[0][2] - outs[1][2]).abs().max()):.3e}'
+    else:
+        assert bool(torch.isfinite(outs[1][0]).all())
+        assert torch.equal(outs[0][0], outs[1][0]), f'x differs: max |dx| {float((outs[0][0] - outs[1][0]).abs().max()):.3e}'
+
+
 def _patches(img):
     """[B, 3, 32, 128] -> [B * 128, 96]: token = 16 gy + gx, k = 32 c + 8 ky + kx (timm PatchEmbed's Conv2d(3, E, (4, 8), stride (4, 8))
     weight flattened)."""

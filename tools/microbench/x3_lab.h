@@ -1,3 +1,5 @@
+// LAB COPY (tools/microbench): parseq_amd/csrc/encoder_blocks_x3.h with its timing ablations (X3_ABLATE), in-kernel phase timers (X3_TIMERS), markers and scheduling switches —
+// the product header carries none of them.  tools/x3_variants.sh builds it, tools/x3_variant_bench.py times the builds.
 // The one-launch encoder of encoder_blocks.h in the exact-tolerance arithmetic (precision bf16x3): the same persistent structure —
 // one workgroup = one image = 128 rows, four waves of 32 rows at 512 registers, the fp32 residual stream resident in the
 // accumulators of the proj / fc2 GEMMs from the first load to the K / V rows of the decoder — with every matrix product evaluated
@@ -26,8 +28,12 @@
 namespace pq {
 namespace x3 {
 
-// (The timing ablations, in-kernel phase timers and scheduling switches of this kernel live in its lab copy, tools/microbench/x3_lab.h:
-// tools/x3_variants.sh builds that, tools/x3_variant_bench.py times the builds; profiles/r04_x3_encoder_variants.md has the results.)
+// Timing ablations (results are WRONG with any bit set; tools/x3_variants.sh builds them, tools/x3_variant_bench.py times them):
+// 1 GELU -> identity, 2 no exp in the soft-max, 4 no LDS-DMA issue, 8 no park / unpark / O round trip, 16 no pair barriers, 32 no waits for
+// the LDS-DMA, 64 one MFMA per product instead of three (hi x hi: the structure's time on bf16 operands)
+#ifndef X3_ABLATE
+#define X3_ABLATE 0
+#endif
 #ifndef X3_MLP_RING
 #define X3_MLP_RING 3          // pair groups of proj and the tail (the MLP phase itself runs triples: MLP_RING_B)
 #endif
@@ -61,8 +67,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     }
 }
 
-__device__ __forceinline__ float x3_gelu(float x) { return gelu_erf(x); }
-__device__ __forceinline__ float x3_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float x3_gelu(float x) { if constexpr ((X3_ABLATE & 1) != 0) return x; else return gelu_erf(x); }
+__device__ __forceinline__ float x3_exp2(float x) { if constexpr ((X3_ABLATE & 2) != 0) return x; else return __builtin_amdgcn_exp2f(x); }
 
 // acc[j] += A B^T for the two row tiles j of the wave, A / B given as (hi, lo) fragments; small terms first, the two row tiles
 // interleaved so that no MFMA waits for the one before it
@@ -70,30 +76,67 @@ __device__ __forceinline__ float x3_exp2(float x) { return __builtin_amdgcn_exp2
 // weights as the first operand (q, k, fc1, proj, fc2, K|V chunks)
 __device__ __forceinline__ void mma3_w(f32x4& c0, f32x4& c1, const bf16x8& wh, const bf16x8& wl, const bf16x8& ah0, const bf16x8& al0,
                                        const bf16x8& ah1, const bf16x8& al1) {
-    c0 = PQ_X3_MFMA(wl, ah0, c0); c1 = PQ_X3_MFMA(wl, ah1, c1);
-    c0 = PQ_X3_MFMA(wh, al0, c0); c1 = PQ_X3_MFMA(wh, al1, c1);
+    if constexpr ((X3_ABLATE & 64) == 0) {      // 64: ONE product (hi x hi only) — how fast this structure would run bf16 operands (wrong results by construction)
+        c0 = PQ_X3_MFMA(wl, ah0, c0); c1 = PQ_X3_MFMA(wl, ah1, c1);
+        c0 = PQ_X3_MFMA(wh, al0, c0); c1 = PQ_X3_MFMA(wh, al1, c1);
+    }
     c0 = PQ_X3_MFMA(wh, ah0, c0); c1 = PQ_X3_MFMA(wh, ah1, c1);
 }
 // weights as the second operand (the v chunk: V^T)
 __device__ __forceinline__ void mma3_a(f32x4& c0, f32x4& c1, const bf16x8& wh, const bf16x8& wl, const bf16x8& ah0, const bf16x8& al0,
                                        const bf16x8& ah1, const bf16x8& al1) {
-    c0 = PQ_X3_MFMA(al0, wh, c0); c1 = PQ_X3_MFMA(al1, wh, c1);
-    c0 = PQ_X3_MFMA(ah0, wl, c0); c1 = PQ_X3_MFMA(ah1, wl, c1);
+    if constexpr ((X3_ABLATE & 64) == 0) {
+        c0 = PQ_X3_MFMA(al0, wh, c0); c1 = PQ_X3_MFMA(al1, wh, c1);
+        c0 = PQ_X3_MFMA(ah0, wl, c0); c1 = PQ_X3_MFMA(ah1, wl, c1);
+    }
     c0 = PQ_X3_MFMA(ah0, wh, c0); c1 = PQ_X3_MFMA(ah1, wh, c1);
 }
 __device__ __forceinline__ void mma3_1(f32x4& c, const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl) {
-    c = PQ_X3_MFMA(al, bh, c); c = PQ_X3_MFMA(ah, bl, c);
+    if constexpr ((X3_ABLATE & 64) == 0) { c = PQ_X3_MFMA(al, bh, c); c = PQ_X3_MFMA(ah, bl, c); }
     c = PQ_X3_MFMA(ah, bh, c);
 }
 
 // Per-lane DMA source offsets in BYTES of the block-planar pack (StreamLane of encoder_blocks.h with 4-byte elements: the row
 // order and the source swizzle are the same, a stage row is 128 bytes = one k-block's hi | lo halves).
+#ifndef X3_SOFTMAX_JOINT
+#define X3_SOFTMAX_JOINT 1     // 1: the soft-max / P V section runs both row tiles at once (K / V^T fragments read once; 100 more live registers)
+#endif
 #ifndef X3_PARK_TILES
 #define X3_PARK_TILES 8        // accumulator tiles (of 24) that leave the register file for the head loop
 #endif
+#ifndef X3_ISSUE_MODE
+#define X3_ISSUE_MODE 0        // LDS-DMA pieces of a later pair: 0 = a stage's four at each stage boundary, 1 = all eight at the pair's start, 2 = one per two positions (12 MFMAs)
+                               // (staggering the four waves' issue positions was measured 6 - 17 % slower: profiles/r04_x3_encoder_variants.md)
+#endif
+// X3_TIMERS=1 (tools/x3_variants.sh builds only): every wave accumulates s_memtime ticks per phase of the kernel and stores them over its image's rows of x
+// (free after the first load; tools/x3_variant_bench.py --timers reads them back).  Slots: 0 parameters + LayerNorm 1, 1 park, 2 head loop: q / k / v pairs,
+// 3 head loop: q / k / v epilogues (bias, split, K / V^T images), 4 head loop: S, soft-max, P V, O stores, 5 unpark + O reload, 6 proj, 7 parameters + LayerNorm 2,
+// 8 MLP: fc1 pairs, 9 MLP: GELU blocks, 10 MLP: fc2 pairs, 11 tail, 12 biases / everything else.  The s_memtime reads wait for lgkmcnt(0): the timed build is ~1 % slower.
+#ifndef X3_TIMERS
+#define X3_TIMERS 0
+#endif
+#if X3_TIMERS
+struct X3Timers { long long acc[13]; long long last; };
+__device__ __forceinline__ void x3_tick(X3Timers& t, int slot) { const long long now = clock64(); t.acc[slot] += now - t.last; t.last = now; }
+#define X3_TICK(slot) x3_tick(*x3t, slot)
+#define X3_TARG , X3Timers* x3t
+#define X3_TPASS , x3t
+#else
+#define X3_TICK(slot)
+#define X3_TARG
+#define X3_TPASS
+#endif
+#ifndef X3_VOFF_RECOMPUTE
+#define X3_VOFF_RECOMPUTE 0    // 1: the per-lane DMA offsets are recomputed at every stage issue instead of living in three registers
+#endif
 struct StreamLaneX {
+#if X3_VOFF_RECOMPUTE
+    int wid, E;
+    __device__ __forceinline__ StreamLaneX(int, int wid_, int E_) : wid(wid_), E(E_) {}
+#else
     unsigned v64_, v128_, v128w_;
     __device__ __forceinline__ StreamLaneX(int lane, int wid, int E) { v64_ = calc<0>(lane, wid, E); v128_ = calc<1>(lane, wid, E); v128w_ = calc<2>(lane, wid, E); }
+#endif
     // KIND 0: 64 rows x two k-blocks at pitch 4E bytes | 1: 128 rows x one k-block at pitch 4E | 2: at pitch 16E
     template <int KIND> static __device__ __forceinline__ unsigned calc(int lane, int wid, int E) {
         const int sc = ((lane & 7) ^ (lane >> 3)) * 16;
@@ -107,10 +150,17 @@ struct StreamLaneX {
             return (unsigned)(p128 * (KIND == 1 ? 4 : 16) * E + sc);
         }
     }
-    template <int KIND> __device__ __forceinline__ unsigned voff() const { return KIND == 0 ? v64_ : (KIND == 1 ? v128_ : v128w_); }
+    template <int KIND> __device__ __forceinline__ unsigned voff() const {
+#if X3_VOFF_RECOMPUTE
+        return calc<KIND>(opaque_lane(), wid, E);
+#else
+        return KIND == 0 ? v64_ : (KIND == 1 ? v128_ : v128w_);
+#endif
+    }
 };
 // one stage (the wave's four 1-KiB pieces): origin_b = byte offset of (row 0, k-block 0) of the stage in the pack, pitch_b = row pitch in bytes
 __device__ __forceinline__ void issue_stage(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned origin_b, unsigned pitch_b, unsigned char* dst, int q = -1) {
+    if constexpr ((X3_ABLATE & 4) != 0) return;
     StreamLane::issue_v(rsrc, voff, origin_b, (int)(pitch_b >> 1), dst, q);      // q = -1: all four pieces, 0..3: that piece
 }
 
@@ -134,7 +184,13 @@ __device__ __forceinline__ void run_pair2(const unsigned char* st0, const unsign
     static_for<0, 16>([&](auto nc) {
         constexpr int n = decltype(nc)::value, s = n >> 3, i = n & 7, nn = n + AHEAD;
         if constexpr (n == 8) mid();
-        if constexpr (i == 0) { issue(s, -1); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (X3_ISSUE_MODE == 2) {
+            if constexpr ((i & 1) == 0) { issue(s, i >> 1); __builtin_amdgcn_sched_barrier(0); }
+        } else if constexpr (X3_ISSUE_MODE == 0 ? i == 0 : n == 0) {
+            issue(s, -1);
+            if constexpr (X3_ISSUE_MODE == 1) issue(1, -1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (nn < 16) {
             const unsigned char* src = ((nn >> 3) ? st1 : st0) + (nn & 7) * 2048;
             wh[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo0);
@@ -158,20 +214,29 @@ __device__ __forceinline__ void run_pair(const unsigned char* grp, Mma&& mma, Is
     run_pair2<AHEAD>(grp, grp + STAGE, mma, issue, mid);
 }
 
-template <int N> __device__ __forceinline__ void x3_wait_vmcnt() { wait_vmcnt<N>(); }
+template <int N> __device__ __forceinline__ void x3_wait_vmcnt() { if constexpr ((X3_ABLATE & 32) == 0) wait_vmcnt<N>(); }
 __device__ __forceinline__ void pair_fence() {          // the pair about to run has landed (caller waited vmcnt); all waves are past the previous one
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr ((X3_ABLATE & 16) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
 
 // One accumulator register -> a VALU register, as an instruction the optimiser cannot merge with another read of the same value:
 // the three passes of the LayerNorm below would otherwise share ONE copy of every accumulator (192 VALU registers live at once next
 // to the 192 fragment registers being produced), which the allocator answers by spilling the fragments at birth.
+#ifndef X3_VGPR_FORM
+#define X3_VGPR_FORM 0         // 1: the unit is compiled with -mllvm -amdgpu-mfma-vgpr-form (accumulators in VGPRs: one register file, no v_accvgpr moves)
+#endif
 __device__ __forceinline__ float acc_read(const float& a) {
+#if X3_VGPR_FORM
+    float v = a;
+    asm volatile("" : "+v"(v));
+    return v;
+#else
     float v;
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
     return v;
+#endif
 }
 __device__ __forceinline__ void acc_read8(const f32x4& a, const f32x4& b, float (&x)[8]) {
 #pragma unroll
@@ -272,7 +337,7 @@ __device__ __forceinline__ void heads_prefetch(const StreamLaneX& sl, unsigned c
 template <int E, int AHEAD>
 __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* img, const float* sbq, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off,
                                             float scale, const StreamLaneX& sl, int wid, int tid, const bf16x8 (&ah)[2][E / 32],
-                                            const bf16x8 (&al)[2][E / 32], float* __restrict__ obuf) {
+                                            const bf16x8 (&al)[2][E / 32], float* __restrict__ obuf X3_TARG) {
     constexpr int H = E / 64;
     static_assert(E == 384, "written for E = 384");
     unsigned char* kimg_h = img; unsigned char* kimg_l = img + KIMG_B;
@@ -307,6 +372,7 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                     mma3_a(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
             }
+            X3_TICK(2);
             if constexpr (u < 2 && pp == 2) {
                 // q -> fragments, k -> the K image planes (rows in the order the P fragments need: encoder_attn_fused.h)
                 const int ln = opaque_lane();
@@ -332,6 +398,7 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                             *reinterpret_cast<bf16x8*>(kimg_l + off) = fl;
                         }
                     }
+                X3_TICK(3);
             } else if constexpr (u == 2 && pp == 2) {
                 const int ln = opaque_lane();
                 const int rr = ln & 15, g = ln >> 4;
@@ -355,6 +422,8 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
+                X3_TICK(3);
+#if X3_SOFTMAX_JOINT
                 // S^T = K Q^T, soft-max, O^T = V^T P^T for both 16-query row tiles at once: every K / V^T fragment is read once
                 f32x4 sc[2][8];
 #pragma unroll
@@ -444,10 +513,76 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                         bf16x8 fh, fl;
                         split8(v, fh, fl);
                         float* o = obuf + ((size_t)((((2 * h + j) * 2 + pr) * 2) * 256) + tid) * 4;
-                        *reinterpret_cast<bf16x8*>(o) = fh;
-                        *reinterpret_cast<bf16x8*>(o + 256 * 4) = fl;
+                        if constexpr ((X3_ABLATE & 8) == 0) {
+                            *reinterpret_cast<bf16x8*>(o) = fh;
+                            *reinterpret_cast<bf16x8*>(o + 256 * 4) = fl;
+                        } else { asm volatile("" :: "v"(fh), "v"(fl)); }
                     }
-            }
+#else
+                // S^T = K Q^T, soft-max, O^T = V^T P^T — one 16-query row tile at a time
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 sc[8];
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt) sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int kt = 0; kt < 8; ++kt) {
+                            const int off = (16 * kt + rr) * AF_KROWB + 64 * ks + 16 * g;
+                            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kimg_h + off), kl = *reinterpret_cast<const bf16x8*>(kimg_l + off);
+                            mma3_1(sc[kt], kh, kl, qh[j][ks], ql[j][ks]);
+                        }
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int kt = 0; kt < 8; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[kt][r]);
+                    mx = rows4_max(mx);
+                    const float mc = mx * sc2;
+                    float sum = 0.f;
+                    bf16x8 ph[4], pl[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = x3_exp2(sc[2 * ks][r] * sc2 - mc);
+                            v[4 + r] = x3_exp2(sc[2 * ks + 1][r] * sc2 - mc);
+                            sum += v[r] + v[4 + r];
+                        }
+                        split8(v, ph[ks], pl[ks]);
+                    }
+                    sum = rows4_sum(sum);
+                    const float inv = 1.0f / sum;
+                    f32x4 ov[4];
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) ov[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                        for (int dt = 0; dt < 4; ++dt) {
+                            const int off = (16 * dt + rr) * AF_VROWB + 64 * ks + 16 * g;
+                            const bf16x8 vh = *reinterpret_cast<const bf16x8*>(vimg_h + off), vl = *reinterpret_cast<const bf16x8*>(vimg_l + off);
+                            mma3_1(ov[dt], vh, vl, ph[ks], pl[ks]);
+                        }
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        float v[8];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { v[r] = ov[2 * pr][r] * inv; v[4 + r] = ov[2 * pr + 1][r] * inv; }
+                        bf16x8 fh, fl;
+                        split8(v, fh, fl);
+                        float* o = obuf + ((size_t)((((2 * h + j) * 2 + pr) * 2) * 256) + tid) * 4;
+                        if constexpr ((X3_ABLATE & 8) == 0) {
+                            *reinterpret_cast<bf16x8*>(o) = fh;
+                            *reinterpret_cast<bf16x8*>(o + 256 * 4) = fl;
+                        } else { asm volatile("" :: "v"(fh), "v"(fl)); }
+                    }
+                }
+#endif
+                X3_TICK(4);
+            } else { X3_TICK(3); }
         });
     }
 }
@@ -556,7 +691,7 @@ __device__ __forceinline__ void mlp3_prefetch(const StreamLaneX& sl, unsigned ch
 template <int E, int AHEAD>
 __device__ __forceinline__ void mlp_phase3(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
                                            const StreamLaneX& sl, int wid, const bf16x8 (&ah)[2][E / 32], const bf16x8 (&al)[2][E / 32],
-                                           f32x4 (&acc2)[E / 16][2]) {
+                                           f32x4 (&acc2)[E / 16][2] X3_TARG) {
     constexpr int F = 4 * E, NCH = F / 64;
     static_assert(E == 384, "written for E = 384");
     for (int c = 0; c < NCH; ++c) {
@@ -566,7 +701,11 @@ __device__ __forceinline__ void mlp_phase3(unsigned char* ring, const float* sb1
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if X3_VGPR_FORM
+            asm volatile("" : "+v"(acc1[i][0]), "+v"(acc1[i][1]));
+#else
             asm volatile("" : "+a"(acc1[i][0]), "+a"(acc1[i][1]));
+#endif
         }
         const int g = opaque_lane() >> 4;
         const float* bp = sb1 + c * 64 + 8 * g;
@@ -574,6 +713,7 @@ __device__ __forceinline__ void mlp_phase3(unsigned char* ring, const float* sb1
             constexpr int k = decltype(kc)::value;
             if constexpr (k >= 2) {      // hidden units 32 (k - 2) .. + 32 of the chunk — this triple's k-block — before the wait and the barrier, not behind them
                 gelu_frag(acc1, bp, k - 2, hh, hl);
+                X3_TICK(9);
             }
             // in flight behind this triple: the next one (12 pieces per wave) — none behind the phase's last
             if (!last || k < 3) x3_wait_vmcnt<12>(); else x3_wait_vmcnt<0>();
@@ -588,10 +728,12 @@ __device__ __forceinline__ void mlp_phase3(unsigned char* ring, const float* sb1
                     const int kb = 2 * (3 * k + s) + (i >> 2);
                     mma3_w(acc1[i & 3][0], acc1[i & 3][1], wh, wl, ah[0][kb], al[0][kb], ah[1][kb], al[1][kb]);
                 }, issue);
+                X3_TICK(8);
             } else {
                 run_group<3, AHEAD>(grp, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                     mma3_w(acc2[s * 8 + i][0], acc2[s * 8 + i][1], wh, wl, hh[0], hl[0], hh[1], hl[1]);
                 }, issue);
+                X3_TICK(10);
             }
         });
     }
@@ -772,6 +914,12 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
 
     f32x4 acc[E / 16][2];
     bf16x8 ah[2][E / 32], al[2][E / 32];
+#if X3_TIMERS
+    X3Timers x3t_storage; X3Timers* x3t = &x3t_storage;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) x3t->acc[i] = 0;
+    x3t->last = clock64();
+#endif
     if (head.images) patch_head_x3<E>(head, ring, wrsrc, wid, lane, blockIdx.x, acc);
     else load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
     float* xbuf = scratch + (size_t)blockIdx.x * (2 * 48 * 1024);      // 48 pieces x 256 lanes x 4 floats: the parked residual stream
@@ -787,17 +935,32 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
         params_to_lds(sph + 4 * E, pbase + bp->ln1_w, E, tid);
         params_to_lds(sph + 5 * E, pbase + bp->ln1_b, E, tid);
         __syncthreads();
+#ifdef X3_MARK
+        asm volatile("; X3MARK LN1");
+#endif
         ln_acc_to_frag<E>(acc, sph + 4 * E, sph + 5 * E, eps, g, ah, al);
-        park_acc<E>(acc, xbuf, tid);
-        heads_phase<E, X3_AHEAD>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, wid, tid, ah, al, obuf);
+        X3_TICK(0);
+#ifdef X3_MARK
+        asm volatile("; X3MARK PARK");
+#endif
+        if constexpr ((X3_ABLATE & 8) == 0) park_acc<E>(acc, xbuf, tid);
+        X3_TICK(1);
+#ifdef X3_MARK
+        asm volatile("; X3MARK HEADS");
+#endif
+        heads_phase<E, X3_AHEAD>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, wid, tid, ah, al, obuf X3_TPASS);
         // ---- attention branch, proj: x and the O fragments come back (each lane re-reads what it wrote)
         __syncthreads();                                                // every wave is done with the K / V^T images and the ring
+#ifdef X3_MARK
+        asm volatile("; X3MARK UNPARK");
+#endif
         proj_prefetch<E, X3_MLP_RING>(sl, ring, wrsrc, bp->wproj, wid);
         // (the addresses go through an empty asm: the optimiser must not forward the stored values to these loads — that would keep
         // the 192 + 32 registers alive across the head loop, the very thing the round trip is for)
         const float* xback = xbuf; const float* oback = obuf;
         asm volatile("" : "+s"(xback), "+s"(oback) :: "memory");
-        unpark_acc<E>(acc, xback, tid);
+        if constexpr ((X3_ABLATE & 8) == 0) unpark_acc<E>(acc, xback, tid);
+        if constexpr ((X3_ABLATE & 8) == 0)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -806,19 +969,39 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
                 ah[j][kb] = *reinterpret_cast<const bf16x8*>(o);
                 al[j][kb] = *reinterpret_cast<const bf16x8*>(o + 256 * 4);
             }
+        X3_TICK(5);
+#ifdef X3_MARK
+        asm volatile("; X3MARK PROJ");
+#endif
         proj_phase<E, X3_MLP_RING, X3_AHEAD>(ring, wrsrc, bp->wproj, sl, wid, ah, al, acc);
+        X3_TICK(6);
         add_bias_to_acc<E>(sph + 3 * E, g, acc);
+        X3_TICK(12);
         // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
         __syncthreads();
+#ifdef X3_MARK
+        asm volatile("; X3MARK MLPPRE");
+#endif
         mlp3_prefetch<E>(sl, ring, wrsrc, bp->w1, bp->w2, wid);
         params_to_lds(sp, pbase + bp->b1, F, tid);
         params_to_lds(sp + F, pbase + bp->b2, E, tid);
         params_to_lds(sp + F + E, pbase + bp->ln2_w, E, tid);
         params_to_lds(sp + F + 2 * E, pbase + bp->ln2_b, E, tid);
         __syncthreads();
+#ifdef X3_MARK
+        asm volatile("; X3MARK LN2");
+#endif
         ln_acc_to_frag<E>(acc, sp + F + E, sp + F + 2 * E, eps, g, ah, al);
-        mlp_phase3<E, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc);
+        X3_TICK(7);
+#ifdef X3_MARK
+        asm volatile("; X3MARK MLP");
+#endif
+        mlp_phase3<E, X3_AHEAD>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, ah, al, acc X3_TPASS);
+#ifdef X3_MARK
+        asm volatile("; X3MARK MLPEND");
+#endif
         add_bias_to_acc<E>(sp + F, g, acc);
+        X3_TICK(12);
     }
     if (tail.kmem == nullptr) {
         store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
@@ -833,6 +1016,13 @@ void enc_blocks_x3_kernel(float* __restrict__ x, const unsigned char* __restrict
     __syncthreads();
     ln_acc_to_frag<E>(acc, sp + 2 * E, sp + 3 * E, eps, g, ah, al);
     kv_phase<E, X3_MLP_RING, X3_AHEAD>(ring, sp, wrsrc, tail.wkv, sl, wid, blockIdx.x, tail.heads, tail.kmem, tail.vmem, tail.plane_elems, ah, al);
+#if X3_TIMERS
+    X3_TICK(11);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) reinterpret_cast<long long*>(x + ((size_t)m0 + 32 * wid) * E)[i] = x3t->acc[i];
+    }
+#endif
 }
 
 template <int E>

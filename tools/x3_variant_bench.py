@@ -15,7 +15,7 @@ from parseq_amd import _native as nat   # noqa: E402
 
 lib = nat.lib()
 DEV = 'cuda'
-E, F, depth, images = 384, 1536, 12, int(os.environ.get('X3_IMAGES', '512'))
+E, F, depth, images = 384, 1536, int(os.environ.get('X3_DEPTH', '12')), int(os.environ.get('X3_IMAGES', '512'))
 M = images * 128
 g = torch.Generator().manual_seed(0)
 shapes = [(E,), (E,), (3 * E, E), (3 * E,), (E, E), (E,), (E,), (E,), (F, E), (F,), (E, F), (E,)]
@@ -47,7 +47,7 @@ kmem = torch.empty(images, 12, 128, 32, device=DEV); vmem = torch.empty_like(kme
 TIMERS = '--timers' in sys.argv       # the named build was compiled with -DX3_TIMERS=1: print its per-phase s_memtime ticks (encoder_blocks_x3.h X3_TIMERS)
 if TIMERS:
     sys.argv.remove('--timers')
-names = [a for i, a in enumerate(sys.argv[1:]) if a != '--sustained' and (i == 0 or sys.argv[i] != '--sustained')] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
+names = [a for i, a in enumerate(sys.argv[1:]) if a != '--sustained' and a != '--timers8' and (i == 0 or sys.argv[i] != '--sustained')] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
 libs = {}
 for n in names:
     L = C.CDLL(os.path.join(ROOT, 'parseq_amd/lib/x3v', n + '.so'))
@@ -93,8 +93,8 @@ for rnd in range(int(os.environ.get('X3_ROUNDS', '5'))):
         run(libs[n]); torch.cuda.synchronize()
         if rnd == 0:
             if ref is None:
-                ref = kmem.clone()
-            diffs[n] = float((kmem - ref).abs().max())
+                ref = torch.stack([kmem, vmem]).clone()
+            diffs[n] = float((torch.stack([kmem, vmem]) - ref).abs().max())
         x = x0.clone()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -102,10 +102,25 @@ for rnd in range(int(os.environ.get('X3_ROUNDS', '5'))):
         r = L.x3_variant_run(nat.ptr(x), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32, nat.ptr(kmem), nat.ptr(vmem), nat.stream_ptr())
         b.record(); torch.cuda.synchronize()
         times[n].append(a.elapsed_time(b))
-print(f'| build | median ms | min ms | max|dK| vs {names[0]} |\n|---|---:|---:|---:|')
+print(f'| build | median ms | min ms | max|dK,dV| vs {names[0]} |\n|---|---:|---:|---:|')
 for n in names:
     t = sorted(times[n])
     print(f'| {n} | {t[len(t) // 2]:.3f} | {t[0]:.3f} | {diffs[n]:.3e} |')
+
+if '--timers8' in sys.argv[1:] or os.environ.get('X3W_TIMERS'):
+    SL8 = ['parameters + LayerNorm', 'park / unpark / O reload', 'head loop: wait + barrier', 'head loop: MFMA pairs', 'head loop: epilogues + soft-max section', 'proj: wait + barrier', 'proj: MFMAs',
+           'MLP: wait + barrier', 'MLP: GELU in front of a group (half B)', 'MLP: fc1 MFMAs', 'MLP: fc2 MFMAs', 'MLP: GELU behind a group (half A)', 'tail + rest']
+    n = names[-1]
+    x = x0.clone()
+    r = libs[n].x3_variant_run(nat.ptr(x), nat.ptr(md), nat.ptr(pack), total, o32, depth, M, nat.ptr(table), nat.ptr(scratch), t32, nat.ptr(kmem), nat.ptr(vmem), nat.stream_ptr())
+    torch.cuda.synchronize()
+    t = x.view(torch.int64).view(M, E // 2)[torch.arange(images * 8, device=DEV) * 16][:, :13].double().view(images, 8, 13)      # one row of 13 counters per wave
+    for half, sel in (('half A (waves 0-3)', slice(0, 4)), ('half B (waves 4-7)', slice(4, 8))):
+        th = t[:, sel].reshape(-1, 13); tot = th.sum(1)
+        print(f'\n| phase of `enc_blocks_x3w_kernel` (build {n}, {half}, mean over {th.shape[0]} waves) | s_memtime ticks per wave | share |\n|---|---:|---:|')
+        for i, name in enumerate(SL8):
+            print(f'| {name} | {th[:, i].mean():,.0f} | {100 * th[:, i].sum() / tot.sum():.1f} % |')
+        print(f'| total | {tot.mean():,.0f} | (min {tot.min():,.0f}, max {tot.max():,.0f}) |')
 
 if TIMERS:
     SLOTS = ['parameters + LayerNorm 1', 'park', 'head loop: q / k / v pairs', 'head loop: q / k / v epilogues', 'head loop: S, soft-max, P V, O stores', 'unpark + O reload', 'proj',
