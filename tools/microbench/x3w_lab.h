@@ -125,12 +125,30 @@ __device__ __forceinline__ void issue_stage(__amdgpu_buffer_rsrc_t rsrc, unsigne
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, l, 16, voff, origin_b + 16u * pitch_b - 1024u, 1024, 0);
 }
 
+#ifndef X3W_DMA_HALF
+#define X3W_DMA_HALF 0         // 1: only waves 0-3 issue LDS-DMA pieces — their own two of a stage and their partner's (wave + 4) two; 2: only waves 4-7
+#endif
+// KIND: the stage's row order / pitch combination (StreamLaneX::calc) — it fixes where wave w + 4's pieces lie relative to wave w's: 64 LDS rows on,
+// i.e. the second k-block of the same source rows (KIND 0: + 128 bytes) or 64 source rows on (KIND 1, 2: + 64 row pitches)
+template <int KIND>
+__device__ __forceinline__ void issue_stage_k(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned origin_b, unsigned pitch_b, unsigned char* dst, int w8) {
+    if constexpr (X3W_DMA_HALF == 0) issue_stage(rsrc, voff, origin_b, pitch_b, dst);
+    else {
+        // the issuing half's lanes hold the voff of THEIR wave; the other half's pieces differ by a wave-uniform delta
+        const unsigned delta = KIND == 0 ? 128u : 64u * pitch_b;
+        if (X3W_DMA_HALF == 1 ? w8 < 4 : w8 >= 4) {
+            issue_stage(rsrc, voff, origin_b, pitch_b, dst);
+            if (X3W_DMA_HALF == 1) issue_stage(rsrc, voff, origin_b + delta, pitch_b, dst + 8192);
+            else issue_stage(rsrc, voff, origin_b - delta, pitch_b, dst - 8192);
+        }
+    }
+}
 __device__ __forceinline__ void group_fence() {         // the group about to run has landed (caller waited vmcnt); all waves are past the previous one
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr ((X3W_ABLATE & 16) == 0) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-template <int N> __device__ __forceinline__ void wait_dma() { if constexpr ((X3W_ABLATE & 32) == 0) wait_vmcnt<N>(); }
+template <int N> __device__ __forceinline__ void wait_dma() { if constexpr ((X3W_ABLATE & 32) == 0) wait_vmcnt<(X3W_DMA_HALF ? 2 * N : N)>(); }
 
 // ---- NS stages under one barrier -------------------------------------------------------------------------------------------------
 // stage_ptr(s): LDS address of stage s; mma(s, i, wh, wl): the three MFMAs that consume the (hi, lo) weight fragments of tile i (16 LDS rows)
@@ -284,7 +302,7 @@ __device__ __forceinline__ void heads_issue(const StreamLane8& sl, unsigned char
     const int m = sigma >> 1, s = sigma & 1, h = m / 9, n = m - 9 * h;
     unsigned char* dst = ring + (sigma % HEADS_SLOTS) * STAGE + w8 * 2048;
     const int u = n / 3, pp = n - 3 * u, t = 2 * pp + s;
-    issue_stage(wrsrc, sl.template voff<0>(), (wqkv_off + (unsigned)((u * E + h * 64) * E + t * 64)) * 4u, 4u * E, dst);
+    issue_stage_k<0>(wrsrc, sl.template voff<0>(), (wqkv_off + (unsigned)((u * E + h * 64) * E + t * 64)) * 4u, 4u * E, dst, w8);
 }
 template <int E>
 __device__ __forceinline__ void heads_prefetch(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, int w8) {
@@ -458,7 +476,7 @@ template <int E, int RING>
 __device__ __forceinline__ void proj_issue(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, int w8, int n, int s) {
     const int t = 2 * n + s, kb = t / 3, ng = t - 3 * kb;
     unsigned char* dst = ring + (n % RING) * PAIRB + s * STAGE + w8 * 2048;
-    issue_stage(wrsrc, sl.template voff<1>(), (wproj_off + (unsigned)(ng * 128 * E + kb * 32)) * 4u, 4u * E, dst);
+    issue_stage_k<1>(wrsrc, sl.template voff<1>(), (wproj_off + (unsigned)(ng * 128 * E + kb * 32)) * 4u, 4u * E, dst, w8);
 }
 template <int E, int RING>
 __device__ __forceinline__ void proj_prefetch(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, int w8) {
@@ -589,8 +607,8 @@ __device__ __forceinline__ void mlp_issue(const StreamLane8& sl, unsigned char* 
                                           int w8, int c, int k, int s) {
     constexpr int F = 4 * E;
     unsigned char* dst = ring + ((4 * c + k) % 3) * TRIPB + s * STAGE + w8 * 2048;
-    if (k < 2) issue_stage(wrsrc, sl.template voff<0>(), (w1_off + (unsigned)(c * 64 * E + (3 * k + s) * 64)) * 4u, 4u * E, dst);
-    else issue_stage(wrsrc, sl.template voff<2>(), (w2_off + (unsigned)(s * 128 * F + c * 64 + (k - 2) * 32)) * 4u, 4u * F, dst);
+    if (k < 2) issue_stage_k<0>(wrsrc, sl.template voff<0>(), (w1_off + (unsigned)(c * 64 * E + (3 * k + s) * 64)) * 4u, 4u * E, dst, w8);
+    else issue_stage_k<2>(wrsrc, sl.template voff<2>(), (w2_off + (unsigned)(s * 128 * F + c * 64 + (k - 2) * 32)) * 4u, 4u * F, dst, w8);
 }
 template <int E>
 __device__ __forceinline__ void mlp_prefetch(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off, int w8) {
@@ -892,7 +910,7 @@ __device__ __forceinline__ void patch_head(const EncHeadX3& hp, unsigned char* r
     const unsigned vpe = StreamLaneX::calc<1>(lane, w8 >> 1, PK) + (unsigned)((w8 & 1) * 4 * 4 * PK);
     static_for<0, 9>([&](auto sc) {
         constexpr int st = decltype(sc)::value, ng = st / 3, kb = st % 3;
-        issue_stage(wrsrc, vpe, (hp.wpe + (unsigned)(ng * 128 * PK + kb * 32)) * 4u, 4u * PK, ring + st * STAGE + w8 * 2048);
+        issue_stage_k<1>(wrsrc, vpe, (hp.wpe + (unsigned)(ng * 128 * PK + kb * 32)) * 4u, 4u * PK, ring + st * STAGE + w8 * 2048, w8);
     });
     load_x_to_acc<E>(hp.posb, 0, 128, w8, rr, g, acc);
     bf16x8 ph[3], pl[3];
@@ -940,7 +958,7 @@ template <int E, int RING>
 __device__ __forceinline__ void kv_issue(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int w8, int m, int s) {
     const int c = m / 3, pp = m - 3 * c;      // pair m = 3 c + pp of the tail (group m % RING, issued RING - 1 pairs ahead), stage s
     unsigned char* dst = ring + (m % RING) * PAIRB + s * STAGE + w8 * 2048;
-    issue_stage(wrsrc, sl.template voff<0>(), (wkv_off + (unsigned)(c * 64 * E + (2 * pp + s) * 64)) * 4u, 4u * E, dst);
+    issue_stage_k<0>(wrsrc, sl.template voff<0>(), (wkv_off + (unsigned)(c * 64 * E + (2 * pp + s) * 64)) * 4u, 4u * E, dst, w8);
 }
 template <int E, int RING>
 __device__ __forceinline__ void kv_prefetch(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wkv_off, int w8) {
@@ -1027,7 +1045,9 @@ void enc_blocks_x3w_kernel(float* __restrict__ x, const unsigned char* __restric
     const int m0 = blockIdx.x * 128;
     const StreamLane8 sl(lane, w8, E);
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wpack), 0, wbytes, 0x00020000);
-    if (X3W_PRIO && w8 < 4) __builtin_amdgcn_s_setprio(1);
+    if (X3W_PRIO == 1 && w8 < 4) __builtin_amdgcn_s_setprio(1);
+    if (X3W_PRIO == 2 && w8 >= 4) __builtin_amdgcn_s_setprio(1);      // the younger half (the arbitration loser at equal priority)
+    if (X3W_PRIO == 3 && (w8 & 1)) __builtin_amdgcn_s_setprio(1);
 
     f32x4 acc[E / 16];
     bf16x8 ah[E / 32], al[E / 32];
