@@ -59,8 +59,8 @@ def cpu_baseline(name, sd_cpu, refine_iters, seconds=12.0, batch=64, check_image
     """The CPU oracle (a port of the reference algorithm, oracle/parseq_oracle.py) on this box's host cores: fp32,
     torch.inference_mode, PARSeq-S AR + refine at batch 64 (the CPU's best operating point in SURVEY 8d), repeated for
     ~`seconds` of wall time.  This function is the ONLY place bench.py touches the oracle: besides being timed as the baseline
-    it serves as the checker of the timed outputs — `check_images` (a few of the timed crops) are run through it and the logits
-    returned for the parity block.  Returns (baseline record, oracle logits of check_images or None)."""
+    it serves as the checker of the timed outputs — the batch it is timed on IS `check_images`, the first 64 of the timed crops, and
+    the logits of its last repetition go to the parity block.  Returns (baseline record, oracle logits of check_images or None)."""
     from oracle import parseq_oracle as O
     from oracle.synth import CONFIGS, synth_images
     cfg = CONFIGS[name]
@@ -69,28 +69,29 @@ def cpu_baseline(name, sd_cpu, refine_iters, seconds=12.0, batch=64, check_image
     host = os.cpu_count() or 1
     cores = min(host, 32)
     torch.set_num_threads(cores)
-    x = synth_images(batch, cfg, seed=1234)
+    x = check_images if check_images is not None else synth_images(batch, cfg, seed=1234)
+    batch = x.shape[0]
     with torch.inference_mode():
         O.forward(sd_cpu, cfg, x[:8], 25, decode_ar=True, refine_iters=refine_iters)      # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
-            O.forward(sd_cpu, cfg, x, 25, decode_ar=True, refine_iters=refine_iters)
+            last = O.forward(sd_cpu, cfg, x, 25, decode_ar=True, refine_iters=refine_iters)
             n += 1
             dt = time.perf_counter() - t0
             if dt >= seconds or n >= 20:
                 break
         check = None
         if check_images is not None:
-            check = O.forward(sd_cpu, cfg, check_images, check_max_length, decode_ar=True, refine_iters=refine_iters)
+            check = last if check_max_length == 25 else O.forward(sd_cpu, cfg, check_images, check_max_length, decode_ar=True, refine_iters=refine_iters)
     return {'value': round(n * batch / dt, 2), 'unit': 'images/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} x batch {batch} PARSeq-S fp32 AR(26 steps)+{refine_iters} refine, oracle/parseq_oracle.py, {dt:.1f} s, '
+            'sample': f'{n} x the first {batch} of the timed crops, PARSeq-S fp32 AR(26 steps)+{refine_iters} refine, oracle/parseq_oracle.py, {dt:.1f} s, '
                       f'{torch.get_num_threads()} threads (host has {host} hardware threads; capped at 32: more threads run this op mix slower)'}, check
 
 
 def parity_block(args, model, make_model, images, max_length, oracle_logits):
     """Parity evidence for the timed path, on the timed weights and the timed inputs: the timed precision's logits of the
-    first 64 crops against the library's exact-tolerance mode on the same crops, and that mode against the CPU oracle's
-    logits of the first 8 of them (`oracle_logits`, computed by cpu_baseline — checker only)."""
+    first 64 crops against the library's fp32-MFMA mode on the same crops, and both against the CPU oracle's logits of the same 64
+    crops (`oracle_logits`: the batch cpu_baseline was timed on — checker only)."""
     n = min(64, images.shape[0])
     x = images[:n]
     exact_prec = args.exact_precision
@@ -174,14 +175,34 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
             model.model.decode_ar, fp32.model.decode_ar = ar_a, ar_b
             model.model.refine_iters, fp32.model.refine_iters = ri_a, ri_b
         if oracle_logits is not None:
+            # the CPU oracle's logits of the same crops (all `no` of them: the batch the baseline was timed on) — the timed mode and the fp32 mode against them,
+            # and for every crop whose decoded string differs from the oracle's the ORACLE's own top-1 / top-2 margin at the first differing position
             want = oracle_logits
+            no = min(want.shape[0], n)
             Lo = min(want.shape[1], ref.shape[1])
-            out['fp32_mode_max_abs_vs_oracle'] = round(float((ref[:8, :Lo].cpu() - want[:, :Lo]).abs().max()), 8)
-            out['fp32_mode_argmax_vs_oracle'] = round(float((ref[:8, :Lo].cpu().argmax(-1) == want[:, :Lo].argmax(-1)).float().mean()), 6)
-            out['timed_max_abs_vs_oracle'] = round(float((got[:8, :Lo].cpu() - want[:, :Lo]).abs().max()), 6)
+            gc, rc, wc = got[:no, :Lo].cpu(), ref[:no, :Lo].cpu(), want[:no, :Lo]
+            out['oracle_crops'] = no
+            out['fp32_mode_max_abs_vs_oracle'] = round(float((rc - wc).abs().max()), 8)
+            out['fp32_mode_argmax_vs_oracle'] = round(float((rc.argmax(-1) == wc.argmax(-1)).float().mean()), 6)
+            out['timed_max_abs_vs_oracle'] = round(float((gc - wc).abs().max()), 6)
+            out['timed_argmax_vs_oracle'] = round(float((gc.argmax(-1) == wc.argmax(-1)).float().mean()), 6)
+            s_orc, _ = tok.decode_logits(want[:no])
+            out['timed_strings_vs_oracle'] = round(sum(a == b for a, b in zip(s_got[:no], s_orc)) / no, 6)
             if exact is not fp32:
-                out['exact_mode_max_abs_vs_oracle'] = round(float((exl[:8, :Lo].cpu() - want[:, :Lo]).abs().max()), 8)
-            out['oracle_crops'] = 8
+                out['exact_mode_max_abs_vs_oracle'] = round(float((exl[:no, :Lo].cpu() - wc).abs().max()), 8)
+            t2o = wc.topk(2, -1).values
+            omargin = t2o[..., 0] - t2o[..., 1]
+            odiff = gc.argmax(-1) != wc.argmax(-1)
+            ofirst = []
+            for i in torch.nonzero(odiff.any(-1)).flatten().tolist():
+                pos = int(torch.nonzero(odiff[i]).flatten()[0])
+                ofirst.append({'crop': i, 'position': pos, 'oracle_margin': round(float(omargin[i, pos]), 8), 'abs_diff_there': round(float((gc[i, pos] - wc[i, pos]).abs().max()), 8)})
+            out['first_divergences_vs_oracle'] = ofirst[:8]
+            odec = omargin.min(-1).values > 2e-3
+            out['oracle_decidable_crops'] = int(odec.sum())
+            if int(odec.sum()):
+                out['timed_max_abs_vs_oracle_decidable'] = round(float((gc[odec] - wc[odec]).abs().max()), 8)
+                out['timed_argmax_vs_oracle_decidable'] = round(float((gc[odec].argmax(-1) == wc[odec].argmax(-1)).float().mean()), 6)
     return out, exact
 
 
@@ -322,6 +343,7 @@ def main():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-natural-exit', action='store_true', help='skip the natural-early-exit leg (natural_exit_value)')
     ap.add_argument('--no-throughput-mode', action='store_true', help='skip the bf16-operand leg (throughput_mode)')
+    ap.add_argument('--no-config3', action='store_true', help='skip the BASELINE.json configs[3] leg (batch 1024, AR + 2 refine iters) reported as "config3"')
     ap.add_argument('--no-train', action='store_true', help='skip the short training-step leg (SURVEY.md section 8f row N3 / BASELINE.json configs[4]) reported as "train"')
     ap.add_argument('--force-dist', action='store_true', help='self-test: initialise the RCCL process group and run the collectives even with one rank')
     ap.add_argument('--repeats', type=int, default=5, help='repetitions of the K-step timed region; the median is reported, min / max alongside')
@@ -528,7 +550,7 @@ def main():
         result['kernel_families'], result['roofline'] = profile_leg(model, images, args.precision)
     oracle_logits = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'], oracle_logits = cpu_baseline(args.model, sd_cpu, args.refine_iters, check_images=images[:8].float().cpu(),     # exactly the timed inputs (bf16-rounded in bf16 mode)
+        result['cpu_baseline'], oracle_logits = cpu_baseline(args.model, sd_cpu, args.refine_iters, check_images=images[:64].float().cpu(),     # exactly the timed inputs (bf16-rounded in bf16 mode)
                                                              check_max_length=max_length)
     exact = None
     if rank == 0 and world == 1 and not args.no_parity and args.model in ('parseq', 'parseq-tiny'):
@@ -578,6 +600,25 @@ def main():
             del tm
         except Exception as e:
             result['throughput_mode'] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0 and world == 1 and not STUB and not args.no_config3 and args.model == 'parseq' and not (B == 1024 and args.refine_iters == 2):
+        # BASELINE.json configs[3] on the driver's record: PARSeq-S, 94-class charset, max_label_length 25, AR (26 steps forced) + 2 refinement iterations, batch 1024
+        # on one MI355X, in the timed precision — a short leg (5 steps per timed region, 2 repeats), in flight and one forward at a time, never part of `value`
+        try:
+            m3 = create_model(args.model, decode_ar=True, refine_iters=2, precision=args.precision)
+            m3.model.load_state_dict(sd_cpu)
+            m3 = m3.eval().to(dev)
+            g3 = torch.Generator().manual_seed(4242)
+            x3 = (torch.rand(1024, 3, ih, iw, generator=g3) * 2 - 1).to(dev)
+            x3 = x3.bfloat16() if args.precision == 'bf16' else x3
+            e3, o3, sp3 = repeated(m3, x3, args.streams, 5, 2, 2)
+            e31, _, sp31 = repeated(m3, x3, 1, 5, 1, 2)
+            result['config3'] = {'workload': f'BASELINE.json configs[3]: {args.model} {args.precision}, batch 1024, AR (26 steps forced) + 2 refine iters, charset {len(m3.hparams.charset_test)} classes, '
+                                             f'max_label_length {m3.hparams.max_label_length}', 'value': round(1024 * 5 / e3, 1), 'sequential_value': round(1024 * 5 / e31, 1), 'unit': 'images/s',
+                                 'ms_per_step': round(1e3 * e3 / 5, 3), 'sequential_ms_per_step': round(1e3 * e31 / 5, 3), 'steps': 5, 'steps_in_flight': args.streams,
+                                 'output_shape': list(o3.shape), 'repeats': {'value': sp3, 'sequential_value': sp31}}
+            del m3, x3
+        except Exception as e:
+            result['config3'] = {'error': f'{type(e).__name__}: {e}'}
     if not args.no_train and args.model == 'parseq' and not (STUB and world == 1):
         # Row N3 on the driver's record (never part of `value`): the training step of BASELINE.json configs[4] — 384 crops per GPU, K = 6
         # permutations, dropout 0.1, forward + backward + (N > 1: gradient all-reduce) + clip + AdamW in the bf16-operand mode — two warm-up
@@ -599,17 +640,29 @@ def main():
             result['exact_precision'] = args.exact_precision
             if 'roofline' in result:
                 result['roofline_at_tolerance'] = result['roofline']
-            # met = within 1e-3 of the fp32 mode and argmax- / string-identical on every crop where that is decidable (no near-tie), every
-            # disagreement elsewhere starting AT a near-tie, the feedback-free pass within 1e-3, and within 1e-3 of the CPU oracle
+            # Two booleans.  tolerance_met_by_timed_dtype (the key of rounds 1-3, strict again): within 1e-3 of the fp32 mode AND of the CPU oracle on EVERY checked
+            # crop, argmax- and string-identical on every one of them.  tolerance_met_decidable (round 4's near-tie-aware reading, under its own name): the same over
+            # the crops where it is decidable (no top-1 / top-2 margin under 2e-3 in the reference logits: below that ANY two implementations inside the tolerance may
+            # pick differently, and under AR decoding the pick changes the context of every later position), every disagreement elsewhere starting AT a near-tie, the
+            # feedback-free pass within 1e-3; decidable_crops / crops says how many that is.
             ok_orc = par.get('timed_max_abs_vs_oracle')
+            ok = par and 'error' not in par
             result['tolerance_met_by_timed_dtype'] = bool(
+                par.get('max_abs_vs_fp32', 1.0) <= 1e-3 and par.get('argmax_agree') == 1.0 and par.get('strings_agree') == 1.0 and
+                (ok_orc is None or (ok_orc <= 1e-3 and par.get('timed_argmax_vs_oracle') == 1.0))) if ok else None
+            ok_orc_d = par.get('timed_max_abs_vs_oracle_decidable')
+            result['tolerance_met_decidable'] = bool(
                 par.get('decidable_crops', 0) > 0 and par.get('max_abs_vs_fp32_decidable', 1.0) <= 1e-3 and par.get('argmax_agree_decidable') == 1.0 and
                 par.get('strings_agree_decidable') == 1.0 and par.get('divergences_at_near_ties_only') is True and
-                par.get('nar_max_abs_vs_fp32', 1.0) <= 1e-3 and (ok_orc is None or ok_orc <= 1e-3)) if par and 'error' not in par else None
+                par.get('nar_max_abs_vs_fp32', 1.0) <= 1e-3 and (ok_orc_d is None or (ok_orc_d <= 1e-3 and par.get('timed_argmax_vs_oracle_decidable') == 1.0)) and
+                all(f['oracle_margin'] <= 2e-3 for f in par.get('first_divergences_vs_oracle', []))) if ok else None
+            result['decidable_crops_of'] = [par.get('decidable_crops'), par.get('crops')] if ok else None
         else:
             result['value_at_tolerance'] = result.get('exact_value')
-            result['tolerance_met_by_timed_dtype'] = bool(par.get('decidable_crops', 0) > 0 and par.get('max_abs_vs_fp32_decidable', 1.0) <= 1e-3 and
-                                                          par.get('argmax_agree_decidable') == 1.0 and par.get('nar_max_abs_vs_fp32', 1.0) <= 1e-3)
+            result['tolerance_met_by_timed_dtype'] = bool(par.get('max_abs_vs_fp32', 1.0) <= 1e-3 and par.get('argmax_agree') == 1.0 and par.get('strings_agree') == 1.0)
+            result['tolerance_met_decidable'] = bool(par.get('decidable_crops', 0) > 0 and par.get('max_abs_vs_fp32_decidable', 1.0) <= 1e-3 and
+                                                     par.get('argmax_agree_decidable') == 1.0 and par.get('nar_max_abs_vs_fp32', 1.0) <= 1e-3)
+            result['decidable_crops_of'] = [par.get('decidable_crops'), par.get('crops')]
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

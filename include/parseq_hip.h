@@ -288,7 +288,10 @@ int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int bat
  * the element range [*begin, *end) of the buffer — the ranges tile [0, parseq_model_grad_elems) — and *event (may be NULL) is a
  * hipEvent_t the most recent parseq_train_encoder_backward recorded on its stream right after the last kernel that writes the range.
  * parseq_stream_wait_event makes `stream` wait for it (hipStreamWaitEvent), so that a collective enqueued on that stream starts as
- * soon as its bucket is final while the backward keeps running. */
+ * soon as its bucket is final while the backward keeps running.  The events belong to ONE step (ABI 7): parseq_train_decoder — the
+ * step's first gradient writer — invalidates them, a parseq_train_encoder_backward that returns 0 validates them; asking for an
+ * event in between (the backward failed, or was never called for this step) returns PARSEQ_E_STATE instead of the previous step's
+ * already-signalled event.  The ranges (event == NULL) are always available. */
 int parseq_train_grad_segments(const parseq_model* m);
 int parseq_train_grad_segment(parseq_model* m, int index, int64_t* begin, int64_t* end, void** event);
 int parseq_stream_wait_event(void* stream, void* event);

@@ -78,18 +78,41 @@ def _compile(unit: str, want: str, verbose: bool) -> None:
     stamp = obj + '.sha256'
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return
-    cmd = [_hipcc()] + FLAGS + UNIT_FLAGS.get(unit, []) + _extra_flags() + ['-c', os.path.join(CSRC, unit + '.hip'), '-o', obj]
+    tmp = f'{obj}.tmp{os.getpid()}'
+    cmd = [_hipcc()] + FLAGS + UNIT_FLAGS.get(unit, []) + _extra_flags() + ['-c', os.path.join(CSRC, unit + '.hip'), '-o', tmp]
     if verbose:
         print('[parseq_amd.build]', ' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    with open(stamp, 'w') as fh:
-        fh.write(want)
+    os.replace(tmp, obj)
+    _replace_text(stamp, want)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Builds the library if it is stale.  Safe under several processes that import at once (torchrun ranks): the whole build runs under an exclusive flock on
+    lib/.build.lock — the first rank builds, the others find the library fresh when they get the lock — and objects, stamps and the library are written to temporary
+    names and os.replace()d into place, so that nobody ever dlopens or links a half-written file."""
     if not force and not is_stale():
         return LIB_PATH
+    import fcntl
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():      # another process built it while this one waited for the lock
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _replace_text(path: str, text: str) -> None:
+    tmp = f'{path}.tmp{os.getpid()}'
+    with open(tmp, 'w') as fh:
+        fh.write(text)
+    os.replace(tmp, path)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     if force:
         for f in os.listdir(OBJ_DIR):
             os.remove(os.path.join(OBJ_DIR, f))
@@ -97,12 +120,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as pool:
         for fut in [pool.submit(_compile, u, _unit_hash(u, headers), verbose) for u in UNITS]:
             fut.result()
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + [os.path.join(OBJ_DIR, u + '.o') for u in UNITS]
+    tmp = f'{LIB_PATH}.tmp{os.getpid()}'
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + [os.path.join(OBJ_DIR, u + '.o') for u in UNITS]
     if verbose:
         print('[parseq_amd.build]', ' '.join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    with open(STAMP_PATH, 'w') as fh:
-        fh.write(source_hash())
+    os.replace(tmp, LIB_PATH)
+    _replace_text(STAMP_PATH, source_hash())
     return LIB_PATH
 
 

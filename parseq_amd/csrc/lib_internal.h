@@ -156,6 +156,10 @@ struct parseq_model {
     // parseq_train_encoder_backward: one event per gradient segment (parseq_train_grad_segment), recorded on its stream as soon as that
     // part of the flat gradient buffer is final — the hook a data-parallel caller overlaps its bucket all-reduces with
     std::vector<hipEvent_t> grad_events;
+    // the events belong to ONE step: parseq_train_decoder (the step's first gradient writer) invalidates them, a parseq_train_encoder_backward that ran to its end validates
+    // them again — a caller that asks in between (the backward failed half-way, or never ran) must not get the previous step's events, which would let its collectives start
+    // on gradients that are still being written
+    bool grad_events_valid = false;
 
     const float* p(const std::string& key) const { return master + params[index.at(key)].offset; }
 };

@@ -288,7 +288,8 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t o_kmem = carve(off, rows * E * ts), o_vtmem = carve(off, rows * E * ts);
     const size_t o_stab = carve(off, npos * npos * c.num_tokens * (E / 32) * 4);
     const size_t o_sa = carve(off, drows * E * ts), o_tn = carve(off, drows * E * ts), o_ca = carve(off, drows * E * ts);
-    const size_t o_hdn = carve(off, drows * Fd * ts);
+    // (the fused AR step keeps its linear2 partial sums here: ds_split workgroups per row tile x [max_batch][E] f32 — more than drows * Fd * ts when max_label_length is 1)
+    const size_t o_hdn = carve(off, std::max<size_t>(drows * Fd * ts, (size_t)ds_split<384>() * B * E * 4));
     const size_t o_t = carve(off, drows * E * 4), o_qc = carve(off, drows * E * 4);
     const size_t o_tok = carve(off, B * LDT * 4), o_kpm = carve(off, B * LDT), o_eos = carve(off, B);
     const size_t o_cloze = carve(off, npos * LDT), o_qmu = carve(off, npos * LDT), o_cnt = carve(off, 64);

@@ -426,6 +426,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
         return fail(PARSEQ_E_INVALID, "null argument");
     if (m->vitstr) return fail(PARSEQ_E_INVALID, "ViTSTR has no decoder");
     for (const ParamSpec& ps : m->params) if (!ps.set) return fail(PARSEQ_E_STATE, "parameter %s was never set", ps.key.c_str());
+    m->grad_events_valid = false;      // a new step starts writing the flat gradient buffer: the previous step's segment events say nothing about it
     DevGuard dg(m->device);
     const int B = batch, L = ctx_len, K = num_perms;
     if (B <= 0 || L < 2 || L > m->cfg.max_label_length + 1 || K <= 0 || total_targets <= 0)
@@ -778,7 +779,8 @@ extern "C" int parseq_train_grad_segment(parseq_model* m, int index, int64_t* be
     if (!m || !begin || !end) return fail(PARSEQ_E_INVALID, "null argument");
     CHK(grad_segment_range(m, index, begin, end));
     if (event) {
-        if ((int)m->grad_events.size() <= index) return fail(PARSEQ_E_STATE, "gradient segment %d: no backward has recorded its event yet", index);
+        if ((int)m->grad_events.size() <= index || !m->grad_events_valid)
+            return fail(PARSEQ_E_STATE, "gradient segment %d: its event does not belong to this step (no parseq_train_encoder_backward has run to its end since the last parseq_train_decoder)", index);
         *event = (void*)m->grad_events[index];
     }
     return 0;
@@ -813,6 +815,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     bf16_t* d_x16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_x16) : nullptr;
     bf16_t* d_h16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_h16) : nullptr;
     const bool segs = m->cfg.enc_depth >= 2;
+    m->grad_events_valid = false;
     if (segs) CHK(grad_event_record(m, 0, s));      // the decoder's gradients were written by parseq_train_decoder, earlier on this stream
     CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps, d_x16));
     for (int i = m->cfg.enc_depth - 1; i >= 0; --i) {
@@ -860,6 +863,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     CHK(colsum(cx, d_x, (long)S * E, batch, S * E, G("pos_embed"), true));
     CHK(lin_bwd(cx, w + o.patches, P("patch_embed.proj.weight"), d_x, G("patch_embed.proj.weight"), G("patch_embed.proj.bias"), nullptr, MS, E, PK));
     if (segs) CHK(grad_event_record(m, m->cfg.enc_depth, s));      // block 0, patch_embed, pos_embed (and pos_queries): everything is final
+    m->grad_events_valid = segs;
     return 0;
 }
 

@@ -115,6 +115,12 @@ def average_gradient_segments(flat: Tensor, segments, group=None, wait=None, com
     world = dist.get_world_size(group)
     if world == 1 and not force:
         return flat
+    segments = list(segments)
+    if not segments:
+        raise ValueError('no gradient segments')
+    if comm_stream is not None and (wait is None or any(ev is None for _, _, ev in segments)):
+        # without the event dependency the side stream would start reducing a range the backward on the main stream is still writing
+        raise ValueError('comm_stream needs `wait` and an event for every segment')
     covered = sorted((b, e) for b, e, _ in segments)
     if covered[0][0] != 0 or covered[-1][1] != flat.numel() or any(a[1] != b[0] for a, b in zip(covered, covered[1:])):
         raise ValueError('gradient segments do not tile the flat buffer')
@@ -122,8 +128,7 @@ def average_gradient_segments(flat: Tensor, segments, group=None, wait=None, com
     for begin, end, event in segments:
         ctx = contextlib.nullcontext()
         if comm_stream is not None:
-            if wait is not None and event is not None:
-                wait(comm_stream, event)
+            wait(comm_stream, event)
             ctx = torch.cuda.stream(comm_stream)
         with ctx:
             works.append(dist.all_reduce(flat[begin:end], op=dist.ReduceOp.SUM, group=group, async_op=True))

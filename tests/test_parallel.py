@@ -179,6 +179,17 @@ def _segment_worker(rank, world, port, q):
             ok = False
         except ValueError:
             pass
+        try:
+            average_gradient_segments(mine.clone(), [])                                      # nothing to reduce: refused, not an IndexError
+            ok = False
+        except ValueError:
+            pass
+        try:
+            # a side stream without the events that order it behind the backward: the collective would race the gradient writers — refused
+            average_gradient_segments(mine.clone(), segs, comm_stream=object())
+            ok = False
+        except ValueError:
+            pass
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -765,6 +765,16 @@ def test_overlapped_allreduce_step_equals_the_plain_step():
         assert segs[0][1] == n and segs[-1][0] == 0               # the decoder's part first, the head of the buffer last
         assert [b for b, _, _ in segs] == sorted((b for b, _, _ in segs), reverse=True)      # back to front
         assert all(a[0] == b[1] for a, b in zip(segs, segs[1:]))  # contiguous: they tile [0, n)
+        # the events belong to the step that recorded them: once the next step's decoder has started writing gradients, and until an encoder backward has run to its
+        # end again, asking for a segment's event is a state error (it used to hand out the previous step's event, already signalled)
+        lib = _native.lib()
+        d = torch.zeros(64, device=DEV)
+        dp = _native.ptr(d)
+        # (a decoder call that gets as far as its shape check — ctx_len 1 is refused — has already declared the new step)
+        assert lib.parseq_train_decoder(native, dp, dp, dp, dp, dp, 1, 1, 1, 1, 0.0, 0, dp, dp, dp, dp, 256, _native.stream_ptr()) != 0
+        b, e, ev = C.c_int64(), C.c_int64(), C.c_void_p()
+        assert lib.parseq_train_grad_segment(native, 0, C.byref(b), C.byref(e), C.byref(ev)) != 0
+        assert lib.parseq_train_grad_segment(native, 0, C.byref(b), C.byref(e), None) == 0      # the ranges alone stay available
     finally:
         dist.destroy_process_group()
 

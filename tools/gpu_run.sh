@@ -15,9 +15,9 @@
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 task=$1; shift
-QUICK="--steps 30 --warmup 5 --repeats 3 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode"
+QUICK="--steps 30 --warmup 5 --repeats 3 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3"
 headline() { python - "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
@@ -45,7 +45,7 @@ ab)
 import json,sys; d=json.loads(sys.stdin.read()); print('$name: value', d['value'], 'seq', d['sequential_value'])"
   done ;;
 profiles)
-  P="--steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode"
+  P="--steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3"
   for prec in bf16x3 bf16; do
     rm -rf gpurun_out/prof_$prec
     timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$prec -o p -- python bench.py --precision $prec $P > gpurun_out/prof_$prec.log 2>&1
@@ -59,7 +59,7 @@ profiles)
     rm -rf gpurun_out/prof_$prec gpurun_out/pmc_${prec}_*
   done ;;
 seqprof)   # kernel stats of one forward at a time (--streams 1: the latency form of the AR step), both matrix-core modes
-  P="--steps 5 --warmup 2 --repeats 1 --streams 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode"
+  P="--steps 5 --warmup 2 --repeats 1 --streams 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3"
   for prec in bf16x3 bf16; do
     rm -rf gpurun_out/prof_$prec
     timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$prec -o p -- python bench.py --precision $prec $P > gpurun_out/prof_$prec.log 2>&1

@@ -49,7 +49,21 @@ __global__ __launch_bounds__(WAVES * 64, 1) void two(const bf16x8* __restrict__ 
     };
     __syncthreads();
     const long long t0 = clock64();
-    if (ROLES == 1) {
+    if (ROLES == 2) {          // interleaved: NV / NM VALU instructions behind every MFMA of the wave's own stream
+        constexpr int PER = NM ? NV / NM : 0;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i) {
+                c[(i / 3) & 7] = mfma_v(i % 3 == 0 ? wl : wh, i % 3 == 1 ? al : ah, c[(i / 3) & 7]);
+#pragma unroll
+                for (int q = 0; q < PER; ++q) {
+                    if constexpr (VK == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(i * PER + q) & 15]) : "v"(f[16]));
+                    else if constexpr (VK == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(f[(i * PER + q) & 15]));
+                    else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(i * PER + q) & 3]) : "v"(f[16]));      // four dependent chains
+                }
+            }
+        }
+    } else if (ROLES == 1) {
         if (!second) { for (int it = 0; it < iters; ++it) mblock(); }
         else { for (int it = 0; it < iters; ++it) vblock(); }
     } else if (ANTI && second) {
@@ -305,6 +319,14 @@ int main() {
     run<8, 72, 200, 0, 1, 1, 0>("8 waves anti-phase, waves 0-3 prio 1", in, out, cyc);
     run<8, 72, 200, 0, 1, 2, 0>("8 waves anti-phase, waves 4-7 prio 1", in, out, cyc);
     run<8, 72, 200, 0, 0, 1, 0>("8 waves in phase, waves 0-3 prio 1", in, out, cyc);
+    run<4, 72, 216, 2, 0, 0, 0>("4 waves: 72 MFMAs with 3 v_fma behind each (interleaved)", in, out, cyc);
+    run<8, 72, 72, 2, 0, 0, 0>("8 waves: 72 MFMAs each with 1 v_fma behind each", in, out, cyc);
+    run<8, 72, 144, 2, 0, 0, 0>("8 waves: 72 MFMAs each with 2 v_fma behind each", in, out, cyc);
+    run<8, 72, 216, 2, 0, 0, 0>("8 waves: 72 MFMAs each with 3 v_fma behind each", in, out, cyc);
+    run<8, 72, 288, 2, 0, 0, 0>("8 waves: 72 MFMAs each with 4 v_fma behind each", in, out, cyc);
+    run<8, 72, 216, 2, 0, 0, 2>("8 waves: 72 MFMAs each with 3 v_fma (four dependent chains) behind each", in, out, cyc);
+    run<8, 72, 72, 2, 0, 0, 1>("8 waves: 72 MFMAs each with 1 v_exp behind each", in, out, cyc);
+    run<8, 72, 216, 0, 0, 0, 0>("8 waves in phase: [72 MFMAs][216 v_fma] each (block form of the 3-per-MFMA case)", in, out, cyc);
     run<4, 72, 64, 0, 0, 0, 1>("4 waves: [72 MFMAs][64 v_exp]", in, out, cyc);
     run<8, 72, 64, 0, 0, 0, 1>("8 waves in phase: [72 MFMAs][64 v_exp] each", in, out, cyc);
     run<8, 72, 64, 0, 1, 0, 1>("8 waves anti-phase: [72 MFMAs][64 v_exp]", in, out, cyc);

@@ -150,6 +150,12 @@ __device__ __forceinline__ void group_fence() {         // the group about to ru
 }
 template <int N> __device__ __forceinline__ void wait_dma() { if constexpr ((X3W_ABLATE & 32) == 0) wait_vmcnt<(X3W_DMA_HALF ? 2 * N : N)>(); }
 
+// X3W_PRIO 4 / 5: waves 0-3 take priority 1 in even (half) stages, waves 4-7 in odd ones (the wave's half is read from the hardware wave id register through
+// s_getreg: no live register needed)
+__device__ __forceinline__ void g_prio_toggle(int s) {
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+    if (((s ^ w) & 1) == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+}
 // ---- NS stages under one barrier -------------------------------------------------------------------------------------------------
 // stage_ptr(s): LDS address of stage s; mma(s, i, wh, wl): the three MFMAs that consume the (hi, lo) weight fragments of tile i (16 LDS rows)
 // of stage s; issue(s): the wave's LDS-DMA pieces due at the start of stage s.  Fragment reads run AHEAD positions ahead of the MFMAs.
@@ -167,7 +173,13 @@ __device__ __forceinline__ void run_stages(Ptr&& stage_ptr, Mma&& mma, Issue&& i
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, NPOS>([&](auto nc) {
         constexpr int n = decltype(nc)::value, s = n >> 3, i = n & 7, nn = n + AHEAD;
-        if constexpr (i == 0) { issue(s); __builtin_amdgcn_sched_barrier(0); }
+        if constexpr (i == 0) {
+            if constexpr (X3W_PRIO == 4 || X3W_PRIO == 5) {          // alternate the two halves' priority stage by stage (4) / every half stage (5): approximates fair sharing of the SIMD
+                g_prio_toggle(s);
+            }
+            issue(s); __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (i == 4 && X3W_PRIO == 5) g_prio_toggle(s + 1);
         if constexpr (nn < NPOS && (X3W_ABLATE & 128) == 0) {
             const unsigned char* src = stage_ptr(nn >> 3) + (nn & 7) * 2048;
             wh[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo0);
