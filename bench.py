@@ -186,7 +186,7 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
             out['fp32_mode_argmax_vs_oracle'] = round(float((rc.argmax(-1) == wc.argmax(-1)).float().mean()), 6)
             out['timed_max_abs_vs_oracle'] = round(float((gc - wc).abs().max()), 6)
             out['timed_argmax_vs_oracle'] = round(float((gc.argmax(-1) == wc.argmax(-1)).float().mean()), 6)
-            s_orc, _ = tok.decode_logits(want[:no])
+            s_orc, _ = tok.decode_logits(want[:no].to(got.device))
             out['timed_strings_vs_oracle'] = round(sum(a == b for a, b in zip(s_got[:no], s_orc)) / no, 6)
             if exact is not fp32:
                 out['exact_mode_max_abs_vs_oracle'] = round(float((exl[:no, :Lo].cpu() - wc).abs().max()), 8)
@@ -612,7 +612,7 @@ def main():
             x3 = x3.bfloat16() if args.precision == 'bf16' else x3
             e3, o3, sp3 = repeated(m3, x3, args.streams, 5, 2, 2)
             e31, _, sp31 = repeated(m3, x3, 1, 5, 1, 2)
-            result['config3'] = {'workload': f'BASELINE.json configs[3]: {args.model} {args.precision}, batch 1024, AR (26 steps forced) + 2 refine iters, charset {len(m3.hparams.charset_test)} classes, '
+            result['config3'] = {'workload': f'BASELINE.json configs[3]: {args.model} {args.precision}, batch 1024, AR (26 steps forced) + 2 refine iters, {len(m3.hparams.charset_train)}-class charset, '
                                              f'max_label_length {m3.hparams.max_label_length}', 'value': round(1024 * 5 / e3, 1), 'sequential_value': round(1024 * 5 / e31, 1), 'unit': 'images/s',
                                  'ms_per_step': round(1e3 * e3 / 5, 3), 'sequential_ms_per_step': round(1e3 * e31 / 5, 3), 'steps': 5, 'steps_in_flight': args.streams,
                                  'output_shape': list(o3.shape), 'repeats': {'value': sp3, 'sequential_value': sp31}}
@@ -640,16 +640,22 @@ def main():
             result['exact_precision'] = args.exact_precision
             if 'roofline' in result:
                 result['roofline_at_tolerance'] = result['roofline']
-            # Two booleans.  tolerance_met_by_timed_dtype (the key of rounds 1-3, strict again): within 1e-3 of the fp32 mode AND of the CPU oracle on EVERY checked
-            # crop, argmax- and string-identical on every one of them.  tolerance_met_decidable (round 4's near-tie-aware reading, under its own name): the same over
+            # Two booleans.  tolerance_met_by_timed_dtype (the key of rounds 1-3, strict again): within 1e-3 of the reference on EVERY checked crop, argmax- and string-identical
+            # on every one of them.  tolerance_met_decidable (round 4's near-tie-aware reading, under its own name): the same over
             # the crops where it is decidable (no top-1 / top-2 margin under 2e-3 in the reference logits: below that ANY two implementations inside the tolerance may
             # pick differently, and under AR decoding the pick changes the context of every later position), every disagreement elsewhere starting AT a near-tie, the
             # feedback-free pass within 1e-3; decidable_crops / crops says how many that is.
             ok_orc = par.get('timed_max_abs_vs_oracle')
             ok = par and 'error' not in par
-            result['tolerance_met_by_timed_dtype'] = bool(
-                par.get('max_abs_vs_fp32', 1.0) <= 1e-3 and par.get('argmax_agree') == 1.0 and par.get('strings_agree') == 1.0 and
-                (ok_orc is None or (ok_orc <= 1e-3 and par.get('timed_argmax_vs_oracle') == 1.0))) if ok else None
+            # the reference of the north star is the CPU path: with the oracle's logits of the checked crops at hand the strict boolean is taken against THEM (every crop within
+            # 1e-3, argmax- and string-identical); the library's own fp32-MFMA mode is a second implementation, reported beside it (it may itself sit on the other side of a
+            # near-tie from the oracle: max_abs_vs_fp32 / first_divergences say so) and is the yardstick only when the oracle leg was skipped
+            if ok and ok_orc is not None:
+                result['tolerance_reference'] = f"CPU oracle (oracle/parseq_oracle.py), {par.get('oracle_crops')} of the timed crops"
+                result['tolerance_met_by_timed_dtype'] = bool(ok_orc <= 1e-3 and par.get('timed_argmax_vs_oracle') == 1.0 and par.get('timed_strings_vs_oracle') == 1.0)
+            else:
+                result['tolerance_reference'] = "the library's fp32-MFMA mode (oracle leg skipped)" if ok else None
+                result['tolerance_met_by_timed_dtype'] = bool(par.get('max_abs_vs_fp32', 1.0) <= 1e-3 and par.get('argmax_agree') == 1.0 and par.get('strings_agree') == 1.0) if ok else None
             ok_orc_d = par.get('timed_max_abs_vs_oracle_decidable')
             result['tolerance_met_decidable'] = bool(
                 par.get('decidable_crops', 0) > 0 and par.get('max_abs_vs_fp32_decidable', 1.0) <= 1e-3 and par.get('argmax_agree_decidable') == 1.0 and

@@ -23,11 +23,11 @@
  *     of the model's device).  The raw-pointer entry points (parseq_op_*, parseq_postprocess, parseq_resize_bicubic,
  *     parseq_cross_entropy, parseq_grad_norm) launch on the CURRENT device.  Per-kernel launch attributes are tracked per
  *     device, so one process may drive several GPUs / host threads (one plan each).
- *   - memory: the caller owns every tensor it passes; each plan owns ONE device arena (hipMalloc in parseq_plan_create:
- *     packed weights, decoder tables and all intermediates, about 0.9 GB at max_batch 512 in bf16) and the model one buffer of
- *     fp32 master weights.  This is a deliberate departure from "all workspace through the host framework's caching
- *     allocator" (SURVEY.md section 8b): the C ABI carries no allocator callback, nothing is allocated on the hot path, and
- *     the arena's lifetime is the plan's.
+ *   - memory: the caller owns every tensor it passes; each plan owns ONE device arena (packed weights, decoder tables and all
+ *     intermediates, about 0.9 GB at max_batch 512 in bf16) taken from hipMalloc (parseq_plan_create) or from the caller's
+ *     allocator (parseq_plan_create_ex, ABI 7: "all workspace through the host framework's caching allocator", SURVEY.md
+ *     section 8b), and the model one hipMalloc'ed buffer of fp32 master weights.  Nothing is allocated on the hot path; the
+ *     arena's lifetime is the plan's.
  */
 #ifndef PARSEQ_HIP_H_
 #define PARSEQ_HIP_H_
@@ -122,6 +122,19 @@ int parseq_model_param_info(const parseq_model* m, int index, const char** key, 
  * Requires every parameter to have been set.  precision: PARSEQ_F32, PARSEQ_BF16 or PARSEQ_BF16X3.  (Re)packs weights for `precision`; call parseq_plan_refresh after
  * parameters change. */
 int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out);
+/* (ABI 7) The same with the plan's ONE device arena taken from the caller's allocator instead of hipMalloc — "all workspace through the
+ * host framework's caching allocator" (what the reference gets for free from torch: every intermediate of
+ * strhub/models/parseq/model.py:86-169 is a caching-allocator block).  alloc(bytes, user) is called exactly once, inside this call, on the
+ * model's device, with bytes == what parseq_plan_workspace_bytes will report; it returns device memory aligned to 256 bytes or NULL
+ * (-> PARSEQ_E_HIP).  release(ptr, user) is called exactly once from parseq_plan_destroy (or from this call if a later step of the
+ * creation fails); the caller's release must not recycle the block while work of this plan is still in flight on any stream (hipFree
+ * synchronises implicitly; a caching allocator does not).  alloc == NULL and release == NULL: hipMalloc / hipFree (parseq_plan_create).
+ * A torch binding hands c10::hip::HIPCachingAllocator::raw_alloc / raw_delete; the ctypes binding of this repository allocates a uint8
+ * torch tensor per plan (parseq_amd/_native.py torch_plan_allocator). */
+typedef void* (*parseq_alloc_fn)(size_t bytes, void* user);
+typedef void (*parseq_release_fn)(void* ptr, void* user);
+int parseq_plan_create_ex(parseq_model* m, int max_batch, int precision, void* stream, parseq_alloc_fn alloc, parseq_release_fn release,
+                          void* user, parseq_plan** out);
 int parseq_plan_refresh(parseq_plan* p, void* stream);
 void parseq_plan_destroy(parseq_plan* p);
 size_t parseq_plan_workspace_bytes(const parseq_plan* p);

@@ -47,6 +47,7 @@ SIGNATURES = {
     'parseq_model_param_info': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64)]),
     'parseq_plan_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
     'parseq_plan_refresh': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'parseq_plan_create_ex': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     'parseq_plan_destroy': (None, [C.c_void_p]),
     'parseq_plan_workspace_bytes': (C.c_size_t, [C.c_void_p]),
     'parseq_resize_workspace_bytes': (C.c_size_t, [C.c_int]),
@@ -140,6 +141,52 @@ def check(status: int) -> None:
     if status != 0:
         msg = lib().parseq_last_error()
         raise NativeError(f'libparseq_hip error {status}: {msg.decode() if msg else "?"}')
+
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+RELEASE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+
+class TorchPlanAllocator:
+    """parseq_plan_create_ex's (alloc, release) pair on top of torch's caching allocator: a plan's arena is one uint8 tensor, alive until the library
+    hands the block back (reference: every intermediate of strhub/models/parseq/model.py:86-169 is a caching-allocator block).  One instance serves any
+    number of plans; `blocks` = {pointer: tensor} is what is out.  release() synchronises the device first: the caching allocator may hand the block
+    to anyone the moment the tensor dies, and a plan's work may still be running on side streams (slots)."""
+
+    def __init__(self, device):
+        import torch
+        self.device = torch.device(device)
+        self.blocks = {}
+        self.bytes_out = 0
+        self.calls = 0
+        self._alloc = ALLOC_FN(self._do_alloc)
+        self._release = RELEASE_FN(self._do_release)
+
+    def _do_alloc(self, nbytes, _user):
+        import torch
+        try:
+            t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        except Exception:
+            return None
+        self.blocks[t.data_ptr()] = t
+        self.bytes_out += int(nbytes)
+        self.calls += 1
+        return t.data_ptr()
+
+    def _do_release(self, ptr, _user):
+        import torch
+        t = self.blocks.pop(ptr, None)
+        if t is not None:
+            torch.cuda.synchronize(self.device)
+            self.bytes_out -= t.numel()
+
+    @property
+    def alloc_ptr(self):
+        return C.cast(self._alloc, C.c_void_p)
+
+    @property
+    def release_ptr(self):
+        return C.cast(self._release, C.c_void_p)
 
 
 def stream_ptr(device=None) -> C.c_void_p:

@@ -241,6 +241,8 @@ struct parseq_plan {
     uint64_t packed_version = ~0ull;
     unsigned char* arena = nullptr;
     size_t arena_bytes = 0;
+    parseq_release_fn arena_release = nullptr;      // parseq_plan_create_ex: the caller's allocator gave the arena and takes it back (nullptr: hipMalloc / hipFree)
+    void* arena_user = nullptr;
     // carved pointers (typed at use)
     void* wpack = nullptr;         // all parameters in storage type T (bf16 mode only; f32 mode aliases the master)
     bf16_t* wstep[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // fragment-packed decoder weights (decoder_step.h):

@@ -258,7 +258,12 @@ static int pack_weights(parseq_plan* p, hipStream_t s) {
 
 extern "C" void parseq_plan_destroy(parseq_plan* p);
 extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision, void* stream, parseq_plan** out) {
+    return parseq_plan_create_ex(m, max_batch, precision, stream, nullptr, nullptr, nullptr, out);
+}
+extern "C" int parseq_plan_create_ex(parseq_model* m, int max_batch, int precision, void* stream, parseq_alloc_fn alloc, parseq_release_fn release, void* user,
+                                     parseq_plan** out) {
     if (!m || !out || max_batch <= 0) return fail(PARSEQ_E_INVALID, "bad argument");
+    if ((alloc == nullptr) != (release == nullptr)) return fail(PARSEQ_E_INVALID, "alloc and release go together");
     if (precision != PARSEQ_F32 && precision != PARSEQ_BF16 && precision != PARSEQ_BF16X3) return fail(PARSEQ_E_INVALID, "precision %d", precision);
     DevGuard dg(m->device);
     const parseq_config& c = m->cfg;
@@ -297,8 +302,15 @@ extern "C" int parseq_plan_create(parseq_model* m, int max_batch, int precision,
     const size_t o_posb = carve(off, N * E * 4);
     const size_t o_qfold = carve(off, (3 * E + npos) * 4);
     p->arena_bytes = off;
-    hipError_t e = hipMalloc(&p->arena, off);
-    if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
+    if (alloc) {
+        p->arena = static_cast<unsigned char*>(alloc(off, user));
+        if (!p->arena) { delete p; return fail(PARSEQ_E_HIP, "the caller's allocator returned NULL for the plan workspace (%zu bytes)", off); }
+        if (reinterpret_cast<uintptr_t>(p->arena) % 256) { release(p->arena, user); delete p; return fail(PARSEQ_E_INVALID, "the caller's allocator returned a block that is not aligned to 256 bytes"); }
+        p->arena_release = release; p->arena_user = user;
+    } else {
+        hipError_t e = hipMalloc(&p->arena, off);
+        if (e != hipSuccess) { delete p; return fail(PARSEQ_E_HIP, "hipMalloc(%zu) for the plan workspace failed: %s", off, hipGetErrorString(e)); }
+    }
     unsigned char* a = p->arena;
     if (step_ok) for (int i = 0; i < 6; ++i) p->wstep[i] = reinterpret_cast<bf16_t*>(a + o_wstep[i]);
     p->wpack = a + o_wpack; p->kvtab = a + o_kvtab; p->qself = (float*)(a + o_qself); p->ctab_ln = a + o_ctab;
@@ -325,7 +337,7 @@ extern "C" int parseq_plan_refresh(parseq_plan* p, void* stream) {
 extern "C" void parseq_plan_destroy(parseq_plan* p) {
     if (!p) return;
     DevGuard dg(p->m->device);
-    if (p->arena) (void)hipFree(p->arena);
+    if (p->arena) { if (p->arena_release) p->arena_release(p->arena, p->arena_user); else (void)hipFree(p->arena); }
     delete p;
 }
 

@@ -153,3 +153,39 @@ def test_occupancy_budgets_of_the_training_kernels(built_lib, tmp_path):
     small, big = one('train_attn_dec_bf16_kernel<true, 2>'), one('train_attn_dec_bf16_kernel<true, 8>')
     assert small[0] <= 128 and small[1] == 0 and small[2] == 0, small
     assert big[1] == 0 and big[2] == 0 and big[0] <= 512, big
+
+
+@pytest.mark.gpu
+def test_plan_arena_through_the_callers_allocator(monkeypatch):
+    """parseq_plan_create_ex (ABI 7): the plan's ONE device arena comes from the caller's allocator — here torch's caching allocator through
+    parseq_amd._native.TorchPlanAllocator — is asked for exactly once per plan with exactly parseq_plan_workspace_bytes, the forward on it equals the
+    forward on a hipMalloc'ed arena bit for bit, and every block goes back when the plans are destroyed.  alloc without release is refused."""
+    import ctypes as C
+
+    import torch
+    from gpu_util import DEV, make_model
+    from oracle.synth import CONFIGS, synth_images
+    from parseq_amd import _native
+    x = synth_images(16, CONFIGS['parseq'], seed=5).to(DEV)
+    monkeypatch.delenv('PARSEQ_PLAN_ALLOCATOR', raising=False)
+    with torch.inference_mode():
+        want = make_model('parseq', 'bf16x3')(x, 25).float().clone()
+    monkeypatch.setenv('PARSEQ_PLAN_ALLOCATOR', 'torch')
+    m = make_model('parseq', 'bf16x3')
+    before = torch.cuda.memory_allocated()
+    with torch.inference_mode():
+        got = m(x, 25).float().clone()
+        got2 = m(x, 25, slot=1).float().clone()      # a second plan (workspace slot) through the same allocator object
+    torch.cuda.synchronize()
+    st = m.model._native_state
+    alloc = st.allocator
+    lib = _native.lib()
+    sizes = sorted(lib.parseq_plan_workspace_bytes(plan) for plan, _ in st.plans.values())
+    assert alloc.calls == len(st.plans) == 2 and sorted(t.numel() for t in alloc.blocks.values()) == sizes
+    assert alloc.bytes_out == sum(sizes) and torch.cuda.memory_allocated() - before >= sum(sizes)      # torch's allocator sees the workspace
+    assert torch.equal(got, want) and torch.equal(got2, want)
+    # the pair goes together
+    handle = C.c_void_p(0)
+    assert lib.parseq_plan_create_ex(st.model, 8, _native.PARSEQ_BF16, _native.stream_ptr(x), alloc.alloc_ptr, None, None, C.byref(handle)) != 0 and not handle.value
+    st.release()
+    assert alloc.bytes_out == 0 and not alloc.blocks

@@ -5,6 +5,7 @@ against golden vectors minted by executing the reference's own `strhub/models/pa
 plus the oracle's autograd gradients against the reference's — the gate the backward kernels will be held to.
 GPU: the device evaluation of the K-permutation loss (`parseq_decode_logits` + `parseq_cross_entropy` per permutation)
 against the oracle on the same crops, labels and permutations."""
+import ctypes as C
 import json
 import math
 import os
