@@ -178,6 +178,30 @@ __device__ __forceinline__ void acc_read8(const f32x4& a, const f32x4& b, float 
     for (int r = 0; r < 4; ++r) { x[r] = acc_read(a[r]); x[4 + r] = acc_read(b[r]); }
 }
 
+// The LayerNorm arithmetic of both bf16x3 one-launch encoders, with every fused multiply-add written out (contraction off): which of a * a + b * b's two products the
+// compiler fuses is its own choice and differs between the two kernels' register forms — spelled out, the four-wave and the eight-wave kernel agree bit for bit.
+__device__ __forceinline__ float ln_sum8(const float (&x)[8]) {
+#pragma clang fp contract(off)
+    return ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+}
+__device__ __forceinline__ float ln_sq8(const float (&x)[8], float mean) {
+#pragma clang fp contract(off)
+    float d[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = x[r] - mean;
+    return (__builtin_fmaf(d[0], d[0], d[1] * d[1]) + __builtin_fmaf(d[2], d[2], d[3] * d[3])) + (__builtin_fmaf(d[4], d[4], d[5] * d[5]) + __builtin_fmaf(d[6], d[6], d[7] * d[7]));
+}
+__device__ __forceinline__ float ln_rstd(float s2, int E, float eps) {
+#pragma clang fp contract(off)
+    return 1.0f / sqrtf(__builtin_fmaf(s2, 1.0f / E, eps));
+}
+__device__ __forceinline__ void ln_norm8(const float (&x)[8], float mean, float rstd, const float4& ga, const float4& gb, const float4& ba, const float4& bb, float (&v)[8]) {
+#pragma clang fp contract(off)
+    v[0] = __builtin_fmaf((x[0] - mean) * rstd, ga.x, ba.x); v[1] = __builtin_fmaf((x[1] - mean) * rstd, ga.y, ba.y);
+    v[2] = __builtin_fmaf((x[2] - mean) * rstd, ga.z, ba.z); v[3] = __builtin_fmaf((x[3] - mean) * rstd, ga.w, ba.w);
+    v[4] = __builtin_fmaf((x[4] - mean) * rstd, gb.x, bb.x); v[5] = __builtin_fmaf((x[5] - mean) * rstd, gb.y, bb.y);
+    v[6] = __builtin_fmaf((x[6] - mean) * rstd, gb.z, bb.z); v[7] = __builtin_fmaf((x[7] - mean) * rstd, gb.w, bb.w);
+}
 // LayerNorm of the rows held in the accumulators -> (hi, lo) operand fragments (fp32 arithmetic, two-pass variance).
 // al1_lds != nullptr: the lo fragments of row tile 1 go to the wave's LDS region ([k-block][lane] x 16 bytes) instead of al[1][.]
 template <int E>
@@ -191,7 +215,7 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16][2], co
         for (int ks = 0; ks < KSTEPS; ++ks) {
             float x[8];
             acc_read8(acc[(ks >> 2) * 8 + 2 * (ks & 3)][j], acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j], x);
-            s1 += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            s1 += ln_sum8(x);
         }
         s1 = rows4_sum(s1);
         const float mean = s1 * (1.0f / E);
@@ -200,13 +224,10 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16][2], co
         for (int ks = 0; ks < KSTEPS; ++ks) {
             float x[8];
             acc_read8(acc[(ks >> 2) * 8 + 2 * (ks & 3)][j], acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1][j], x);
-            float d[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) d[r] = x[r] - mean;
-            s2 += ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) + ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7]));
+            s2 += ln_sq8(x, mean);
         }
         s2 = rows4_sum(s2);
-        const float rstd = 1.0f / sqrtf(s2 * (1.0f / E) + eps);
+        const float rstd = ln_rstd(s2, E, eps);
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             float x[8];
@@ -214,10 +235,7 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16][2], co
             const float4 ga = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g), gb = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g + 4);
             const float4 ba = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g), bb = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g + 4);
             float v[8];
-            v[0] = (x[0] - mean) * rstd * ga.x + ba.x; v[1] = (x[1] - mean) * rstd * ga.y + ba.y;
-            v[2] = (x[2] - mean) * rstd * ga.z + ba.z; v[3] = (x[3] - mean) * rstd * ga.w + ba.w;
-            v[4] = (x[4] - mean) * rstd * gb.x + bb.x; v[5] = (x[5] - mean) * rstd * gb.y + bb.y;
-            v[6] = (x[6] - mean) * rstd * gb.z + bb.z; v[7] = (x[7] - mean) * rstd * gb.w + bb.w;
+            ln_norm8(x, mean, rstd, ga, gb, ba, bb, v);
             if (j == 1 && al1_lds != nullptr) {
                 bf16x8 lo;
                 split8(v, ah[j][ks], lo);

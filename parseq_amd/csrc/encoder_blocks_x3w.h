@@ -39,10 +39,7 @@ constexpr int PARK8 = 8;        // accumulator tiles (of 24) that leave the regi
 constexpr int NT = 512;        // threads of the workgroup: eight waves
 // The kernel unit is compiled with -mllvm -amdgpu-mfma-vgpr-form (parseq_amd/build.py): accumulators live in VGPRs, one 256-register file per wave instead of a
 // 128 | 128 VGPR / AGPR partition that neither the LayerNorm'd operand (96 + fragments + temporaries) nor the residual stream (96 + chunk accumulators) fits
-// (in AGPR form the same source spills 183 registers, 35 - 48 in this form, and the kernel is 4 % slower).  acc_read: one accumulator value through an empty asm, so
-// that the three passes of the LayerNorm do not share one copy of every accumulator and the contraction of the arithmetic stays what it is in encoder_blocks_x3.h
-// (bit-identical results).
-__device__ __forceinline__ float acc_read(const float& a) { float v = a; asm volatile("" : "+v"(v)); return v; }
+// (in AGPR form the same source spills 183 registers, 35 - 48 in this form, and the kernel is 4 % slower).
 #define PQ_X3W_ACC_PIN(x) asm volatile("" : "+v"(x))
 #define PQ_X3W_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 // c += W A^T for ONE row tile, (hi, lo) fragments, small terms first — the order of x3::mma3_w per accumulator
@@ -176,14 +173,14 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16], const
     auto read8 = [&](int ks, float (&x)[8]) {
         const f32x4& a = acc[(ks >> 2) * 8 + 2 * (ks & 3)]; const f32x4& b = acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { x[r] = acc_read(a[r]); x[4 + r] = acc_read(b[r]); }
+        for (int r = 0; r < 4; ++r) { x[r] = a[r]; x[4 + r] = b[r]; }
     };
     float s1 = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
         float x[8];
         read8(ks, x);
-        s1 += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        s1 += x3::ln_sum8(x);
     }
     s1 = rows4_sum(s1);
     const float mean = s1 * (1.0f / E);
@@ -192,13 +189,10 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16], const
     for (int ks = 0; ks < KSTEPS; ++ks) {
         float x[8];
         read8(ks, x);
-        float d[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) d[r] = x[r] - mean;
-        s2 += ((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3])) + ((d[4] * d[4] + d[5] * d[5]) + (d[6] * d[6] + d[7] * d[7]));
+        s2 += x3::ln_sq8(x, mean);
     }
     s2 = rows4_sum(s2);
-    const float rstd = 1.0f / sqrtf(s2 * (1.0f / E) + eps);
+    const float rstd = x3::ln_rstd(s2, E, eps);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
         float x[8];
@@ -206,10 +200,7 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16], const
         const float4 ga = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g), gb = *reinterpret_cast<const float4*>(sgam + ks * 32 + 8 * g + 4);
         const float4 ba = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g), bb = *reinterpret_cast<const float4*>(sbet + ks * 32 + 8 * g + 4);
         float v[8];
-        v[0] = (x[0] - mean) * rstd * ga.x + ba.x; v[1] = (x[1] - mean) * rstd * ga.y + ba.y;
-        v[2] = (x[2] - mean) * rstd * ga.z + ba.z; v[3] = (x[3] - mean) * rstd * ga.w + ba.w;
-        v[4] = (x[4] - mean) * rstd * gb.x + bb.x; v[5] = (x[5] - mean) * rstd * gb.y + bb.y;
-        v[6] = (x[6] - mean) * rstd * gb.z + bb.z; v[7] = (x[7] - mean) * rstd * gb.w + bb.w;
+        x3::ln_norm8(x, mean, rstd, ga, gb, ba, bb, v);
         split8(v, ah[ks], al[ks]);
     }
 }

@@ -26,6 +26,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void two(const bf16x8* __restrict__ 
     float f[17];
 #pragma unroll
     for (int i = 0; i < 17; ++i) f[i] = 1.0f + 1e-3f * (float)(t + i);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t pk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pk[i] = f32x2_t{f[i], f[i + 8]};
     const bool second = w >= 4;
     if (PRIO == 1 && !second) __builtin_amdgcn_s_setprio(1);
     if (PRIO == 2 && second) __builtin_amdgcn_s_setprio(1);
@@ -59,7 +63,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void two(const bf16x8* __restrict__ 
                 for (int q = 0; q < PER; ++q) {
                     if constexpr (VK == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(i * PER + q) & 15]) : "v"(f[16]));
                     else if constexpr (VK == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(f[(i * PER + q) & 15]));
-                    else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(i * PER + q) & 3]) : "v"(f[16]));      // four dependent chains
+                    else if constexpr (VK == 2) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[(i * PER + q) & 3]) : "v"(f[16]));      // four dependent chains
+                    else if constexpr (VK == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(pk[(i * PER + q) & 7]) : "v"(pk[7]));      // packed fp32 (two values per lane)
+                    else if constexpr (VK == 4) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(f[(i * PER + q) & 7]) : "v"(f[8 + ((i + q) & 7)]), "v"(f[16]));
+                    else asm volatile("v_rcp_f32 %0, %0" : "+v"(f[(i * PER + q) & 15]));
                 }
             }
         }
@@ -77,6 +84,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void two(const bf16x8* __restrict__ 
     for (int i = 0; i < 8; ++i) s += c[i];
 #pragma unroll
     for (int i = 0; i < 17; ++i) s[0] += f[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[1] += pk[i][0] + pk[i][1];
     out[blockIdx.x * 512 + t] = s;
     if ((t & 63) == 0) cycles[blockIdx.x * 8 + w] = t1 - t0;
 }
@@ -327,6 +336,13 @@ int main() {
     run<8, 72, 216, 2, 0, 0, 2>("8 waves: 72 MFMAs each with 3 v_fma (four dependent chains) behind each", in, out, cyc);
     run<8, 72, 72, 2, 0, 0, 1>("8 waves: 72 MFMAs each with 1 v_exp behind each", in, out, cyc);
     run<8, 72, 216, 0, 0, 0, 0>("8 waves in phase: [72 MFMAs][216 v_fma] each (block form of the 3-per-MFMA case)", in, out, cyc);
+    run<8, 72, 72, 2, 0, 0, 3>("8 waves: 72 MFMAs each with 1 v_pk_fma_f32 behind each", in, out, cyc);
+    run<8, 72, 144, 2, 0, 0, 3>("8 waves: 72 MFMAs each with 2 v_pk_fma_f32 behind each", in, out, cyc);
+    run<8, 72, 216, 2, 0, 0, 3>("8 waves: 72 MFMAs each with 3 v_pk_fma_f32 behind each", in, out, cyc);
+    run<8, 72, 144, 2, 0, 0, 4>("8 waves: 72 MFMAs each with 2 v_cvt_pk_bf16_f32 behind each", in, out, cyc);
+    run<8, 72, 144, 2, 0, 0, 5>("8 waves: 72 MFMAs each with 2 v_rcp_f32 behind each", in, out, cyc);
+    run<8, 72, 144, 2, 0, 0, 1>("8 waves: 72 MFMAs each with 2 v_exp_f32 behind each", in, out, cyc);
+    run<4, 0, 200, 0, 0, 0, 0>("(4 waves: 200 v_fma alone, again)", in, out, cyc);
     run<4, 72, 64, 0, 0, 0, 1>("4 waves: [72 MFMAs][64 v_exp]", in, out, cyc);
     run<8, 72, 64, 0, 0, 0, 1>("8 waves in phase: [72 MFMAs][64 v_exp] each", in, out, cyc);
     run<8, 72, 64, 0, 1, 0, 1>("8 waves anti-phase: [72 MFMAs][64 v_exp]", in, out, cyc);

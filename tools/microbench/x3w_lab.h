@@ -159,8 +159,9 @@ __device__ __forceinline__ void g_prio_toggle(int s) {
 // ---- NS stages under one barrier -------------------------------------------------------------------------------------------------
 // stage_ptr(s): LDS address of stage s; mma(s, i, wh, wl): the three MFMAs that consume the (hi, lo) weight fragments of tile i (16 LDS rows)
 // of stage s; issue(s): the wave's LDS-DMA pieces due at the start of stage s.  Fragment reads run AHEAD positions ahead of the MFMAs.
-template <int NS, int AHEAD, class Ptr, class Mma, class Issue>
-__device__ __forceinline__ void run_stages(Ptr&& stage_ptr, Mma&& mma, Issue&& issue) {
+struct NoFill { template <int N> __device__ __forceinline__ void at() const {} static constexpr int per_pos = 0; };
+template <int NS, int AHEAD, class Ptr, class Mma, class Issue, class Fill = NoFill>
+__device__ __forceinline__ void run_stages(Ptr&& stage_ptr, Mma&& mma, Issue&& issue, Fill&& fill = Fill{}) {
     const int ln = opaque_lane();
     const int fo0 = stage_frag_off(ln), fo1 = fo0 ^ 64;
     constexpr int NB = AHEAD + 1, NPOS = 8 * NS;
@@ -186,14 +187,25 @@ __device__ __forceinline__ void run_stages(Ptr&& stage_ptr, Mma&& mma, Issue&& i
             wl[nn % NB] = *reinterpret_cast<const bf16x8*>(src + fo1);
         }
         if constexpr ((X3W_ABLATE & 128) != 0) asm volatile("" : "+v"(wh[n % NB]), "+v"(wl[n % NB]));
+        fill.template at<n>();          // a slice of VALU work that rides between this position's MFMAs (NoFill: nothing)
         mma(s, i, wh[n % NB], wl[n % NB]);
+        constexpr int FP = std::remove_reference_t<Fill>::per_pos;      // VALU instructions of the slice, spread behind the three MFMAs
         if constexpr (nn < NPOS) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (FP > 0) __builtin_amdgcn_sched_group_barrier(0x002, (FP + 2) / 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (FP > 0) __builtin_amdgcn_sched_group_barrier(0x002, (FP + 1) / 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (FP > 0) __builtin_amdgcn_sched_group_barrier(0x002, FP / 3, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (FP > 0) __builtin_amdgcn_sched_group_barrier(0x002, (FP + 2) / 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (FP > 0) __builtin_amdgcn_sched_group_barrier(0x002, (FP + 1) / 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if constexpr (FP > 0) __builtin_amdgcn_sched_group_barrier(0x002, FP / 3, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -613,6 +625,64 @@ __device__ __forceinline__ void gelu_frag(const f32x4 (&acc1)[4], const float* b
     split8(v, hh, hl);
 #endif
 }
+// X3W_GELU_FILL: the chunk's SECOND GELU block (hidden units 32 .. 63: complete when the second fc1 triple is) evaluated in 24 slices that ride between the MFMAs of the
+// first fc2 triple (which consumes the first block's fragments), one element pair per six positions: the arithmetic of gelu8_split (bit-identical to gelu_erf + split8).
+// With two waves on a SIMD a wave's own MFMAs are ~32 clk apart: up to two VALU instructions behind each cost nothing (tools/microbench/two_wave.hip).
+#ifndef X3W_GELU_FILL
+#define X3W_GELU_FILL 0
+#endif
+struct GeluFill {
+    static constexpr int per_pos = 5;
+    const f32x4 (&acc1)[4];
+    const float* bp;
+    bf16x8& hh; bf16x8& hl;
+    f32x2 v, z, hx, t, e, p;
+    __device__ __forceinline__ GeluFill(const f32x4 (&a)[4], const float* b, bf16x8& h, bf16x8& l) : acc1(a), bp(b), hh(h), hl(l) {}
+    template <int N> __device__ __forceinline__ void at() {
+#pragma clang fp contract(off)
+        constexpr int pr = N / 6, st = N % 6;          // element pair 0..3 of the block: values (2 pr, 2 pr + 1) of the lane's eight
+        if constexpr (N < 24) {
+            // (every slice starts from values pinned by an empty volatile asm: without it instruction selection gathers the whole chain at its first use — sched_barrier only
+            // binds the later machine scheduler)
+            if constexpr (st == 0) {
+                constexpr int tile = 2 + (pr >> 1), q = 2 * (pr & 1);
+                float a0 = acc1[tile][q], a1 = acc1[tile][q + 1];
+                asm volatile("" : "+v"(a0), "+v"(a1));
+                v = f32x2{a0 + bp[32 + 4 * (pr >> 1) + q], a1 + bp[32 + 4 * (pr >> 1) + q + 1]};
+                z = v * 0.70710678118654752440f;
+                hx = v * 0.5f;
+            } else if constexpr (st == 1) {
+                asm volatile("" : "+v"(z));
+                const f32x2 az = __builtin_elementwise_abs(z);
+                t = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, az, f32x2{1.0f, 1.0f});
+                t[0] = __builtin_amdgcn_rcpf(t[0]); t[1] = __builtin_amdgcn_rcpf(t[1]);
+                e = (az * -az) * 1.44269502162933349609f;
+            } else if constexpr (st == 2) {
+                asm volatile("" : "+v"(e), "+v"(t));
+                e[0] = __builtin_amdgcn_exp2f(e[0]); e[1] = __builtin_amdgcn_exp2f(e[1]);
+                p = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+                p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+            } else if constexpr (st == 3) {
+                asm volatile("" : "+v"(p), "+v"(t));
+                p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+                p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+                p = t * p;
+            } else if constexpr (st == 4) {
+                asm volatile("" : "+v"(p), "+v"(e));
+                p = __builtin_elementwise_fma(-e, p, f32x2{1.0f, 1.0f});
+                p[0] = __builtin_copysignf(p[0], z[0]); p[1] = __builtin_copysignf(p[1], z[1]);
+                p = p + 1.0f;
+            } else {
+                asm volatile("" : "+v"(p), "+v"(hx));
+                const f32x2 y = hx * p;
+                hh[2 * pr] = static_cast<bf16_t>(y[0]); hh[2 * pr + 1] = static_cast<bf16_t>(y[1]);
+                const f32x2 hf = {static_cast<float>(hh[2 * pr]), static_cast<float>(hh[2 * pr + 1])};
+                const f32x2 l = __builtin_elementwise_fma(hx, p, -hf);
+                hl[2 * pr] = static_cast<bf16_t>(l[0]); hl[2 * pr + 1] = static_cast<bf16_t>(l[1]);
+            }
+        }
+    }
+};
 // triple k of chunk c (k = 0, 1: fc1 stages 3 k .. 3 k + 2; k = 2, 3: fc2 k-block k - 2, row groups 0 .. 2), stage s, into ring group (4 c + k) % 3
 template <int E>
 __device__ __forceinline__ void mlp_issue(const StreamLane8& sl, unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
@@ -638,6 +708,9 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         const bool last = c + 1 == NCH;
         f32x4 acc1[4];
         bf16x8 hh, hl;
+#if X3W_GELU_FILL
+        bf16x8 hh1, hl1;          // the second block's fragments, produced while the first block's are being consumed
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -651,7 +724,11 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
             if (!last || k < 3) wait_dma<6>(); else wait_dma<0>();
             group_fence();
             X3W_TICK(7);
+#if X3W_GELU_FILL
+            if constexpr (k == 2) gelu_frag(acc1, bp, 0, hh, hl);
+#else
             if constexpr (k >= 2) { if (half_b) gelu_frag(acc1, bp, k - 2, hh, hl); }
+#endif
             X3W_TICK(8);
             auto issue = [&](int s) {      // the triple two ahead
                 if constexpr (k < 2) mlp_issue<E>(sl, ring, wrsrc, w1_off, w2_off, w8, c, k + 2, s);
@@ -666,12 +743,27 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
                 }, issue);
                 X3W_TICK(9);
             } else {
+#if X3W_GELU_FILL
+                if constexpr (k == 2) {
+                    GeluFill gf(acc1, bp, hh1, hl1);
+                    run_stages<3, AHEAD>(sptr, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+                        mma3_w(acc2[s * 8 + i], wh, wl, hh, hl);
+                    }, issue, gf);
+                } else {
+                    run_stages<3, AHEAD>(sptr, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
+                        mma3_w(acc2[s * 8 + i], wh, wl, hh1, hl1);
+                    }, issue);
+                }
+#else
                 run_stages<3, AHEAD>(sptr, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
                     mma3_w(acc2[s * 8 + i], wh, wl, hh, hl);
                 }, issue);
+#endif
                 X3W_TICK(10);
             }
+#if !X3W_GELU_FILL
             if constexpr (k == 1 || k == 2) { if (!half_b) gelu_frag(acc1, bp, k - 1, hh, hl); }      // half A: behind its own MFMAs, under half B's
+#endif
             X3W_TICK(11);
         });
     }

@@ -49,7 +49,19 @@ if TIMERS:
     sys.argv.remove('--timers')
 names = [a for i, a in enumerate(sys.argv[1:]) if a != '--sustained' and a != '--timers8' and (i == 0 or sys.argv[i] != '--sustained')] or sorted(os.path.basename(p)[:-3] for p in glob.glob(os.path.join(ROOT, 'parseq_amd/lib/x3v/*.so')))
 libs = {}
+
+
+class _Product:
+    """`prod_w8` / `prod_w4`: the product library's own kernels through its test hooks (parseq_op_enc_blocks_x3w / _x3: the same argument list as x3_variant_run)."""
+
+    def __init__(self, fn):
+        self.x3_variant_run = fn
+
+
 for n in names:
+    if n in ('prod_w8', 'prod_w4'):
+        libs[n] = _Product(lib.parseq_op_enc_blocks_x3w if n == 'prod_w8' else lib.parseq_op_enc_blocks_x3)
+        continue
     L = C.CDLL(os.path.join(ROOT, 'parseq_amd/lib/x3v', n + '.so'))
     L.x3_variant_run.restype = C.c_int
     L.x3_variant_run.argtypes = [C.c_void_p] * 3 + [C.c_longlong, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)] + [C.c_void_p] * 3
