@@ -538,7 +538,7 @@ def main():
         # `achieved` counts ALGORITHMIC FLOPs (one product per product); the peak is the dense bf16 matrix-core peak for both matrix-core
         # modes — the bf16x3 kernel issues three bf16 MFMAs per algorithmic product, so the share of the peak its MFMAs occupy is 3 x frac
         peak = PEAK['bf16' if precision == 'bf16x3' else precision]
-        roof = {'bound': 'mfma', 'kernel': dom + (' (enc_blocks_x3_kernel)' if tkey == 'enc.blocks_x3' else ''), 'achieved': round(ach, 2), 'peak': peak,
+        roof = {'bound': 'mfma', 'kernel': dom + (' (x3w::enc_blocks_x3w_kernel: eight waves of 16 rows, two per SIMD)' if tkey == 'enc.blocks_x3' else ''), 'achieved': round(ach, 2), 'peak': peak,
                 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'traffic': traffic, 'flops_per_launch': fl, 'avg_launch_us': fam[dom]['avg_us'],
                 'traffic_unit': f'bytes/launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, profiles/pmc_traffic.json["{tkey}"])'}
         if precision == 'bf16x3':

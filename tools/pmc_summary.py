@@ -20,7 +20,7 @@ def per_kernel(path, counter):
     return {r[0]: (r[1], r[2], r[3]) for r in rows}
 
 
-FAMILY = {'enc_blocks_kernel': 'enc.blocks_fused', 'enc_blocks_x3_kernel': 'enc.blocks_x3', 'fused_attn_kernel': 'enc.attn_fused', 'fused_mlp_kernel': 'enc.mlp_fused', 'ln_panel_gemm_kernelILi384ENS_10PanelHeads': 'enc.qkv_gemm', 'attn_mfma_kernel': 'enc.attention',
+FAMILY = {'enc_blocks_kernel': 'enc.blocks_fused', 'enc_blocks_x3w_kernel': 'enc.blocks_x3', 'enc_blocks_x3_kernel': 'enc.blocks_x3', 'fused_attn_kernel': 'enc.attn_fused', 'fused_mlp_kernel': 'enc.mlp_fused', 'ln_panel_gemm_kernelILi384ENS_10PanelHeads': 'enc.qkv_gemm', 'attn_mfma_kernel': 'enc.attention',
           'dec_cross_attn_ar_kernel': 'dec.cross_attention'}
 
 
