@@ -324,3 +324,25 @@ def test_bench_py_force_dist_runs_the_rccl_path_on_one_gpu():
     assert rc2 == 0 and len(lines2) == 1, err2
     assert d['config']['steps_in_flight'] == lines2[0]['config']['steps_in_flight'] >= 2
     assert d['output_sha256_16'] == lines2[0]['output_sha256_16'], (d['output_sha256_16'], lines2[0]['output_sha256_16'])
+
+
+def test_scale_curve_tool_under_the_stub(tmp_path):
+    """tools/scale_curve.py — the one command that turns a multi-GPU box into profiles/scale.json — on CPU under PARSEQ_BENCH_STUB=1 at N = 1, 2: one row per N with the
+    whole-job value, the global batch, the parallelism string and the weak-scaling efficiency against N = 1; the record says it is a stub."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / 'scale.json'
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'scale_curve.py'), '--gpus', '1', '2', '--out', str(out), '--stub', '--', '--steps', '3', '--warmup', '1',
+                        '--repeats', '2'], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.load(open(out))
+    rows = {row['n_gpus']: row for row in rec['rows']}
+    assert set(rows) == {1, 2} and all('value' in row and row['stub'] for row in rows.values()), rec
+    assert rows[1]['global_batch'] == 512 and rows[2]['global_batch'] == 1024 and rows[2]['parallelism'].startswith('dp2')
+    assert rows[1]['weak_scaling_efficiency'] == 1.0 and rows[2]['weak_scaling_efficiency'] > 0
+    assert rows[2]['train_value'] is not None                      # the training leg's multi-rank plumbing ran too

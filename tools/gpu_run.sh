@@ -12,6 +12,7 @@
 #   x3v <builds...>  builds of the bf16x3 encoder against each other (tools/x3_variants.sh -> parseq_amd/lib/x3v/*.so)
 #   train            training tests, tools/train_bench.py, kernel stats of a step; `train pmc` adds the counter passes
 #   configs          bench.py on the other BASELINE / model configurations
+#   scale [N ...]    tools/scale_curve.py: bench.py --gpus N for N in 1 2 4 8 (or the given list) -> profiles/scale.json (needs a multi-GPU box; an N the box cannot serve is recorded as refused)
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -107,5 +108,8 @@ configs)
   run --batch 1024 --refine-iters 2; run --natural-exit; run --precision bf16; run --precision bf16 --batch 1024 --refine-iters 2
   run --precision fp32 --batch 128; run --model parseq-tiny; run --model vitstr --precision bf16; run --model parseq-patch16-224 --batch 64 --precision bf16
   run --batch 256; run --batch 128 ;;
+scale)
+  if [ $# -gt 0 ]; then G="--gpus $*"; else G=""; fi
+  timeout 3000 python tools/scale_curve.py $G --out gpurun_out/scale.json -- --steps 40 --repeats 3 --no-cpu-baseline --no-parity --no-profile --no-natural-exit --no-throughput-mode --no-config3 | tail -1 | cut -c1-1500 ;;
 *) echo "unknown task $task"; exit 2 ;;
 esac
