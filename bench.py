@@ -301,7 +301,7 @@ def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
             roof = {'bound': 'mfma', 'kernel': 'mfma_bgemm16_kernel (encoder forward / dX products)', 'achieved': round(ach, 1), 'peak': PEAK['bf16'], 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK['bf16'], 4), 'avg_launch_us': rec['avg_us'], 'launches_per_step': rec['launches_per_step'],
                     'share_of_step': rec.get('share'), 'mfma_busy_pct': rec.get('mfma_busy_pct'), 'source': rec.get('source')}
-    return {'roofline': roof,
+    return {'roofline_from_committed_trace': roof,      # NOT re-measured by this run: profiles/train_kernels.json (rocprofv3 trace + counter pass of tools/train_bench.py)
             'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], {world} GPU' + ('s, gradient all-reduce over RCCL)' if world > 1 else ')'),
             'value': round(world * batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
             'global_batch': world * batch, 'n_gpus': world,

@@ -325,6 +325,26 @@ def test_encoder_tail_in_launch_vs_separate(golden, monkeypatch):
     assert (a.argmax(-1) == b.argmax(-1)).float().mean() >= 0.99
 
 
+def test_bf16x3_forward_eight_waves_equals_four_waves_bit_for_bit(golden, monkeypatch):
+    """parseq_forward in the exact-tolerance mode launches the encoder on eight waves of 16 rows per workgroup (encoder_blocks_x3w.h, round 5); PARSEQ_X3_FOUR_WAVES=1 puts
+    round 4's four-wave kernel back.  The two accumulate the same products in the same order, so the whole forward — patch head from the raw crops, twelve blocks, 24-bit K / V
+    tail, AR loop, refinement — must agree bit for bit: logits, and for u8 crops as well."""
+    g, _ = golden('parseq')
+    images = g['images'].to(DEV).repeat(9, 1, 1, 1)[:20]
+    w8 = make_model('parseq', 'bf16x3')
+    a = _run(w8, images, 'ar1')
+    u8 = ((images * 0.5 + 0.5) * 255).round().clamp(0, 255).to(torch.uint8)
+    with torch.inference_mode():
+        a8 = w8(u8, 25).float().clone()
+    monkeypatch.setenv('PARSEQ_X3_FOUR_WAVES', '1')
+    w4 = make_model('parseq', 'bf16x3')                      # the switch is read when a plan is created
+    b = _run(w4, images, 'ar1')
+    with torch.inference_mode():
+        b8 = w4(u8, 25).float().clone()
+    assert torch.equal(a, b), report('bf16x3 forward: eight waves vs four waves', a, b)[1]
+    assert torch.equal(a8, b8), report('bf16x3 forward on u8 crops: eight waves vs four waves', a8, b8)[1]
+
+
 def test_kv_rows_24_bit_vs_f32(golden, monkeypatch):
     """bf16x3 mode, PARSeq-S: the one-launch encoder's tail leaves the decoder's K / V rows as 24-bit floats (16 significant bits in a
     u16 + a u8 plane: decoder_attn.h F24; 25 % less of the AR loop's HBM stream) against the same model with f32 rows
