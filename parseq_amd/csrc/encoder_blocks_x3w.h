@@ -35,7 +35,8 @@ using x3::STAGE; using x3::PAIRB; using x3::TRIPB; using x3::KIMG_B; using x3::V
 using x3::HEADS_PARAM_OFF; using x3::MLP_PARAM_OFF; using x3::split8; using x3::StreamLaneX; using x3::EncHeadX3; using x3::EncTailX3;
 
 constexpr int AHEAD8 = 2;       // weight-fragment positions read ahead of the MFMAs (1: 7.22 ms, 2: 6.96 ms; profiles/r05_x3w_encoder.md)
-constexpr int PARK8 = 8;        // accumulator tiles (of 24) that leave the register file for the head loop
+constexpr int PARK8 = 4;        // accumulator tiles (of 24) that leave the register file for the head loop (4 .. 12 within 1 % of each other once proj reads the attention output just in time; fewest bytes)
+constexpr int OSLOTS = 6;       // k-blocks of the attention output that proj keeps in registers at a time (of 12)
 constexpr int NT = 512;        // threads of the workgroup: eight waves
 // The kernel unit is compiled with -mllvm -amdgpu-mfma-vgpr-form (parseq_amd/build.py): accumulators live in VGPRs, one 256-register file per wave instead of a
 // 128 | 128 VGPR / AGPR partition that neither the LayerNorm'd operand (96 + fragments + temporaries) nor the residual stream (96 + chunk accumulators) fits
@@ -172,8 +173,10 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16], const
     constexpr int KSTEPS = E / 32;
     auto read8 = [&](int ks, float (&x)[8]) {
         const f32x4& a = acc[(ks >> 2) * 8 + 2 * (ks & 3)]; const f32x4& b = acc[(ks >> 2) * 8 + 2 * (ks & 3) + 1];
+        // (every value through an empty asm, once per pass: without it the three passes share ONE copy of the 96 accumulator values, the allocator answers with twice the spills,
+        // and the kernel is 1.8 % slower than with the 288 extra moves — profiles/r05_x3w_encoder.md)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { x[r] = a[r]; x[4 + r] = b[r]; }
+        for (int r = 0; r < 4; ++r) { x[r] = a[r]; x[4 + r] = b[r]; asm volatile("" : "+v"(x[r]), "+v"(x[4 + r])); }
     };
     float s1 = 0.f;
 #pragma unroll
@@ -404,20 +407,32 @@ __device__ __forceinline__ void proj_prefetch(const StreamLane8& sl, unsigned ch
         proj_issue<E, RING>(sl, ring, wrsrc, wproj_off, w8, decltype(nc)::value, 1);
     });
 }
+// The attention output is read back from the workgroup's scratch JUST IN TIME: only OSLOTS = 6 of its 12 k-blocks are in registers at a time — k-block kb + 6's (hi, lo)
+// fragments are loaded into k-block kb's registers at the first pair boundary behind kb's last stage (3 kb + 2; first use seven pairs on).  The loads are older than every
+// LDS-DMA piece issued from there on, so the pair boundaries' counted vmcnt waits cover them.  48 registers fewer in the phase that holds all of x again: no scratch reload
+// (with its s_waitcnt vmcnt(0), which drains the weight stream) is left inside the stream (-3 %, profiles/r05_x3w_encoder.md).
 template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, const StreamLane8& sl, int w8,
-                                           const bf16x8 (&oh)[E / 32], const bf16x8 (&ol)[E / 32], f32x4 (&acc2)[E / 16]) {
+                                           bf16x8 (&oh)[E / 32], bf16x8 (&ol)[E / 32], f32x4 (&acc2)[E / 16], const float* oback, int tid) {
     constexpr int NP = 3 * (E / 32) / 2, D = RING - 1;
-    static_assert(E == 384, "written for E = 384");
+    static_assert(E == 384 && OSLOTS == 6, "written for E = 384");
     static_for<0, NP>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
         constexpr int behind = (NP - 1 - n) < (D - 1) ? (NP - 1 - n) : (D - 1);       // pairs issued after this one and still in flight
         wait_dma<4 * behind>();
         group_fence();
+        static_for<0, OSLOTS>([&](auto kc) {
+            constexpr int kb = decltype(kc)::value;
+            if constexpr ((3 * kb + 2) / 2 + 1 == n) {
+                const float* o = oback + ((size_t)(((kb + OSLOTS) * 2) * NT) + tid) * 4;
+                oh[kb] = *reinterpret_cast<const bf16x8*>(o);
+                ol[kb] = *reinterpret_cast<const bf16x8*>(o + NT * 4);
+            }
+        });
         const unsigned char* grp = ring + (n % RING) * PAIRB;
         run_stages<2, AHEAD>([&](int s) { return grp + s * STAGE; }, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
             const int t = 2 * n + s, kb = t / 3, ng = t % 3;
-            mma3_w(acc2[ng * 8 + i], wh, wl, oh[kb], ol[kb]);
+            mma3_w(acc2[ng * 8 + i], wh, wl, oh[kb % OSLOTS], ol[kb % OSLOTS]);
         }, [&](int s) { if constexpr (n + D < NP) proj_issue<E, RING>(sl, ring, wrsrc, wproj_off, w8, n + D, s); });
     });
 }
@@ -656,18 +671,24 @@ void enc_blocks_x3w_kernel(float* __restrict__ x, const unsigned char* __restric
             heads_phase<E, AHEAD8>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, w8, tid, ah, al, obuf);
             // ---- attention branch, proj: x and the O fragments come back (each lane re-reads what it wrote)
             __syncthreads();                                                // every wave is done with the K / V^T images and the ring
-            proj_prefetch<E, RING>(sl, ring, wrsrc, bp->wproj, w8);
-            // (the addresses go through an empty asm: the optimiser must not forward the stored values to these loads)
-            const float* xback = xbuf; const float* oback = obuf;
-            asm volatile("" : "+s"(xback), "+s"(oback) :: "memory");
-            unpark_acc<E>(acc, xback, tid);
+            // whatever the compiler itself moved out of the register file for the head loop comes back HERE, while no LDS-DMA is in flight
 #pragma unroll
-            for (int kb = 0; kb < E / 32; ++kb) {
-                const float* o = oback + ((size_t)((kb * 2) * NT) + tid) * 4;
+            for (int i = PARK8; i < E / 16; ++i) PQ_X3W_ACC_PIN(acc[i]);
+            // (the addresses go through an empty asm: the optimiser must not forward the stored values to these loads; the lane's byte offset too, so that it is a live
+            // register — not a scratch reload — behind the prefetch)
+            const float* xback = xbuf; const float* oback = obuf;
+            unsigned lane_off = (unsigned)tid * 4u;
+            asm volatile("" : "+s"(xback), "+s"(oback), "+v"(lane_off) :: "memory");
+            proj_prefetch<E, RING>(sl, ring, wrsrc, bp->wproj, w8);
+            xback += lane_off; oback += lane_off;
+            unpark_acc<E>(acc, xback, 0);
+#pragma unroll
+            for (int kb = 0; kb < OSLOTS; ++kb) {
+                const float* o = oback + (size_t)((kb * 2) * NT) * 4;
                 ah[kb] = *reinterpret_cast<const bf16x8*>(o);
                 al[kb] = *reinterpret_cast<const bf16x8*>(o + NT * 4);
             }
-            proj_phase<E, RING, AHEAD8>(ring, wrsrc, bp->wproj, sl, w8, ah, al, acc);
+            proj_phase<E, RING, AHEAD8>(ring, wrsrc, bp->wproj, sl, w8, ah, al, acc, oback, 0);
             add_bias_to_acc<E>(sph + 3 * E, g, acc);
         }
         {

@@ -509,10 +509,14 @@ __device__ __forceinline__ void proj_prefetch(const StreamLane8& sl, unsigned ch
         proj_issue<E, RING>(sl, ring, wrsrc, wproj_off, w8, decltype(nc)::value, 1);
     });
 }
+#ifndef X3W_O_JIT
+#define X3W_O_JIT 0            // 1: proj keeps only SIX k-blocks of the attention output in registers: k-block kb + 6's (hi, lo) fragments are loaded from the workgroup's scratch into
+                               // k-block kb's registers at the first pair boundary behind kb's last stage (48 registers fewer in the phase that holds all of x again)
+#endif
 template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, const StreamLane8& sl, int w8,
-                                           const bf16x8 (&oh)[E / 32], const bf16x8 (&ol)[E / 32], f32x4 (&acc2)[E / 16] X3W_TARG) {
-    constexpr int NP = 3 * (E / 32) / 2, D = RING - 1;
+                                           bf16x8 (&oh)[E / 32], bf16x8 (&ol)[E / 32], f32x4 (&acc2)[E / 16], const float* oback, int tid X3W_TARG) {
+    constexpr int NP = 3 * (E / 32) / 2, D = RING - 1, OS = X3W_O_JIT ? 6 : E / 32;
     static_assert(E == 384, "written for E = 384");
     static_for<0, NP>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
@@ -520,10 +524,22 @@ __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_
         wait_dma<4 * behind>();
         group_fence();
         X3W_TICK(5);
+        if constexpr (X3W_O_JIT) {
+            // k-block kb's last stage is 3 kb + 2, in pair (3 kb + 2) / 2: behind it its registers take k-block kb + 6 (first used in stage 3 kb + 18, seven pairs on; the loads are older
+            // than every LDS-DMA piece issued from here on, so the pair boundaries' counted vmcnt waits cover them)
+            static_for<0, 6>([&](auto kc) {
+                constexpr int kb = decltype(kc)::value;
+                if constexpr ((3 * kb + 2) / 2 + 1 == n) {
+                    const float* o = oback + ((size_t)(((kb + 6) * 2) * NT) + tid) * 4;
+                    oh[kb] = *reinterpret_cast<const bf16x8*>(o);
+                    ol[kb] = *reinterpret_cast<const bf16x8*>(o + NT * 4);
+                }
+            });
+        }
         const unsigned char* grp = ring + (n % RING) * PAIRB;
         run_stages<2, AHEAD>([&](int s) { return grp + s * STAGE; }, [&](int s, int i, const bf16x8& wh, const bf16x8& wl) {
             const int t = 2 * n + s, kb = t / 3, ng = t % 3;
-            mma3_w(acc2[ng * 8 + i], wh, wl, oh[kb], ol[kb]);
+            mma3_w(acc2[ng * 8 + i], wh, wl, oh[kb % OS], ol[kb % OS]);
         }, [&](int s) { if constexpr (n + D < NP) proj_issue<E, RING>(sl, ring, wrsrc, wproj_off, w8, n + D, s); });
         X3W_TICK(6);
     });
@@ -1184,19 +1200,25 @@ void enc_blocks_x3w_kernel(float* __restrict__ x, const unsigned char* __restric
             heads_phase<E, X3W_AHEAD>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, w8, tid, ah, al, obuf X3W_TPASS);
             // ---- attention branch, proj: x and the O fragments come back (each lane re-reads what it wrote)
             __syncthreads();                                                // every wave is done with the K / V^T images and the ring
+#if X3W_O_JIT
+            // whatever the compiler itself moved out of the register file for the head loop comes back HERE, while no LDS-DMA is in flight: a scratch reload inside the proj
+            // stream carries an s_waitcnt vmcnt(0) that drains the pieces issued just before it
+#pragma unroll
+            for (int i = X3W_PARK_TILES; i < E / 16; ++i) asm volatile("" : "+v"(acc[i]));
+#endif
             proj_prefetch<E, RING>(sl, ring, wrsrc, bp->wproj, w8);
             // (the addresses go through an empty asm: the optimiser must not forward the stored values to these loads)
             const float* xback = xbuf; const float* oback = obuf;
             asm volatile("" : "+s"(xback), "+s"(oback) :: "memory");
             unpark_acc<E>(acc, xback, tid);
 #pragma unroll
-            for (int kb = 0; kb < E / 32; ++kb) {
+            for (int kb = 0; kb < (X3W_O_JIT ? 6 : E / 32); ++kb) {
                 const float* o = oback + ((size_t)((kb * 2) * NT) + tid) * 4;
                 ah[kb] = *reinterpret_cast<const bf16x8*>(o);
                 al[kb] = *reinterpret_cast<const bf16x8*>(o + NT * 4);
             }
             X3W_TICK(1);
-            proj_phase<E, RING, X3W_AHEAD>(ring, wrsrc, bp->wproj, sl, w8, ah, al, acc X3W_TPASS);
+            proj_phase<E, RING, X3W_AHEAD>(ring, wrsrc, bp->wproj, sl, w8, ah, al, acc, oback, tid X3W_TPASS);
             add_bias_to_acc<E>(sph + 3 * E, g, acc);
             X3W_TICK(12);
         }
