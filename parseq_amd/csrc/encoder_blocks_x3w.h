@@ -208,16 +208,21 @@ __device__ __forceinline__ void ln_acc_to_frag(const f32x4 (&acc)[E / 16], const
     }
 }
 
+// A lane's element of a piece-major scratch buffer: wave-uniform base (SGPR pair) + the lane's 32-bit byte offset (ONE register, 16 tid) — the global_load / _store saddr +
+// voffset form.  As 64-bit per-lane pointers these addresses are register pairs the allocator spills and reloads inside the MFMA streams (each reload with an s_waitcnt vmcnt(0)).
+template <class T> __device__ __forceinline__ T* lane_at(T* uniform_base, unsigned lane_bytes) {
+    return reinterpret_cast<T*>(reinterpret_cast<unsigned char*>(const_cast<std::remove_const_t<T>*>(uniform_base)) + lane_bytes);
+}
 // ---- the residual stream's first PARK8 tiles leave the register file for the head loop (piece-major across the 512 lanes) ----
 template <int E>
-__device__ __forceinline__ void park_acc(const f32x4 (&acc)[E / 16], float* __restrict__ dst, int tid) {
+__device__ __forceinline__ void park_acc(const f32x4 (&acc)[E / 16], float* __restrict__ dst, unsigned lb) {
 #pragma unroll
-    for (int i = 0; i < PARK8; ++i) *reinterpret_cast<f32x4*>(dst + ((size_t)i * NT + tid) * 4) = acc[i];
+    for (int i = 0; i < PARK8; ++i) *reinterpret_cast<f32x4*>(lane_at(dst + (size_t)i * NT * 4, lb)) = acc[i];
 }
 template <int E>
-__device__ __forceinline__ void unpark_acc(f32x4 (&acc)[E / 16], const float* __restrict__ src, int tid) {
+__device__ __forceinline__ void unpark_acc(f32x4 (&acc)[E / 16], const float* __restrict__ src, unsigned lb) {
 #pragma unroll
-    for (int i = 0; i < PARK8; ++i) acc[i] = *reinterpret_cast<const f32x4*>(src + ((size_t)i * NT + tid) * 4);
+    for (int i = 0; i < PARK8; ++i) acc[i] = *reinterpret_cast<const f32x4*>(lane_at(src + (size_t)i * NT * 4, lb));
 }
 
 // ---- head loop (x3::heads_phase for one row tile per wave) -----------------------------------------------------------------------------
@@ -384,9 +389,9 @@ __device__ __forceinline__ void heads_phase(unsigned char* ring, unsigned char* 
                     for (int r = 0; r < 4; ++r) { v[r] = ov[2 * pr][r] * inv; v[4 + r] = ov[2 * pr + 1][r] * inv; }
                     bf16x8 fh, fl;
                     split8(v, fh, fl);
-                    float* o = obuf + ((size_t)(((2 * h + pr) * 2) * NT) + tid) * 4;
-                    *reinterpret_cast<bf16x8*>(o) = fh;
-                    *reinterpret_cast<bf16x8*>(o + NT * 4) = fl;
+                    float* o = obuf + (size_t)(((2 * h + pr) * 2) * NT) * 4;
+                    *reinterpret_cast<bf16x8*>(lane_at(o, (unsigned)tid * 16u)) = fh;
+                    *reinterpret_cast<bf16x8*>(lane_at(o + NT * 4, (unsigned)tid * 16u)) = fl;
                 }
             }
         });
@@ -413,7 +418,7 @@ __device__ __forceinline__ void proj_prefetch(const StreamLane8& sl, unsigned ch
 // (with its s_waitcnt vmcnt(0), which drains the weight stream) is left inside the stream (-3 %, profiles/r05_x3w_encoder.md).
 template <int E, int RING, int AHEAD>
 __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_rsrc_t wrsrc, unsigned wproj_off, const StreamLane8& sl, int w8,
-                                           bf16x8 (&oh)[E / 32], bf16x8 (&ol)[E / 32], f32x4 (&acc2)[E / 16], const float* oback, int tid) {
+                                           bf16x8 (&oh)[E / 32], bf16x8 (&ol)[E / 32], f32x4 (&acc2)[E / 16], const float* oback, unsigned lb) {
     constexpr int NP = 3 * (E / 32) / 2, D = RING - 1;
     static_assert(E == 384 && OSLOTS == 6, "written for E = 384");
     static_for<0, NP>([&](auto nc) {
@@ -424,9 +429,9 @@ __device__ __forceinline__ void proj_phase(unsigned char* ring, __amdgpu_buffer_
         static_for<0, OSLOTS>([&](auto kc) {
             constexpr int kb = decltype(kc)::value;
             if constexpr ((3 * kb + 2) / 2 + 1 == n) {
-                const float* o = oback + ((size_t)(((kb + OSLOTS) * 2) * NT) + tid) * 4;
-                oh[kb] = *reinterpret_cast<const bf16x8*>(o);
-                ol[kb] = *reinterpret_cast<const bf16x8*>(o + NT * 4);
+                const float* o = oback + (size_t)(((kb + OSLOTS) * 2) * NT) * 4;
+                oh[kb] = *reinterpret_cast<const bf16x8*>(lane_at(o, lb));
+                ol[kb] = *reinterpret_cast<const bf16x8*>(lane_at(o + NT * 4, lb));
             }
         });
         const unsigned char* grp = ring + (n % RING) * PAIRB;
@@ -667,7 +672,7 @@ void enc_blocks_x3w_kernel(float* __restrict__ x, const unsigned char* __restric
             params_to_lds(sph + 5 * E, pbase + bp->ln1_b, E, tid);
             __syncthreads();
             ln_acc_to_frag<E>(acc, sph + 4 * E, sph + 5 * E, eps, g, ah, al);
-            park_acc<E>(acc, xbuf, tid);
+            park_acc<E>(acc, xbuf, (unsigned)tid * 16u);
             heads_phase<E, AHEAD8>(ring, img, sph, wrsrc, bp->wqkv, 0.125f, sl, w8, tid, ah, al, obuf);
             // ---- attention branch, proj: x and the O fragments come back (each lane re-reads what it wrote)
             __syncthreads();                                                // every wave is done with the K / V^T images and the ring
@@ -677,18 +682,17 @@ void enc_blocks_x3w_kernel(float* __restrict__ x, const unsigned char* __restric
             // (the addresses go through an empty asm: the optimiser must not forward the stored values to these loads; the lane's byte offset too, so that it is a live
             // register — not a scratch reload — behind the prefetch)
             const float* xback = xbuf; const float* oback = obuf;
-            unsigned lane_off = (unsigned)tid * 4u;
-            asm volatile("" : "+s"(xback), "+s"(oback), "+v"(lane_off) :: "memory");
+            unsigned lb = (unsigned)tid * 16u;
+            asm volatile("" : "+s"(xback), "+s"(oback), "+v"(lb) :: "memory");
             proj_prefetch<E, RING>(sl, ring, wrsrc, bp->wproj, w8);
-            xback += lane_off; oback += lane_off;
-            unpark_acc<E>(acc, xback, 0);
+            unpark_acc<E>(acc, xback, lb);
 #pragma unroll
             for (int kb = 0; kb < OSLOTS; ++kb) {
                 const float* o = oback + (size_t)((kb * 2) * NT) * 4;
-                ah[kb] = *reinterpret_cast<const bf16x8*>(o);
-                al[kb] = *reinterpret_cast<const bf16x8*>(o + NT * 4);
+                ah[kb] = *reinterpret_cast<const bf16x8*>(lane_at(o, lb));
+                al[kb] = *reinterpret_cast<const bf16x8*>(lane_at(o + NT * 4, lb));
             }
-            proj_phase<E, RING, AHEAD8>(ring, wrsrc, bp->wproj, sl, w8, ah, al, acc, oback, 0);
+            proj_phase<E, RING, AHEAD8>(ring, wrsrc, bp->wproj, sl, w8, ah, al, acc, oback, lb);
             add_bias_to_acc<E>(sph + 3 * E, g, acc);
         }
         {
