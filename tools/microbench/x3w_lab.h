@@ -159,6 +159,10 @@ __device__ __forceinline__ void g_prio_toggle(int s) {
 // ---- NS stages under one barrier -------------------------------------------------------------------------------------------------
 // stage_ptr(s): LDS address of stage s; mma(s, i, wh, wl): the three MFMAs that consume the (hi, lo) weight fragments of tile i (16 LDS rows)
 // of stage s; issue(s): the wave's LDS-DMA pieces due at the start of stage s.  Fragment reads run AHEAD positions ahead of the MFMAs.
+#ifndef X3W_FO_LIVE
+#define X3W_FO_LIVE 0          // 1: the per-lane LDS fragment offsets of run_stages come from threadIdx (loop-invariant to the compiler: two live registers) instead of being
+                               // recomputed at every call through opaque_lane() (~10 VALU instructions x ~170 calls per block)
+#endif
 struct NoFill { template <int N> __device__ __forceinline__ void at() const {} static constexpr int per_pos = 0; };
 template <int NS, int AHEAD, class Ptr, class Mma, class Issue, class Fill = NoFill>
 __device__ __forceinline__ void run_stages(Ptr&& stage_ptr, Mma&& mma, Issue&& issue, Fill&& fill = Fill{}) {
