@@ -166,6 +166,73 @@ __device__ __forceinline__ int opaque_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
     return l;
 }
+// ---- record mode (the training forward, lib_train.hip parseq_train_encoder_forward) ------------------------------------------------
+// The same walk over the blocks, which additionally WRITES what the hand-derived backward reads: per block the input rows x (f32), the
+// two LayerNorm outputs n1 / n2 (bf16), q | k | v with their biases (f32, [rows][3E]), the attention output (bf16), x after the
+// attention branch (f32), the fc1 pre-activation and its GELU (bf16, [rows][4E]) — the slots of TrainEncoderLayout, rows in token
+// order.  Every store goes through ONE buffer descriptor per block (a block's record spans < 4 GB): a 32-bit per-lane offset, the
+// uniform part in a scalar register — no 64-bit per-lane pointers in a kernel that has no registers to spare.  The stores count in
+// vmcnt beside the LDS-DMA pieces; the phases' waits stay correct as they are (vmcnt <= N leaves at most N LOADS outstanding, loads
+// complete in order, so everything older than the newest N loads has landed) and merely also wait for older stores.
+struct EncRecordParams {
+    float* base;                 // block 0's record; block l's starts layer_stride floats further
+    size_t layer_stride;
+    unsigned layer_bytes;        // bytes a block's record spans (the descriptor's range)
+    unsigned qkv, ao, x_mid, hpre, hact, n1, n2;       // BYTE offsets of the slots inside a block's record; x is at 0
+};
+struct RecCtx {                  // one block's record as the phases see it
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned row0;               // first row of the workgroup's image
+    unsigned qkv, ao, hpre, hact;
+};
+// A gfx950 hazard the compiler does not know (tools/microbench/store_hazard.hip, profiles/r05_store_hazard.md): a VALU write of the data
+// registers of a buffer_store_dwordx4 WITH AN SGPR soffset, issued in the very next slot, reaches memory — dword 1 of lanes 12-15 of
+// every row of 16 lanes carries the new value.  LLVM's createsVALUHazard covers only the form whose soffset is not a register (which
+// needs two wait states, and gets them).  So the 16-byte record stores use THAT form: soffset 0, the uniform part added into the
+// per-lane offset (one v_add_u32 per store).  (An asm statement "store; s_nop" is no way out: the hazard recogniser does not look
+// into asm either, and a v_readlane feeding the asm's soffset in the slot before it is the next unhandled hazard.)
+__device__ __forceinline__ void rec_store16(const RecCtx& rc, unsigned voff, unsigned soff, const u32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rc.rsrc, voff + soff, 0, 0);
+}
+__device__ __forceinline__ void rec_store16(const RecCtx& rc, unsigned voff, unsigned soff, const bf16x8& v) {
+    rec_store16(rc, voff, soff, __builtin_bit_cast(u32x4, v));
+}
+__device__ __forceinline__ void rec_store16(const RecCtx& rc, unsigned voff, unsigned soff, float a, float b, float c, float d) {
+    rec_store16(rc, voff, soff, u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)});
+}
+// bf16 operand fragments (lane (r16, g), row tile j, k-step ks: columns 32 ks + 8 g + [0, 8) of row 32 wid + 16 j + r16) -> [rows][E] bf16 at `slot`
+template <int E>
+__device__ __forceinline__ void rec_store_frag(const RecCtx& rc, unsigned slot, int wid, const bf16x8 (&afrag)[2][E / 32]) {
+    const int ln = opaque_lane();
+    const unsigned voff = (unsigned)((ln & 15) * E + 8 * (ln >> 4)) * 2u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int ks = 0; ks < E / 32; ++ks)
+            rec_store16(rc, voff, slot + ((rc.row0 + 32u * wid + 16u * j) * E + 32u * ks) * 2u, afrag[j][ks]);
+}
+// the fp32 rows in the accumulators -> [rows][E] f32 at `slot` (store_acc_to_x's pieces through the descriptor)
+template <int E>
+__device__ __forceinline__ void rec_store_acc(const RecCtx& rc, unsigned slot, int wid, const f32x4 (&acc)[E / 16][2]) {
+    const int ln = opaque_lane();
+    const int rr = ln & 15, g = ln >> 4;
+    const bool lo_half = rr < 8;
+    const unsigned voff = (unsigned)((rr & 7) * E + 8 * g + (lo_half ? 0 : 4)) * 4u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q32 = 0; q32 < E / 32; ++q32) {
+            const f32x4 ta = acc[(q32 >> 2) * 8 + 2 * (q32 & 3)][j], tb = acc[(q32 >> 2) * 8 + 2 * (q32 & 3) + 1][j];
+            const u32x4 pa = {__float_as_uint(ta[0]), __float_as_uint(ta[1]), __float_as_uint(ta[2]), __float_as_uint(ta[3])};
+            const u32x4 pb = {__float_as_uint(tb[0]), __float_as_uint(tb[1]), __float_as_uint(tb[2]), __float_as_uint(tb[3])};
+            const u32x4 got = swap_half_rows(lo_half ? pb : pa);
+            const u32x4 first = lo_half ? pa : got, second = lo_half ? got : pb;
+            const unsigned soff = slot + ((rc.row0 + 32u * wid + 16u * j) * E + 32u * q32) * 4u;
+            rec_store16(rc, voff, soff, first);
+            rec_store16(rc, voff, soff + 8u * E * 4u, second);
+        }
+}
+
 // byte offset of lane (r16, g)'s first-k-step fragment inside a ring stage; the second k-step's is this ^ 64
 __device__ __forceinline__ int stage_frag_off(int ln) { const int r16 = ln & 15, g_ = ln >> 4; return r16 * 128 + ((g_ ^ (r16 & 7)) << 4); }
 
@@ -297,11 +364,11 @@ __device__ __forceinline__ void attn_prefetch(const StreamLane& sl, unsigned cha
     static_for<0, 3>([&](auto tc) { attn_issue_stage<E>(sl, ring, wrsrc, wqkv_off, 0u, wid, 0, decltype(tc)::value); });
 }
 
-template <int E>
+template <int E, bool REC = false>
 __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* kimg, unsigned char* vimg, const float* sbq,
                                            __amdgpu_buffer_rsrc_t wrsrc, unsigned wqkv_off, unsigned wproj_off, float scale,
                                            const StreamLane& sl, int wid, int rr, int g, const bf16x8 (&afrag)[2][E / 32],
-                                           f32x4 (&acc2)[E / 16][2]) {
+                                           f32x4 (&acc2)[E / 16][2], const RecCtx& rc = RecCtx{}) {
     constexpr int H = E / 64, KS1 = E / 128, NG = E / 128;
     static_assert(E == 384 && KS1 == 3 && NG == 3, "written for E = 384: every chunk is one triple");
     const float sc2 = scale * 1.44269504088896340736f;
@@ -348,6 +415,14 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                         }
                         if constexpr (u == 0) qfrag[j][pr] = f;
                         else *reinterpret_cast<bf16x8*>(kimg + (krow_j0 + 8 * j) * AF_KROWB + 64 * pr + 16 * g) = f;
+                        if constexpr (REC) {       // q | k with their biases, f32: columns u E + 64 h + 32 pr + 8 g + [0, 8) of row 32 wid + 16 j + r16
+                            const unsigned voff = (unsigned)(rr * 3 * E + 8 * g) * 4u;
+                            const unsigned soff = rc.qkv + ((rc.row0 + 32u * wid + 16u * j) * (3u * E) + u * E + h * 64u + 32u * pr) * 4u;
+                            rec_store16(rc, voff, soff, acc1[2 * pr][j][0] + bp0[32 * pr], acc1[2 * pr][j][1] + bp0[32 * pr + 1],
+                                        acc1[2 * pr][j][2] + bp0[32 * pr + 2], acc1[2 * pr][j][3] + bp0[32 * pr + 3]);
+                            rec_store16(rc, voff, soff + 16u, acc1[2 * pr + 1][j][0] + bp0[32 * pr + 4], acc1[2 * pr + 1][j][1] + bp0[32 * pr + 5],
+                                        acc1[2 * pr + 1][j][2] + bp0[32 * pr + 6], acc1[2 * pr + 1][j][3] + bp0[32 * pr + 7]);
+                        }
                     }
             } else if constexpr (u == 2) {
                 run_triple(grp, [&](int k, int half, int i, const bf16x8& w) {
@@ -363,6 +438,13 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                     for (int j = 0; j < 2; ++j) {
                         const float o4[4] = {acc1[i][j][0] + bv, acc1[i][j][1] + bv, acc1[i][j][2] + bv, acc1[i][j][3] + bv};
                         store4<bf16_t>(reinterpret_cast<bf16_t*>(vimg + (16 * i + rr) * AF_VROWB) + 32 * wid + 16 * j + 4 * g, o4);
+                        if constexpr (REC) {       // v with its bias, f32: this lane's unit of tokens 32 wid + 16 j + 4 g + [0, 4) (the operand roles are swapped)
+                            const unsigned voff = (unsigned)(4 * g * 3 * E + (rr >> 2) * 8 + (rr & 3)) * 4u;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o4[r]), rc.rsrc, voff,
+                                    rc.qkv + ((rc.row0 + 32u * wid + 16u * j + r) * (3u * E) + 2u * E + h * 64u + ((i >> 1) & 1) * 32u + (i & 1) * 4u) * 4u, 0);
+                        }
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -430,6 +512,8 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                             f[4 + r] = static_cast<bf16_t>(ov[2 * pr + 1][j][r] * inv[j]);
                         }
                         ofrag[j][pr] = f;
+                        if constexpr (REC)
+                            rec_store16(rc, (unsigned)(rr * E + 8 * g) * 2u, rc.ao + ((rc.row0 + 32u * wid + 16u * j) * E + h * 64u + 32u * pr) * 2u, f);
                     }
                 }
             } else {
@@ -459,10 +543,10 @@ __device__ __forceinline__ void mlp_prefetch(const StreamLane& sl, unsigned char
     static_for<0, 6>([&](auto tc) { constexpr int t = decltype(tc)::value; mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, 0, t, t / 3); });
 }
 
-template <int E>
+template <int E, bool REC = false>
 __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1, __amdgpu_buffer_rsrc_t wrsrc, unsigned w1_off, unsigned w2_off,
                                           const StreamLane& sl, int wid, int rr, int g, const bf16x8 (&afrag)[2][E / 32],
-                                          f32x4 (&acc2)[E / 16][2]) {
+                                          f32x4 (&acc2)[E / 16][2], const RecCtx& rc = RecCtx{}) {
     constexpr int F = 4 * E, KS1 = E / 128, KS2 = E / 128, NCH = F / MLP_HC;
     static_assert(KS1 == 3 && KS2 == 3, "every GEMM slice of a hidden chunk is one triple");
     int gcur = 0;                                                // group of the triple about to run
@@ -484,7 +568,8 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
             if (more) mlp_issue_stage<E>(sl, ring, wrsrc, w1_off, w2_off, wid, c + 1, k, gcur == 0 ? 2 : gcur - 1, q);
         });
         {
-            const int g = opaque_lane() >> 4;                    // (shadows the argument: see opaque_lane)
+            const int ln_ = opaque_lane();
+            const int g = ln_ >> 4;                              // (shadows the argument: see opaque_lane)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 f32x2 xv[8], yv[8];
@@ -504,6 +589,15 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { f[2 * e] = static_cast<bf16_t>(yv[4 * pr + e][0]); f[2 * e + 1] = static_cast<bf16_t>(yv[4 * pr + e][1]); }
                     hfrag[j][pr] = f;
+                    if constexpr (REC) {           // the pre-activation and its GELU, bf16: hidden units 64 c + 32 pr + 8 g + [0, 8) of row 32 wid + 16 j + r16
+                        bf16x8 pre;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pre[2 * e] = static_cast<bf16_t>(xv[4 * pr + e][0]); pre[2 * e + 1] = static_cast<bf16_t>(xv[4 * pr + e][1]); }
+                        const unsigned voff = (unsigned)((ln_ & 15) * F + 8 * g) * 2u;
+                        const unsigned soff = ((rc.row0 + 32u * wid + 16u * j) * F + c * MLP_HC + 32u * pr) * 2u;
+                        rec_store16(rc, voff, rc.hpre + soff, pre);
+                        rec_store16(rc, voff, rc.hact + soff, f);
+                    }
                 }
             }
         }
@@ -659,10 +753,13 @@ __device__ __forceinline__ void params_to_lds(float* dst, const float* __restric
     for (int i = tid; i < n; i += 256) dst[i] = src[i];
 }
 
-template <int E>
+// REC (record mode, see EncRecordParams): x is read from block 0's record slot (where the patch embedding left it), every block's
+// tensors are written on the way, the final rows go to `x`; no head, no tail; M must be a multiple of 128.
+template <int E, bool REC = false>
 __global__ __launch_bounds__(256, 1)
 void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, unsigned wbytes, const float* __restrict__ pbase,
-                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, const EncTailParams tail, const EncHeadParams head) {
+                       const EncBlockParams* __restrict__ blocks, int depth, float eps, int M, const EncTailParams tail, const EncHeadParams head,
+                       const EncRecordParams rec) {
     constexpr int F = 4 * E;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ring = smem;                                  // groups 0-1 (attention) / 0-2 (MLP)
@@ -680,11 +777,18 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
 
     f32x4 acc[E / 16][2];
     bf16x8 afrag[2][E / 32];
-    if (head.images) patch_head<E>(head, ring, wrsrc, wid, lane, blockIdx.x, acc);
+    if constexpr (REC) load_x_to_acc<E>(rec.base, m0, M, wid, rr, g, acc);
+    else if (head.images) patch_head<E>(head, ring, wrsrc, wid, lane, blockIdx.x, acc);
     else load_x_to_acc<E>(x, m0, M, wid, rr, g, acc);
 
     for (int l = 0; l < depth; ++l) {
         const EncBlockParams* bp = blocks + l;
+        RecCtx rc{};
+        if constexpr (REC) {
+            rc.rsrc = __builtin_amdgcn_make_buffer_rsrc(rec.base + (size_t)l * rec.layer_stride, 0, rec.layer_bytes, 0x00020000);
+            rc.row0 = (unsigned)m0; rc.qkv = rec.qkv; rc.ao = rec.ao; rc.hpre = rec.hpre; rc.hact = rec.hact;
+            if (l > 0) rec_store_acc<E>(rc, 0u, wid, acc);         // this block's input rows (block 0's are where they were read from)
+        }
         // ---- attention branch: parameters bqkv (3E) | bproj (E) | ln1 gamma (E) | ln1 beta (E)
         __syncthreads();                                         // everyone is done with the previous phase's parameters and ring
         attn_prefetch<E>(sl, ring, wrsrc, bp->wqkv, wid);            // head 0's q triple lands behind the parameter copies and LayerNorm
@@ -694,8 +798,10 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
         params_to_lds(sp + 5 * E, pbase + bp->ln1_b, E, tid);
         __syncthreads();
         ln_acc_to_frag<E>(acc, sp + 4 * E, sp + 5 * E, eps, g, afrag);
-        attn_phase<E>(ring, kimg, vimg, sp, wrsrc, bp->wqkv, bp->wproj, 0.125f, sl, wid, rr, g, afrag, acc);
+        if constexpr (REC) rec_store_frag<E>(rc, rec.n1, wid, afrag);
+        attn_phase<E, REC>(ring, kimg, vimg, sp, wrsrc, bp->wqkv, bp->wproj, 0.125f, sl, wid, rr, g, afrag, acc, rc);
         add_bias_to_acc<E>(sp + 3 * E, g, acc);
+        if constexpr (REC) rec_store_acc<E>(rc, rec.x_mid, wid, acc);
         // ---- MLP branch: parameters b1 (4E) | b2 (E) | ln2 gamma (E) | ln2 beta (E)
         __syncthreads();
         mlp_prefetch<E>(sl, ring, wrsrc, bp->w1, bp->w2, wid);       // chunk 0's two triples
@@ -705,10 +811,11 @@ void enc_blocks_kernel(float* __restrict__ x, const bf16_t* __restrict__ wbase, 
         params_to_lds(sp + F + 2 * E, pbase + bp->ln2_b, E, tid);
         __syncthreads();
         ln_acc_to_frag<E>(acc, sp + F + E, sp + F + 2 * E, eps, g, afrag);
-        mlp_phase<E>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, rr, g, afrag, acc);
+        if constexpr (REC) rec_store_frag<E>(rc, rec.n2, wid, afrag);
+        mlp_phase<E, REC>(ring, sp, wrsrc, bp->w1, bp->w2, sl, wid, rr, g, afrag, acc, rc);
         add_bias_to_acc<E>(sp + F, g, acc);
     }
-    if (tail.kmem == nullptr) {
+    if (REC || tail.kmem == nullptr) {
         store_acc_to_x<E>(x, m0, M, wid, rr, g, acc);
         return;
     }
@@ -832,7 +939,20 @@ hipError_t launch_enc_blocks(hipStream_t s, float* x, const bf16_t* wbase, size_
     auto kern = enc_blocks_kernel<E>;
     static LdsAttr attr;
     if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M, tail, head);
+    hipLaunchKernelGGL(kern, dim3((M + 127) / 128), dim3(256), lds, s, x, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M, tail, head, EncRecordParams{});
+    return hipGetLastError();
+}
+// The record-mode walk (training forward): rows rec.base[0 .. M) in, rows x_last out, every block's record written.
+template <int E>
+hipError_t launch_enc_blocks_record(hipStream_t s, float* x_last, const bf16_t* wbase, size_t wbytes, const float* pbase, const EncBlockParams* blocks,
+                                    int depth, float eps, int M, const EncRecordParams& rec) {
+    constexpr size_t lds = enc_blocks_lds<E>();
+    if (wbytes >= ((size_t)1 << 32) || M % 128 || !rec.base) return hipErrorInvalidValue;
+    auto kern = enc_blocks_kernel<E, true>;
+    static LdsAttr attr;
+    if (hipError_t e = attr.ensure(reinterpret_cast<const void*>(kern), lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(M / 128), dim3(256), lds, s, x_last, wbase, (unsigned)wbytes, pbase, blocks, depth, eps, M,
+                       EncTailParams{0, 0, 0, 0, nullptr, nullptr, 0}, EncHeadParams{nullptr, 0, 0, nullptr}, rec);
     return hipGetLastError();
 }
 
@@ -849,6 +969,8 @@ PQ_ENC_BLOCKS_EXTERN template hipError_t launch_mlp_branch<384>(hipStream_t, flo
                                                                   const float*, int);
 PQ_ENC_BLOCKS_EXTERN template hipError_t launch_enc_blocks<384>(hipStream_t, float*, const bf16_t*, size_t, const float*, const EncBlockParams*, int, float, int,
                                                                   const EncTailParams&, const EncHeadParams&);
+PQ_ENC_BLOCKS_EXTERN template hipError_t launch_enc_blocks_record<384>(hipStream_t, float*, const bf16_t*, size_t, const float*, const EncBlockParams*, int, float, int,
+                                                                         const EncRecordParams&);
 #undef PQ_ENC_BLOCKS_EXTERN
 
 }  // namespace pq

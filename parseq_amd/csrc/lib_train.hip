@@ -599,6 +599,7 @@ struct TrainEncoderLayout {          // offsets in floats
     size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, scratch_floats, total;
     size_t w16, w16_layer, d_x16, d_h16;      // bf16 shadows (train_enc_shadows): the Linear weights and their transposes ([layer][qkv, proj, fc1, fc2][W16 | Wt16]),
                                               // the residual-stream gradient and the fc1-output gradient
+    size_t blocks_tab;                        // the one-launch forward's EncBlockParams table (encoder_blocks.h), depth entries
     size_t x(int i) const { return layer0 + i * layer_stride; }
     size_t qkv, ao, x_mid, hpre, hact_l, n1, n2;     // offsets inside one layer's record (x at 0); hact_l, n1, n2: the GELU output and the two
                                              // LayerNorm outputs, kept for the backward (round 3: they used to be recomputed there — a 600 MB and two
@@ -622,6 +623,7 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     o.scratch_floats = train_scratch_floats(MS, E); o.scratch = take(o.scratch_floats);
     o.w16_layer = 4 * E * E + 2 * E * F;      // floats = 2 bf16 each: W16 and Wt16 of the block's four Linear weights
     o.w16 = take(o.w16_layer * (size_t)m->cfg.enc_depth); o.d_x16 = take(MS * E / 2 + 8); o.d_h16 = take(MS * F / 2 + 8);
+    o.blocks_tab = take((size_t)m->cfg.enc_depth * sizeof(EncBlockParams) / sizeof(float));
     o.total = off;
     return o;
 }
@@ -665,6 +667,13 @@ static bool train_enc_shadows(const parseq_model* m) {
 static bool train_enc_bf16_only(const parseq_model* m) {
     const char* lv = getenv("PARSEQ_TRAIN_SHADOW_LEVEL");
     return train_enc_shadows(m) && !(lv && lv[0] == '1');
+}
+// The forward as one launch: the bf16-only record (level 2) at the geometry encoder_blocks.h is written for (E = 384, six 64-wide heads,
+// 128 tokens, hidden = 4 E) with a block's record inside one 32-bit buffer descriptor.  PARSEQ_TRAIN_ENC_PER_OP=1: the per-operation
+// launches (the A/B; also what every other geometry and record mode runs).
+static bool train_enc_one_launch(const parseq_model* m, const TrainEncoderLayout& o) {
+    return train_enc_bf16_only(m) && m->cfg.embed_dim == 384 && m->cfg.enc_mlp_ratio == 4 && m->tokens == 128 &&
+           o.layer_stride * sizeof(float) < ((size_t)1 << 32) && !getenv("PARSEQ_TRAIN_ENC_PER_OP");
 }
 struct EncShadowW { bf16_t* w; bf16_t* wt; };
 // which: 0 attn.qkv [3E, E], 1 attn.proj [E, E], 2 mlp.fc1 [F, E], 3 mlp.fc2 [E, F]
@@ -712,6 +721,29 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
                 hipLaunchKernelGGL(weight_shadow_kernel, dim3(wk[j] / 32, wn[j] / 32), dim3(256), 0, s, P("blocks." + std::to_string(i) + "." + names[j]), wn[j], wk[j], sw.w, sw.wt);
             }
         HIPCHK(hipGetLastError());
+    }
+    if (train_enc_one_launch(m, o)) {
+        // The twelve blocks as ONE launch (encoder_blocks.h record mode): the inference throughput kernel's walk — x resident in the
+        // accumulators, the weights streamed from this step's bf16 shadows — writing the record on the way; 48 GEMM, 24 LayerNorm and
+        // 12 attention launches and every re-read of an activation disappear, what is left is the record's own bytes.
+        const int depth = m->cfg.enc_depth;
+        m->train_blocks_host.resize(depth);
+        auto off = [&](const std::string& key) { return (unsigned)m->params[m->index.at(m->enc + key)].offset; };
+        for (int i = 0; i < depth; ++i) {
+            const std::string b = "blocks." + std::to_string(i) + ".";
+            const unsigned w0 = (unsigned)(2 * o.w16_layer * (size_t)i), EE = (unsigned)(E * E), EF = (unsigned)(E * F);      // bf16 elements from the shadows' base
+            EncBlockParams& e = m->train_blocks_host[i];
+            e.ln1_w = off(b + "norm1.weight"); e.ln1_b = off(b + "norm1.bias"); e.bqkv = off(b + "attn.qkv.bias"); e.bproj = off(b + "attn.proj.bias");
+            e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias"); e.b1 = off(b + "mlp.fc1.bias"); e.b2 = off(b + "mlp.fc2.bias");
+            e.wqkv = w0; e.wproj = w0 + 6 * EE; e.w1 = w0 + 8 * EE; e.w2 = w0 + 8 * EE + 2 * EF;       // enc_shadow_w's W16 of each pair
+        }
+        EncBlockParams* tab = reinterpret_cast<EncBlockParams*>(w + o.blocks_tab);
+        HIPCHK(hipMemcpyAsync(tab, m->train_blocks_host.data(), depth * sizeof(EncBlockParams), hipMemcpyHostToDevice, s));
+        const EncRecordParams rec{w + o.layer0, o.layer_stride, (unsigned)(o.layer_stride * sizeof(float)), (unsigned)(o.qkv * 4), (unsigned)(o.ao * 4),
+                                  (unsigned)(o.x_mid * 4), (unsigned)(o.hpre * 4), (unsigned)(o.hact_l * 4), (unsigned)(o.n1 * 4), (unsigned)(o.n2 * 4)};
+        HIPCHK((launch_enc_blocks_record<384>(s, w + o.x_last, reinterpret_cast<const bf16_t*>(w + o.w16), o.w16_layer * (size_t)depth * sizeof(float),
+                                              m->master, tab, depth, eps, MS, rec)));
+        return run_layernorm<float>(s, w + o.x_last, P("norm.weight"), P("norm.bias"), memory_out, nullptr, MS, E, eps);
     }
     for (int i = 0; i < m->cfg.enc_depth; ++i) {
         const std::string p = "blocks." + std::to_string(i) + ".";

@@ -870,6 +870,57 @@ def test_bf16_shadow_operands_change_no_bit():
 
 
 @pytest.mark.gpu
+def test_one_launch_training_forward_against_the_per_operation_forward():
+    """Round 5: in the bf16-operand mode the encoder's training forward is ONE launch (encoder_blocks.h record mode: the inference
+    throughput kernel's walk over the twelve blocks with the residual rows resident, writing the record the hand-derived backward reads —
+    x, LayerNorm outputs, q | k | v, attention output, fc1 pre-activation and its GELU) instead of 48 GEMM + 24 LayerNorm + 12 attention
+    launches.  Same operands rounded to bfloat16, fp32 accumulation; the rounding POINTS differ a little (probabilities rounded before
+    the normalisation, the polynomial GELU of common.h), so the step is compared with the per-operation forward
+    (PARSEQ_TRAIN_ENC_PER_OP=1) at the bf16 noise level — loss 2e-3 relative, every gradient within 5e-2 in L2 and cosine 0.999 — and
+    must not be that path (some gradient differs).  The gate against the exact fp32 backward is
+    test_bf16_operand_step_within_the_rounding_budget, which runs through the one-launch forward."""
+    import os
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import loss_and_grads
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    gen = torch.Generator().manual_seed(15)
+    images = synth_images(40, cfg, seed=23).to(DEV)
+    lengths = torch.randint(1, 26, (40,), generator=gen).tolist()
+    lengths[3] = 25
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+
+    def run():
+        m.rng = np.random.default_rng(8)
+        torch.manual_seed(9)
+        r = loss_and_grads(m, images, labels)
+        torch.cuda.synchronize()
+        return float(r.loss), {k: v.clone() for k, v in r.grads.items()}
+
+    assert 'PARSEQ_TRAIN_ENC_PER_OP' not in os.environ
+    loss_a, grads_a = run()
+    os.environ['PARSEQ_TRAIN_ENC_PER_OP'] = '1'
+    try:
+        loss_b, grads_b = run()
+    finally:
+        del os.environ['PARSEQ_TRAIN_ENC_PER_OP']
+    assert abs(loss_a - loss_b) <= 2e-3 * abs(loss_b), (loss_a, loss_b)
+    rel, cos = [], []
+    for k, b in grads_b.items():
+        a, b = grads_a[k].double().flatten(), b.double().flatten()
+        if float(b.norm()) < 1e-7:
+            continue
+        rel.append((float((a - b).norm() / b.norm()), k))
+        cos.append(float(a @ b / (a.norm() * b.norm())))
+    rel.sort()
+    print(f'one-launch vs per-operation forward: loss {loss_a:.6f} / {loss_b:.6f}, per-tensor L2 difference median {rel[len(rel) // 2][0]:.2e}, '
+          f'worst {rel[-1][0]:.2e} ({rel[-1][1]}), min cosine {min(cos):.5f}')
+    assert rel[-1][0] < 5e-2 and min(cos) > 0.999
+    assert any(not torch.equal(grads_a[k], grads_b[k]) for k in grads_a)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_permutation_passes_as_one_batch_equal_one_after_the_other(train_golden, precision, monkeypatch):
     """Round 3: the decoder runs the K permutation passes of a step as ONE batch of K * B images (parseq_train_decoder,
