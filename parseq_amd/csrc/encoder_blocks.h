@@ -378,7 +378,13 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
         bf16x8 qfrag[2][2], ofrag[2][2];
         static_for<0, 4>([&](auto uc) {
             constexpr int u = decltype(uc)::value;               // 0 q, 1 k, 2 v (operand roles swapped: V^T), 3 proj
-            eb_wait_vmcnt<0>();                                  // this triple (issued during the previous one) has landed
+            // this triple (issued during the previous one) has landed.  Record mode: the stores issued BEHIND its pieces — the previous
+            // triple's epilogue (q: 8, k: 8, v and the attention output: 32 + 4), before head 0 the 24 of LayerNorm1's output — may stay in
+            // flight (vmcnt retires loads and stores in issue order on gfx9); waiting for them too would expose a write's latency per triple
+            if constexpr (!REC) eb_wait_vmcnt<0>();
+            else if constexpr (u == 0) { if (h == 0) eb_wait_vmcnt<2 * (E / 32)>(); else eb_wait_vmcnt<0>(); }
+            else if constexpr (u == 3) eb_wait_vmcnt<36>();
+            else eb_wait_vmcnt<8>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -556,8 +562,9 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         bf16x8 hfrag[2][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave)
-        eb_wait_vmcnt<12>();
+        // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave) — and, in record mode before chunk 0,
+        // the 24 stores of LayerNorm2's output issued behind the prefetch
+        if (REC && c == 0) eb_wait_vmcnt<12 + 2 * (E / 32)>(); else eb_wait_vmcnt<12>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -603,7 +610,8 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         }
         gcur = gcur == 2 ? 0 : gcur + 1;
         // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
-        if (more) eb_wait_vmcnt<12>(); else eb_wait_vmcnt<0>();
+        // (record mode: plus this chunk's 8 stores of the pre-activation and its GELU, issued behind the next chunk's fc1 pieces)
+        if (more) eb_wait_vmcnt<REC ? 20 : 12>(); else eb_wait_vmcnt<REC ? 8 : 0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
