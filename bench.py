@@ -289,19 +289,56 @@ def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
     mmac_img = 12 * 239.08 + 4.72 + (6 * 26 * (14 * E * E + 95 * E) + 128 * 2 * E * E) / 1e6
     tflop = 3 * 2 * mmac_img * 1e6 * batch / 1e12      # per GPU
     ms = 1e3 * el / steps
-    # the step's dominant kernel (the encoder's forward / dX products), from the committed kernel trace + counter pass of tools/train_bench.py
-    # (profiles/train_kernels.json: average launch time, launches per step, MFMA-busy) — bench.py does not re-profile the training step
+    # The encoder's forward (one launch in record mode since round 5: encoder_blocks.h) timed LIVE by this run — the call alone, HIP events on
+    # the stream it is enqueued on: patches, patch embedding, weight shadows, the twelve blocks in one launch, final LayerNorm.  The launch
+    # is bound by the record it writes (TrainEncoderLayout: 16 E floats' worth of slots per token and block, some of them bf16).
+    live = None
+    try:
+        from parseq_amd import _native
+        from parseq_amd.train import _set_train_precision
+        lib = _native.lib()
+        native = system.model._sync_native().model
+        _set_train_precision(system, native)
+        nbytes = lib.parseq_train_encoder_workspace_bytes(native, batch)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        mem = torch.empty(batch, 128, 384, dtype=torch.float32, device=dev)
+        img = images.float() if images.dtype != torch.float32 else images
+
+        def fwd():
+            _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(img), batch, _native.ptr(mem), _native.ptr(ws), nbytes, _native.stream_ptr(img)))
+        for _ in range(2):
+            fwd()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_live = 5
+        ev0.record()
+        for _ in range(n_live):
+            fwd()
+        ev1.record()
+        torch.cuda.synchronize()
+        fms = ev0.elapsed_time(ev1) / n_live
+        rec_bytes = 12 * batch * 128 * (384 * 4 * 2 + 3 * 384 * 4 + 384 * 2 * 3 + 1536 * 2 * 2)      # x, x_mid f32; q|k|v f32; n1, n2, ao bf16; hpre, hact bf16
+        fwd_flop = 2 * (12 * 239.08 + 4.72) * 1e6 * batch
+        live = {'what': 'parseq_train_encoder_forward alone, timed by this run (events): patches, patch embedding, weight shadows, the twelve blocks as ONE launch '
+                        '(enc_blocks_kernel<384, true>, record mode), final LayerNorm', 'ms': round(fms, 3), 'calls': n_live,
+                'record_bytes': rec_bytes, 'bound': 'hbm', 'achieved': round(rec_bytes / (fms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': round(rec_bytes / (fms * 1e-3) / 1e9 / 8000.0, 4), 'algorithmic_tflops': round(fwd_flop / (fms * 1e-3) / 1e12, 1)}
+        del ws, mem
+    except Exception as e:      # the step above is the measurement; this block is an annotation
+        live = {'error': f'{type(e).__name__}: {e}'}
+    # the step's heaviest kernels from the committed kernel trace + counter passes of tools/train_bench.py (profiles/train_kernels.json)
     roof = None
     kpath = os.path.join(ROOT, 'profiles', 'train_kernels.json')
     if os.path.exists(kpath):
-        rec = json.load(open(kpath)).get('mfma_bgemm16_kernel')
+        recs = json.load(open(kpath))
+        rec = recs.get('enc_blocks_kernel_record')
         if rec and rec.get('batch') == batch:
-            fl = 2 * 12 * 2.0 * batch * 128 * (3 * E * E + E * E + 2 * 4 * E * E) / rec['launches_per_step']      # forward + dX of the four Linears, per launch
-            ach = fl / (rec['avg_us'] * 1e-6) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'mfma_bgemm16_kernel (encoder forward / dX products)', 'achieved': round(ach, 1), 'peak': PEAK['bf16'], 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK['bf16'], 4), 'avg_launch_us': rec['avg_us'], 'launches_per_step': rec['launches_per_step'],
-                    'share_of_step': rec.get('share'), 'mfma_busy_pct': rec.get('mfma_busy_pct'), 'source': rec.get('source')}
-    return {'roofline_from_committed_trace': roof,      # NOT re-measured by this run: profiles/train_kernels.json (rocprofv3 trace + counter pass of tools/train_bench.py)
+            ach = rec['write_bytes'] / (rec['avg_us'] * 1e-6) / 1e9
+            roof = {'bound': 'hbm', 'kernel': rec['kernel'], 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4),
+                    'traffic': rec['write_bytes'] + rec['fetch_bytes_x2'], 'avg_launch_us': rec['avg_us'], 'launches_per_step': rec['launches_per_step'],
+                    'share_of_step': rec.get('share'), 'mfma_busy_pct': rec.get('mfma_busy_pct'), 'source': rec.get('source'),
+                    'other_kernels': {k: {kk: v[kk] for kk in ('avg_us', 'launches_per_step', 'share', 'mfma_busy_pct') if kk in v} for k, v in recs.items() if k != 'enc_blocks_kernel_record'}}
+    return {'encoder_forward_live': live,
+            'roofline_from_committed_trace': roof,      # NOT re-measured by this run: profiles/train_kernels.json (rocprofv3 trace + counter passes of tools/train_bench.py)
             'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], {world} GPU' + ('s, gradient all-reduce over RCCL)' if world > 1 else ')'),
             'value': round(world * batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
             'global_batch': world * batch, 'n_gpus': world,

@@ -153,7 +153,10 @@ struct parseq_model {
     // parseq_train_encoder_forward: which storage mode (bit 0 bf16 shadows, bit 1 bf16-only slots) the record in `enc_record_ws` was written in
     int enc_record_mode = 0;
     const void* enc_record_ws = nullptr;
-    std::vector<EncBlockParams> train_blocks_host;                  // the one-launch training forward's block table: source of its asynchronous upload
+    // model constants of the training forward, built on first use: the one-launch encoder's block table (encoder_blocks.h; weight offsets relative
+    // to the workspace's bf16 shadows, parameter offsets into the master) and the table of the one-launch weight-shadow kernel (train_ops.h)
+    EncBlockParams* train_blocks_dev = nullptr;
+    void* shadow_tab_dev = nullptr; int shadow_tiles = 0;
     // parseq_train_encoder_backward: one event per gradient segment (parseq_train_grad_segment), recorded on its stream as soon as that
     // part of the flat gradient buffer is final — the hook a data-parallel caller overlaps its bucket all-reduces with
     std::vector<hipEvent_t> grad_events;

@@ -75,6 +75,8 @@ extern "C" void parseq_model_destroy(parseq_model* m) {
     DevGuard dg(m->device);
     if (m->master) (void)hipFree(m->master);
     if (m->out_chunks) (void)hipFree(m->out_chunks);
+    if (m->train_blocks_dev) (void)hipFree(m->train_blocks_dev);
+    if (m->shadow_tab_dev) (void)hipFree(m->shadow_tab_dev);
     for (hipEvent_t e : m->grad_events) (void)hipEventDestroy(e);
     delete m;
 }

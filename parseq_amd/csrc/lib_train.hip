@@ -599,7 +599,6 @@ struct TrainEncoderLayout {          // offsets in floats
     size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, scratch_floats, total;
     size_t w16, w16_layer, d_x16, d_h16;      // bf16 shadows (train_enc_shadows): the Linear weights and their transposes ([layer][qkv, proj, fc1, fc2][W16 | Wt16]),
                                               // the residual-stream gradient and the fc1-output gradient
-    size_t blocks_tab;                        // the one-launch forward's EncBlockParams table (encoder_blocks.h), depth entries
     size_t x(int i) const { return layer0 + i * layer_stride; }
     size_t qkv, ao, x_mid, hpre, hact_l, n1, n2;     // offsets inside one layer's record (x at 0); hact_l, n1, n2: the GELU output and the two
                                              // LayerNorm outputs, kept for the backward (round 3: they used to be recomputed there — a 600 MB and two
@@ -623,7 +622,6 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     o.scratch_floats = train_scratch_floats(MS, E); o.scratch = take(o.scratch_floats);
     o.w16_layer = 4 * E * E + 2 * E * F;      // floats = 2 bf16 each: W16 and Wt16 of the block's four Linear weights
     o.w16 = take(o.w16_layer * (size_t)m->cfg.enc_depth); o.d_x16 = take(MS * E / 2 + 8); o.d_h16 = take(MS * F / 2 + 8);
-    o.blocks_tab = take((size_t)m->cfg.enc_depth * sizeof(EncBlockParams) / sizeof(float));
     o.total = off;
     return o;
 }
@@ -712,14 +710,26 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
     m->enc_record_mode = (shadows ? 1 : 0) | (only16 ? 2 : 0);      // what the record's slots hold; the backward entry must read them the same way
     m->enc_record_ws = workspace;
     if (shadows) {
-        // this step's weights as bf16, both ways round (the backward entry reads the transposes from the same workspace)
-        const char* names[4] = {"attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"};
-        const int wn[4] = {3 * E, E, F, E}, wk[4] = {E, E, E, F};
-        for (int i = 0; i < m->cfg.enc_depth; ++i)
-            for (int j = 0; j < 4; ++j) {
-                const EncShadowW sw = enc_shadow_w(o, w, i, j, E, F);
-                hipLaunchKernelGGL(weight_shadow_kernel, dim3(wk[j] / 32, wn[j] / 32), dim3(256), 0, s, P("blocks." + std::to_string(i) + "." + names[j]), wn[j], wk[j], sw.w, sw.wt);
-            }
+        // this step's weights as bf16, both ways round (the backward entry reads the transposes from the same workspace): one launch over
+        // the 4 * depth matrices (it was one launch per matrix: 48 launches of 2 - 7 us); the table is a model constant
+        if (!m->shadow_tab_dev) {
+            const char* names[4] = {"attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"};
+            const int wn[4] = {3 * E, E, F, E}, wk[4] = {E, E, E, F};
+            std::vector<ShadowEntry> tab;
+            unsigned tile = 0;
+            for (int i = 0; i < m->cfg.enc_depth; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const EncShadowW sw = enc_shadow_w(o, w, i, j, E, F);
+                    tab.push_back(ShadowEntry{(unsigned)m->params[m->index.at(m->enc + "blocks." + std::to_string(i) + "." + names[j])].offset, (unsigned)wn[j], (unsigned)wk[j],
+                                              tile, (unsigned long long)(sw.w - reinterpret_cast<bf16_t*>(w + o.w16))});
+                    tile += (unsigned)((wn[j] / 32) * (wk[j] / 32));
+                }
+            HIPCHK(hipMalloc(&m->shadow_tab_dev, tab.size() * sizeof(ShadowEntry)));
+            HIPCHK(hipMemcpy(m->shadow_tab_dev, tab.data(), tab.size() * sizeof(ShadowEntry), hipMemcpyHostToDevice));
+            m->shadow_tiles = (int)tile;
+        }
+        hipLaunchKernelGGL(weight_shadows_kernel, dim3(m->shadow_tiles), dim3(256), 0, s, m->master, reinterpret_cast<const ShadowEntry*>(m->shadow_tab_dev),
+                           4 * m->cfg.enc_depth, reinterpret_cast<bf16_t*>(w + o.w16));
         HIPCHK(hipGetLastError());
     }
     if (train_enc_one_launch(m, o)) {
@@ -727,18 +737,21 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
         // accumulators, the weights streamed from this step's bf16 shadows — writing the record on the way; 48 GEMM, 24 LayerNorm and
         // 12 attention launches and every re-read of an activation disappear, what is left is the record's own bytes.
         const int depth = m->cfg.enc_depth;
-        m->train_blocks_host.resize(depth);
-        auto off = [&](const std::string& key) { return (unsigned)m->params[m->index.at(m->enc + key)].offset; };
-        for (int i = 0; i < depth; ++i) {
-            const std::string b = "blocks." + std::to_string(i) + ".";
-            const unsigned w0 = (unsigned)(2 * o.w16_layer * (size_t)i), EE = (unsigned)(E * E), EF = (unsigned)(E * F);      // bf16 elements from the shadows' base
-            EncBlockParams& e = m->train_blocks_host[i];
-            e.ln1_w = off(b + "norm1.weight"); e.ln1_b = off(b + "norm1.bias"); e.bqkv = off(b + "attn.qkv.bias"); e.bproj = off(b + "attn.proj.bias");
-            e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias"); e.b1 = off(b + "mlp.fc1.bias"); e.b2 = off(b + "mlp.fc2.bias");
-            e.wqkv = w0; e.wproj = w0 + 6 * EE; e.w1 = w0 + 8 * EE; e.w2 = w0 + 8 * EE + 2 * EF;       // enc_shadow_w's W16 of each pair
+        if (!m->train_blocks_dev) {      // a model constant: parameter offsets into the master, weight offsets relative to the shadows' base
+            std::vector<EncBlockParams> tab(depth);
+            auto off = [&](const std::string& key) { return (unsigned)m->params[m->index.at(m->enc + key)].offset; };
+            for (int i = 0; i < depth; ++i) {
+                const std::string b = "blocks." + std::to_string(i) + ".";
+                const unsigned w0 = (unsigned)(2 * o.w16_layer * (size_t)i), EE = (unsigned)(E * E), EF = (unsigned)(E * F);      // bf16 elements from the shadows' base
+                EncBlockParams& e = tab[i];
+                e.ln1_w = off(b + "norm1.weight"); e.ln1_b = off(b + "norm1.bias"); e.bqkv = off(b + "attn.qkv.bias"); e.bproj = off(b + "attn.proj.bias");
+                e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias"); e.b1 = off(b + "mlp.fc1.bias"); e.b2 = off(b + "mlp.fc2.bias");
+                e.wqkv = w0; e.wproj = w0 + 6 * EE; e.w1 = w0 + 8 * EE; e.w2 = w0 + 8 * EE + 2 * EF;       // enc_shadow_w's W16 of each pair
+            }
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->train_blocks_dev), depth * sizeof(EncBlockParams)));
+            HIPCHK(hipMemcpy(m->train_blocks_dev, tab.data(), depth * sizeof(EncBlockParams), hipMemcpyHostToDevice));
         }
-        EncBlockParams* tab = reinterpret_cast<EncBlockParams*>(w + o.blocks_tab);
-        HIPCHK(hipMemcpyAsync(tab, m->train_blocks_host.data(), depth * sizeof(EncBlockParams), hipMemcpyHostToDevice, s));
+        const EncBlockParams* tab = m->train_blocks_dev;
         const EncRecordParams rec{w + o.layer0, o.layer_stride, (unsigned)(o.layer_stride * sizeof(float)), (unsigned)(o.qkv * 4), (unsigned)(o.ao * 4),
                                   (unsigned)(o.x_mid * 4), (unsigned)(o.hpre * 4), (unsigned)(o.hact_l * 4), (unsigned)(o.n1 * 4), (unsigned)(o.n2 * 4)};
         HIPCHK((launch_enc_blocks_record<384>(s, w + o.x_last, reinterpret_cast<const bf16_t*>(w + o.w16), o.w16_layer * (size_t)depth * sizeof(float),

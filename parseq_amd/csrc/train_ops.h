@@ -794,11 +794,20 @@ void mfma_bgemm16t_kernel(const SgemmArgs a, int k_chunk, float* __restrict__ pa
 }
 
 // bf16 shadows of a Linear weight W [N, K] (fp32 master): W16 [N, K] and its transpose Wt16 [K, N], once per step.  N, K multiples of 32.
+// All of a step's weight shadows in ONE launch: the table lists the matrices (master offset, shape, first tile, destination relative to the
+// shadows' base: W16 there, Wt16 right behind it); workgroup t converts tile t - tile0 of the matrix whose range holds t.
+struct ShadowEntry { unsigned src, N, K, tile0; unsigned long long dst; };
 static __global__ __launch_bounds__(256)
-void weight_shadow_kernel(const float* __restrict__ W, int N, int K, bf16_t* __restrict__ W16, bf16_t* __restrict__ Wt16) {
+void weight_shadows_kernel(const float* __restrict__ master, const ShadowEntry* __restrict__ tab, int entries, bf16_t* __restrict__ base) {
     __shared__ float t[32][33];
+    int e = 0;
+    while (e + 1 < entries && tab[e + 1].tile0 <= blockIdx.x) ++e;
+    const ShadowEntry se = tab[e];
+    const int N = (int)se.N, K = (int)se.K, tile = (int)(blockIdx.x - se.tile0), kt = K / 32;
+    const float* W = master + se.src;
+    bf16_t* W16 = base + se.dst; bf16_t* Wt16 = W16 + (size_t)N * K;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int n0 = (tile / kt) * 32, k0 = (tile % kt) * 32;
 #pragma unroll
     for (int r = ty; r < 32; r += 8) {
         const float v = W[(size_t)(n0 + r) * K + k0 + tx];
