@@ -200,16 +200,32 @@ __device__ __forceinline__ void rec_store16(const RecCtx& rc, unsigned voff, uns
 __device__ __forceinline__ void rec_store16(const RecCtx& rc, unsigned voff, unsigned soff, float a, float b, float c, float d) {
     rec_store16(rc, voff, soff, u32x4{__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)});
 }
+// What a CU's store path costs is the number of 128-byte lines an instruction touches, not its bytes (tools/microbench/store_patterns.hip,
+// profiles/r05_store_patterns.log: 8 rows x 128 B, 4 x 256 B or 1 KB contiguous per instruction 51 B/clk per CU; 16 rows x 64 B, or 16 rows
+// x four 16-B pieces, 16 B/clk — and with one in-order wave per SIMD the store that finds the path busy holds the MFMA stream).  A lane of
+// the fragment layouts owns 16 bytes of a row of which the four lanes (r16, 0..3) make 64: two pieces A, B that are neighbours in memory
+// are therefore stored as TWO instructions of 8 rows x 128 B — the half-row swap of store_acc_to_x: rows r16 < 8 by the first (lanes
+// r16 < 8 their own A, lanes r16 >= 8 the B of row r16 - 8), rows r16 >= 8 by the second.  GSTRIDE: bytes between the pieces of lanes g
+// and g + 1; BSTRIDE: bytes from A to B.  `soff`: byte offset of (row tile's row 0, A's column of g = 0).
+template <int GSTRIDE, int BSTRIDE>
+__device__ __forceinline__ void rec_store_pair(const RecCtx& rc, int ln, unsigned pitch_b, unsigned soff, const u32x4& A, const u32x4& B) {
+    const int r16 = ln & 15, g = ln >> 4;
+    const bool lo_half = r16 < 8;
+    const u32x4 got = swap_half_rows(lo_half ? B : A);
+    const unsigned voff = (unsigned)(r16 & 7) * pitch_b + (unsigned)(g * GSTRIDE + (lo_half ? 0 : BSTRIDE));
+    rec_store16(rc, voff, soff, lo_half ? A : got);
+    rec_store16(rc, voff, soff + 8u * pitch_b, lo_half ? got : B);
+}
+__device__ __forceinline__ u32x4 rec_bits(const bf16x8& v) { return __builtin_bit_cast(u32x4, v); }
 // bf16 operand fragments (lane (r16, g), row tile j, k-step ks: columns 32 ks + 8 g + [0, 8) of row 32 wid + 16 j + r16) -> [rows][E] bf16 at `slot`
 template <int E>
 __device__ __forceinline__ void rec_store_frag(const RecCtx& rc, unsigned slot, int wid, const bf16x8 (&afrag)[2][E / 32]) {
     const int ln = opaque_lane();
-    const unsigned voff = (unsigned)((ln & 15) * E + 8 * (ln >> 4)) * 2u;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int ks = 0; ks < E / 32; ++ks)
-            rec_store16(rc, voff, slot + ((rc.row0 + 32u * wid + 16u * j) * E + 32u * ks) * 2u, afrag[j][ks]);
+        for (int ks = 0; ks < E / 32; ks += 2)
+            rec_store_pair<16, 64>(rc, ln, 2u * E, slot + ((rc.row0 + 32u * wid + 16u * j) * E + 32u * ks) * 2u, rec_bits(afrag[j][ks]), rec_bits(afrag[j][ks + 1]));
 }
 // the fp32 rows in the accumulators -> [rows][E] f32 at `slot` (store_acc_to_x's pieces through the descriptor)
 template <int E>
@@ -422,12 +438,11 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                         if constexpr (u == 0) qfrag[j][pr] = f;
                         else *reinterpret_cast<bf16x8*>(kimg + (krow_j0 + 8 * j) * AF_KROWB + 64 * pr + 16 * g) = f;
                         if constexpr (REC) {       // q | k with their biases, f32: columns u E + 64 h + 32 pr + 8 g + [0, 8) of row 32 wid + 16 j + r16
-                            const unsigned voff = (unsigned)(rr * 3 * E + 8 * g) * 4u;
-                            const unsigned soff = rc.qkv + ((rc.row0 + 32u * wid + 16u * j) * (3u * E) + u * E + h * 64u + 32u * pr) * 4u;
-                            rec_store16(rc, voff, soff, acc1[2 * pr][j][0] + bp0[32 * pr], acc1[2 * pr][j][1] + bp0[32 * pr + 1],
-                                        acc1[2 * pr][j][2] + bp0[32 * pr + 2], acc1[2 * pr][j][3] + bp0[32 * pr + 3]);
-                            rec_store16(rc, voff, soff + 16u, acc1[2 * pr + 1][j][0] + bp0[32 * pr + 4], acc1[2 * pr + 1][j][1] + bp0[32 * pr + 5],
-                                        acc1[2 * pr + 1][j][2] + bp0[32 * pr + 6], acc1[2 * pr + 1][j][3] + bp0[32 * pr + 7]);
+                            const u32x4 pa = {__float_as_uint(acc1[2 * pr][j][0] + bp0[32 * pr]), __float_as_uint(acc1[2 * pr][j][1] + bp0[32 * pr + 1]),
+                                              __float_as_uint(acc1[2 * pr][j][2] + bp0[32 * pr + 2]), __float_as_uint(acc1[2 * pr][j][3] + bp0[32 * pr + 3])};
+                            const u32x4 pb = {__float_as_uint(acc1[2 * pr + 1][j][0] + bp0[32 * pr + 4]), __float_as_uint(acc1[2 * pr + 1][j][1] + bp0[32 * pr + 5]),
+                                              __float_as_uint(acc1[2 * pr + 1][j][2] + bp0[32 * pr + 6]), __float_as_uint(acc1[2 * pr + 1][j][3] + bp0[32 * pr + 7])};
+                            rec_store_pair<32, 16>(rc, ln, 12u * E, rc.qkv + ((rc.row0 + 32u * wid + 16u * j) * (3u * E) + u * E + h * 64u + 32u * pr) * 4u, pa, pb);
                         }
                     }
             } else if constexpr (u == 2) {
@@ -518,9 +533,13 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
                             f[4 + r] = static_cast<bf16_t>(ov[2 * pr + 1][j][r] * inv[j]);
                         }
                         ofrag[j][pr] = f;
-                        if constexpr (REC)
-                            rec_store16(rc, (unsigned)(rr * E + 8 * g) * 2u, rc.ao + ((rc.row0 + 32u * wid + 16u * j) * E + h * 64u + 32u * pr) * 2u, f);
                     }
+                if constexpr (REC) {               // the attention output, bf16: columns 64 h + [0, 64) of rows 32 wid + 16 j + r16
+                    const int ln = opaque_lane();
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        rec_store_pair<16, 64>(rc, ln, 2u * E, rc.ao + ((rc.row0 + 32u * wid + 16u * j) * E + h * 64u) * 2u, rec_bits(ofrag[j][0]), rec_bits(ofrag[j][1]));
+                }
                 }
             } else {
                 run_triple(grp, [&](int k, int half, int i, const bf16x8& w) {
@@ -596,15 +615,16 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { f[2 * e] = static_cast<bf16_t>(yv[4 * pr + e][0]); f[2 * e + 1] = static_cast<bf16_t>(yv[4 * pr + e][1]); }
                     hfrag[j][pr] = f;
-                    if constexpr (REC) {           // the pre-activation and its GELU, bf16: hidden units 64 c + 32 pr + 8 g + [0, 8) of row 32 wid + 16 j + r16
-                        bf16x8 pre;
+                }
+                if constexpr (REC) {               // the pre-activation and its GELU, bf16: hidden units 64 c + [0, 64) of rows 32 wid + 16 j + r16
+                    bf16x8 pre[2];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { pre[2 * e] = static_cast<bf16_t>(xv[4 * pr + e][0]); pre[2 * e + 1] = static_cast<bf16_t>(xv[4 * pr + e][1]); }
-                        const unsigned voff = (unsigned)((ln_ & 15) * F + 8 * g) * 2u;
-                        const unsigned soff = ((rc.row0 + 32u * wid + 16u * j) * F + c * MLP_HC + 32u * pr) * 2u;
-                        rec_store16(rc, voff, rc.hpre + soff, pre);
-                        rec_store16(rc, voff, rc.hact + soff, f);
-                    }
+                    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { pre[pr][2 * e] = static_cast<bf16_t>(xv[4 * pr + e][0]); pre[pr][2 * e + 1] = static_cast<bf16_t>(xv[4 * pr + e][1]); }
+                    const unsigned soff = ((rc.row0 + 32u * wid + 16u * j) * F + c * MLP_HC) * 2u;
+                    rec_store_pair<16, 64>(rc, ln_, 2u * F, rc.hpre + soff, rec_bits(pre[0]), rec_bits(pre[1]));
+                    rec_store_pair<16, 64>(rc, ln_, 2u * F, rc.hact + soff, rec_bits(hfrag[j][0]), rec_bits(hfrag[j][1]));
                 }
             }
         }

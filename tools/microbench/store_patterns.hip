@@ -29,6 +29,13 @@ __global__ __launch_bounds__(256) void k(unsigned char* out, size_t region, int 
         } else if constexpr (MODE == 3 || MODE == 5) {
             for (int j = 0; j < 2; ++j)            // 16 rows x 64 B, consecutive instructions fill consecutive 64-B pieces of the same rows
                 for (int c = 0; c < 12; ++c) *reinterpret_cast<u32x4*>(tile + (wave * 32 + j * 16 + (lane & 15)) * P + c * 64 + (lane >> 4) * 16) = v;
+        } else if constexpr (MODE == 6) {
+            for (int j = 0; j < 8; ++j)            // 4 rows x 256 B per instruction; 3 column groups
+                for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x4*>(tile + (wave * 32 + j * 4 + (lane >> 4)) * P + c * 256 + (lane & 15) * 16) = v;
+        } else if constexpr (MODE == 7) {
+            for (int j = 0; j < 2; ++j)            // 16 rows, per row 4 pieces of 16 B at a 32-B stride; the odd pieces by the next instruction
+                for (int c = 0; c < 6; ++c)
+                    for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<u32x4*>(tile + (wave * 32 + j * 16 + (lane & 15)) * P + c * 128 + (lane >> 4) * 32 + hh * 16) = v;
         } else if constexpr (MODE == 4) {
             // dword stores: lane (rr, g): d = (rr >> 2) * 8 + (rr & 3) (+ 4 (i & 1) + 32 (i >> 1)), token 4 g + r; [rows][192 f32 = 768 B]
             for (int j = 0; j < 2; ++j)
@@ -51,7 +58,7 @@ void run(const char* what, unsigned char* dev, size_t region, int blocks) {
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double bytes = (double)blocks * iters * 128 * 768;
-    printf("%-78s %7.3f ms  %6.2f TB/s\n", what, ms, bytes / ms / 1e9);
+    printf("%-92s %7.3f ms  %6.2f TB/s  %6.1f B/clk per workgroup at 2.4 GHz\n", what, ms, bytes / ms / 1e9, bytes / (ms * 1e-3) / blocks / 2.4e9);
 }
 int main() {
     const int blocks = 512; const size_t region = 4 << 20;
@@ -61,5 +68,19 @@ int main() {
     run<2>("16 rows x 64 B, a row's second 64 B two instructions later", dev, region, blocks);
     run<3>("16 rows x 64 B, consecutive instructions complete the rows", dev, region, blocks);
     run<4>("dword stores in the V^T accumulator layout (runs of 16 B)", dev, region, blocks);
+    // fewer workgroups: is ~6 TB/s the chip's write rate or 256 x one CU's?  (rate per CU = TB/s / workgroups resident)
+    for (int b : {32, 64, 128, 256}) {
+        char what[96]; snprintf(what, sizeof what, "16 rows x 64 B (mode 3), %d workgroups", b);
+        run<3>(what, dev, region, b);
+    }
+    for (int b : {32, 128}) {
+        char what[96]; snprintf(what, sizeof what, "1 KB contiguous (mode 0), %d workgroups", b);
+        run<0>(what, dev, region, b);
+    }
+    run<1>("8 rows x 128 B (mode 1), 32 workgroups", dev, region, 32);
+    run<2>("16 rows x 64 B, rows completed late (mode 2), 32 workgroups", dev, region, 32);
+    run<4>("dword stores, V^T layout (mode 4), 32 workgroups", dev, region, 32);
+    run<6>("4 rows x 256 B (mode 6), 32 workgroups", dev, region, 32);
+    run<7>("16 rows x 4 pieces of 16 B at 32-B stride (the q | k f32 stores) (mode 7), 32 workgroups", dev, region, 32);
     return 0;
 }
