@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define PARSEQ_ABI_VERSION 7
+#define PARSEQ_ABI_VERSION 8
 
 typedef struct parseq_model parseq_model;   /* weights of one PARSeq instance on one device */
 typedef struct parseq_plan parseq_plan;     /* workspace + derived tables for (model, max_batch, precision) */
@@ -308,6 +308,14 @@ int parseq_train_encoder_backward(parseq_model* m, const float* dmemory, int bat
 int parseq_train_grad_segments(const parseq_model* m);
 int parseq_train_grad_segment(parseq_model* m, int index, int64_t* begin, int64_t* end, void** event);
 int parseq_stream_wait_event(void* stream, void* event);
+
+/* Data-parallel sharding (ABI 8; SURVEY.md §8(e): the path shards over independent crops, reference bench.py / test.py loop over batches
+ * per device under Lightning).  The contiguous split the Python mirror uses (parseq_amd/parallel.py shard_bounds): `world` shards of n
+ * items whose sizes differ by at most one, shard `rank` = [*begin, *end).  A caller without torch shards its batch with this, runs
+ * parseq_forward on its own shard with its own plan, and exchanges the [b_local, L, C] logits itself — ONE all-gather on its own RCCL
+ * communicator when n is a multiple of world (INTEGRATION.md shows the calls); there is no collective inside the library.
+ * Returns PARSEQ_E_INVALID for n < 0, world < 1 or rank outside [0, world). */
+int parseq_shard_bounds(int64_t n, int world, int rank, int64_t* begin, int64_t* end);
 
 /* Optimiser half of the training step (strhub/models/base.py:98-107: timm create_optimizer_v2('adamw') = torch.optim.AdamW;
  * configs/main.yaml:39 gradient_clip_val = torch.nn.utils.clip_grad_norm_), over the flat buffers:

@@ -16,7 +16,7 @@ from . import build as _build
 PARSEQ_F32, PARSEQ_BF16, PARSEQ_U8, PARSEQ_BF16X3 = 0, 1, 2, 3
 ARCH_PARSEQ, ARCH_VITSTR = 0, 1
 FLAG_DECODE_AR, FLAG_TESTING, FLAG_LATENCY = 1, 2, 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ParseqConfig(C.Structure):
@@ -80,6 +80,7 @@ SIGNATURES = {
     'parseq_train_grad_segments': (C.c_int, [C.c_void_p]),
     'parseq_train_grad_segment': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
     'parseq_stream_wait_event': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'parseq_shard_bounds': (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'parseq_grad_norm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'parseq_adamw_step': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_float, C.c_float, C.c_float,
                                     C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_float, C.c_void_p]),

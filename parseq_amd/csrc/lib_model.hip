@@ -2,6 +2,14 @@
 #include "lib_internal.h"
 
 extern "C" int parseq_abi_version(void) { return PARSEQ_ABI_VERSION; }
+extern "C" int parseq_shard_bounds(int64_t n, int world, int rank, int64_t* begin, int64_t* end) {
+    if (!begin || !end) return fail(PARSEQ_E_INVALID, "null argument");
+    if (n < 0 || world < 1 || rank < 0 || rank >= world) return fail(PARSEQ_E_INVALID, "shard %d of %d over %lld items", rank, world, (long long)n);
+    const int64_t base = n / world, extra = n % world;
+    *begin = rank * base + (rank < extra ? rank : extra);
+    *end = *begin + base + (rank < extra ? 1 : 0);
+    return 0;
+}
 extern "C" const char* parseq_last_error(void) { return g_err; }
 
 extern "C" int parseq_model_create(const parseq_config* c, parseq_model** out) {

@@ -37,6 +37,23 @@ def test_library_loads_and_reports_abi(built_lib):
     assert lib.parseq_abi_version() == _native.ABI_VERSION
 
 
+def test_shard_bounds_of_the_library_equal_the_python_mirror(built_lib):
+    """parseq_shard_bounds (ABI 8): the split a caller without torch shards its crops with is the one parseq_amd.parallel uses — host
+    arithmetic only, so it runs without a device — and nonsense arguments are refused."""
+    from parseq_amd import _native
+    from parseq_amd.parallel import shard_bounds
+    lib = _native.lib()
+    b, e = ctypes.c_int64(), ctypes.c_int64()
+    for n in (0, 1, 7, 8, 512, 4096, 4099):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                assert lib.parseq_shard_bounds(n, world, rank, ctypes.byref(b), ctypes.byref(e)) == 0
+                assert (b.value, e.value) == shard_bounds(n, world, rank)
+    for n, world, rank in ((-1, 2, 0), (8, 0, 0), (8, 2, 2), (8, 2, -1)):
+        assert lib.parseq_shard_bounds(n, world, rank, ctypes.byref(b), ctypes.byref(e)) != 0
+    assert lib.parseq_shard_bounds(8, 2, 0, None, ctypes.byref(e)) != 0
+
+
 def test_no_device_means_loud_failure(built_lib):
     """Without a gfx950 device the library must refuse, not emulate."""
     import torch
