@@ -398,6 +398,137 @@ void attn_mfma_n_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__
 }
 template <int NT32> constexpr size_t attn_mfma_n_lds() { return (size_t)32 * NT32 * ATT_KROWB + (size_t)ATT_HD * (32 * NT32 * 2 + 8); }
 
+// attn_mfma_n_kernel in the exact (split-bf16) arithmetic of attn_split_kernel, for fp32 q / k / v [B][H][N][64] (row-major V) and any
+// token count N <= 32 * NT32 — ViTSTR's 129 tokens and patch16-224's 196 in the bf16x3 mode, which ran the scalar attn_generic_kernel
+// (730 us per block at 512 x 6 heads x 129 tokens, 40 % of ViTSTR's forward).  Every fp32 operand is the pair (hi, lo) of bfloat16
+// values with hi + lo = the value to 16 significant bits; every product is the three MFMAs lo x hi + hi x lo + hi x hi (small terms
+// first).  K and V^T live in LDS as two planes each, zero-padded to 32 * NT32 keys; the padded keys are excluded from the soft-max.
+template <int NT32>
+__global__ __launch_bounds__(64 * NT32)
+void attn_split_n_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                         float* __restrict__ ao, int heads, int N, float scale) {
+    constexpr int NP = 32 * NT32, NTHR = 64 * NT32;
+    constexpr int VROWB = NP * 2 + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_attn_sn[];
+    unsigned char* Kh = smem_attn_sn;                        // [NP][ATT_KROWB]
+    unsigned char* Kl = Kh + NP * ATT_KROWB;
+    unsigned char* Vh = Kl + NP * ATT_KROWB;                 // [64][VROWB]  (V^T)
+    unsigned char* Vl = Vh + ATT_HD * VROWB;
+
+    const int bh = blockIdx.x;
+    const int b = bh / heads, h = bh - b * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const size_t base = (size_t)bh * N * ATT_HD;
+    const int E = heads * ATT_HD;
+
+    for (int c = tid; c < NP * 16; c += NTHR) {             // chunk c = 4 consecutive d of token t = c >> 4
+        const int t = c >> 4, d0 = (c & 15) * 4;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < N) {
+            kv = reinterpret_cast<const float4*>(k + base)[c];
+            vv = reinterpret_cast<const float4*>(v + base)[c];
+        }
+        const float k4[4] = {kv.x, kv.y, kv.z, kv.w}, v4[4] = {vv.x, vv.y, vv.z, vv.w};
+        union { uint2 u; bf16_t e[4]; } kh, kl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            kh.e[i] = static_cast<bf16_t>(k4[i]);
+            kl.e[i] = static_cast<bf16_t>(k4[i] - static_cast<float>(kh.e[i]));
+            const bf16_t vh = static_cast<bf16_t>(v4[i]);
+            const bf16_t vl = static_cast<bf16_t>(v4[i] - static_cast<float>(vh));
+            *reinterpret_cast<bf16_t*>(Vh + (d0 + i) * VROWB + t * 2) = vh;
+            *reinterpret_cast<bf16_t*>(Vl + (d0 + i) * VROWB + t * 2) = vl;
+        }
+        *reinterpret_cast<uint2*>(Kh + t * ATT_KROWB + d0 * 2) = kh.u;
+        *reinterpret_cast<uint2*>(Kl + t * ATT_KROWB + d0 * 2) = kl.u;
+    }
+
+    const int qi = lane & 31, hi = lane >> 5;
+    const int q0 = wid * 32;
+    const int qrow_i = min(q0 + qi, N - 1);
+    bf16x8 qh[4], ql[4];
+    {
+        const float* qrow = q + base + (size_t)qrow_i * ATT_HD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(qrow + ks * 16), c4 = *reinterpret_cast<const float4*>(qrow + ks * 16 + 4);
+            const float f[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                qh[ks][j] = static_cast<bf16_t>(f[j]);
+                ql[ks][j] = static_cast<bf16_t>(f[j] - static_cast<float>(qh[ks][j]));
+            }
+        }
+    }
+    __syncthreads();
+
+    // S^T tiles: st[t][r] = score(key = 32 t + (r & 3) + 8 (r >> 2) + 4 hi, query = qi)
+    f32x16 st[NT32];
+#pragma unroll
+    for (int t = 0; t < NT32; ++t) {
+        st[t] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int ko = (t * 32 + qi) * ATT_KROWB + hi * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 fh = *reinterpret_cast<const bf16x8*>(Kh + ko + ks * 32), fl = *reinterpret_cast<const bf16x8*>(Kl + ko + ks * 32);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl, qh[ks], st[t], 0, 0, 0);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, ql[ks], st[t], 0, 0, 0);
+            st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh, qh[ks], st[t], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= N) st[t][r] = -INFINITY;
+            mx = fmaxf(mx, st[t][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float c = scale * 1.44269504088896340736f;
+    const float mc = mx * c;
+    float sum = 0.f;
+    f32x16 ot[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) ot[nt] = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NT32; ++t)
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2) {
+            bf16x8 ph, pl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = exp2f(st[t][m2 * 8 + j] * c - mc);      // exp2(-inf) = 0 for the padded keys
+                sum += pv;
+                ph[j] = static_cast<bf16_t>(pv);
+                pl[j] = static_cast<bf16_t>(pv - static_cast<float>(ph[j]));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int vo = (nt * 32 + qi) * VROWB + hi * 8 + (t * 32 + m2 * 16) * 2;
+                union { bf16x8 v; uint2 u[2]; } fh, fl;
+                fh.u[0] = *reinterpret_cast<const uint2*>(Vh + vo); fh.u[1] = *reinterpret_cast<const uint2*>(Vh + vo + 16);
+                fl.u[0] = *reinterpret_cast<const uint2*>(Vl + vo); fl.u[1] = *reinterpret_cast<const uint2*>(Vl + vo + 16);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fl.v, ph, ot[nt], 0, 0, 0);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh.v, pl, ot[nt], 0, 0, 0);
+                ot[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fh.v, ph, ot[nt], 0, 0, 0);
+            }
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (q0 + qi < N) {
+        float* orow = ao + ((size_t)b * N + q0 + qi) * E + h * ATT_HD + 4 * hi;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                *reinterpret_cast<float4*>(orow + nt * 32 + rg * 8) =
+                    make_float4(ot[nt][rg * 4 + 0] * inv, ot[nt][rg * 4 + 1] * inv, ot[nt][rg * 4 + 2] * inv, ot[nt][rg * 4 + 3] * inv);
+    }
+}
+template <int NT32> constexpr size_t attn_split_n_lds() { return (size_t)2 * (32 * NT32 * ATT_KROWB + (size_t)ATT_HD * (32 * NT32 * 2 + 8)); }
+
 // Exact-f32 attention: 128 threads, thread = query; K [128][64] and V^T [64][128] broadcast-read from LDS.
 static __global__ __launch_bounds__(128)
 void attn_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ vt,

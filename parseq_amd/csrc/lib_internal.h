@@ -428,6 +428,22 @@ static int run_enc_attention(hipStream_t s, const T* q, const T* k, const T* vt,
             PQ_ATTN_N(1) PQ_ATTN_N(2) PQ_ATTN_N(3) PQ_ATTN_N(4) PQ_ATTN_N(5) PQ_ATTN_N(6) PQ_ATTN_N(7) PQ_ATTN_N(8)
 #undef PQ_ATTN_N
         }
+        if constexpr (sizeof(T) == 4) {
+            // bf16x3: the same kernel in the split arithmetic (three MFMAs per product); the fp32 mode keeps the scalar kernel below
+            if (g_split && !getenv("PARSEQ_ATTN_GENERIC")) {
+                const int nt32 = (tokens + 31) / 32;
+#define PQ_ATTN_SN(NT)                                                                                                                  \
+                if (nt32 == NT) {                                                                                                       \
+                    static LdsAttr attr_;                                                                                               \
+                    HIPCHK(attr_.ensure(reinterpret_cast<const void*>(attn_split_n_kernel<NT>), attn_split_n_lds<NT>()));               \
+                    hipLaunchKernelGGL((attn_split_n_kernel<NT>), dim3(bh), dim3(64 * NT), attn_split_n_lds<NT>(), s, q, k, vt, ao, heads, tokens, scale); \
+                    HIPCHK(hipGetLastError());                                                                                          \
+                    return 0;                                                                                                           \
+                }
+                PQ_ATTN_SN(1) PQ_ATTN_SN(2) PQ_ATTN_SN(3) PQ_ATTN_SN(4) PQ_ATTN_SN(5) PQ_ATTN_SN(6) PQ_ATTN_SN(7)
+#undef PQ_ATTN_SN
+            }
+        }
         const size_t lds = (size_t)2 * tokens * ATT_HD * sizeof(float);
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_generic_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   // size varies per call
         hipLaunchKernelGGL((attn_generic_kernel<T>), dim3(bh), dim3(ATTG_THREADS), lds, s, q, k, vt, ao, heads, tokens, scale);

@@ -16,7 +16,7 @@ MODES = {'nar0': (False, 0, None), 'nar1': (False, 1, None), 'ar0': (True, 0, No
 
 @pytest.fixture(scope='module')
 def models():
-    return {p: make_model(NAME, p) for p in ('fp32', 'bf16')}
+    return {p: make_model(NAME, p) for p in ('fp32', 'bf16', 'bf16x3')}
 
 
 def _run(m, images, mode):
@@ -46,6 +46,21 @@ def test_forward_fp32_matches_reference(models, golden, mode):
     assert d <= 1e-3, msg
     assert torch.equal(got.argmax(-1), want.argmax(-1))
     labels, _ = models['fp32'].tokenizer.decode(got.softmax(-1))
+    assert labels == meta['modes'][mode]['strings']
+
+
+@pytest.mark.parametrize('mode', ['nar0', 'ar0', 'ar1'])
+def test_forward_bf16x3_matches_reference(models, golden, mode):
+    """The exact-tolerance mode on 196 tokens: encoder attention through attn_split_n_kernel (encoder_attn.h: the token-count-generic
+    MFMA kernel in the three-product arithmetic; round 5 — it was the scalar generic kernel), everything else the split GEMMs.  Same
+    bar as fp32: 1e-3 on the logits, identical arg-max and strings.  PARSEQ_ATTN_GENERIC=1 keeps the scalar kernel (the A/B)."""
+    g, meta = golden(NAME)
+    got = _run(models['bf16x3'], g['images'].to(DEV), mode)
+    want = g[f'logits.{mode}']
+    d, msg = report(f'patch16 {mode} bf16x3', got, want)
+    assert d <= 1e-3, msg
+    assert torch.equal(got.argmax(-1), want.argmax(-1))
+    labels, _ = models['bf16x3'].tokenizer.decode(got.softmax(-1))
     assert labels == meta['modes'][mode]['strings']
 
 
