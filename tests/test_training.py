@@ -921,6 +921,43 @@ def test_one_launch_training_forward_against_the_per_operation_forward():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('batch', [1, 3, 130])
+def test_one_launch_training_forward_at_ragged_batch_sizes(batch):
+    """parseq_train_encoder_forward through the C ABI, one launch against per-operation launches, at batch sizes that leave most of the chip
+    empty (1, 3) and that need a second, partly filled round of workgroups (130 images on 256 CUs is one round; the point is a grid that is
+    not a multiple of anything): `memory` within the bf16 noise of the two forwards (3e-2 on values of about 4)."""
+    import os
+    from gpu_util import DEV, make_model
+    from parseq_amd import _native
+    from parseq_amd.train import _set_train_precision
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    lib = _native.lib()
+    native = m.model._sync_native().model
+    _set_train_precision(m, native)
+    images = synth_images(batch, cfg, seed=31).to(DEV)
+    nbytes = lib.parseq_train_encoder_workspace_bytes(native, batch)
+
+    def fwd():
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=DEV)
+        mem = torch.empty(batch, 128, 384, dtype=torch.float32, device=DEV)
+        _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), batch, _native.ptr(mem), _native.ptr(ws), nbytes, _native.stream_ptr(images)))
+        torch.cuda.synchronize()
+        return mem.cpu()
+
+    assert 'PARSEQ_TRAIN_ENC_PER_OP' not in os.environ
+    a = fwd()
+    os.environ['PARSEQ_TRAIN_ENC_PER_OP'] = '1'
+    try:
+        b = fwd()
+    finally:
+        del os.environ['PARSEQ_TRAIN_ENC_PER_OP']
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) <= 3e-2 and not torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
 def test_permutation_passes_as_one_batch_equal_one_after_the_other(train_golden, precision, monkeypatch):
     """Round 3: the decoder runs the K permutation passes of a step as ONE batch of K * B images (parseq_train_decoder,
