@@ -164,6 +164,10 @@ struct parseq_model {
     // them again — a caller that asks in between (the backward failed half-way, or never ran) must not get the previous step's events, which would let its collectives start
     // on gradients that are still being written
     bool grad_events_valid = false;
+    // parseq_train_encoder_backward's second stream (the weight-gradient products run beside the dX / LayerNorm / attention chain) and the events
+    // that order the two; created on first use
+    hipStream_t train_side = nullptr;
+    hipEvent_t train_ev[8] = {};
 
     const float* p(const std::string& key) const { return master + params[index.at(key)].offset; }
 };

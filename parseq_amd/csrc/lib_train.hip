@@ -216,16 +216,24 @@ static int lin_fwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* W16, c
 }
 // dy may be nullptr when dy16 is given (the gradient exists as bf16 only: both products read it, the bias gradient sums the bf16 values);
 // dx may be nullptr when dx16 is given; dx_gelu_pre16: the pre-activation as bf16
-static int lin_bwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* Wt16, const float* dy, const bf16_t* dy16, float* dW, float* db, float* dx,
-                     bf16_t* dx16, int M, int N, int K, const float* dx_gelu_pre = nullptr, const bf16_t* dx_gelu_pre16 = nullptr) {
+static int lin_bwd16_dw(const TrainCtx& cx, const bf16_t* x16, const float* dy, const bf16_t* dy16, float* dW, float* db, int M, int N, int K) {
     if (!dy && !dy16) return fail(PARSEQ_E_INVALID, "lin_bwd16: no gradient");
     GemmExt ew; ew.b16 = true; ew.a16 = dy == nullptr;
-    CHK(sgemm(cx, dy ? dy : reinterpret_cast<const float*>(dy16), 1, N, reinterpret_cast<const float*>(x16), K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true,
-              db, nullptr, nullptr, nullptr, &ew));
+    return sgemm(cx, dy ? dy : reinterpret_cast<const float*>(dy16), 1, N, reinterpret_cast<const float*>(x16), K, 1, nullptr, nullptr, 0, 0, dW, K, N, K, M, 1.f, true,
+                 db, nullptr, nullptr, nullptr, &ew);
+}
+static int lin_bwd16_dx(const TrainCtx& cx, const bf16_t* Wt16, const float* dy, const bf16_t* dy16, float* dx, bf16_t* dx16, int M, int N, int K,
+                        const float* dx_gelu_pre = nullptr, const bf16_t* dx_gelu_pre16 = nullptr) {
+    if (!dy && !dy16) return fail(PARSEQ_E_INVALID, "lin_bwd16: no gradient");
     if (!dx && !dx16) return 0;
     GemmExt ex; ex.b16 = true; ex.a16 = dy16 != nullptr; ex.c16 = dx16; ex.gelu_pre16 = dx_gelu_pre16;
     return sgemm(cx, dy16 ? reinterpret_cast<const float*>(dy16) : dy, N, 1, reinterpret_cast<const float*>(Wt16), 1, N, nullptr, nullptr, 0, 0, dx, K, M, K, N,
                  1.f, false, nullptr, nullptr, dx_gelu_pre, nullptr, &ex);
+}
+static int lin_bwd16(const TrainCtx& cx, const bf16_t* x16, const bf16_t* Wt16, const float* dy, const bf16_t* dy16, float* dW, float* db, float* dx,
+                     bf16_t* dx16, int M, int N, int K, const float* dx_gelu_pre = nullptr, const bf16_t* dx_gelu_pre16 = nullptr) {
+    CHK(lin_bwd16_dw(cx, x16, dy, dy16, dW, db, M, N, K));
+    return lin_bwd16_dx(cx, Wt16, dy, dy16, dx, dx16, M, N, K, dx_gelu_pre, dx_gelu_pre16);
 }
 // dx = add + LayerNorm backward; dgamma += column sums of dy * xhat; dbeta += column sums of dy.  `tmp` is [rows, E] scratch.
 // dx16 (optional): dx again as bf16, the operand shadow of the dX product that follows.
@@ -596,7 +604,7 @@ extern "C" int parseq_train_decoder(parseq_model* m, const float* memory, const 
 
 // ---- training step, encoder side: forward that keeps what the backward needs, and the backward ------------------------------
 struct TrainEncoderLayout {          // offsets in floats
-    size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, scratch_floats, total;
+    size_t patches, layer0, layer_stride, x_last, n, hact, d_x, d_a, d_h, dqkv, tmp, scratch, scratch2, scratch_floats, total;      // scratch2: the backward's second stream
     size_t w16, w16_layer, d_x16, d_h16;      // bf16 shadows (train_enc_shadows): the Linear weights and their transposes ([layer][qkv, proj, fc1, fc2][W16 | Wt16]),
                                               // the residual-stream gradient and the fc1-output gradient
     size_t x(int i) const { return layer0 + i * layer_stride; }
@@ -619,7 +627,7 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
     o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
     o.dqkv = take(MS * 3 * E); o.tmp = take(MS * E);
-    o.scratch_floats = train_scratch_floats(MS, E); o.scratch = take(o.scratch_floats);
+    o.scratch_floats = train_scratch_floats(MS, E); o.scratch = take(o.scratch_floats); o.scratch2 = take(o.scratch_floats);
     o.w16_layer = 4 * E * E + 2 * E * F;      // floats = 2 bf16 each: W16 and Wt16 of the block's four Linear weights
     o.w16 = take(o.w16_layer * (size_t)m->cfg.enc_depth); o.d_x16 = take(MS * E / 2 + 8); o.d_h16 = take(MS * F / 2 + 8);
     o.total = off;
@@ -860,6 +868,14 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     bf16_t* d_x16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_x16) : nullptr;
     bf16_t* d_h16 = shadows ? reinterpret_cast<bf16_t*>(w + o.d_h16) : nullptr;
     const bool segs = m->cfg.enc_depth >= 2;
+    const bool two_streams = only16 && !getenv("PARSEQ_TRAIN_ONE_STREAM");
+    hipStream_t side = nullptr;
+    if (two_streams) {
+        if (!m->train_side) HIPCHK(hipStreamCreateWithFlags(&m->train_side, hipStreamNonBlocking));
+        for (hipEvent_t& e : m->train_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        side = m->train_side;
+    }
+    const TrainCtx cxs{side, w + o.scratch2, m->train_precision == PARSEQ_BF16, o.scratch_floats};
     m->grad_events_valid = false;
     if (segs) CHK(grad_event_record(m, 0, s));      // the decoder's gradients were written by parseq_train_decoder, earlier on this stream
     CHK(ln_bwd(cx, w + o.x_last, P("norm.weight"), dmemory, nullptr, d_x, G("norm.weight"), G("norm.bias"), tmp, MS, E, eps, d_x16));
@@ -871,6 +887,39 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
         if (shadows) {
             const bf16_t* n1 = reinterpret_cast<const bf16_t*>(x + o.n1); const bf16_t* n2 = reinterpret_cast<const bf16_t*>(x + o.n2);
             const bf16_t* ao16 = reinterpret_cast<const bf16_t*>(ao); const bf16_t* hact16 = reinterpret_cast<const bf16_t*>(x + o.hact_l);
+            if (two_streams) {
+                // The block's four weight-gradient products on the SECOND stream, beside the chain dX -> LayerNorm / attention backward -> dX that
+                // needs them for nothing: each starts when its dY exists (an event of the main stream) and is waited for only where the main
+                // stream is about to overwrite that dY (the residual-stream gradient's shadow d_x16) or closes the block.  Same kernels, same
+                // operands, same order inside every buffer: bit-identical to the one-stream schedule (PARSEQ_TRAIN_ONE_STREAM=1).
+                hipEvent_t* ev = m->train_ev;
+                const bf16_t* hpre16 = reinterpret_cast<const bf16_t*>(hpre);
+                bf16_t* dqkv16 = reinterpret_cast<bf16_t*>(dqkv);
+                HIPCHK(hipEventRecord(ev[0], s)); HIPCHK(hipStreamWaitEvent(side, ev[0], 0));                    // d_x16 of this block exists
+                CHK(lin_bwd16_dw(cxs, hact16, nullptr, d_x16, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), MS, E, F));
+                HIPCHK(hipEventRecord(ev[4], side));
+                CHK(lin_bwd16_dx(cx, enc_shadow_w(o, w, i, 3, E, F).wt, nullptr, d_x16, nullptr, d_h16, MS, E, F, nullptr, hpre16));
+                HIPCHK(hipEventRecord(ev[1], s)); HIPCHK(hipStreamWaitEvent(side, ev[1], 0));                    // d_h16 exists
+                CHK(lin_bwd16_dw(cxs, n2, nullptr, d_h16, G(p + "mlp.fc1.weight"), G(p + "mlp.fc1.bias"), MS, F, E));
+                CHK(lin_bwd16_dx(cx, enc_shadow_w(o, w, i, 2, E, F).wt, nullptr, d_h16, d_a, nullptr, MS, F, E));
+                HIPCHK(hipStreamWaitEvent(s, ev[4], 0));                                                          // fc2's dW has read d_x16
+                CHK(ln_bwd(cx, x_mid, P(p + "norm2.weight"), d_a, d_x, d_x, G(p + "norm2.weight"), G(p + "norm2.bias"), tmp, MS, E, eps, d_x16));
+                HIPCHK(hipEventRecord(ev[2], s)); HIPCHK(hipStreamWaitEvent(side, ev[2], 0));                    // the new d_x16 exists
+                CHK(lin_bwd16_dw(cxs, ao16, nullptr, d_x16, G(p + "attn.proj.weight"), G(p + "attn.proj.bias"), MS, E, E));
+                HIPCHK(hipEventRecord(ev[5], side));
+                CHK(lin_bwd16_dx(cx, enc_shadow_w(o, w, i, 1, E, F).wt, nullptr, d_x16, d_a, nullptr, MS, E, E));
+                TrainAttnArgs ab = enc_attn_args(m, qkv, ao, d_a, dqkv);
+                ab.dq16 = dqkv16; ab.dk16 = dqkv16 + E; ab.dv16 = dqkv16 + 2 * E;
+                CHK(train_attn(cx, ab, batch, true, ATT_HD));
+                HIPCHK(hipEventRecord(ev[3], s)); HIPCHK(hipStreamWaitEvent(side, ev[3], 0));                    // dqkv16 exists
+                CHK(lin_bwd16_dw(cxs, n1, nullptr, dqkv16, G(p + "attn.qkv.weight"), G(p + "attn.qkv.bias"), MS, 3 * E, E));
+                HIPCHK(hipEventRecord(ev[6], side));
+                CHK(lin_bwd16_dx(cx, enc_shadow_w(o, w, i, 0, E, F).wt, nullptr, dqkv16, d_a, nullptr, MS, 3 * E, E));
+                HIPCHK(hipStreamWaitEvent(s, ev[5], 0));                                                          // proj's dW has read d_x16
+                CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps, d_x16));
+                HIPCHK(hipStreamWaitEvent(s, ev[6], 0));       // the block's gradients are final on the main stream too (the segment event that follows covers them)
+                continue;
+            }
             if (only16) {
                 CHK(lin_bwd16(cx, hact16, enc_shadow_w(o, w, i, 3, E, F).wt, nullptr, d_x16, G(p + "mlp.fc2.weight"), G(p + "mlp.fc2.bias"), nullptr, d_h16, MS, E, F,
                               nullptr, reinterpret_cast<const bf16_t*>(hpre)));

@@ -921,6 +921,44 @@ def test_one_launch_training_forward_against_the_per_operation_forward():
 
 
 @pytest.mark.gpu
+def test_two_stream_backward_changes_no_bit():
+    """Round 5: in the bf16-operand mode parseq_train_encoder_backward runs the blocks' weight-gradient products on a second stream beside
+    the dX / LayerNorm / attention chain (events order the two; lib_train.hip).  Same kernels on the same operands in the same order per
+    buffer: loss and every gradient must equal the one-stream schedule (PARSEQ_TRAIN_ONE_STREAM=1) bit for bit — which they only do if no
+    product ever read a gradient buffer before its producer finished or after its next writer started.  Three runs of each, batch 48."""
+    import os
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import loss_and_grads
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    gen = torch.Generator().manual_seed(25)
+    images = synth_images(48, cfg, seed=27).to(DEV)
+    lengths = torch.randint(1, 26, (48,), generator=gen).tolist()
+    lengths[3] = 25
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+
+    def run():
+        m.rng = np.random.default_rng(8)
+        torch.manual_seed(9)
+        r = loss_and_grads(m, images, labels)
+        torch.cuda.synchronize()
+        return float(r.loss), {k: v.clone() for k, v in r.grads.items()}
+
+    assert 'PARSEQ_TRAIN_ONE_STREAM' not in os.environ
+    two = [run() for _ in range(3)]
+    os.environ['PARSEQ_TRAIN_ONE_STREAM'] = '1'
+    try:
+        one = run()
+    finally:
+        del os.environ['PARSEQ_TRAIN_ONE_STREAM']
+    for loss, grads in two:
+        assert loss == one[0]
+        diff = [k for k in grads if not torch.equal(grads[k], one[1][k])]
+        assert not diff, diff[:5]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('batch', [1, 3, 130])
 def test_one_launch_training_forward_at_ragged_batch_sizes(batch):
     """parseq_train_encoder_forward through the C ABI, one launch against per-operation launches, at batch sizes that leave most of the chip
