@@ -381,6 +381,7 @@ def main():
     ap.add_argument('--no-natural-exit', action='store_true', help='skip the natural-early-exit leg (natural_exit_value)')
     ap.add_argument('--no-throughput-mode', action='store_true', help='skip the bf16-operand leg (throughput_mode)')
     ap.add_argument('--no-config3', action='store_true', help='skip the BASELINE.json configs[3] leg (batch 1024, AR + 2 refine iters) reported as "config3"')
+    ap.add_argument('--no-latency', action='store_true', help='skip the batch-1 latency leg (the reference\'s published operating point: NAR + 3 refine iters) reported as "latency_b1_nar3"')
     ap.add_argument('--no-train', action='store_true', help='skip the short training-step leg (SURVEY.md section 8f row N3 / BASELINE.json configs[4]) reported as "train"')
     ap.add_argument('--force-dist', action='store_true', help='self-test: initialise the RCCL process group and run the collectives even with one rank')
     ap.add_argument('--repeats', type=int, default=5, help='repetitions of the K-step timed region; the median is reported, min / max alongside')
@@ -482,14 +483,21 @@ def main():
     # synchronise + barrier, MAX over ranks) and the MEDIAN repeat is the one reported; min / max show the spread, which on one box is
     # ~1 % and between boxes ~5 % (reference bench.py:43-49 reports median / IQR the same way).
     def repeated(mdl, x, in_flight, steps, warmup, repeats):
+        # Round 5's driver record of configs[3] read 40 % low because of two things fixed here: (1) a model's workspace slots (plan arena,
+        # weight pack, decoder tables) are created on the FIRST use of each slot, so the first repeat's warm-up must touch every slot at least
+        # once — warm-up is never fewer than in_flight + 1 steps; (2) with two repeats `sorted(runs)[n // 2]` is the maximum — at least three
+        # repeats are run and the median is the statistical one (mean of the two middle runs when n is even).
+        import statistics
+        repeats = repeats if repeats == 1 else max(repeats, 3)      # --repeats 1: profiling runs that want the fewest launches
         runs = []
         for r in range(repeats):
-            el, out_ = timed(mdl, x, in_flight, steps, warmup if r == 0 else 1)
+            el, out_ = timed(mdl, x, in_flight, steps, max(warmup, in_flight + 1) if r == 0 else 1)
             runs.append(el)
         srt = sorted(runs)
-        return srt[len(srt) // 2], out_, {'n': repeats, 'steps_each': steps, 'ms_per_step_min': round(1e3 * srt[0] / steps, 4),
-                                          'ms_per_step_median': round(1e3 * srt[len(srt) // 2] / steps, 4),
-                                          'ms_per_step_max': round(1e3 * srt[-1] / steps, 4)}
+        med = statistics.median(srt)
+        return med, out_, {'n': repeats, 'steps_each': steps, 'ms_per_step_min': round(1e3 * srt[0] / steps, 4),
+                           'ms_per_step_median': round(1e3 * med / steps, 4),
+                           'ms_per_step_max': round(1e3 * srt[-1] / steps, 4)}
 
     elapsed, out, spread = repeated(model, images, args.streams, args.steps, args.warmup, args.repeats)
     seq_elapsed, _, seq_spread = repeated(model, images, 1, args.steps, args.warmup, args.repeats) if args.streams > 1 else (elapsed, None, spread)
@@ -639,7 +647,7 @@ def main():
             result['throughput_mode'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0 and world == 1 and not STUB and not args.no_config3 and args.model == 'parseq' and not (B == 1024 and args.refine_iters == 2):
         # BASELINE.json configs[3] on the driver's record: PARSeq-S, 94-class charset, max_label_length 25, AR (26 steps forced) + 2 refinement iterations, batch 1024
-        # on one MI355X, in the timed precision — a short leg (5 steps per timed region, 2 repeats), in flight and one forward at a time, never part of `value`
+        # on one MI355X, in the timed precision — a short leg (5 steps per timed region, 3 repeats, every slot warmed first), in flight and one forward at a time, never part of `value`
         try:
             m3 = create_model(args.model, decode_ar=True, refine_iters=2, precision=args.precision)
             m3.model.load_state_dict(sd_cpu)
@@ -647,8 +655,8 @@ def main():
             g3 = torch.Generator().manual_seed(4242)
             x3 = (torch.rand(1024, 3, ih, iw, generator=g3) * 2 - 1).to(dev)
             x3 = x3.bfloat16() if args.precision == 'bf16' else x3
-            e3, o3, sp3 = repeated(m3, x3, args.streams, 5, 2, 2)
-            e31, _, sp31 = repeated(m3, x3, 1, 5, 1, 2)
+            e3, o3, sp3 = repeated(m3, x3, args.streams, 5, args.streams + 1, 3)
+            e31, _, sp31 = repeated(m3, x3, 1, 5, 2, 3)
             result['config3'] = {'workload': f'BASELINE.json configs[3]: {args.model} {args.precision}, batch 1024, AR (26 steps forced) + 2 refine iters, {len(m3.hparams.charset_train)}-class charset, '
                                              f'max_label_length {m3.hparams.max_label_length}', 'value': round(1024 * 5 / e3, 1), 'sequential_value': round(1024 * 5 / e31, 1), 'unit': 'images/s',
                                  'ms_per_step': round(1e3 * e3 / 5, 3), 'sequential_ms_per_step': round(1e3 * e31 / 5, 3), 'steps': 5, 'steps_in_flight': args.streams,
@@ -656,6 +664,37 @@ def main():
             del m3, x3
         except Exception as e:
             result['config3'] = {'error': f'{type(e).__name__}: {e}'}
+    if rank == 0 and world == 1 and not STUB and not args.no_latency and args.model == 'parseq':
+        # The reference's ONLY published operating point for this path (README.md:214-219): `./bench.py model=parseq model.decode_ar=false
+        # model.refine_iters=3` -> batch 1, one 32 x 128 crop of torch.rand, `benchmark.Timer(stmt='model(x)').blocked_autorange(min_run_time=1)`
+        # under torch.inference_mode (bench.py:25,38,45-48): median 14.87 ms, IQR 0.33 ms, hardware not stated.  Timed here the same way, in the
+        # timed precision; vs_baseline = 14.87 ms / this median (> 1: faster than the published sample).  The default decode mode (AR + 1
+        # refinement) at batch 1 is timed beside it.  Never part of `value`.
+        try:
+            from torch.utils import benchmark
+            lat = {'method': "torch.utils.benchmark.Timer(stmt='model(x)').blocked_autorange(min_run_time=1), batch 1, x = torch.rand(1, 3, 32, 128) on the device "
+                             '(reference bench.py:38-48)', 'dtype': args.precision,
+                   'published': {'median_ms': 14.87, 'iqr_ms': 0.33, 'source': 'reference README.md:214-219 (decode_ar=false refine_iters=3)', 'hardware': 'not stated by the reference'}}
+            x1 = torch.rand(1, 3, ih, iw, device=dev)
+            x1 = x1.bfloat16() if args.precision == 'bf16' else x1
+            for key, ar, ri in (('nar3', False, 3), ('ar1', True, 1)):
+                ml = create_model(args.model, decode_ar=ar, refine_iters=ri, precision=args.precision)
+                ml.model.load_state_dict(sd_cpu)
+                ml = ml.eval().to(dev)
+                with torch.inference_mode():
+                    for _ in range(3):
+                        o1 = ml(x1)
+                    torch.cuda.synchronize()
+                    meas = benchmark.Timer(stmt='model(x)', globals={'model': ml, 'x': x1}).blocked_autorange(min_run_time=1)
+                lat[key] = {'decode_ar': ar, 'refine_iters': ri, 'median_ms': round(meas.median * 1e3, 4), 'iqr_ms': round(meas.iqr * 1e3, 4),
+                            'measurements': len(meas.times), 'runs_per_measurement': meas.number_per_run, 'output_shape': list(o1.shape),
+                            'images_per_s': round(1.0 / meas.median, 1)}
+                del ml
+            lat['vs_baseline'] = round(14.87 / lat['nar3']['median_ms'], 3)
+            lat['vs_baseline_note'] = 'published 14.87 ms / measured median of the same mode (time-like: > 1 means faster); the reference does not say what device its sample ran on'
+            result['latency_b1_nar3'] = lat
+        except Exception as e:
+            result['latency_b1_nar3'] = {'error': f'{type(e).__name__}: {e}'}
     if not args.no_train and args.model == 'parseq' and not (STUB and world == 1):
         # Row N3 on the driver's record (never part of `value`): the training step of BASELINE.json configs[4] — 384 crops per GPU, K = 6
         # permutations, dropout 0.1, forward + backward + (N > 1: gradient all-reduce) + clip + AdamW in the bf16-operand mode — two warm-up

@@ -287,7 +287,11 @@ int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* to
  * fp32 from the master weights that keeps in `workspace` what the backward needs (per block: the residual stream before
  * it, qkv, the attention output, the stream after the attention residual, the fc1 pre-activation), and the backward from
  * `dmemory` (parseq_train_decoder) to the gradient of every encoder.* parameter, ACCUMULATED into `grads`.
- * images: device fp32 [batch, 3, H, W], normalised as the reference's transform leaves them. */
+ * images: device fp32 [batch, 3, H, W], normalised as the reference's transform leaves them.
+ * Streams: in the bf16-operand mode parseq_train_encoder_backward runs the blocks' weight-gradient products on a second, library-owned
+ * non-blocking stream beside the chain on `stream` (PARSEQ_TRAIN_ONE_STREAM=1 turns that off).  Every block ends with `stream` waiting
+ * for it, so on return everything is ordered behind `stream` as usual — on an error return as well: a failure inside a block
+ * synchronises the second stream before it is reported, so `grads` and `workspace` are not in use behind the caller's back. */
 size_t parseq_train_encoder_workspace_bytes(const parseq_model* m, int batch);
 int parseq_train_encoder_forward(parseq_model* m, const float* images, int batch, float* memory_out, void* workspace,
                                  size_t workspace_bytes, void* stream);

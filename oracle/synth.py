@@ -122,6 +122,17 @@ def state_dict_fingerprint(sd) -> float:
     return acc
 
 
+CHARSET_36 = "0123456789abcdefghijklmnopqrstuvwxyz"                       # configs/charset/36_lowercase.yaml:3 (a fact, restated)
+CHARSET_62 = CHARSET_36 + "ABCDEFGHIJKLMNOPQRSTUVWXYZ"                      # configs/charset/62_mixed-case.yaml:3
+
+
+def charset_config(base: OracleConfig, charset: str, **overrides) -> OracleConfig:
+    """The model shape `Tokenizer(charset)` implies (strhub/data/utils.py:101-111: [E] = 0, the characters, [B], [P])."""
+    import dataclasses
+    n = len(charset)
+    return dataclasses.replace(base, num_tokens=n + 3, bos_id=n + 1, pad_id=n + 2, **overrides)
+
+
 CONFIGS = {
     # configs/model/parseq.yaml:5-14 + configs/main.yaml:9-10 + configs/charset/94_full.yaml (94 chars -> 97 tokens)
     'parseq': OracleConfig(),
@@ -130,3 +141,23 @@ CONFIGS = {
     # configs/experiment/parseq-patch16-224.yaml:5-7 (row N4): 14 x 14 = 196 visual tokens, 768-wide patches
     'parseq-patch16-224': OracleConfig(img_size=(224, 224), patch_size=(16, 16)),
 }
+
+# Configurations reached through the hub keyword arguments the reference accepts (strhub/models/utils.py:41 `config.update(kwargs)`):
+# name -> (experiment, keyword overrides, EOS bias of the synthetic head: narrower heads need less of it for [E] to land at mixed
+# positions).  Goldens: oracle/make_golden_hub.py -> tests/golden/<name>.*; the name is NOT an experiment — build with
+# create_model(experiment, **overrides) and load variant_state_dict(name).
+HUB_VARIANTS = {
+    'parseq_c36_len10': ('parseq', {'charset_train': CHARSET_36, 'max_label_length': 10}, 0.5),
+    'parseq_c62': ('parseq', {'charset_train': CHARSET_62}, 1.25),
+    'parseq-tiny_c62_len10': ('parseq-tiny', {'charset_train': CHARSET_62, 'max_label_length': 10}, 1.5),
+}
+
+
+def variant_config(name: str) -> OracleConfig:
+    experiment, kw, _ = HUB_VARIANTS[name]
+    extra = {'max_label_length': kw['max_label_length']} if 'max_label_length' in kw else {}
+    return charset_config(CONFIGS[experiment], kw['charset_train'], **extra)
+
+
+def variant_state_dict(name: str, seed: int = 0):
+    return synth_state_dict(variant_config(name), seed, eos_bias=HUB_VARIANTS[name][2])

@@ -216,6 +216,18 @@ __device__ __forceinline__ void rec_store_pair(const RecCtx& rc, int ln, unsigne
     rec_store16(rc, voff, soff, lo_half ? A : got);
     rec_store16(rc, voff, soff + 8u * pitch_b, lo_half ? got : B);
 }
+// Record stores a wave issues BEHIND the LDS-DMA pieces of a ring triple: the ring-stage waits count them (vmcnt retires loads and stores
+// in issue order on gfx9, so "all but the N youngest" lets exactly these stay in flight).  The waits are written in these constants and
+// the loops that issue the stores are static_assert'ed against them — a change to a store helper cannot silently loosen a wait.
+constexpr int kRecStoresPerPair = 2;                                    // rec_store_pair: two buffer_store_b128
+constexpr int kRecRowTiles = 2;                                         // 16-row tiles per wave (32 rows)
+template <int E> constexpr int kRecStoresFrag = kRecRowTiles * (E / 64) * kRecStoresPerPair;      // rec_store_frag: a LayerNorm output (24 at E = 384)
+constexpr int kRecStoresQK = kRecRowTiles * 2 * kRecStoresPerPair;      // q or k epilogue of a head: 2 column pairs per row tile (8)
+constexpr int kRecStoresV = 4 * kRecRowTiles * 4;                       // v epilogue of a head: 4 column groups x 2 row tiles x 4 b32 stores (32)
+constexpr int kRecStoresAO = kRecRowTiles * kRecStoresPerPair;          // a head's attention output (4)
+constexpr int kRecStoresMlpChunk = kRecRowTiles * 2 * kRecStoresPerPair;   // pre-activation + GELU of a 64-wide hidden chunk (8)
+constexpr int kTriplePieces = 12;                                       // LDS-DMA pieces per wave of one triple of 16 KiB stages
+static_assert(kRecStoresFrag<384> == 24 && kRecStoresQK == 8 && kRecStoresV + kRecStoresAO == 36 && kRecStoresMlpChunk == 8, "record-mode store counts");
 __device__ __forceinline__ u32x4 rec_bits(const bf16x8& v) { return __builtin_bit_cast(u32x4, v); }
 // bf16 operand fragments (lane (r16, g), row tile j, k-step ks: columns 32 ks + 8 g + [0, 8) of row 32 wid + 16 j + r16) -> [rows][E] bf16 at `slot`
 template <int E>
@@ -398,9 +410,9 @@ __device__ __forceinline__ void attn_phase(unsigned char* ring, unsigned char* k
             // triple's epilogue (q: 8, k: 8, v and the attention output: 32 + 4), before head 0 the 24 of LayerNorm1's output — may stay in
             // flight (vmcnt retires loads and stores in issue order on gfx9); waiting for them too would expose a write's latency per triple
             if constexpr (!REC) eb_wait_vmcnt<0>();
-            else if constexpr (u == 0) { if (h == 0) eb_wait_vmcnt<2 * (E / 32)>(); else eb_wait_vmcnt<0>(); }
-            else if constexpr (u == 3) eb_wait_vmcnt<36>();
-            else eb_wait_vmcnt<8>();
+            else if constexpr (u == 0) { if (h == 0) eb_wait_vmcnt<kRecStoresFrag<E>>(); else eb_wait_vmcnt<0>(); }
+            else if constexpr (u == 3) eb_wait_vmcnt<kRecStoresV + kRecStoresAO>();
+            else eb_wait_vmcnt<kRecStoresQK>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -583,7 +595,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         for (int i = 0; i < 4; ++i) { acc1[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // ---- fc1 triple: in flight behind it is only this chunk's fc2 triple (12 pieces per wave) — and, in record mode before chunk 0,
         // the 24 stores of LayerNorm2's output issued behind the prefetch
-        if (REC && c == 0) eb_wait_vmcnt<12 + 2 * (E / 32)>(); else eb_wait_vmcnt<12>();
+        if (REC && c == 0) eb_wait_vmcnt<kTriplePieces + kRecStoresFrag<E>>(); else eb_wait_vmcnt<kTriplePieces>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -631,7 +643,7 @@ __device__ __forceinline__ void mlp_phase(unsigned char* ring, const float* sb1,
         gcur = gcur == 2 ? 0 : gcur + 1;
         // ---- fc2 triple: in flight behind it is only the next chunk's fc1 triple
         // (record mode: plus this chunk's 8 stores of the pre-activation and its GELU, issued behind the next chunk's fc1 pieces)
-        if (more) eb_wait_vmcnt<REC ? 20 : 12>(); else eb_wait_vmcnt<REC ? 8 : 0>();
+        if (more) eb_wait_vmcnt<kTriplePieces + (REC ? kRecStoresMlpChunk : 0)>(); else eb_wait_vmcnt<REC ? kRecStoresMlpChunk : 0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");

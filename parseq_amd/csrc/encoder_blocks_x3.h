@@ -26,8 +26,8 @@
 namespace pq {
 namespace x3 {
 
-// (The timing ablations, in-kernel phase timers and scheduling switches of this kernel live in its lab copy, tools/microbench/x3_lab.h:
-// tools/x3_variants.sh builds that, tools/x3_variant_bench.py times the builds; profiles/r04_x3_encoder_variants.md has the results.)
+// (The timing ablations, in-kernel phase timers and scheduling switches of this kernel lived in a lab copy removed in round 6 (`git show 186cd8e:tools/microbench/x3_lab.h`, built by tools/x3_variants.sh and timed by tools/x3_variant_bench.py of the same commit):
+// profiles/r04_x3_encoder_variants.md has the results.)
 #ifndef X3_MLP_RING
 #define X3_MLP_RING 3          // pair groups of proj and the tail (the MLP phase itself runs triples: MLP_RING_B)
 #endif

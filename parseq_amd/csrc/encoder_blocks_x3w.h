@@ -9,7 +9,7 @@
 // launches, batch 512, same box; profiles/r05_x3w_encoder.md) — the two waves run the SAME program between the SAME barriers, so a wave's GELU
 // block still finds only its partner's share of one group of MFMAs to hide under.  What was tried on top and did not pay (asymmetric GELU
 // placement with static priorities, a step-major GELU, a producer / consumer split of the MLP phase — half the waves fc1 + GELU, half fc2) is
-// recorded in profiles/r05_x3w_encoder.md and kept buildable in tools/microbench/x3w_lab.h.
+// recorded in profiles/r05_x3w_encoder.md (the lab copy of this kernel that carried their switches was removed in round 6: `git show 186cd8e:tools/microbench/x3w_lab.h`).
 // The price of 16 rows per wave is LDS traffic — a (hi, lo) weight-fragment pair feeds THREE MFMAs instead of six: 2 KiB per 48 clk per
 // SIMD = 170 B/clk of the LDS's 256 B/clk for ds_read_b128 — and a register budget of 256 per lane: x (96) + the LayerNorm'd (hi, lo)
 // operand (96) leave 64 for the accumulators of the running chunk, weight fragments and addresses.

@@ -282,9 +282,9 @@ struct parseq_plan {
     bool mlp_resident = getenv("PARSEQ_MLP_RELOAD") == nullptr;    // diagnostics: the fused MLP's first form (x re-read by the epilogue)
     bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h
     bool fused_x3 = getenv("PARSEQ_NO_FUSED_X3") == nullptr;
+         // diagnostics: bf16x3 encoder through the per-op kernels instead of encoder_blocks_x3.h
     bool x3_four_waves = getenv("PARSEQ_X3_FOUR_WAVES") != nullptr;
          // diagnostics: the bf16x3 one-launch encoder on four waves of 32 rows (encoder_blocks_x3.h) instead of eight of 16 (encoder_blocks_x3w.h); bit-identical results
-         // diagnostics: bf16x3 encoder through the per-op kernels instead of encoder_blocks_x3.h
     EncBlockParams* blocks_dev = nullptr;                           // [enc_depth] parameter pointers of encoder_blocks.h (bf16 mode)
     std::vector<EncBlockParams> blocks_host;                        // source of the asynchronous upload (must outlive it)
     EncTailParams enc_tail{0, 0, 0, 0, nullptr, nullptr, 0};        // final norm + memory K / V projection inside the one-launch encoder (offsets; pointers filled per call)

@@ -627,7 +627,9 @@ static TrainEncoderLayout train_encoder_layout(const parseq_model* m, int B) {
     off = o.layer0 + o.layer_stride * (size_t)m->cfg.enc_depth;
     o.x_last = take(MS * E); o.n = take(MS * E); o.hact = take(MS * F); o.d_x = take(MS * E); o.d_a = take(MS * E); o.d_h = take(MS * F);
     o.dqkv = take(MS * 3 * E); o.tmp = take(MS * E);
-    o.scratch_floats = train_scratch_floats(MS, E); o.scratch = take(o.scratch_floats); o.scratch2 = take(o.scratch_floats);
+    o.scratch_floats = train_scratch_floats(MS, E); o.scratch = take(o.scratch_floats);
+    // the second scratch belongs to the backward's second stream, which only the bf16-operand mode has (the fp32 mode carves nothing for it)
+    o.scratch2 = m->train_precision == PARSEQ_BF16 ? take(o.scratch_floats) : o.scratch;
     o.w16_layer = 4 * E * E + 2 * E * F;      // floats = 2 bf16 each: W16 and Wt16 of the block's four Linear weights
     o.w16 = take(o.w16_layer * (size_t)m->cfg.enc_depth); o.d_x16 = take(MS * E / 2 + 8); o.d_h16 = take(MS * F / 2 + 8);
     o.total = off;
@@ -732,9 +734,15 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
                                               tile, (unsigned long long)(sw.w - reinterpret_cast<bf16_t*>(w + o.w16))});
                     tile += (unsigned)((wn[j] / 32) * (wk[j] / 32));
                 }
-            HIPCHK(hipMalloc(&m->shadow_tab_dev, tab.size() * sizeof(ShadowEntry)));
-            HIPCHK(hipMemcpy(m->shadow_tab_dev, tab.data(), tab.size() * sizeof(ShadowEntry), hipMemcpyHostToDevice));
+            // published only when valid: a failed upload must not leave a non-null table of garbage offsets behind for the next call
+            void* dev = nullptr;
+            HIPCHK(hipMalloc(&dev, tab.size() * sizeof(ShadowEntry)));
+            if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(ShadowEntry), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(dev);
+                return fail(PARSEQ_E_HIP, "upload of the weight-shadow table failed: %s", hipGetErrorString(hipGetLastError()));
+            }
             m->shadow_tiles = (int)tile;
+            m->shadow_tab_dev = dev;
         }
         hipLaunchKernelGGL(weight_shadows_kernel, dim3(m->shadow_tiles), dim3(256), 0, s, m->master, reinterpret_cast<const ShadowEntry*>(m->shadow_tab_dev),
                            4 * m->cfg.enc_depth, reinterpret_cast<bf16_t*>(w + o.w16));
@@ -756,8 +764,13 @@ extern "C" int parseq_train_encoder_forward(parseq_model* m, const float* images
                 e.ln2_w = off(b + "norm2.weight"); e.ln2_b = off(b + "norm2.bias"); e.b1 = off(b + "mlp.fc1.bias"); e.b2 = off(b + "mlp.fc2.bias");
                 e.wqkv = w0; e.wproj = w0 + 6 * EE; e.w1 = w0 + 8 * EE; e.w2 = w0 + 8 * EE + 2 * EF;       // enc_shadow_w's W16 of each pair
             }
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&m->train_blocks_dev), depth * sizeof(EncBlockParams)));
-            HIPCHK(hipMemcpy(m->train_blocks_dev, tab.data(), depth * sizeof(EncBlockParams), hipMemcpyHostToDevice));
+            EncBlockParams* dev = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), depth * sizeof(EncBlockParams)));
+            if (hipMemcpy(dev, tab.data(), depth * sizeof(EncBlockParams), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(dev);
+                return fail(PARSEQ_E_HIP, "upload of the training block table failed: %s", hipGetErrorString(hipGetLastError()));
+            }
+            m->train_blocks_dev = dev;
         }
         const EncBlockParams* tab = m->train_blocks_dev;
         const EncRecordParams rec{w + o.layer0, o.layer_stride, (unsigned)(o.layer_stride * sizeof(float)), (unsigned)(o.qkv * 4), (unsigned)(o.ao * 4),
@@ -892,6 +905,9 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
                 // needs them for nothing: each starts when its dY exists (an event of the main stream) and is waited for only where the main
                 // stream is about to overwrite that dY (the residual-stream gradient's shadow d_x16) or closes the block.  Same kernels, same
                 // operands, same order inside every buffer: bit-identical to the one-stream schedule (PARSEQ_TRAIN_ONE_STREAM=1).
+                // (an error return inside the block must not leave weight-gradient kernels running on the hidden stream behind the caller's back:
+                // the block is a lambda and a failure joins the side stream before it is reported)
+                auto block = [&]() -> int {
                 hipEvent_t* ev = m->train_ev;
                 const bf16_t* hpre16 = reinterpret_cast<const bf16_t*>(hpre);
                 bf16_t* dqkv16 = reinterpret_cast<bf16_t*>(dqkv);
@@ -918,6 +934,13 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
                 HIPCHK(hipStreamWaitEvent(s, ev[5], 0));                                                          // proj's dW has read d_x16
                 CHK(ln_bwd(cx, x, P(p + "norm1.weight"), d_a, d_x, d_x, G(p + "norm1.weight"), G(p + "norm1.bias"), tmp, MS, E, eps, d_x16));
                 HIPCHK(hipStreamWaitEvent(s, ev[6], 0));       // the block's gradients are final on the main stream too (the segment event that follows covers them)
+                return 0;
+                };
+                const int rc = block();
+                if (rc) {
+                    (void)hipStreamSynchronize(side);          // whatever was enqueued there has finished with `grads` and the workspace before the caller hears of the failure
+                    return rc;
+                }
                 continue;
             }
             if (only16) {

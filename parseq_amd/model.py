@@ -341,8 +341,9 @@ class _NativeBacked(nn.Module):
             cap = max(8, 1 << (batch - 1).bit_length())
             handle = C.c_void_p(0)
             with torch.cuda.device(self._device):
-                if os.environ.get('PARSEQ_PLAN_ALLOCATOR', 'hip') == 'torch':
-                    # the plan's arena as a block of torch's caching allocator (parseq_plan_create_ex) instead of a hipMalloc outside it
+                if os.environ.get('PARSEQ_PLAN_ALLOCATOR', 'torch') == 'torch':
+                    # the plan's arena is a block of the CALLER's allocator — torch's caching allocator (parseq_plan_create_ex; SURVEY.md section 8(b)'s
+                    # ownership clause) — the default since round 6; PARSEQ_PLAN_ALLOCATOR=hip opts out to a hipMalloc outside it
                     if getattr(st, 'allocator', None) is None:
                         st.allocator = _native.TorchPlanAllocator(self._device)
                     _native.check(lib.parseq_plan_create_ex(st.model, cap, code, _native.stream_ptr(self._device), st.allocator.alloc_ptr, st.allocator.release_ptr,

@@ -47,7 +47,10 @@ def create_model(experiment: str, pretrained: bool = False, **kwargs):
         raise InvalidModelError(f"No configuration found for '{experiment}'") from None
     system = _get_model_class(experiment)(**config)
     if pretrained:
-        system.model.load_state_dict(get_pretrained_weights(experiment))
+        # utils.py:80-82: the released PARSeq files hold the INNER model's keys, every other released file (ViTSTR) the system's
+        # ('model.'-prefixed) keys
+        target = system.model if 'parseq' in experiment else system
+        target.load_state_dict(get_pretrained_weights(experiment))
     return system
 
 

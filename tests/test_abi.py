@@ -184,10 +184,10 @@ def test_plan_arena_through_the_callers_allocator(monkeypatch):
     from oracle.synth import CONFIGS, synth_images
     from parseq_amd import _native
     x = synth_images(16, CONFIGS['parseq'], seed=5).to(DEV)
-    monkeypatch.delenv('PARSEQ_PLAN_ALLOCATOR', raising=False)
+    monkeypatch.setenv('PARSEQ_PLAN_ALLOCATOR', 'hip')        # the opt-out: a hipMalloc outside torch's allocator
     with torch.inference_mode():
         want = make_model('parseq', 'bf16x3')(x, 25).float().clone()
-    monkeypatch.setenv('PARSEQ_PLAN_ALLOCATOR', 'torch')
+    monkeypatch.delenv('PARSEQ_PLAN_ALLOCATOR')               # the default (round 6): torch's caching allocator
     m = make_model('parseq', 'bf16x3')
     before = torch.cuda.memory_allocated()
     with torch.inference_mode():
@@ -206,3 +206,49 @@ def test_plan_arena_through_the_callers_allocator(monkeypatch):
     assert lib.parseq_plan_create_ex(st.model, 8, _native.PARSEQ_BF16, _native.stream_ptr(x), alloc.alloc_ptr, None, None, C.byref(handle)) != 0 and not handle.value
     st.release()
     assert alloc.bytes_out == 0 and not alloc.blocks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['bf16x3', 'bf16', 'fp32'])
+def test_plan_arena_recycled_from_a_poisoned_block(precision, monkeypatch):
+    """The caller's allocator hands out RECYCLED memory: a caching allocator's block holds whatever its previous owner left (NaNs, old
+    activations).  Nothing in a plan may rely on a zero-initialised arena — padding rows of ragged row tiles, partially written tables,
+    counters.  A tensor of exactly the arena's size is filled with 0xFF bytes (NaN as f32 and as bf16, -1 as an integer), freed, and the plan
+    created next gets that block back; every decode mode on a ragged batch must equal the run on a fresh hipMalloc'ed arena bit for bit."""
+    import torch
+    from gpu_util import DEV, make_model
+    from oracle.synth import CONFIGS, synth_images
+    from parseq_amd import _native
+    x = synth_images(13, CONFIGS['parseq'], seed=6).to(DEV)
+    cases = [(True, 1, 25), (True, 0, None), (False, 2, None), (True, 2, 7)]
+
+    def run(m, **kw):
+        outs = []
+        for ar, ri, ml in cases:
+            m.model.decode_ar, m.model.refine_iters = ar, ri
+            with torch.inference_mode():
+                outs.append(m(x, ml, **kw).float().clone())
+        torch.cuda.synchronize()
+        return outs
+    monkeypatch.setenv('PARSEQ_PLAN_ALLOCATOR', 'hip')
+    ref = make_model('parseq', precision)
+    want, want_slot = run(ref), run(ref, slot=1)
+    monkeypatch.delenv('PARSEQ_PLAN_ALLOCATOR')
+    probe = make_model('parseq', precision)
+    run(probe)
+    st = probe.model._native_state
+    sizes = {lib_bytes for lib_bytes in (_native.lib().parseq_plan_workspace_bytes(plan) for plan, _ in st.plans.values())}
+    st.release()
+    del probe
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    poison = [torch.full((n,), 0xFF, dtype=torch.uint8, device=DEV) for n in sizes for _ in range(2)]
+    ptrs = {t.data_ptr() for t in poison}
+    torch.cuda.synchronize()
+    del poison                                   # back to the caching allocator, contents intact
+    m = make_model('parseq', precision)
+    got, got_slot = run(m), run(m, slot=1)
+    reused = {t.data_ptr() for t in m.model._native_state.allocator.blocks.values()}
+    assert reused & ptrs, 'the caching allocator did not hand the poisoned blocks back: the test did not test anything'
+    for a, b in zip(got + got_slot, want + want_slot):
+        assert not torch.isnan(a).any() and torch.equal(a, b)

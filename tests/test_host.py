@@ -112,3 +112,24 @@ def test_product_code_never_imports_the_oracle():
             head = src[:m.start()]
             last_def = re.findall(r'^def (\w+)\(', head, re.M)[-1]
             assert last_def == func, (name, last_def)
+
+
+@pytest.mark.parametrize('experiment', ['parseq-tiny', 'vitstr'])
+def test_pretrained_weights_go_where_the_reference_puts_them(experiment, monkeypatch):
+    """`create_model(experiment, pretrained=True)` (strhub/models/utils.py:80-82): the released PARSeq files carry the INNER model's
+    keys and are loaded into `system.model`; every other released file (ViTSTR) carries the system's 'model.'-prefixed keys and is
+    loaded into the system.  The download is replaced by a state dict of the released files' key layout."""
+    import torch
+    from parseq_amd import utils
+    donor = utils.create_model(experiment)
+    gen = torch.Generator().manual_seed(5)
+    inner = {k: torch.randn(v.shape, generator=gen) for k, v in donor.model.state_dict().items()}
+    released = inner if 'parseq' in experiment else {'model.' + k: v for k, v in inner.items()}
+    monkeypatch.setattr(utils, 'get_pretrained_weights', lambda name: released)
+    m = utils.create_model(experiment, pretrained=True)
+    for k, v in m.model.state_dict().items():
+        assert torch.equal(v, inner[k]), k
+    wrong = {'model.' + k: v for k, v in inner.items()} if 'parseq' in experiment else inner
+    monkeypatch.setattr(utils, 'get_pretrained_weights', lambda name: wrong)
+    with pytest.raises(RuntimeError):          # the other layout is refused, as the reference's strict load would
+        utils.create_model(experiment, pretrained=True)

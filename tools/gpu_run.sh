@@ -9,16 +9,15 @@
 #   seqprof          rocprofv3 kernel stats of bench.py --streams 1 (one forward at a time), exact mode and bf16 mode
 #   sq <kernel-substring> [bench args]   SQ counter passes over bench.py --steps 1 for one kernel (tools/pmc_generic.py)
 #   tcc              L2 hit / miss and memory-side request counters for the decoder kernels and the encoder
-#   x3v <builds...>  builds of the bf16x3 encoder against each other (tools/x3_variants.sh -> parseq_amd/lib/x3v/*.so)
 #   train            training tests, tools/train_bench.py, kernel stats of a step; `train pmc` adds the counter passes
 #   configs          bench.py on the other BASELINE / model configurations
 #   scale [N ...]    tools/scale_curve.py: bench.py --gpus N for N in 1 2 4 8 (or the given list) -> profiles/scale.json (needs a multi-GPU box; an N the box cannot serve is recorded as refused)
 set -x
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 task=$1; shift
-QUICK="--steps 30 --warmup 5 --repeats 3 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3"
+QUICK="--steps 30 --warmup 5 --repeats 3 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3 --no-latency"
 headline() { python - "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
@@ -46,7 +45,7 @@ ab)
 import json,sys; d=json.loads(sys.stdin.read()); print('$name: value', d['value'], 'seq', d['sequential_value'])"
   done ;;
 profiles)
-  P="--steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3"
+  P="--steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3 --no-latency"
   for prec in bf16x3 bf16; do
     rm -rf gpurun_out/prof_$prec
     timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$prec -o p -- python bench.py --precision $prec $P > gpurun_out/prof_$prec.log 2>&1
@@ -60,7 +59,7 @@ profiles)
     rm -rf gpurun_out/prof_$prec gpurun_out/pmc_${prec}_*
   done ;;
 seqprof)   # kernel stats of one forward at a time (--streams 1: the latency form of the AR step), both matrix-core modes
-  P="--steps 5 --warmup 2 --repeats 1 --streams 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3"
+  P="--steps 5 --warmup 2 --repeats 1 --streams 1 --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3 --no-latency"
   for prec in bf16x3 bf16; do
     rm -rf gpurun_out/prof_$prec
     timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$prec -o p -- python bench.py --precision $prec $P > gpurun_out/prof_$prec.log 2>&1
@@ -84,8 +83,6 @@ tcc)
   done
   for k in dec_cross_attn_ar enc_blocks dec_step_mid dec_step_mlp; do echo "== $k"; python tools/pmc_generic.py $k $(find gpurun_out/pmcc* -name "*results.db"); done | tee gpurun_out/${R}_tcc_counters.md
   rm -rf gpurun_out/pmcc[0-9]* ;;
-x3v)
-  X3_ROUNDS=${X3_ROUNDS:-7} timeout 600 python tools/x3_variant_bench.py "$@" 2>&1 | tee gpurun_out/x3_variants.log | tail -12 ;;
 train)
   timeout 1200 python -m pytest tests/test_training.py -m gpu -q --timeout 900 2>&1 | tail -3
   timeout 600 python tools/train_bench.py --steps 5 --warmup 2 2>/dev/null | tee gpurun_out/${R}_train_bench.json | cut -c1-300
