@@ -98,9 +98,11 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
     fp32 = make_model('fp32')                   # outside inference_mode: parameters must be ordinary (version-counted) tensors
     exact = fp32 if exact_prec == 'fp32' else (model if args.precision == exact_prec else make_model(exact_prec))
     with torch.inference_mode():
-        got = model(x, max_length).float()
+        # the timed precision's rows come out of a forward of the WHOLE timed batch (the kernels that were timed: a 64-crop call would take the
+        # library's small-batch route, lib_internal.h small_batch_max); every crop's result is independent of its batch neighbours
+        got = model(images, max_length).float()[:n]
         ref = fp32(x.float(), max_length).float()
-        exl = ref if exact is fp32 else exact(x.float(), max_length).float()
+        exl = ref if exact is fp32 else (got if exact is model else exact(images.float(), max_length).float()[:n])
         tok = model.tokenizer
         s_got, _ = tok.decode_logits(got)
         s_ref, _ = tok.decode_logits(ref)
@@ -123,7 +125,7 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
             keep = model.model.refine_iters, fp32.model.refine_iters
             try:
                 model.model.refine_iters = fp32.model.refine_iters = 0
-                ga, ra = model(x, 25).float(), fp32(x.float(), 25).float()
+                ga, ra = model(images, 25).float()[:n], fp32(x.float(), 25).float()
             finally:
                 model.model.refine_iters, fp32.model.refine_iters = keep
             t2 = ra.topk(2, -1).values
@@ -166,7 +168,7 @@ def parity_block(args, model, make_model, images, max_length, oracle_logits):
         try:
             model.model.decode_ar = fp32.model.decode_ar = False
             model.model.refine_iters = fp32.model.refine_iters = 0
-            g0, r0 = model(x, max_length).float(), fp32(x.float(), max_length).float()
+            g0, r0 = model(images, max_length).float()[:n], fp32(x.float(), max_length).float()
             out['nar_max_abs_vs_fp32'] = round(float((g0 - r0).abs().max()), 6)
             out['nar_argmax_agree'] = round(float((g0.argmax(-1) == r0.argmax(-1)).float().mean()), 6)
             top2 = r0.topk(2, -1).values
@@ -633,7 +635,7 @@ def main():
                 blk['kernel_families'], blk['roofline'] = profile_leg(tm, xb, 'bf16')
             with torch.inference_mode():
                 n = min(64, B)
-                got, ref = tm(xb[:n], max_length).float(), model(images[:n], max_length).float()
+                got, ref = tm(xb, max_length).float()[:n], model(images, max_length).float()[:n]
                 L = min(got.shape[1], ref.shape[1])
                 s_got, _ = tm.tokenizer.decode_logits(got)
                 s_ref, _ = model.tokenizer.decode_logits(ref)

@@ -24,7 +24,8 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
                                 E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128 &&
                                 p->wpe_off >= EB_HEAD_MIN_WPE;     // see EB_HEAD_MIN_WPE (always true with pos_embed ahead of the weight)
     // the same for the bf16x3 one-launch encoder (encoder_blocks_x3.h patch_head_x3; conditions of its launch below)
-    const bool head_x3 = sizeof(T) == 4 && g_split && p->fused_x3 && p->fused_blocks && p->fused_head && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 &&
+    const bool one_launch_x3 = p->fused_x3 && B > p->small_batch_max;      // small batches: per-operation launches (lib_internal.h small_batch_max)
+    const bool head_x3 = sizeof(T) == 4 && g_split && one_launch_x3 && p->fused_blocks && p->fused_head && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 &&
                          N == ATT_N && M % 128 == 0 && c.patch_h == 4 && c.patch_w == 8 && c.img_h == 32 && c.img_w == 128 && p->wpe_off >= x3::X3_HEAD_MIN_WPE;
     if (head_in_launch || head_x3) {
         // nothing here: x is produced inside the launch
@@ -101,7 +102,7 @@ static int encode_impl(parseq_plan* p, const TI* images, int B, float* memory_ou
         // bf16x3, PARSeq-S geometry: the twelve blocks — and, when nobody asked for `memory` itself, the final LayerNorm and the decoder's
         // K / V projection of it — in one launch with x resident in registers (encoder_blocks_x3w.h: eight waves of 16 rows; encoder_blocks_x3.h: four of 32); the MLP hidden buffer (idle on this
         // path) is the launch's per-image scratch (the parked residual stream and the attention output, 384 KiB per image)
-        if (g_split && p->fused_x3 && p->fused_blocks && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && M % 128 == 0) {
+        if (g_split && one_launch_x3 && p->fused_blocks && !m->vitstr && E == 384 && c.enc_mlp_ratio == 4 && N == ATT_N && M % 128 == 0) {
             const bool tail = p->fused_tail && memory_out == nullptr && c.dec_heads * DEC_HD == E;
             x3::EncTailX3 et{p->enc_tail.norm_w, p->enc_tail.norm_b, p->enc_tail.wkv, p->enc_tail.bkv, nullptr, nullptr, p->enc_tail.heads};
             if (tail) { et.kmem = reinterpret_cast<float*>(p->kmem); et.vmem = reinterpret_cast<float*>(p->vmem); }

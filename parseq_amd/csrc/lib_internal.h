@@ -283,6 +283,12 @@ struct parseq_plan {
     bool fused_blocks = getenv("PARSEQ_NO_FUSED_BLOCKS") == nullptr;   // diagnostics: one launch per branch instead of encoder_blocks.h
     bool fused_x3 = getenv("PARSEQ_NO_FUSED_X3") == nullptr;
          // diagnostics: bf16x3 encoder through the per-op kernels instead of encoder_blocks_x3.h
+    // The small-batch route (round 6): the one-launch bf16x3 encoder is one workgroup per image — a batch of B images occupies B of the 256
+    // compute units for a whole twelve-block walk (3.3 ms) however small B is.  Up to this batch size the encoder runs as per-operation
+    // launches instead, whose tiles spread one image's rows and columns over the device (profiles/r06_small_batch_route.md: batch 1
+    // 4.10 -> 1.90 ms AR + 1, 3.32 -> 1.08 ms NAR + 3; crossover between 64 and 128).  Same arithmetic (three bf16 products per
+    // product), another summation order: logits agree to 1e-5.  PARSEQ_SMALL_BATCH=<n> moves the threshold, 0 turns the route off.
+    int small_batch_max = [] { const char* e = getenv("PARSEQ_SMALL_BATCH"); const int v = e ? atoi(e) : 64; return v < 0 ? 0 : v; }();
     bool x3_four_waves = getenv("PARSEQ_X3_FOUR_WAVES") != nullptr;
          // diagnostics: the bf16x3 one-launch encoder on four waves of 32 rows (encoder_blocks_x3.h) instead of eight of 16 (encoder_blocks_x3w.h); bit-identical results
     EncBlockParams* blocks_dev = nullptr;                           // [enc_depth] parameter pointers of encoder_blocks.h (bf16 mode)

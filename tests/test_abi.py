@@ -213,8 +213,8 @@ def test_plan_arena_through_the_callers_allocator(monkeypatch):
 def test_plan_arena_recycled_from_a_poisoned_block(precision, monkeypatch):
     """The caller's allocator hands out RECYCLED memory: a caching allocator's block holds whatever its previous owner left (NaNs, old
     activations).  Nothing in a plan may rely on a zero-initialised arena — padding rows of ragged row tiles, partially written tables,
-    counters.  A tensor of exactly the arena's size is filled with 0xFF bytes (NaN as f32 and as bf16, -1 as an integer), freed, and the plan
-    created next gets that block back; every decode mode on a ragged batch must equal the run on a fresh hipMalloc'ed arena bit for bit."""
+    counters.  The allocator handed to parseq_plan_create_ex here fills every arena with 0xFF bytes (NaN as f32 and as bf16, -1 as an
+    integer) before the library sees it; every decode mode on a ragged batch must equal the run on a hipMalloc'ed arena bit for bit."""
     import torch
     from gpu_util import DEV, make_model
     from oracle.synth import CONFIGS, synth_images
@@ -230,25 +230,22 @@ def test_plan_arena_recycled_from_a_poisoned_block(precision, monkeypatch):
                 outs.append(m(x, ml, **kw).float().clone())
         torch.cuda.synchronize()
         return outs
+
+    class PoisonedBlocks(_native.TorchPlanAllocator):
+        def _do_alloc(self, nbytes, _user):
+            ptr = super()._do_alloc(nbytes, _user)
+            if ptr:
+                self.blocks[ptr].fill_(0xFF)
+                torch.cuda.synchronize()
+            return ptr
     monkeypatch.setenv('PARSEQ_PLAN_ALLOCATOR', 'hip')
     ref = make_model('parseq', precision)
     want, want_slot = run(ref), run(ref, slot=1)
     monkeypatch.delenv('PARSEQ_PLAN_ALLOCATOR')
-    probe = make_model('parseq', precision)
-    run(probe)
-    st = probe.model._native_state
-    sizes = {lib_bytes for lib_bytes in (_native.lib().parseq_plan_workspace_bytes(plan) for plan, _ in st.plans.values())}
-    st.release()
-    del probe
-    torch.cuda.synchronize()
-    torch.cuda.empty_cache()
-    poison = [torch.full((n,), 0xFF, dtype=torch.uint8, device=DEV) for n in sizes for _ in range(2)]
-    ptrs = {t.data_ptr() for t in poison}
-    torch.cuda.synchronize()
-    del poison                                   # back to the caching allocator, contents intact
     m = make_model('parseq', precision)
+    st = m.model._sync_native()
+    st.allocator = PoisonedBlocks(DEV)
     got, got_slot = run(m), run(m, slot=1)
-    reused = {t.data_ptr() for t in m.model._native_state.allocator.blocks.values()}
-    assert reused & ptrs, 'the caching allocator did not hand the poisoned blocks back: the test did not test anything'
+    assert st.allocator.calls == len(st.plans) == 2          # both arenas came through the poisoning allocator
     for a, b in zip(got + got_slot, want + want_slot):
         assert not torch.isnan(a).any() and torch.equal(a, b)

@@ -29,7 +29,7 @@ def main():
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
     out = {}
     batch = int(sys.argv[sys.argv.index('--batch') + 1]) if '--batch' in sys.argv else 512
-    print('| kernel | dispatches | FETCH_SIZE MB (raw / x2) | WRITE_SIZE MB | avg us (profiled) |')
+    print('| kernel | dispatches | FETCH_SIZE MiB (raw / x2) | WRITE_SIZE MiB | avg us (profiled) |')
     print('|---|---:|---:|---:|---:|')
     for k in sorted(fetch, key=lambda k: -fetch[k][0] * fetch[k][1]):
         n, f_kib, dur = fetch[k]
