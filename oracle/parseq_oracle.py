@@ -93,8 +93,16 @@ def _r(x: Tensor, rounding, site: str = '') -> Tensor:
     raise ValueError(rounding)
 
 
+# product emulations registered by studies (tools/cheap_exact_study.py): name -> f(x, w) = the value a candidate matrix-core scheme computes
+# for x W^T (e.g. integer-slice or scaled-fp8 products); selected per site with rounding = {'enc.prod': name} / {'dec.prod': name}
+PRODUCT_EMULATIONS = {}
+
+
 def _linear(x: Tensor, w: Tensor, b: Optional[Tensor], rounding, site: str = 'dec') -> Tensor:
     """y = x W^T + b with both GEMM operands rounded (fp32 accumulate), bias added in fp32."""
+    if isinstance(rounding, dict) and rounding.get(site + '.prod') is not None:
+        y = PRODUCT_EMULATIONS[rounding[site + '.prod']](x, w)
+        return y if b is None else y + b
     return F.linear(_r(x, rounding, site + '.act'), _r(w, rounding, site + '.w'), b)
 
 
