@@ -120,10 +120,30 @@ __device__ __forceinline__ float fast_erf(float x) {
     return copysignf(r, x);
 }
 
+#ifdef PQ_GELU_AS_WRITTEN      // the A/B of round 6: 0.5 x (1 + erf(x / sqrt 2)) through fast_erf, 16 VALU instructions per value
 __device__ __forceinline__ float gelu_erf(float x) {
     // exact-erf GELU (torch.nn.GELU() default / F.gelu): 0.5 x (1 + erf(x / sqrt(2)))
     return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f));
 }
+#else
+// exact-erf GELU (torch.nn.GELU() default / F.gelu), the same A & S 7.1.26 erf with the algebra done before the arithmetic (round 6: the
+// one-launch bf16x3 encoder is bound by the instructions it issues beside its MFMAs, and the GELU is one per MFMA of the MLP phase):
+//   0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| q(|x|),   q(u) = 0.5 P(t) t exp(-u^2 / 2),   t = 1 / (1 + (0.3275911 / sqrt 2) u)
+// — the 1 / sqrt 2 lives in the reciprocal's constant, the 0.5 in the polynomial's coefficients (exact: a power of two), exp(-u^2 / 2) is
+// one v_exp_f32 of -(u sqrt(0.5 log2 e))^2, and sign handling is the max: 13 VALU instructions per value (two of them transcendental)
+// instead of 16.  For x < 0 there is no 1 - (1 - small) cancellation any more: |error| <= 0.5 |x| 1.2e-7 as before, smaller in the left tail.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float u = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, u, 1.0f));
+    float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+    const float s = u * 0.84932180028801904272f;                     // sqrt(0.5 log2 e)
+    const float e = __builtin_amdgcn_exp2f(-(s * s));
+    return fmaf(-u, p * t * e, __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_inff()));      // med3(x, 0, inf) = max(x, 0) in one instruction
+}
+#endif
 
 // GELU for bf16-stored outputs: erf(z) = z * P(z^2) on |z| <= 3.5 (clamped; erf(3.5) = 1 - 7e-7), P of degree 9 from Chebyshev
 // interpolation — 13 full-rate FMAs / MULs that pack into v_pk_fma_f32, no transcendental.  |erf error| <= 7.2e-5,
