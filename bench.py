@@ -266,7 +266,7 @@ def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
     lengths = torch.randint(1, 26, (batch,), generator=g).tolist()
     lengths[0] = 25
     labels = [''.join(charset[int(i)] for i in torch.randint(0, len(charset), (n,), generator=g)) for n in lengths]
-    step = TrainStep(system, total_steps=steps + warmup + 1, num_devices=world)
+    step = TrainStep(system, total_steps=steps + warmup + 4, num_devices=world)
     for _ in range(warmup):
         step(images, labels)
     torch.cuda.synchronize()
@@ -327,6 +327,40 @@ def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
         del ws, mem
     except Exception as e:      # the step above is the measurement; this block is an annotation
         live = {'error': f'{type(e).__name__}: {e}'}
+    # the step's three library calls timed LIVE by this run (HIP events on the step's stream around each call, two extra steps after the timed ones)
+    phases = None
+    try:
+        from parseq_amd import _native
+        lib = _native.lib()
+        names = ['parseq_train_encoder_forward', 'parseq_train_decoder', 'parseq_train_encoder_backward', 'parseq_grad_norm', 'parseq_adamw_step']
+        originals = {n: getattr(lib, n) for n in names}
+        marks = []
+
+        def wrap(fn, name):
+            def call(*a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*a)
+                e1.record()
+                marks.append((name, e0, e1))
+                return rc
+            return call
+        for n in names:
+            setattr(lib, n, wrap(originals[n], n))
+        try:
+            n_ph = 2
+            for _ in range(n_ph):
+                step(images, labels)
+            torch.cuda.synchronize()
+        finally:
+            for n in names:
+                setattr(lib, n, originals[n])
+        phases = {}
+        for n, e0, e1 in marks:
+            phases[n] = phases.get(n, 0.0) + e0.elapsed_time(e1) / n_ph
+        phases = {k: round(v, 3) for k, v in phases.items()}
+    except Exception as e:
+        phases = {'error': f'{type(e).__name__}: {e}'}
     # the step's heaviest kernels from the committed kernel trace + counter passes of tools/train_bench.py (profiles/train_kernels.json)
     roof = None
     kpath = os.path.join(ROOT, 'profiles', 'train_kernels.json')
@@ -339,9 +373,11 @@ def train_leg(dev, batch=384, steps=5, warmup=2, dist=None, world=1, rank=0):
                     'traffic': rec['write_bytes'] + rec['fetch_bytes_x2'], 'avg_launch_us': rec['avg_us'], 'launches_per_step': rec['launches_per_step'],
                     'share_of_step': rec.get('share'), 'mfma_busy_pct': rec.get('mfma_busy_pct'), 'source': rec.get('source'),
                     'other_kernels': {k: {kk: v[kk] for kk in ('avg_us', 'launches_per_step', 'share', 'mfma_busy_pct') if kk in v} for k, v in recs.items() if k != 'enc_blocks_kernel_record'}}
-    return {'encoder_forward_live': live,
+    return {'roofline': live,                    # measured live by this run: the step's largest single launch (the encoder's record-mode forward), bytes it writes / its time against the HBM peak
+            'phases_ms_live': phases,             # encoder forward | decoder (six passes, forward + backward) | encoder backward | clip | AdamW: HIP events around the library calls of two extra steps
+            'encoder_forward_live': live,
             'roofline_from_committed_trace': roof,      # NOT re-measured by this run: profiles/train_kernels.json (rocprofv3 trace + counter passes of tools/train_bench.py)
-            'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4], {world} GPU' + ('s, gradient all-reduce over RCCL)' if world > 1 else ')'),
+            'metric': f'training images/sec (32x128 crops) PARSeq-S, K=6 permutations, AdamW (BASELINE.json configs[4]' + (': global batch 3072 = 8 x 384, gradient all-reduce over RCCL)' if world == 8 else (f' shard: {world} x 384, gradient all-reduce over RCCL)' if world > 1 else ' shard: 384 crops on 1 GPU)')),
             'value': round(world * batch * steps / el, 1), 'unit': 'images/s', 'ms_per_step': round(ms, 2), 'steps': steps, 'warmup': warmup, 'batch': batch,
             'global_batch': world * batch, 'n_gpus': world,
             'dtype': 'bf16 operands (Linear and attention products), fp32 accumulate / master weights / LayerNorm / soft-max / loss / AdamW',
@@ -507,6 +543,11 @@ def main():
     value = world * B * args.steps / elapsed
 
     named = BASELINE_CONFIGS.get((args.model, B, args.refine_iters))
+    if named == 'BASELINE.json configs[1]' and world == 8:
+        # the same per-GPU shard at eight ranks IS configs[2] ("batch=4096 sharded DP over 8xMI355X via RCCL/xGMI": 8 x 512, one all-gather of logits per step)
+        named = 'BASELINE.json configs[2] (8 x the configs[1] shard)'
+    elif named and world > 1:
+        named += f' per rank, {world} ranks (weak scaling towards configs[2])'
     dtype_note = {'bf16x3': 'bf16x3 = every matrix-core product on bf16 hi + lo operand pairs (three MFMAs), fp32 accumulate / LayerNorm / soft-max: the mode '
                             'that meets the 1e-3 logit tolerance against the reference\'s fp32 arithmetic',
                   'bf16': 'bf16 operands, fp32 accumulate (does NOT meet the 1e-3 logit tolerance on these weights: throughput mode)',
