@@ -154,3 +154,49 @@ def test_vit_block_against_transformers_vitlayer():
 def test_synth_images_range():
     x = synth_images(4, CONFIGS['parseq'])
     assert x.shape == (4, 3, 32, 128) and x.min() >= -1 and x.max() <= 1
+
+
+def test_whole_vit_encoder_against_transformers_vitmodel():
+    """The timm boundary, pinned as far as an offline box allows: the WHOLE encoder the stand-in restates — Conv2d patch embedding with (4, 8)
+    patches of a 32 x 128 crop, class token, position embedding added after the projection, twelve pre-LN blocks (eps 1e-6, exact GELU,
+    fused-qkv row order, 1 / sqrt(64) soft-max scale), final LayerNorm — against an INDEPENDENT implementation of the same architecture
+    (HF transformers `ViTModel`, which like timm's ViT with `class_token=True` prepends a class token: the ViTSTR encoder,
+    strhub/models/vitstr/model.py:14-28) with the same synthetic weights, on the crops of the ViTSTR goldens.  `parseq_oracle.vit_features`
+    is the ONE function both oracles' encoders run (PARSeq's without the class-token row), so this covers every operation of the PARSeq
+    encoder as well.  Not a reference-held vector — timm itself is unobtainable here — but a second opinion on every line of Appendix A."""
+    mv = pytest.importorskip('transformers.models.vit.modeling_vit')
+    import os
+    from safetensors.torch import load_file
+    from oracle import vitstr_oracle as V
+    cfg = V.vitstr_config()
+    sd = V.synth_state_dict(cfg, 0)
+    E, H, depth = cfg.embed_dim, cfg.enc_num_heads, cfg.enc_depth
+    hf_cfg = mv.ViTConfig(hidden_size=E, num_hidden_layers=depth, num_attention_heads=H, intermediate_size=4 * E, hidden_act='gelu',
+                          layer_norm_eps=1e-6, qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                          image_size=tuple(cfg.img_size), patch_size=tuple(cfg.patch_size), num_channels=3)
+    hf_cfg._attn_implementation = 'eager'
+    model = mv.ViTModel(hf_cfg, add_pooling_layer=False).eval()
+    m = {'embeddings.cls_token': sd['cls_token'], 'embeddings.position_embeddings': sd['pos_embed'],
+         'embeddings.patch_embeddings.projection.weight': sd['patch_embed.proj.weight'],
+         'embeddings.patch_embeddings.projection.bias': sd['patch_embed.proj.bias'],
+         'layernorm.weight': sd['norm.weight'], 'layernorm.bias': sd['norm.bias']}
+    for i in range(depth):
+        p, q = f'blocks.{i}.', f'layers.{i}.'
+        w, b = sd[p + 'attn.qkv.weight'], sd[p + 'attn.qkv.bias']
+        m.update({q + 'layernorm_before.weight': sd[p + 'norm1.weight'], q + 'layernorm_before.bias': sd[p + 'norm1.bias'],
+                  q + 'layernorm_after.weight': sd[p + 'norm2.weight'], q + 'layernorm_after.bias': sd[p + 'norm2.bias'],
+                  q + 'attention.q_proj.weight': w[:E], q + 'attention.k_proj.weight': w[E:2 * E], q + 'attention.v_proj.weight': w[2 * E:],
+                  q + 'attention.q_proj.bias': b[:E], q + 'attention.k_proj.bias': b[E:2 * E], q + 'attention.v_proj.bias': b[2 * E:],
+                  q + 'attention.o_proj.weight': sd[p + 'attn.proj.weight'], q + 'attention.o_proj.bias': sd[p + 'attn.proj.bias'],
+                  q + 'mlp.fc1.weight': sd[p + 'mlp.fc1.weight'], q + 'mlp.fc1.bias': sd[p + 'mlp.fc1.bias'],
+                  q + 'mlp.fc2.weight': sd[p + 'mlp.fc2.weight'], q + 'mlp.fc2.bias': sd[p + 'mlp.fc2.bias']})
+    res = model.load_state_dict(m, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    images = load_file(os.path.join(os.path.dirname(__file__), 'golden', 'vitstr.safetensors'))['images']
+    with torch.inference_mode():
+        want = model(images).last_hidden_state                      # [B, 129, E]
+        got = O.vit_features(sd, '', cfg, images)
+    assert got.shape == want.shape == (images.shape[0], cfg.num_patches + 1, E)
+    err = (got - want).abs().max().item()
+    print(f'[oracle encoder vs transformers ViTModel] tokens {tuple(got.shape)} max|d| {err:.3e}, |want| max {want.abs().max().item():.3e}')
+    assert err <= 5e-5          # twelve blocks of fp32 reassociation on O(1) activations (measured 1e-5)

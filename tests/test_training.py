@@ -1073,3 +1073,61 @@ def test_optimiser_step_hands_every_weight_back_in_one_launch(train_golden):
         _native.check(lib.parseq_model_get_param(st.model, key.encode(), _native.ptr(one), one.numel(), _native.stream_ptr(one)))
         torch.cuda.synchronize()
         assert torch.equal(one, t), key
+
+
+@pytest.mark.gpu
+def test_one_launch_training_forward_record_slot_by_slot(monkeypatch):
+    """the record mode's ring-stage waits let the record's own stores stay in flight (encoder_blocks.h kRecStores*); a wait that
+    became too loose would let a stage be read before it has landed, and `memory` alone (bf16-noise tolerance) might not show it.  So the
+    RECORD is compared slot by slot — x, q | k | v, attention output, x after the attention branch, fc1 pre-activation, its GELU, the two
+    LayerNorm outputs, for each of the twelve blocks — between the one launch and the per-operation forward (PARSEQ_TRAIN_ENC_PER_OP=1),
+    batch 8: relative rms within bf16 rounding compounded over the blocks (measured 2e-5 in block 0 growing to 5e-3 in block 11).  The
+    layout is lib_train.hip TrainEncoderLayout's, restated here (a change there fails this test loudly, which is the point)."""
+    from gpu_util import DEV, make_model
+    from parseq_amd import _native
+    from parseq_amd.train import _set_train_precision
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'bf16'
+    B, E, F, S, PK, depth = 8, 384, 1536, 128, 96, 12
+    images = synth_images(B, cfg, seed=23).to(DEV)
+    lib = _native.lib()
+    native = m.model._sync_native().model
+    _set_train_precision(m, native)
+    MS = B * S
+    r64 = lambda n: (n + 63) // 64 * 64
+    layer0, cur, slots = r64(MS * PK), 0, {}
+    for name, n in [('x', MS * E), ('qkv', MS * 3 * E), ('ao', MS * E), ('x_mid', MS * E), ('hpre', MS * F), ('hact', MS * F), ('n1', MS * E), ('n2', MS * E)]:
+        slots[name] = (cur, n)
+        cur += r64(n)
+    stride = cur
+    nbytes = lib.parseq_train_encoder_workspace_bytes(native, B)
+    assert nbytes // 4 >= layer0 + stride * depth + MS * E
+
+    def fwd():
+        ws = torch.zeros(nbytes // 4, dtype=torch.float32, device=DEV)
+        mem = torch.empty(B, S, E, dtype=torch.float32, device=DEV)
+        _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), B, _native.ptr(mem), _native.ptr(ws), nbytes, _native.stream_ptr(images)))
+        torch.cuda.synchronize()
+        return ws, mem
+    monkeypatch.delenv('PARSEQ_TRAIN_ENC_PER_OP', raising=False)
+    wa, ma = fwd()
+    monkeypatch.setenv('PARSEQ_TRAIN_ENC_PER_OP', '1')
+    wb, mb = fwd()
+    assert not torch.equal(wa, wb)                                   # two different forwards ran
+
+    def view(ws, layer, name):
+        o, n = slots[name]
+        t = ws[layer0 + layer * stride + o: layer0 + layer * stride + o + n]
+        return t.view(torch.bfloat16)[:n].float() if name in ('ao', 'hpre', 'hact', 'n1', 'n2') else t
+    worst = {}
+    for layer in range(depth):
+        for name in slots:
+            a, b = view(wa, layer, name), view(wb, layer, name)
+            assert torch.isfinite(a).all() and torch.isfinite(b).all(), (layer, name)
+            rel = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12))
+            worst[name] = max(worst.get(name, 0.0), rel)
+            assert rel <= (1e-3 if layer == 0 else 2e-2), (layer, name, rel)
+    print('[record, one launch vs per-operation] worst relative rms per slot over the twelve blocks:', {k: f'{v:.1e}' for k, v in worst.items()})
+    rel = float((ma - mb).pow(2).mean().sqrt() / mb.pow(2).mean().sqrt())
+    assert rel <= 2e-2, rel
