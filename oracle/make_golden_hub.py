@@ -119,5 +119,46 @@ def main():
             print('  ', mode, meta['modes'][mode]['shape'], meta['modes'][mode]['strings'])
 
 
+def main_vitstr(ref='/root/reference', out_dir=os.path.join(ROOT, 'tests', 'golden'), candidates=32, keep=4):
+    """ViTSTR built through the reference's create_model('vitstr', **kwargs): resolved configuration, logits of the system's forward at the
+    full and at a shorter max_length, strings of the system's tokenizer."""
+    from safetensors.torch import save_file
+    from oracle import vitstr_oracle as V
+    from oracle.synth import VITSTR_HUB_VARIANTS, vitstr_variant_config
+    install_stubs()
+    if ref not in sys.path:
+        sys.path.insert(0, ref)
+    from strhub.models import utils as ref_utils
+    for name, kwargs in VITSTR_HUB_VARIANTS.items():
+        cfg = vitstr_variant_config(name)
+        resolved = ref_utils._get_config('vitstr', **kwargs)
+        system = ref_utils.create_model('vitstr', **kwargs).eval()
+        tok = system.tokenizer
+        assert len(tok) == cfg.num_tokens and system.max_label_length == cfg.max_label_length
+        sd = V.synth_state_dict(cfg, 0)
+        res = system.model.load_state_dict(sd, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        cand = synth_images(candidates, cfg, seed=4321)
+        with torch.inference_mode():
+            top2 = system.forward(cand).topk(2, dim=-1).values
+            margin = (top2[..., 0] - top2[..., 1]).amin(-1)
+            order = margin.argsort(descending=True)[:keep].sort().values
+            images = cand[order].contiguous()
+            short = max(cfg.max_label_length - 3, 1)
+            out = {'images': images, 'logits': system.forward(images).contiguous(), 'logits.short': system.forward(images, short).contiguous()}
+        strings, probs = tok.decode(out['logits'].softmax(-1))
+        meta = {'model': name, 'experiment': 'vitstr', 'kwargs': kwargs, 'resolved_config': resolved, 'short_max_length': short,
+                'num_params': sum(p.numel() for p in system.model.parameters()), 'candidate_ids': order.tolist(),
+                'sd_fingerprint': state_dict_fingerprint(sd), 'min_margin': float(margin[order].min()),
+                'tokenizer': {'len': len(tok), 'eos_id': tok.eos_id, 'bos_id': tok.bos_id, 'pad_id': tok.pad_id},
+                'shapes': {k: list(v.shape) for k, v in out.items()}, 'strings': strings, 'confidence': [float(p.prod()) for p in probs]}
+        save_file(out, os.path.join(out_dir, f'{name}.safetensors'))
+        with open(os.path.join(out_dir, f'{name}.json'), 'w') as f:
+            json.dump(meta, f, indent=1)
+        print(name, meta['num_params'], meta['shapes'], strings, meta['min_margin'])
+
+
 if __name__ == '__main__':
-    main()
+    if '--vitstr-only' not in sys.argv:
+        main()
+    main_vitstr()

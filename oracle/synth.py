@@ -161,3 +161,17 @@ def variant_config(name: str) -> OracleConfig:
 
 def variant_state_dict(name: str, seed: int = 0):
     return synth_state_dict(variant_config(name), seed, eos_bias=HUB_VARIANTS[name][2])
+
+
+# ViTSTR through the same hub keyword arguments (strhub/models/vitstr/system.py:41-60: the head is len(charset) + 1 wide, forward returns
+# max_label_length + 1 positions): name -> keyword overrides of create_model('vitstr', ...).  Goldens: oracle/make_golden_hub.py.
+VITSTR_HUB_VARIANTS = {
+    'vitstr_c36_len10': {'charset_train': CHARSET_36, 'max_label_length': 10},
+}
+
+
+def vitstr_variant_config(name: str) -> OracleConfig:
+    from .vitstr_oracle import vitstr_config
+    kw = VITSTR_HUB_VARIANTS[name]
+    extra = {'max_label_length': kw['max_label_length']} if 'max_label_length' in kw else {}
+    return charset_config(vitstr_config(), kw['charset_train'], **extra)

@@ -214,3 +214,60 @@ def test_postprocess_and_test_step_on_the_variant(variant, variant_models, golde
     labels = [m.charset_adapter(s) for s in spec['strings']]
     out = m.test_step((g['images'].to(DEV), labels), 0)['output']
     assert out.num_samples == 4 and out.correct == 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# ViTSTR through the same keyword arguments (strhub/models/vitstr/system.py:41-60)
+# ---------------------------------------------------------------------------------------------------------------------------------
+
+def _build_vitstr(variant, precision=None):
+    from oracle import vitstr_oracle as V
+    from oracle.synth import VITSTR_HUB_VARIANTS, vitstr_variant_config
+    from parseq_amd import create_model
+    extra = {'precision': precision} if precision else {}
+    m = create_model('vitstr', **VITSTR_HUB_VARIANTS[variant], **extra)
+    m.model.load_state_dict(V.synth_state_dict(vitstr_variant_config(variant), 0), strict=True)
+    return m.eval()
+
+
+def test_vitstr_variant_config_shapes_and_oracle(golden):
+    from oracle import vitstr_oracle as V
+    from oracle.synth import VITSTR_HUB_VARIANTS, vitstr_variant_config
+    from parseq_amd.configs import get_config
+    for variant, kwargs in VITSTR_HUB_VARIANTS.items():
+        g, meta = golden(variant)
+        ours, ref = get_config('vitstr', **kwargs), meta['resolved_config']
+        assert set(ours) == set(ref) and all(ours[k] == ref[k] for k in ref)
+        cfg = vitstr_variant_config(variant)
+        m = _build_vitstr(variant)
+        assert {'len': len(m.tokenizer), 'eos_id': m.tokenizer.eos_id, 'bos_id': m.tokenizer.bos_id, 'pad_id': m.tokenizer.pad_id} == meta['tokenizer']
+        assert tuple(m.model.state_dict()['head.weight'].shape) == (cfg.num_tokens - 2, cfg.embed_dim)
+        assert sum(p.numel() for p in m.model.parameters()) == meta['num_params']
+        sd = V.synth_state_dict(cfg, 0)
+        with torch.inference_mode():
+            assert (V.forward(sd, cfg, g['images']) - g['logits']).abs().max().item() <= 5e-6
+            assert (V.forward(sd, cfg, g['images'], meta['short_max_length']) - g['logits.short']).abs().max().item() <= 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3', 'bf16'])
+def test_vitstr_variant_matches_reference(precision, golden):
+    from gpu_util import report
+    from oracle.synth import VITSTR_HUB_VARIANTS
+    for variant in VITSTR_HUB_VARIANTS:
+        g, meta = golden(variant)
+        m = _build_vitstr(variant, precision).to(DEV)
+        x = g['images'].to(DEV)
+        with torch.inference_mode():
+            full, short = m(x).float().cpu(), m(x, meta['short_max_length']).float().cpu()
+            big = m(x.repeat(16, 1, 1, 1)).float().cpu()
+        assert list(full.shape) == meta['shapes']['logits'] and list(short.shape) == meta['shapes']['logits.short']
+        tol = 1e-3 if precision != 'bf16' else 6e-2
+        for tag, got, ref in (('full', full, g['logits']), ('short', short, g['logits.short']), ('batch 64, first rows', big[:4], g['logits'])):
+            err, msg = report(f'{variant} {precision} {tag}', got, ref)
+            assert err <= tol, msg
+            if precision != 'bf16':
+                assert torch.equal(got.argmax(-1), ref.argmax(-1)), msg
+        if precision != 'bf16':
+            strings, _ = m.tokenizer.decode(full.softmax(-1))
+            assert strings == meta['strings']
