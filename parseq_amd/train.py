@@ -82,27 +82,90 @@ def _set_train_precision(system, native):
     _native.check(_native.lib().parseq_model_set_train_precision(native, _native.PARSEQ_BF16 if mode == 'bf16' else _native.PARSEQ_F32))
 
 
-def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None,
-                     dropout: Optional[float] = None, seed: Optional[int] = None) -> DecoderBackward:
-    """One training batch up to and including the decoder's backward.  `perms` defaults to a fresh draw from the system's
-    sampler (system.py:175); `memory` defaults to `system.model.encode(images)` in the system's precision; `dropout` defaults
-    to the model's rate in training mode (`system.train()`) and to 0 in evaluation mode; `seed` (the step's dropout masks)
-    defaults to a draw from the system's numpy generator."""
-    lib = _native.lib()
-    model = system.model
+class _PinnedStaging:
+    """Host -> device uploads of a step's small integer inputs without stalling anybody.  A `.to(device)` of a pageable tensor makes the
+    host wait until the stream has reached the copy — in the middle of a training step that is the end of the encoder's forward, and
+    whatever host work is left behind it then runs with the device idle (measured: 0.5 ms per step).  Here the values are written into a
+    pinned buffer and copied with non_blocking=True; a ring of slots, each guarded by the event recorded behind its last copy, keeps a
+    buffer from being rewritten before the device has read it (the host runs about one step ahead of the device)."""
+
+    SLOTS = 4
+
+    def __init__(self):
+        self.slots = [dict() for _ in range(self.SLOTS)]
+        self.events = [None] * self.SLOTS
+        self.next = 0
+
+    def upload(self, named: Dict[str, Tensor], device) -> Dict[str, Tensor]:
+        k = self.next
+        self.next = (k + 1) % self.SLOTS
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # the copies that last read this slot have run (never waits in practice: four steps ago)
+        out = {}
+        for name, t in named.items():
+            buf = self.slots[k].get(name)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = self.slots[k][name] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            buf.copy_(t)
+            out[name] = buf.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        self.events[k] = ev
+        return out
+
+
+@dataclass
+class _DecoderInputs:
+    tokens: Tensor                  # int32 [B, L] on the device
+    targets: Tensor                 # int32 [2, B * L]: all targets | <eos> dropped (system.py:191-195)
+    padding: Tensor                 # uint8 [B, L]
+    masks: Tensor                   # uint8 [K, L, L] query masks of the K permutations
+    perms: Tensor
+    shape: tuple                    # (B, L, K)
+    total: int                      # loss denominator
+
+
+def prepare_decoder_inputs(system, labels, perms: Optional[Tensor] = None) -> _DecoderInputs:
+    """Everything `parseq_train_decoder` reads besides `memory`, computed on the HOST (tokenizer, permutation sampler, masks, padding,
+    targets: system.py:171-196) and uploaded asynchronously — no device work is waited for, so the caller may run this before or after
+    enqueueing the encoder's forward without stalling either side."""
     dev = system.device
-    tgt = system.tokenizer.encode(labels, dev)
+    tgt = system.tokenizer.encode(labels, None)                      # on the CPU
     if perms is None:
         perms = system.gen_tgt_perms(tgt)
+    perms = perms.cpu()
     tgt_in, tgt_out = tgt[:, :-1], tgt[:, 1:]
     B, L = tgt_in.shape
     K = len(perms)
     late = torch.where(tgt_out == system.eos_id, system.pad_id, tgt_out)
-    targets = torch.stack([tgt_out.reshape(-1), late.reshape(-1)]).to(torch.int32).contiguous()
-    total = loss_denominator(labels, K)          # on the host: no device round trip
-    masks = torch.stack([generate_attn_masks(p)[1] for p in perms.cpu()]).to(torch.uint8).to(dev).contiguous()
-    padding = ((tgt_in == system.pad_id) | (tgt_in == system.eos_id)).to(torch.uint8).contiguous()
-    tokens = tgt_in.to(torch.int32).contiguous()
+    host = {'targets': torch.stack([tgt_out.reshape(-1), late.reshape(-1)]).to(torch.int32).contiguous(),
+            'masks': torch.stack([generate_attn_masks(p)[1] for p in perms]).to(torch.uint8).contiguous(),
+            'padding': ((tgt_in == system.pad_id) | (tgt_in == system.eos_id)).to(torch.uint8).contiguous(),
+            'tokens': tgt_in.to(torch.int32).contiguous()}
+    if dev.type == 'cuda':
+        staging = getattr(system, '_train_staging', None)
+        if staging is None:
+            staging = system._train_staging = _PinnedStaging()
+        d = staging.upload(host, dev)
+    else:
+        d = {k: v.to(dev) for k, v in host.items()}
+    return _DecoderInputs(tokens=d['tokens'], targets=d['targets'], padding=d['padding'], masks=d['masks'], perms=perms, shape=(B, L, K),
+                          total=loss_denominator(labels, K))
+
+
+def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None,
+                     dropout: Optional[float] = None, seed: Optional[int] = None, inputs: Optional[_DecoderInputs] = None) -> DecoderBackward:
+    """One training batch up to and including the decoder's backward.  `perms` defaults to a fresh draw from the system's
+    sampler (system.py:175); `memory` defaults to `system.model.encode(images)` in the system's precision; `dropout` defaults
+    to the model's rate in training mode (`system.train()`) and to 0 in evaluation mode; `seed` (the step's dropout masks)
+    defaults to a draw from the system's numpy generator.  `inputs`: the result of `prepare_decoder_inputs` when the caller made it
+    earlier (loss_and_grads does, ahead of the encoder's forward)."""
+    lib = _native.lib()
+    model = system.model
+    dev = system.device
+    if inputs is None:
+        inputs = prepare_decoder_inputs(system, labels, perms)
+    B, L, K = inputs.shape
     if memory is None:
         memory = model.encode(images)
     memory = memory.float().contiguous()
@@ -117,12 +180,12 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
     ws_bytes = lib.parseq_train_decoder_workspace_bytes(native, B, L, K)
     workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
     loss = torch.empty(1 + K, dtype=torch.float32, device=dev)
-    _native.check(lib.parseq_train_decoder(native, _native.ptr(memory), _native.ptr(tokens), _native.ptr(targets), _native.ptr(padding),
-                                           _native.ptr(masks), B, L, K, total, float(dropout), int(seed), _native.ptr(loss), _native.ptr(flat),
+    _native.check(lib.parseq_train_decoder(native, _native.ptr(memory), _native.ptr(inputs.tokens), _native.ptr(inputs.targets), _native.ptr(inputs.padding),
+                                           _native.ptr(inputs.masks), B, L, K, inputs.total, float(dropout), int(seed), _native.ptr(loss), _native.ptr(flat),
                                            _native.ptr(dmemory),
                                            _native.ptr(workspace), ws_bytes, _native.stream_ptr(dev)))
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    return DecoderBackward(loss=loss[0], perm_losses=loss[1:], grads=param_views(native, flat, shapes), flat=flat, dmemory=dmemory, perms=perms,
+    return DecoderBackward(loss=loss[0], perm_losses=loss[1:], grads=param_views(native, flat, shapes), flat=flat, dmemory=dmemory, perms=inputs.perms,
                            workspace=workspace, _shape=(B, L, K), _model=native)
 
 
@@ -135,6 +198,9 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
     images = model._check_images(images)
     if images.dtype != torch.float32:
         images = ((images.float() / 255.0) - 0.5) / 0.5 if images.dtype == torch.uint8 else images.float()
+    # the decoder's integer inputs first: host work + asynchronous uploads, nothing of it waits for the device (the draws from the system's
+    # generators happen in the reference's order: permutations, then the dropout seed inside decoder_backward)
+    inputs = prepare_decoder_inputs(system, labels, perms)
     native = model._sync_native().model
     _set_train_precision(system, native)
     B = images.shape[0]
@@ -143,7 +209,7 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
     memory = torch.empty(B, model.encoder.pos_embed.shape[1], model._cfg['embed_dim'], dtype=torch.float32, device=images.device)
     _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), B, _native.ptr(memory), _native.ptr(ws), ws_bytes,
                                                    _native.stream_ptr(images)))
-    res = decoder_backward(system, images, labels, perms, memory=memory, dropout=dropout, seed=seed)
+    res = decoder_backward(system, images, labels, perms, memory=memory, dropout=dropout, seed=seed, inputs=inputs)
     _native.check(lib.parseq_train_encoder_backward(native, _native.ptr(res.dmemory), B, _native.ptr(res.flat), _native.ptr(ws), ws_bytes,
                                                     _native.stream_ptr(images)))
     res.memory = memory

@@ -25,8 +25,11 @@ def main():
     starts = [i for i, r in enumerate(rows) if after in r[0]]
     if not starts:
         raise SystemExit(f'no kernel matching {after}')
-    i0 = starts[-1]
-    i1 = next((i for i in range(i0 + 1, len(rows)) if before in rows[i][0]), len(rows))
+    if after == before and len(starts) >= 2:      # one whole step: from the second-last launch of the kernel to the last
+        i0, i1 = starts[-2], starts[-1]
+    else:
+        i0 = starts[-1]
+        i1 = next((i for i in range(i0 + 1, len(rows)) if before in rows[i][0]), len(rows))
     win = rows[i0 + 1:i1]
     wall = (win[-1][2] - rows[i0][2]) / 1e3 if win else 0.0
     agg = {}
