@@ -1127,7 +1127,10 @@ def test_one_launch_training_forward_record_slot_by_slot(monkeypatch):
             assert torch.isfinite(a).all() and torch.isfinite(b).all(), (layer, name)
             rel = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12))
             worst[name] = max(worst.get(name, 0.0), rel)
-            assert rel <= (1e-3 if layer == 0 else 2e-2), (layer, name, rel)
+            # block 0: the two forwards' values agree to fp32 rounding BEFORE storage; a slot stored as bf16 then differs where a value sits on a
+            # rounding boundary (relative rms of one bf16 ulp flip ~ 2^-9: measured 1.0e-3 on hpre), a fp32 slot hardly at all
+            first = 4e-3 if name in ('ao', 'hpre', 'hact', 'n1', 'n2') else 1e-3
+            assert rel <= (first if layer == 0 else 2e-2), (layer, name, rel)
     print('[record, one launch vs per-operation] worst relative rms per slot over the twelve blocks:', {k: f'{v:.1e}' for k, v in worst.items()})
     rel = float((ma - mb).pow(2).mean().sqrt() / mb.pow(2).mean().sqrt())
     assert rel <= 2e-2, rel
