@@ -124,6 +124,7 @@ def state_dict_fingerprint(sd) -> float:
 
 CHARSET_36 = "0123456789abcdefghijklmnopqrstuvwxyz"                       # configs/charset/36_lowercase.yaml:3 (a fact, restated)
 CHARSET_62 = CHARSET_36 + "ABCDEFGHIJKLMNOPQRSTUVWXYZ"                      # configs/charset/62_mixed-case.yaml:3
+CHARSET_200 = CHARSET_62 + "".join(chr(0x4E00 + i) for i in range(138))      # 62 + 138 CJK ideographs: a charset the reference accepts like any other string
 
 
 def charset_config(base: OracleConfig, charset: str, **overrides) -> OracleConfig:
@@ -150,6 +151,9 @@ HUB_VARIANTS = {
     'parseq_c36_len10': ('parseq', {'charset_train': CHARSET_36, 'max_label_length': 10}, 0.5),
     'parseq_c62': ('parseq', {'charset_train': CHARSET_62}, 1.25),
     'parseq-tiny_c62_len10': ('parseq-tiny', {'charset_train': CHARSET_62, 'max_label_length': 10}, 1.5),
+    # more classes than one 128-column head tile of the fused AR step (decoder_step.h): the AR loop must take the per-operation kernels; 201-wide
+    # head rows are not 16-byte multiples; non-ASCII characters through the tokenizer
+    'parseq_c200': ('parseq', {'charset_train': CHARSET_200}, 1.5),
 }
 
 
