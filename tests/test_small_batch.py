@@ -102,3 +102,24 @@ def test_uint8_and_bf16_inputs_on_the_default_route(default_model):
     a = _run(default_model, u8.to(DEV), 'ar1')
     b = _run(default_model, f32.to(DEV), 'ar1')
     assert torch.equal(a, b)
+
+
+def test_routes_alternate_on_one_plan(default_model, golden):
+    """One plan (workspace capacity 128) serves both routes in turn: 65 crops (one launch: K / V of the memory as 24-bit rows), the 8 golden
+    crops (per-operation launches: f32 rows), 65 again — the plan must remember which format its K / V hold (parseq_plan::kv24) and nothing
+    of one route's state may leak into the other: every result equals its first occurrence bit for bit, and the goldens hold in between."""
+    g, _ = golden('parseq')
+    x65 = synth_images(65, CONFIGS['parseq'], seed=33).to(DEV)
+    x8 = g['images'].to(DEV)
+    first65 = _run(default_model, x65, 'ar1')
+    first8 = _run(default_model, x8, 'ar1')
+    for _ in range(2):
+        assert torch.equal(_run(default_model, x65, 'ar1'), first65)
+        assert torch.equal(_run(default_model, x8, 'ar1'), first8)
+    err, msg = report('small-batch route after a one-launch forward on the same plan', first8, g['logits.ar1'])
+    assert err <= 1e-3 and torch.equal(first8.argmax(-1), g['logits.ar1'].argmax(-1)), msg
+    # and through encode() + forward on the other route: the K / V cache of an encode() must not survive a forward of another batch
+    mem8 = default_model.model.encode(x8)
+    assert torch.equal(_run(default_model, x65, 'nar0'), _run(default_model, x65, 'nar0'))
+    err, msg = report('memory of the small-batch route after the alternation', mem8.cpu(), g['memory'])
+    assert err <= 5e-4, msg
