@@ -165,9 +165,10 @@ struct parseq_model {
     // on gradients that are still being written
     bool grad_events_valid = false;
     // parseq_train_encoder_backward's second stream (the weight-gradient products run beside the dX / LayerNorm / attention chain) and the events
-    // that order the two; created on first use
-    hipStream_t train_side = nullptr;
-    hipEvent_t train_ev[8] = {};
+    // that order the two; created on first use — ONE SET PER CALLER STREAM (round 6: a step may run as micro-batches on several streams at
+    // once, parseq_amd/train.py; two backwards that shared a side stream and its events would order each other's kernels)
+    struct TrainSide { hipStream_t key = nullptr; hipStream_t side = nullptr; hipEvent_t ev[8] = {}; };
+    std::vector<TrainSide> train_sides;
 
     const float* p(const std::string& key) const { return master + params[index.at(key)].offset; }
 };

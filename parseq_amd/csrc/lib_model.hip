@@ -86,8 +86,10 @@ extern "C" void parseq_model_destroy(parseq_model* m) {
     if (m->train_blocks_dev) (void)hipFree(m->train_blocks_dev);
     if (m->shadow_tab_dev) (void)hipFree(m->shadow_tab_dev);
     for (hipEvent_t e : m->grad_events) (void)hipEventDestroy(e);
-    for (hipEvent_t e : m->train_ev) if (e) (void)hipEventDestroy(e);
-    if (m->train_side) (void)hipStreamDestroy(m->train_side);
+    for (auto& ts : m->train_sides) {
+        for (hipEvent_t e : ts.ev) if (e) (void)hipEventDestroy(e);
+        if (ts.side) (void)hipStreamDestroy(ts.side);
+    }
     delete m;
 }
 

@@ -883,10 +883,21 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
     const bool segs = m->cfg.enc_depth >= 2;
     const bool two_streams = only16 && !getenv("PARSEQ_TRAIN_ONE_STREAM");
     hipStream_t side = nullptr;
+    hipEvent_t* side_ev = nullptr;
     if (two_streams) {
-        if (!m->train_side) HIPCHK(hipStreamCreateWithFlags(&m->train_side, hipStreamNonBlocking));
-        for (hipEvent_t& e : m->train_ev) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        side = m->train_side;
+        // the caller stream's own side stream and events (a step split into micro-batches runs several backwards at once, each on its own stream)
+        size_t slot = 0;
+        while (slot < m->train_sides.size() && m->train_sides[slot].key != s) ++slot;
+        if (slot == m->train_sides.size()) {
+            if (slot >= 8) return fail(PARSEQ_E_STATE, "training encoder backward: more than 8 distinct caller streams on one model");
+            parseq_model::TrainSide ts;
+            ts.key = s;
+            HIPCHK(hipStreamCreateWithFlags(&ts.side, hipStreamNonBlocking));
+            for (hipEvent_t& e : ts.ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            m->train_sides.push_back(ts);
+        }
+        side = m->train_sides[slot].side;
+        side_ev = m->train_sides[slot].ev;
     }
     const TrainCtx cxs{side, w + o.scratch2, m->train_precision == PARSEQ_BF16, o.scratch_floats};
     m->grad_events_valid = false;
@@ -908,7 +919,7 @@ extern "C" int parseq_train_encoder_backward(parseq_model* m, const float* dmemo
                 // (an error return inside the block must not leave weight-gradient kernels running on the hidden stream behind the caller's back:
                 // the block is a lambda and a failure joins the side stream before it is reported)
                 auto block = [&]() -> int {
-                hipEvent_t* ev = m->train_ev;
+                hipEvent_t* ev = side_ev;
                 const bf16_t* hpre16 = reinterpret_cast<const bf16_t*>(hpre);
                 bf16_t* dqkv16 = reinterpret_cast<bf16_t*>(dqkv);
                 HIPCHK(hipEventRecord(ev[0], s)); HIPCHK(hipStreamWaitEvent(side, ev[0], 0));                    // d_x16 of this block exists

@@ -89,7 +89,7 @@ class _PinnedStaging:
     pinned buffer and copied with non_blocking=True; a ring of slots, each guarded by the event recorded behind its last copy, keeps a
     buffer from being rewritten before the device has read it (the host runs about one step ahead of the device)."""
 
-    SLOTS = 4
+    SLOTS = 8        # uploads per step = micro-batches (<= 4): at least two steps' worth
 
     def __init__(self):
         self.slots = [dict() for _ in range(self.SLOTS)]
@@ -125,36 +125,46 @@ class _DecoderInputs:
     total: int                      # loss denominator
 
 
-def prepare_decoder_inputs(system, labels, perms: Optional[Tensor] = None) -> _DecoderInputs:
+def prepare_decoder_inputs(system, labels, perms: Optional[Tensor] = None, parts: int = 1):
     """Everything `parseq_train_decoder` reads besides `memory`, computed on the HOST (tokenizer, permutation sampler, masks, padding,
     targets: system.py:171-196) and uploaded asynchronously — no device work is waited for, so the caller may run this before or after
-    enqueueing the encoder's forward without stalling either side."""
+    enqueueing the encoder's forward without stalling either side.
+
+    parts > 1 (micro-batches of one step, `loss_and_grads_micro`): the batch is tokenised and its permutations drawn ONCE — every part keeps
+    the whole batch's sequence length, permutations, masks and loss denominator, so that the parts' gradients add up to the batch's — and
+    a list of `parts` inputs over consecutive row ranges is returned."""
     dev = system.device
     tgt = system.tokenizer.encode(labels, None)                      # on the CPU
     if perms is None:
         perms = system.gen_tgt_perms(tgt)
     perms = perms.cpu()
-    tgt_in, tgt_out = tgt[:, :-1], tgt[:, 1:]
-    B, L = tgt_in.shape
-    K = len(perms)
-    late = torch.where(tgt_out == system.eos_id, system.pad_id, tgt_out)
-    host = {'targets': torch.stack([tgt_out.reshape(-1), late.reshape(-1)]).to(torch.int32).contiguous(),
-            'masks': torch.stack([generate_attn_masks(p)[1] for p in perms]).to(torch.uint8).contiguous(),
-            'padding': ((tgt_in == system.pad_id) | (tgt_in == system.eos_id)).to(torch.uint8).contiguous(),
-            'tokens': tgt_in.to(torch.int32).contiguous()}
+    B, K = tgt.shape[0], len(perms)
+    if parts < 1 or B % parts:
+        raise ValueError(f'a batch of {B} does not split into {parts} equal parts')
+    total = loss_denominator(labels, K)
+    masks = torch.stack([generate_attn_masks(p)[1] for p in perms]).to(torch.uint8).contiguous()
+    staging = None
     if dev.type == 'cuda':
         staging = getattr(system, '_train_staging', None)
         if staging is None:
             staging = system._train_staging = _PinnedStaging()
-        d = staging.upload(host, dev)
-    else:
-        d = {k: v.to(dev) for k, v in host.items()}
-    return _DecoderInputs(tokens=d['tokens'], targets=d['targets'], padding=d['padding'], masks=d['masks'], perms=perms, shape=(B, L, K),
-                          total=loss_denominator(labels, K))
+    out = []
+    for j in range(parts):
+        rows = tgt[j * (B // parts):(j + 1) * (B // parts)]
+        tgt_in, tgt_out = rows[:, :-1], rows[:, 1:]
+        late = torch.where(tgt_out == system.eos_id, system.pad_id, tgt_out)
+        host = {'targets': torch.stack([tgt_out.reshape(-1), late.reshape(-1)]).to(torch.int32).contiguous(), 'masks': masks,
+                'padding': ((tgt_in == system.pad_id) | (tgt_in == system.eos_id)).to(torch.uint8).contiguous(),
+                'tokens': tgt_in.to(torch.int32).contiguous()}
+        d = staging.upload(host, dev) if staging is not None else {k: v.to(dev) for k, v in host.items()}
+        out.append(_DecoderInputs(tokens=d['tokens'], targets=d['targets'], padding=d['padding'], masks=d['masks'], perms=perms,
+                                  shape=(tgt_in.shape[0], tgt_in.shape[1], K), total=total))
+    return out[0] if parts == 1 else out
 
 
 def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = None, memory: Optional[Tensor] = None,
-                     dropout: Optional[float] = None, seed: Optional[int] = None, inputs: Optional[_DecoderInputs] = None) -> DecoderBackward:
+                     dropout: Optional[float] = None, seed: Optional[int] = None, inputs: Optional[_DecoderInputs] = None,
+                     flat: Optional[Tensor] = None) -> DecoderBackward:
     """One training batch up to and including the decoder's backward.  `perms` defaults to a fresh draw from the system's
     sampler (system.py:175); `memory` defaults to `system.model.encode(images)` in the system's precision; `dropout` defaults
     to the model's rate in training mode (`system.train()`) and to 0 in evaluation mode; `seed` (the step's dropout masks)
@@ -175,7 +185,10 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
         seed = int(system.rng.integers(0, 2 ** 63)) if dropout > 0 else 0
     native = model._sync_native().model
     _set_train_precision(system, native)
-    flat = torch.zeros(lib.parseq_model_grad_elems(native), dtype=torch.float32, device=dev)
+    if flat is None:
+        flat = torch.zeros(lib.parseq_model_grad_elems(native), dtype=torch.float32, device=dev)
+    else:                                          # the caller's buffer (a micro-batch's persistent gradient buffer): zeroed on this stream
+        flat.zero_()
     dmemory = torch.empty_like(memory)
     ws_bytes = lib.parseq_train_decoder_workspace_bytes(native, B, L, K)
     workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
@@ -190,9 +203,10 @@ def decoder_backward(system, images: Tensor, labels, perms: Optional[Tensor] = N
 
 
 def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = None, dropout: Optional[float] = None,
-                   seed: Optional[int] = None) -> DecoderBackward:
+                   seed: Optional[int] = None, inputs: Optional[_DecoderInputs] = None, flat: Optional[Tensor] = None) -> DecoderBackward:
     """Loss and the gradient of EVERY parameter for one batch — the state `loss.backward()` leaves after the reference's
-    `training_step` (system.py:168-199), dropout off.  `images`: fp32 [B, 3, H, W] on the device, normalised."""
+    `training_step` (system.py:168-199), dropout off.  `images`: fp32 [B, 3, H, W] on the device, normalised.  Everything is enqueued on
+    the CURRENT stream (`inputs`: prepared ahead by the caller — loss_and_grads_micro)."""
     lib = _native.lib()
     model = system.model
     images = model._check_images(images)
@@ -200,7 +214,8 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
         images = ((images.float() / 255.0) - 0.5) / 0.5 if images.dtype == torch.uint8 else images.float()
     # the decoder's integer inputs first: host work + asynchronous uploads, nothing of it waits for the device (the draws from the system's
     # generators happen in the reference's order: permutations, then the dropout seed inside decoder_backward)
-    inputs = prepare_decoder_inputs(system, labels, perms)
+    if inputs is None:
+        inputs = prepare_decoder_inputs(system, labels, perms)
     native = model._sync_native().model
     _set_train_precision(system, native)
     B = images.shape[0]
@@ -209,10 +224,56 @@ def loss_and_grads(system, images: Tensor, labels, perms: Optional[Tensor] = Non
     memory = torch.empty(B, model.encoder.pos_embed.shape[1], model._cfg['embed_dim'], dtype=torch.float32, device=images.device)
     _native.check(lib.parseq_train_encoder_forward(native, _native.ptr(images), B, _native.ptr(memory), _native.ptr(ws), ws_bytes,
                                                    _native.stream_ptr(images)))
-    res = decoder_backward(system, images, labels, perms, memory=memory, dropout=dropout, seed=seed, inputs=inputs)
+    res = decoder_backward(system, images, labels, perms, memory=memory, dropout=dropout, seed=seed, inputs=inputs, flat=flat)
     _native.check(lib.parseq_train_encoder_backward(native, _native.ptr(res.dmemory), B, _native.ptr(res.flat), _native.ptr(ws), ws_bytes,
                                                     _native.stream_ptr(images)))
     res.memory = memory
+    return res
+
+
+def loss_and_grads_micro(system, images: Tensor, labels, perms: Optional[Tensor] = None, parts: int = 2, streams=None,
+                         dropout: Optional[float] = None, flats=None) -> DecoderBackward:
+    """The same loss and gradients with the batch cut into `parts` micro-batches that run AT ONCE, each on its own stream with its own
+    workspaces and gradient buffer (the library keeps one second stream per caller stream for the backward), summed at the end.  NOT faster
+    on one MI355X (batch 384: 27.0 ms in two parts against 24.7 ms in one piece — profiles/r06_train_step.md); kept as the tested guarantee
+    that independent training chains may share a model on different streams, and for callers whose batch does not fit one workspace.  What is shared so that the sum IS the
+    batch's gradient: one tokenisation (every part has the batch's sequence length), one draw of permutations, the batch's loss
+    denominator (`total_targets`), the weights.  What differs from the one-piece schedule: the fp32 summation order of the weight gradients,
+    and — with dropout on — which elements are dropped (the masks are counters of (seed, site, element index): every part draws its own seed).
+    Returns the first part's record with `flat` / `grads` / `loss` replaced by the batch's.  `flats`: gradient buffers of parts 1 .. n - 1 kept by the
+    caller across steps (TrainStep does): a buffer allocated on a part's stream and read on the caller's would have to be handed between the
+    caching allocator's per-stream pools every step (deferred frees, fresh hipMallocs — and their synchronisations — in the middle of the step)."""
+    model, dev = system.model, system.device
+    images = model._check_images(images)
+    B = images.shape[0]
+    if parts <= 1:
+        return loss_and_grads(system, images, labels, perms, dropout=dropout)
+    inputs = prepare_decoder_inputs(system, labels, perms, parts=parts)
+    cur = torch.cuda.current_stream(dev)
+    if streams is None:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(parts - 1)]
+    Bp = B // parts
+    results, counts = [], []
+    for j in range(parts):
+        st = cur if j == 0 else streams[j - 1]
+        if j:
+            st.wait_stream(cur)                                  # the images (and whatever produced them) are ordered on the caller's stream
+        with torch.cuda.stream(st):
+            part_labels = labels[j * Bp:(j + 1) * Bp]
+            results.append(loss_and_grads(system, images[j * Bp:(j + 1) * Bp], part_labels, inputs[j].perms, dropout=dropout, inputs=inputs[j],
+                                          flat=flats[j - 1] if (flats is not None and j) else None))
+            counts.append(loss_denominator(part_labels, inputs[j].shape[2]))
+    res = results[0]
+    loss = res.loss * (counts[0] / float(sum(counts)))
+    for j in range(1, parts):
+        cur.wait_stream(streams[j - 1])
+        results[j].loss.record_stream(cur)                       # (a 4-byte tensor allocated on the part's stream, read here on the caller's)
+        if flats is None:
+            results[j].flat.record_stream(cur)
+        res.flat.add_(results[j].flat)
+        loss = loss + results[j].loss * (counts[j] / float(sum(counts)))
+    res.loss = loss
+    res.memory = None                                            # (the parts' encoder outputs are not stitched together)
     return res
 
 
@@ -239,7 +300,7 @@ class TrainStep:
 
     def __init__(self, system, total_steps: int, lr: Optional[float] = None, weight_decay: Optional[float] = None,
                  warmup_pct: Optional[float] = None, clip_val: float = 20.0, betas=(0.9, 0.999), eps: float = 1e-8,
-                 num_devices: Optional[int] = None, accumulate_grad_batches: int = 1, process_group=None):
+                 num_devices: Optional[int] = None, accumulate_grad_batches: int = 1, process_group=None, micro_batches: Optional[int] = None):
         import math
         self.system = system
         self.total_steps = total_steps
@@ -254,6 +315,13 @@ class TrainStep:
         self.pct_start = system.warmup_pct if warmup_pct is None else warmup_pct
         self.clip_val, self.betas, self.eps = clip_val, betas, eps
         self.process_group = process_group
+        # micro-batches of a step that run at once on separate streams (loss_and_grads_micro).  Default ONE: measured at batch 384, two parts at
+        # once take 27.0 ms against 24.7 ms in one piece, three 28.7, four 34.0 (profiles/r06_train_step.md) — the parts run the same phase at the
+        # same time and compete for what that phase is short of; round 5's probe (two free-running half-steps: 23.6 ms) had overlapped DIFFERENT
+        # phases of consecutive iterations, which a real step — joined at the optimiser — cannot.  (PARSEQ_TRAIN_MICRO_BATCHES overrides.)
+        self.micro_batches = micro_batches
+        self._micro_streams = None
+        self._micro_flats = None
         self.overlap_allreduce = True       # segment-wise all-reduce behind the backward's events (False: one pass after the backward)
         self.force_collectives = False      # run the collectives in a one-rank group too (self-test of the overlapped path on one GPU)
         self._comm_stream = None
@@ -275,14 +343,32 @@ class TrainStep:
     def lr(self) -> float:
         return one_cycle_lr(self.step_count, self.total_steps, self.max_lr, self.pct_start)
 
+    def _parts(self, batch: int, distributed: bool) -> int:
+        import os
+        n = self.micro_batches
+        env = os.environ.get('PARSEQ_TRAIN_MICRO_BATCHES')
+        if env:
+            n = int(env)
+        if n is None:
+            n = 1
+        return n if n >= 1 and batch % n == 0 else 1
+
     def __call__(self, images: Tensor, labels, perms: Optional[Tensor] = None) -> Tensor:
         lib = _native.lib()
         system, model = self.system, self.system.model
-        res = loss_and_grads(system, images, labels, perms)      # enqueued, not waited for: the device is still in the backward here
+        distributed = self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized())
+        parts = self._parts(images.shape[0], distributed)
+        if parts > 1:
+            if self._micro_streams is None or len(self._micro_streams) != parts - 1:
+                self._micro_streams = [torch.cuda.Stream(device=system.device) for _ in range(parts - 1)]
+                self._micro_flats = [torch.empty(lib.parseq_model_grad_elems(model._sync_native().model), dtype=torch.float32, device=system.device) for _ in range(parts - 1)]
+            res = loss_and_grads_micro(system, images, labels, perms, parts=parts, streams=self._micro_streams, flats=self._micro_flats)
+        else:
+            res = loss_and_grads(system, images, labels, perms)      # enqueued, not waited for: the device is still in the backward here
         native = model._sync_native().model
-        if self.process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if distributed:
             from .parallel import average_gradient_segments, average_gradients
-            if self.overlap_allreduce and res.flat.is_cuda and lib.parseq_train_grad_segments(native) > 0:
+            if parts == 1 and self.overlap_allreduce and res.flat.is_cuda and lib.parseq_train_grad_segments(native) > 0:
                 # the all-reduce of each gradient segment starts when the backward has finished writing it (events recorded by
                 # parseq_train_encoder_backward), on a side stream, while the earlier blocks' backward is still running
                 if self._comm_stream is None:

@@ -1134,3 +1134,40 @@ def test_one_launch_training_forward_record_slot_by_slot(monkeypatch):
     print('[record, one launch vs per-operation] worst relative rms per slot over the twelve blocks:', {k: f'{v:.1e}' for k, v in worst.items()})
     rel = float((ma - mb).pow(2).mean().sqrt() / mb.pow(2).mean().sqrt())
     assert rel <= 2e-2, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('parts', [2, 4])
+def test_micro_batched_step_equals_the_one_piece_step(parts):
+    """Round 6: a step cut into micro-batches that run AT ONCE on separate streams (loss_and_grads_micro: own workspaces and gradient
+    buffers per part, the library's second backward stream per caller stream, one tokenisation / one draw of permutations / the batch's
+    loss denominator shared) must produce the one-piece step's loss and gradients — dropout off: the same products, only the fp32 summation
+    order of the weight gradients differs.  Run three times: the parts race each other on the device, a shared buffer would show."""
+    from gpu_util import DEV, make_model
+    from parseq_amd.train import loss_and_grads, loss_and_grads_micro
+    cfg = CONFIGS['parseq']
+    m = make_model('parseq', 'bf16')
+    m.train_precision = 'fp32'                            # exact products: what is left between the two schedules is fp32 summation order
+    gen = torch.Generator().manual_seed(31)
+    B = 64
+    images = synth_images(B, cfg, seed=29).to(DEV)
+    lengths = torch.randint(1, 26, (B,), generator=gen).tolist()
+    lengths[B - 3] = 25                                   # the longest label sits in the LAST part: every part must still run 26 positions
+    labels = [''.join(CHARSET_94[int(i)] for i in torch.randint(0, 94, (n,), generator=gen)) for n in lengths]
+    m.rng = np.random.default_rng(4)
+    torch.manual_seed(5)
+    perms = m.gen_tgt_perms(m.tokenizer.encode(labels))
+    one = loss_and_grads(m, images, labels, perms)
+    torch.cuda.synchronize()
+    want_loss, want = float(one.loss), one.flat.clone()
+    for _ in range(3):
+        got = loss_and_grads_micro(m, images, labels, perms, parts=parts)
+        torch.cuda.synchronize()
+        assert abs(float(got.loss) - want_loss) <= 5e-6 * abs(want_loss), (float(got.loss), want_loss)
+        d = (got.flat - want).double()
+        rel = float(d.norm() / want.double().norm())
+        assert rel <= 1e-5, rel
+        for k, g in got.grads.items():                    # per tensor as well: a small tensor's error would drown in the norm of the whole buffer
+            w = one.grads[k].double()
+            if float(w.norm()) > 1e-9:
+                assert float((g.double() - w).norm() / w.norm()) <= 1e-4, k
