@@ -289,7 +289,9 @@ int parseq_train_decoder(parseq_model* m, const float* memory, const int32_t* to
  * `dmemory` (parseq_train_decoder) to the gradient of every encoder.* parameter, ACCUMULATED into `grads`.
  * images: device fp32 [batch, 3, H, W], normalised as the reference's transform leaves them.
  * Streams: in the bf16-operand mode parseq_train_encoder_backward runs the blocks' weight-gradient products on a second, library-owned
- * non-blocking stream beside the chain on `stream` (PARSEQ_TRAIN_ONE_STREAM=1 turns that off).  Every block ends with `stream` waiting
+ * non-blocking stream beside the chain on `stream` (PARSEQ_TRAIN_ONE_STREAM=1 turns that off) — one such stream per distinct caller stream
+ * (up to eight per model), so independent training chains may share a model on different streams (tests/test_training.py
+ * test_micro_batched_step_equals_the_one_piece_step).  Every block ends with `stream` waiting
  * for it, so on return everything is ordered behind `stream` as usual — on an error return as well: a failure inside a block
  * synchronises the second stream before it is reported, so `grads` and `workspace` are not in use behind the caller's back. */
 size_t parseq_train_encoder_workspace_bytes(const parseq_model* m, int batch);
