@@ -101,7 +101,7 @@ train)
     rm -rf gpurun_out/tp_*
   fi ;;
 configs)
-  run() { timeout 300 python bench.py --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --steps 40 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '->', d['value'], d['sequential_value'])"; }
+  run() { timeout 300 python bench.py --no-cpu-baseline --no-parity --no-profile --no-train --no-natural-exit --no-throughput-mode --no-config3 --no-latency --steps 40 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '->', d['value'], d['sequential_value'])"; }
   run --batch 1024 --refine-iters 2; run --natural-exit; run --precision bf16; run --precision bf16 --batch 1024 --refine-iters 2
   run --precision fp32 --batch 128; run --model parseq-tiny; run --model vitstr --precision bf16; run --model parseq-patch16-224 --batch 64 --precision bf16
   run --batch 256; run --batch 128; run --model vitstr; run --model parseq-patch16-224 --batch 64; run --model parseq-tiny --precision bf16 ;;
